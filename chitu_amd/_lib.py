@@ -1,0 +1,117 @@
+"""ctypes binding of libchitu_hip.so (the C-ABI in include/chitu_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or a call fails,
+the op raises.  PyTorch is used only for device memory and the current stream.
+"""
+
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchitu_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every .hip under csrc/ for gfx950 and link libchitu_hip.so (in-tree)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j", str(os.cpu_count() or 4)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building libchitu_hip.so failed")
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C chitu_amd/csrc`). There is no CPU fallback."
+            )
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def ptr(t):
+    """Device (or host) address of a tensor's first element; None -> NULL."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    """Raw hipStream_t of torch's current stream, so launches are graph-capturable."""
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(status: int, what: str):
+    if status != 0:
+        if status > 0:
+            raise HipCallError(f"{what}: HIP error {status}")
+        raise HipCallError(f"{what}: bad argument (code {status})")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipCallError(
+                "chitu_amd ops run only on a ROCm device tensor (no CPU fallback); got a CPU tensor"
+            )
+
+
+_INT_DTYPE_CODE = {
+    torch.uint8: 0,
+    torch.int8: 1,
+    torch.int16: 2,
+    torch.int32: 3,
+    torch.int64: 4,
+}
+
+# activation / output element codes shared by the C-ABI
+DT_BF16 = 0
+DT_F16 = 1
+DT_F32 = 2
+_FLOAT_DTYPE_CODE = {torch.bfloat16: DT_BF16, torch.float16: DT_F16, torch.float32: DT_F32}
+
+
+def int_dtype_code(dt):
+    try:
+        return _INT_DTYPE_CODE[dt]
+    except KeyError:
+        raise HipCallError(f"unsupported integer dtype {dt}")
+
+
+def float_dtype_code(dt):
+    try:
+        return _FLOAT_DTYPE_CODE[dt]
+    except KeyError:
+        raise HipCallError(f"unsupported float dtype {dt}")
+
+
+def i64(v):
+    return ctypes.c_int64(int(v))
+
+
+def i32(v):
+    return ctypes.c_int32(int(v))
+
+
+def f32(v):
+    return ctypes.c_float(float(v))

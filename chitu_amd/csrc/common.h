@@ -1,0 +1,93 @@
+// Shared device/host helpers for the gfx950 decode kernels.
+// Wave width is 64 everywhere (CDNA4); nothing here is portable to 32-wide warps.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CHITU_OK 0
+#define CHITU_ERR_BAD_ARG (-1)
+#define CHITU_ERR_UNSUPPORTED (-2)
+
+// Every entry point returns CHITU_OK, a negative CHITU_ERR_* for argument
+// errors, or the positive hipError_t of a failed launch (never exit()).
+#define CHITU_RETURN_LAUNCH_STATUS()            \
+    do {                                        \
+        hipError_t e__ = hipGetLastError();     \
+        return e__ == hipSuccess ? CHITU_OK : (int)e__; \
+    } while (0)
+
+#define CHITU_REQUIRE(cond)                     \
+    do {                                        \
+        if (!(cond)) return CHITU_ERR_BAD_ARG;  \
+    } while (0)
+
+namespace chitu {
+
+constexpr int kWave = 64;
+
+typedef uint16_t bf16_t;  // raw bits
+typedef uint8_t fp8_t;    // OCP e4m3fn raw bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+
+// Round-to-nearest-even, NaN preserved (same as torch's float->bfloat16).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ float f16_to_f32(uint16_t h) {
+    return (float)__builtin_bit_cast(_Float16, h);
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+// OCP e4m3fn byte -> f32 (gfx950's v_cvt_f32_fp8 decodes the OCP encoding).
+template <int BYTE>
+__device__ __forceinline__ float fp8_to_f32(uint32_t packed) {
+    return __builtin_amdgcn_cvt_f32_fp8((int)packed, BYTE);
+}
+
+// Two f32 -> two OCP e4m3fn bytes, RNE, NaN stays NaN (act_quant_deepseek_v3 has
+// no clamp: an all-zero group is 0/0 = NaN in the reference, triton_kernels.py:210-212).
+__device__ __forceinline__ uint32_t f32x2_to_fp8x2(float a, float b) {
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+// Saturating form: clamp to +-448 first (the reference's tl.clamp, fused_moe.py:646/703).
+__device__ __forceinline__ uint32_t f32x2_to_fp8x2_sat(float a, float b) {
+    a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
+    b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
+    return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+static inline int ceil_div_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace chitu

@@ -1,0 +1,355 @@
+// Weight-streaming FP8 GEMMs for decode (M = batch <= 64 per pass), gfx950.
+//
+// Replaces (reference, read-only):
+//   chitu/triton_kernels.py:302-365  fp8_gemm_deepseek_v3_kernel       (W8A8, fp32 block scales)
+//   chitu/triton_kernels.py:388-508  soft_fp8_gemm_deepseek_v3_kernel  (fp8 weight -> bf16, bf16 dot)
+//   chitu/ops.py:453-511             their launchers
+//
+// Design (not a translation of the Triton tiling): at M <= 64 the op is a stream of the
+// [N,K] e4m3 weight matrix, read exactly once, so the kernel is built around the weight
+// load.  One wave owns 16 weight rows x a contiguous range of 128-wide K blocks.  Each lane
+// loads 16 B of one row (`row = n0 + lane%16`, `k = kb*128 + c*64 + (lane/16)*16`), i.e. a
+// wave-load covers 16 rows x 64 B and two of them cover the 128-B lines of a K block.
+// Those 16 B are two MFMA A-fragments of v_mfma_f32_16x16x32_fp8_fp8 (weights = A, so a
+// lane ends up with 4 consecutive output columns of one token -> one 8-B bf16 store).  The
+// dot product is order-free in k, so the k-permutation implied by the 16-B load is simply
+// applied to the activation fragment as well (same addressing on the [M,K] fp8 matrix,
+// which is L2-resident).  Per K block the 4 MFMAs accumulate into a fresh register and the
+// result is folded in as (dot * a_s) * b_s in fp32 -- the reference's order
+// (triton_kernels.py:357).  K is split over the waves of a workgroup (LDS reduce) and, when
+// N is too small to fill 256 CUs, over S workgroups (fp32 partials + a tiny ordered reduce
+// kernel): deterministic, no atomics.
+#include "common.h"
+
+namespace chitu {
+
+typedef long mfma_ab_t;  // 8 fp8
+
+__device__ __forceinline__ mfma_ab_t pack_lo(const i32x4& v) {
+    return (long)(((unsigned long long)(uint32_t)v[1] << 32) | (uint32_t)v[0]);
+}
+__device__ __forceinline__ mfma_ab_t pack_hi(const i32x4& v) {
+    return (long)(((unsigned long long)(uint32_t)v[3] << 32) | (uint32_t)v[2]);
+}
+
+template <int MT>
+struct GemmStage {
+    i32x4 w[2];
+    i32x4 x[MT][2];
+    float xs[MT];
+    float ws;
+};
+
+
+// Epilogue shared by both kernels: K-split reduce across the workgroup's waves through LDS
+// in fixed wave order, then one token-tile per wave is written (bf16/f16/f32, or the fp32
+// partial slab of cross-workgroup split `blockIdx.y`).
+template <int MT, int WK>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT], float* red, void* out, int out_dt,
+                                              float* partial, int M, int N, int S, int m_base,
+                                              int n0) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    auto store = [&](int mt, const f32x4& v) {
+        const int m = m_base + mt * 16 + j;
+        const int n = n0 + g * 4;
+        if (m >= M) return;
+        if (S > 1) {
+            float* dst = partial + ((size_t)blockIdx.y * M + m) * N + n;
+            if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+            else
+                for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = v[r];
+        } else if (out_dt == 2) {
+            float* dst = (float*)out + (size_t)m * N + n;
+            for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = v[r];
+        } else {
+            uint16_t* dst = (uint16_t*)out + (size_t)m * N + n;
+            uint16_t h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = out_dt == 0 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
+            if (n + 3 < N && (N & 3) == 0) {
+                i32x2 o;
+                o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
+                o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<i32x2*>(dst) = o;
+            } else {
+                for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = h[r];
+            }
+        }
+    };
+    if (WK > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<f32x4*>(&red[((wave * MT + mt) * 64 + lane) * 4]) = acc[mt];
+        __syncthreads();
+        for (int mt = wave; mt < MT; mt += WK) {
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[((w * MT + mt) * 64 + lane) * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] += v[r];
+            }
+            store(mt, sum);
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) store(mt, acc[mt]);
+    }
+}
+
+// ---------------------------------------------------------------- W8A8 block-scaled
+template <int MT, int WK>
+__global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
+    const fp8_t* __restrict__ X, const float* __restrict__ XS, const fp8_t* __restrict__ W,
+    const float* __restrict__ WS, void* __restrict__ out, int out_dt, float* __restrict__ partial,
+    int M, int N, int K, int S, int m_base) {
+    __shared__ float red[WK > 1 ? WK * MT * 256 : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int KB = K >> 7;
+    const int T = S * WK;
+    const int t = blockIdx.y * WK + wave;
+    const int kb0 = (int)((long)KB * t / T), kb1 = (int)((long)KB * (t + 1) / T);
+
+    const int nrow = min(n0 + j, N - 1);
+    const fp8_t* wp = W + (size_t)nrow * K + g * 16;
+    const float* wsp = WS + (size_t)(n0 >> 7) * KB;
+    const fp8_t* xp[MT];
+    const float* xsp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = min(m_base + mt * 16 + j, M - 1);
+        xp[mt] = X + (size_t)m * K + g * 16;
+        xsp[mt] = XS + (size_t)m * KB;
+    }
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load = [&](GemmStage<MT>& st, int kb) {
+        const int off = kb << 7;
+        st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
+        st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off + 64));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            st.x[mt][0] = *reinterpret_cast<const i32x4*>(xp[mt] + off);
+            st.x[mt][1] = *reinterpret_cast<const i32x4*>(xp[mt] + off + 64);
+            st.xs[mt] = xsp[mt][kb];
+        }
+        st.ws = wsp[kb];
+    };
+    auto compute = [&](const GemmStage<MT>& st) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f32x4 blk = f32x4{0.f, 0.f, 0.f, 0.f};
+            blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack_lo(st.w[0]), pack_lo(st.x[mt][0]), blk, 0, 0, 0);
+            blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack_hi(st.w[0]), pack_hi(st.x[mt][0]), blk, 0, 0, 0);
+            blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack_lo(st.w[1]), pack_lo(st.x[mt][1]), blk, 0, 0, 0);
+            blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack_hi(st.w[1]), pack_hi(st.x[mt][1]), blk, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][r] += (blk[r] * st.xs[mt]) * st.ws;
+        }
+    };
+
+    GemmStage<MT> a, b;
+    int kb = kb0;
+    if (kb < kb1) load(a, kb);
+    while (kb < kb1) {
+        if (kb + 1 < kb1) load(b, kb + 1);
+        compute(a);
+        ++kb;
+        if (kb >= kb1) break;
+        if (kb + 1 < kb1) load(a, kb + 1);
+        compute(b);
+        ++kb;
+    }
+
+    gemm_epilogue<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
+}
+
+// out[m][n] = sum_s partial[s][m][n] in s order, then cast.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial,
+                                                            void* __restrict__ out, int out_dt,
+                                                            int S, int64_t MN) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < MN;
+         i += (int64_t)gridDim.x * blockDim.x * 4) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const int cnt = (int)min((int64_t)4, MN - i);
+        for (int s = 0; s < S; ++s)
+            for (int r = 0; r < cnt; ++r) v[r] += partial[(size_t)s * MN + i + r];
+        for (int r = 0; r < cnt; ++r) {
+            if (out_dt == 2) ((float*)out)[i + r] = v[r];
+            else ((uint16_t*)out)[i + r] = out_dt == 0 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- soft-fp8 (w8 a16)
+// b = bf16( bits(((w&0x80)<<24)|((w&0x7f)<<20)) * (b_s * 2^120) ), acc += dot_bf16(a, b)
+// (triton_kernels.py:453-488).  Weights = A operand of v_mfma_f32_16x16x32_bf16; a lane's
+// 16-B weight load feeds two MFMAs, the bf16 activation fragment uses the same k order.
+__device__ __forceinline__ s16x8 soft_decode8(uint32_t w0, uint32_t w1, float s2) {
+    s16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t byte = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
+        const uint32_t bits = ((byte & 0x80u) << 24) | ((byte & 0x7fu) << 20);
+        r[i] = (short)f32_to_bf16(__uint_as_float(bits) * s2);
+    }
+    return r;
+}
+
+template <int MT, int WK>
+__global__ __launch_bounds__(64 * WK) void soft_fp8_gemm_kernel(
+    const bf16_t* __restrict__ X, const fp8_t* __restrict__ W, const float* __restrict__ WS,
+    void* __restrict__ out, int out_dt, float* __restrict__ partial, int M, int N, int K, int S,
+    int m_base) {
+    __shared__ float red[WK > 1 ? WK * MT * 256 : 1];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int KB = (K + 127) >> 7;
+    const int T = S * WK;
+    const int t = blockIdx.y * WK + wave;
+    const int kb0 = (int)((long)KB * t / T), kb1 = (int)((long)KB * (t + 1) / T);
+    const int nrow = min(n0 + j, N - 1);
+    const fp8_t* wp = W + (size_t)nrow * K + g * 16;
+    const float* wsp = WS + (size_t)(n0 >> 7) * KB;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const float s2 = wsp[kb] * __uint_as_float(0x7B800000u);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int off = (kb << 7) + c * 64;
+            const i32x4 w = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
+            const s16x8 wa = soft_decode8((uint32_t)w[0], (uint32_t)w[1], s2);
+            const s16x8 wb = soft_decode8((uint32_t)w[2], (uint32_t)w[3], s2);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = min(m_base + mt * 16 + j, M - 1);
+                const bf16_t* xq = X + (size_t)m * K + off + g * 16;
+                const s16x8 xa = *reinterpret_cast<const s16x8*>(xq);
+                const s16x8 xb = *reinterpret_cast<const s16x8*>(xq + 8);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xa, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+
+    gemm_epilogue<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
+}
+
+struct SplitPlan {
+    int WK, S;
+};
+
+static SplitPlan plan_split(int N, int K) {
+    const int tiles = (N + 15) / 16;
+    const int KB = (K + 127) / 128;
+    int T = (1536 + tiles - 1) / tiles;
+    if (T > KB) T = KB;
+    if (T < 1) T = 1;
+    int WK = 1;
+    while (WK * 2 <= T && WK < 8) WK *= 2;
+    int S = (T + WK - 1) / WK;
+    if (S > 8) S = 8;
+    if (S * WK > KB) S = KB / WK > 0 ? KB / WK : 1;
+    return {WK, S};
+}
+
+}  // namespace chitu
+
+#define DISPATCH_WK(KERNEL, MT, ...)                                                          \
+    switch (plan.WK) {                                                                        \
+        case 1: hipLaunchKernelGGL((KERNEL<MT, 1>), grid, dim3(64), 0, st, __VA_ARGS__); break;   \
+        case 2: hipLaunchKernelGGL((KERNEL<MT, 2>), grid, dim3(128), 0, st, __VA_ARGS__); break;  \
+        case 4: hipLaunchKernelGGL((KERNEL<MT, 4>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((KERNEL<MT, 8>), grid, dim3(512), 0, st, __VA_ARGS__); break; \
+    }
+
+extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_scale,
+                                             const void* b_fp8, const float* b_scale, void* out,
+                                             int out_dtype, int64_t M, int64_t N, int64_t K,
+                                             void* workspace, int64_t workspace_bytes,
+                                             void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(a_fp8 && a_scale && b_fp8 && b_scale && out);
+    CHITU_REQUIRE(M >= 0 && N >= 1 && K >= 128 && N < (1 << 30) && K < (1 << 30));
+    CHITU_REQUIRE(out_dtype >= 0 && out_dtype <= 2);
+    if (K % 128 != 0) return CHITU_ERR_UNSUPPORTED;  // act_quant's contract, ops.py:345-348
+    if (M == 0) return CHITU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SplitPlan plan = plan_split((int)N, (int)K);
+    if (plan.S > 1 && (!workspace || workspace_bytes < (int64_t)plan.S * M * N * 4)) plan.S = 1;
+    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)plan.S);
+    float* partial = (float*)workspace;
+    for (int64_t mb = 0; mb < M; mb += 64) {
+        const int rem = (int)(M - mb);
+        const int mbase = (int)mb;
+        if (rem <= 16) {
+            DISPATCH_WK(fp8_gemm_kernel, 1, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale,
+                        out, out_dtype, partial, (int)M, (int)N, (int)K, plan.S, mbase)
+        } else if (rem <= 32) {
+            DISPATCH_WK(fp8_gemm_kernel, 2, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale,
+                        out, out_dtype, partial, (int)M, (int)N, (int)K, plan.S, mbase)
+        } else {
+            DISPATCH_WK(fp8_gemm_kernel, 4, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale,
+                        out, out_dtype, partial, (int)M, (int)N, (int)K, plan.S, mbase)
+        }
+    }
+    if (plan.S > 1) {
+        const int64_t MN = M * N;
+        int blocks = (int)((MN / 4 + 255) / 256);
+        if (blocks < 1) blocks = 1;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, out,
+                           out_dtype, plan.S, MN);
+    }
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_soft_fp8_gemm(const void* a_bf16, const void* b_fp8, const float* b_scale,
+                                       void* out, int out_dtype, int64_t M, int64_t N, int64_t K,
+                                       void* workspace, int64_t workspace_bytes, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(a_bf16 && b_fp8 && b_scale && out);
+    CHITU_REQUIRE(M >= 0 && N >= 1 && K >= 128 && N < (1 << 30) && K < (1 << 30));
+    CHITU_REQUIRE(out_dtype >= 0 && out_dtype <= 2);
+    if (K % 128 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (M == 0) return CHITU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SplitPlan plan = plan_split((int)N, (int)K);
+    if (plan.S > 1 && (!workspace || workspace_bytes < (int64_t)plan.S * M * N * 4)) plan.S = 1;
+    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)plan.S);
+    float* partial = (float*)workspace;
+    for (int64_t mb = 0; mb < M; mb += 32) {
+        const int rem = (int)(M - mb);
+        const int mbase = (int)mb;
+        if (rem <= 16) {
+            DISPATCH_WK(soft_fp8_gemm_kernel, 1, (const bf16_t*)a_bf16, (const fp8_t*)b_fp8, b_scale, out,
+                        out_dtype, partial, (int)M, (int)N, (int)K, plan.S, mbase)
+        } else {
+            DISPATCH_WK(soft_fp8_gemm_kernel, 2, (const bf16_t*)a_bf16, (const fp8_t*)b_fp8, b_scale, out,
+                        out_dtype, partial, (int)M, (int)N, (int)K, plan.S, mbase)
+        }
+    }
+    if (plan.S > 1) {
+        const int64_t MN = M * N;
+        int blocks = (int)((MN / 4 + 255) / 256);
+        if (blocks < 1) blocks = 1;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, out,
+                           out_dtype, plan.S, MN);
+    }
+    CHITU_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,196 @@
+"""HIP launchers with the reference's `chitu/ops.py` names, signatures and asserts.
+
+Reference (read-only): chitu/ops.py:51-511.  Each function below calls one C-ABI entry
+point of libchitu_hip.so on torch's current stream.  There is no Triton and no fallback.
+"""
+
+from typing import Tuple
+
+import torch
+
+from . import _lib, workspace
+from ._lib import check, f32, float_dtype_code, i32, i64, ptr, require_cuda, stream_ptr
+
+__all__ = [
+    "append_to_paged_kv_cache",
+    "apply_rotary_pos_emb",
+    "apply_rotary_pos_emb_torch",
+    "act_quant_deepseek_v3",
+    "weight_dequant_deepseek_v3",
+    "weight_dequant_soft_fp8_deepseek_v3",
+    "fp8_gemm_deepseek_v3",
+    "soft_fp8_gemm_deepseek_v3",
+]
+
+_GEMM_WS_BYTES = 64 << 20
+
+
+def act_quant_deepseek_v3(x: torch.Tensor, block_size: int = 128) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Block-wise e4m3 quantisation: s = max|x|/448 per 128 contiguous values, y = x/s.
+
+    Same contract as chitu/ops.py:330-353 (kernel triton_kernels.py:193-214): no eps and no
+    clamp, so an all-zero group yields scale 0 and NaN codes exactly like the reference.
+    """
+    assert x.is_contiguous(), "Input tensor must be contiguous"
+    assert (
+        x.size(-1) % block_size == 0
+    ), f"Last dimension size must be divisible by block_size (block_size={block_size})"
+    require_cuda(x)
+    y = torch.empty_like(x, dtype=torch.float8_e4m3fn)
+    s = x.new_empty(*x.size()[:-1], x.size(-1) // block_size, dtype=torch.float32)
+    cols = x.size(-1)
+    rows = x.numel() // cols if cols else 0
+    check(
+        _lib.lib().chitu_hip_act_quant_fp8(
+            ptr(x), float_dtype_code(x.dtype), i64(rows), i64(cols), i32(block_size), i32(0),
+            f32(0.0), ptr(y), ptr(s), stream_ptr(),
+        ),
+        "act_quant_deepseek_v3",
+    )
+    return y, s
+
+
+def _weight_dequant(x, s, block_size, soft):
+    assert x.is_contiguous() and s.is_contiguous(), "Input tensors must be contiguous"
+    assert s.dim() == x.dim(), "Scale tensors must have the same number of dimensions with the weight tensor"
+    if x.dim() == 2:
+        M, N = x.size()
+        B = 1
+    elif x.dim() == 3:
+        B, M, N = x.size()
+    else:
+        assert False, "Weight tensor must have 2 or 3 dimensions"
+    require_cuda(x, s)
+    y = torch.empty_like(x, dtype=torch.get_default_dtype())
+    check(
+        _lib.lib().chitu_hip_weight_dequant_fp8(
+            ptr(x), ptr(s), i64(B), i64(M), i64(N), i32(block_size), i32(1 if soft else 0),
+            float_dtype_code(y.dtype), ptr(y), stream_ptr(),
+        ),
+        "weight_dequant",
+    )
+    return y
+
+
+def weight_dequant_deepseek_v3(x: torch.Tensor, s: torch.Tensor, block_size: int = 128) -> torch.Tensor:
+    """y = float(x) * s[block] in the default dtype (chitu/ops.py:357-392)."""
+    return _weight_dequant(x, s, block_size, soft=False)
+
+
+def weight_dequant_soft_fp8_deepseek_v3(x: torch.Tensor, s: torch.Tensor, block_size: int = 128) -> torch.Tensor:
+    """The reference's bit-placement decode (chitu/ops.py:396-449), one fused kernel here."""
+    return _weight_dequant(x, s, block_size, soft=True)
+
+
+def fp8_gemm_deepseek_v3(a: torch.Tensor, a_s: torch.Tensor, b: torch.Tensor, b_s: torch.Tensor):
+    """c = sum_kb (a_kb . b_kb^T) * a_s[:, kb] * b_s[n//128, kb]   (chitu/ops.py:453-483)."""
+    assert a.is_contiguous() and b.is_contiguous(), "Input tensors must be contiguous"
+    assert a_s.is_contiguous() and b_s.is_contiguous(), "Scaling factor tensors must be contiguous"
+    require_cuda(a, a_s, b, b_s)
+    K = a.size(-1)
+    M = a.numel() // K
+    N = b.size(0)
+    c = a.new_empty(*a.size()[:-1], N, dtype=torch.get_default_dtype())
+    ws = workspace.get(_GEMM_WS_BYTES, a.device, "gemm")
+    check(
+        _lib.lib().chitu_hip_fp8_gemm_blockscale(
+            ptr(a), ptr(a_s), ptr(b), ptr(b_s), ptr(c), float_dtype_code(c.dtype), i64(M), i64(N),
+            i64(K), ptr(ws), i64(ws.numel()), stream_ptr(),
+        ),
+        "fp8_gemm_deepseek_v3",
+    )
+    return c
+
+
+def soft_fp8_gemm_deepseek_v3(a: torch.Tensor, b: torch.Tensor, b_s: torch.Tensor):
+    """FP8 weights decoded to bf16 on the fly, bf16 x bf16 dot (chitu/ops.py:487-511)."""
+    assert a.is_contiguous() and b.is_contiguous(), "Input tensors must be contiguous"
+    assert b_s.is_contiguous(), "Scaling factor tensor must be contiguous"
+    assert a.dtype == torch.bfloat16, "soft-fp8 GEMM takes bf16 activations"
+    require_cuda(a, b, b_s)
+    K = a.size(-1)
+    M = a.numel() // K
+    N = b.size(0)
+    c = a.new_empty(*a.size()[:-1], N, dtype=torch.get_default_dtype())
+    ws = workspace.get(_GEMM_WS_BYTES, a.device, "gemm")
+    check(
+        _lib.lib().chitu_hip_soft_fp8_gemm(
+            ptr(a), ptr(b.view(torch.uint8)), ptr(b_s), ptr(c), float_dtype_code(c.dtype), i64(M),
+            i64(N), i64(K), ptr(ws), i64(ws.numel()), stream_ptr(),
+        ),
+        "soft_fp8_gemm_deepseek_v3",
+    )
+    return c
+
+
+# ---- paged KV append and RoPE are defined further down (kv.hip) -------------------------
+
+
+def append_to_paged_kv_cache(kv_cache, page_table, this_kv, old_seq_lens):
+    """kv_cache[page_table[i][L_i // page]][L_i % page] = this_kv[i]   (chitu/ops.py:51-91).
+
+    The reference kernel hard-codes 64 in the page arithmetic (triton_kernels.py:38,42); here
+    the page size is kv_cache.shape[1], which is identical for the MLA cache (page 64).
+    """
+    assert kv_cache.is_contiguous()
+    assert page_table.is_contiguous()
+    assert this_kv.is_contiguous()
+    assert old_seq_lens.is_contiguous()
+    require_cuda(kv_cache, page_table, this_kv, old_seq_lens)
+    page_size = kv_cache.shape[1]
+    batch_size, num_pages_per_sample = page_table.shape
+    assert this_kv.shape[0] == batch_size
+    assert old_seq_lens.shape[0] == batch_size
+    row = this_kv.numel() // batch_size if batch_size else 0
+    assert kv_cache.numel() // (kv_cache.shape[0] * kv_cache.shape[1]) == row
+    assert page_table.dtype == torch.int32 and old_seq_lens.dtype == torch.int32
+    assert this_kv.dtype == kv_cache.dtype
+    check(
+        _lib.lib().chitu_hip_append_paged_kv(
+            ptr(kv_cache), i64(kv_cache.shape[0]), i32(page_size), i64(row * kv_cache.element_size()),
+            ptr(page_table), i32(num_pages_per_sample), ptr(this_kv), ptr(old_seq_lens),
+            i32(batch_size), stream_ptr(),
+        ),
+        "append_to_paged_kv_cache",
+    )
+
+
+def apply_rotary_pos_emb_torch(q, k, cos, sin, rotary_type="hf-llama"):
+    """Name kept for source compatibility with chitu/ops.py:243-308; runs the HIP kernel."""
+    return apply_rotary_pos_emb(q, k, cos, sin, rotary_type=rotary_type)
+
+
+def apply_rotary_pos_emb(q, k, cos, sin, rotary_type="hf-llama"):
+    """RoPE on q [bs, heads, d] and k [bs, d] or [bs, kv_heads, d]   (chitu/ops.py:311-326).
+
+    rotary_type "llama": interleaved (re, im) pairs (DeepSeek MLA); "hf-llama": half-split.
+    cos/sin are fp32 [bs, d/2].  Math in fp32, one rounding to the input dtype.
+    """
+    if rotary_type not in ("llama", "hf-llama"):
+        raise ValueError(f"Unknown rotary type: {rotary_type}")
+    require_cuda(q, k, cos, sin)
+    assert cos.dtype == torch.float32 and sin.dtype == torch.float32
+    assert cos.is_contiguous() and sin.is_contiguous()
+    assert q.stride(-1) == 1 and k.stride(-1) == 1
+    bs = q.shape[0]
+    d = q.shape[-1]
+    assert cos.shape == (bs, d // 2), f"{cos.shape} {q.shape}"
+    assert q.dim() == 3 and k.dim() in (2, 3)
+    out_q = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    out_k = torch.empty(k.shape, dtype=k.dtype, device=k.device)
+    kh = 1 if k.dim() == 2 else k.shape[1]
+    k_sb = k.stride(0)
+    k_sh = 0 if k.dim() == 2 else k.stride(1)
+    ok_sb = out_k.stride(0)
+    ok_sh = 0 if k.dim() == 2 else out_k.stride(1)
+    check(
+        _lib.lib().chitu_hip_rope(
+            ptr(q), ptr(k), ptr(out_q), ptr(out_k), ptr(cos), ptr(sin), float_dtype_code(q.dtype),
+            i32(bs), i32(q.shape[1]), i32(kh), i32(d),
+            i64(q.stride(0)), i64(q.stride(1)), i64(k_sb), i64(k_sh),
+            i64(out_q.stride(0)), i64(out_q.stride(1)), i64(ok_sb), i64(ok_sh),
+            i32(0 if rotary_type == "llama" else 1), stream_ptr(),
+        ),
+        "apply_rotary_pos_emb",
+    )
+    return out_q, out_k

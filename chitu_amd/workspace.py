@@ -1,0 +1,25 @@
+"""Persistent device scratch for split-K partials and MoE intermediates.
+
+Allocated once per device and reused, so graph-captured launches always see the same
+addresses (the reference allocates scratch per call, e.g. fused_moe.py:1176-1187,
+attn_backend.py:737-746 -- that is not capture-safe without the caching allocator's pool).
+"""
+
+import torch
+
+_ws = {}
+
+
+def get(nbytes: int, device, tag: str = "default") -> torch.Tensor:
+    key = (torch.device(device).index or 0, tag)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(
+                f"workspace '{tag}' must grow ({buf.numel()} -> {nbytes} B) during graph capture; "
+                "run one eager step first"
+            )
+        size = max(nbytes, 1 << 20)
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf

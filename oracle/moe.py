@@ -1,0 +1,37 @@
+"""Oracle for the fused MoE (fp8 block-scaled W8A8 path), torch CPU.  TEST INFRASTRUCTURE ONLY.
+
+Restates chitu/fused_moe.py:1130-1307 (fused_experts_impl) as a per-(token, slot) loop with the
+reference's rounding points: activations re-quantised to e4m3 per 128-group before each GEMM
+(:829), GEMM outputs rounded to the activation dtype (:299-301), SiLU-and-mul in that dtype
+(:37-39), routed weight applied on the fp32 accumulator of GEMM2 (:290-292), top-k sum (:1299).
+"""
+
+import torch
+import torch.nn.functional as F
+
+from . import fp8
+
+
+def fused_experts_fp8(x, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale):
+    """x [M,K] bf16; w1 [E,2I,K] fp8; w2 [E,K,I] fp8; scales [E, rows/128, cols/128] f32."""
+    M, K = x.shape
+    topk = topk_ids.shape[1]
+    dt = x.dtype
+    a1_q, a1_s = fp8.per_token_group_quant_fp8(x)
+    c1 = torch.empty(M, topk, w1.shape[1], dtype=dt)
+    for t in range(M):
+        for j in range(topk):
+            e = int(topk_ids[t, j])
+            c1[t, j] = fp8.fp8_gemm_deepseek_v3(a1_q[t : t + 1], a1_s[t : t + 1], w1[e], w1_scale[e], dt)[0]
+    d = w1.shape[1] // 2
+    c1 = c1.view(-1, w1.shape[1])
+    c2 = F.silu(c1[..., :d]) * c1[..., d:]
+    a2_q, a2_s = fp8.per_token_group_quant_fp8(c2)
+    c3 = torch.empty(M, topk, w2.shape[1], dtype=dt)
+    for t in range(M):
+        for j in range(topk):
+            e = int(topk_ids[t, j])
+            r = t * topk + j
+            acc = fp8.fp8_gemm_deepseek_v3(a2_q[r : r + 1], a2_s[r : r + 1], w2[e], w2_scale[e], torch.float32)[0]
+            c3[t, j] = fp8.to_out(acc * topk_weights[t, j].float(), dt)
+    return c3.sum(dim=1)

@@ -1,0 +1,216 @@
+"""Generate golden input/output fixtures by running the REFERENCE's own code on CPU.
+
+Run in the build container only:   python tests/golden/gen_golden.py [name ...]
+Writes tests/golden/<name>.npz.  The reference kernels are Triton; they run here
+under TRITON_INTERPRET=1 (numpy), see ref_shims.py.  Known interpreter limits
+(SURVEY.md 8c): bf16 tl.dot is broken (so MLA decode / bf16 MoE goldens are fed
+bf16-representable values held in fp32), autotuned kernels must be called through
+`kernel.fn[grid]` with one explicit config.
+fp8 / bf16 arrays are stored as raw uint8 / uint16 bits.
+"""
+
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def bits16(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def bits8(t):
+    return t.contiguous().view(torch.uint8).numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+
+
+# ---------------------------------------------------------------- moe_align
+def gen_moe_align():
+    from chitu.fused_moe import moe_align_block_size_native
+
+    cases = {}
+    # the reference's own known-answer vector, fused_moe.py:478-487 (ids reach 4 => E=5)
+    doc = torch.tensor([[2, 3, 4], [1, 2, 4], [1, 3, 4], [1, 2, 3]], dtype=torch.int64)
+    cases["doc"] = (doc, 4, 5)
+    g = torch.Generator().manual_seed(0)
+    # the reference test's configuration, test/pytest/test_moe_align.py:11-14
+    cases["reftest"] = (torch.randint(0, 256, (1000,), generator=g), 64, 256)
+    # DeepSeek-R1 decode, bs=16, top-8 of 256, BLOCK_SIZE_M=64 (fused_moe.py:904-914)
+    ids = torch.stack([torch.randperm(256, generator=g)[:8] for _ in range(16)])
+    cases["r1_bs16"] = (ids, 64, 256)
+    # block 16 (our grouped-GEMM tile), skewed routing
+    cases["skew_b16"] = ((torch.randint(0, 1000, (300,), generator=g) % 7) * 3, 16, 32)
+    out = {}
+    for name, (ids, block, E) in cases.items():
+        s, e, n = moe_align_block_size_native(ids, block, E)
+        out[f"{name}_ids"] = ids.numpy()
+        out[f"{name}_cfg"] = np.array([block, E], dtype=np.int64)
+        out[f"{name}_sorted"] = s.numpy()
+        out[f"{name}_experts"] = e.numpy()
+        out[f"{name}_npost"] = n.numpy()
+    save("moe_align", **out)
+
+
+# ---------------------------------------------------------------- act quant + fp8 gemm
+def gen_fp8_linear():
+    import triton
+    from chitu import ops
+    from chitu.triton_kernels import fp8_gemm_deepseek_v3_kernel
+
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 5, 384, 512
+    x = (torch.randn(M, K, generator=g) * 0.7).to(torch.bfloat16)
+    x[3, 128:256] *= 40.0  # one hot group
+    xq, xs = ops.act_quant_deepseek_v3(x, 128)
+    w = (torch.randn(N, K, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    ws = torch.rand(N // 128, K // 128, generator=g) * 0.02 + 0.01
+
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        c = x.new_empty(M, N, dtype=torch.bfloat16)
+        grid = (triton.cdiv(M, 16), triton.cdiv(N, 32))
+        fp8_gemm_deepseek_v3_kernel.fn[grid](
+            xq, w, c, xs, ws, M, N, K, group_n=128, group_k=128,
+            BLOCK_SIZE_M=16, BLOCK_SIZE_N=32, BLOCK_SIZE_K=128,
+        )
+        wd = ops.weight_dequant_deepseek_v3(w, ws, 128)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    save(
+        "fp8_linear",
+        x=bits16(x), xq=bits8(xq), xs=xs.numpy(), w=bits8(w), ws=ws.numpy(),
+        c=bits16(c), w_dequant=bits16(wd),
+    )
+
+
+# ---------------------------------------------------------------- per-token-group quant (MoE flavour)
+def gen_group_quant():
+    from chitu.fused_moe import per_token_group_quant_fp8
+
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(6, 384, generator=g) * 1.3).to(torch.bfloat16)
+    x[2, :128] = 0  # all-zero group: eps path (fused_moe.py:701)
+    q, s = per_token_group_quant_fp8(x, 128)
+    save("group_quant", x=bits16(x), q=bits8(q), s=s.numpy())
+
+
+# ---------------------------------------------------------------- paged append + rope
+def pattern_cache(pages, page, dim):
+    """Deterministic cache fill, recomputed (not stored) by the tests."""
+    p = torch.arange(pages).view(-1, 1, 1)
+    s = torch.arange(page).view(1, -1, 1)
+    d = torch.arange(dim).view(1, 1, -1)
+    return (((p * 64 + s) % 251).float() * 0.25 + (d % 7).float() - 3.0).to(torch.bfloat16)
+
+
+def gen_append_rope():
+    from chitu import ops
+
+    g = torch.Generator().manual_seed(3)
+    pages, page, dim, bs = 12, 64, 576, 3
+    cache = pattern_cache(pages, page, dim)
+    table = torch.tensor([[3, 7, 0], [5, 1, 9], [2, 11, 4]], dtype=torch.int32)
+    lens = torch.tensor([0, 64, 130], dtype=torch.int32)
+    kv = torch.randn(bs, 1, 1, dim, generator=g).to(torch.bfloat16)
+    before = cache.clone()
+    ops.append_to_paged_kv_cache(cache, table, kv, lens)
+
+    q = torch.randn(bs, 4, 64, generator=g).to(torch.bfloat16)
+    k = torch.randn(bs, 64, generator=g).to(torch.bfloat16)
+    cos = torch.randn(bs, 32, generator=g)
+    sin = torch.randn(bs, 32, generator=g)
+    oq, ok = ops.apply_rotary_pos_emb_torch(q, k, cos, sin, rotary_type="llama")
+    tq, tk = ops.apply_rotary_pos_emb_triton(q, k, cos, sin, rotary_type="llama")
+    changed = (cache != before).any(dim=-1).nonzero()  # [n, 2] (page, slot)
+    save(
+        "append_rope",
+        cache_shape=np.array([pages, page, dim]), changed=changed.numpy(),
+        changed_rows=bits16(cache[changed[:, 0], changed[:, 1]]), table=table.numpy(),
+        lens=lens.numpy(), kv=bits16(kv),
+        q=bits16(q), k=bits16(k), cos=cos.numpy(), sin=sin.numpy(),
+        oq_torch=bits16(oq), ok_torch=bits16(ok), oq_triton=bits16(tq), ok_triton=bits16(tk),
+    )
+
+
+# ---------------------------------------------------------------- fused MoE (fp8 block w8a8)
+def gen_fused_moe():
+    from chitu.fused_moe import fused_experts_impl
+
+    g = torch.Generator().manual_seed(4)
+    M, E, topk, K, I = 6, 8, 2, 256, 128
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    w1 = (torch.randn(E, 2 * I, K, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    w2 = (torch.randn(E, K, I, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    w1s = torch.rand(E, 2 * I // 128, K // 128, generator=g) * 0.02 + 0.01
+    w2s = torch.rand(E, K // 128, I // 128, generator=g) * 0.02 + 0.01
+    ids = torch.stack([torch.randperm(E, generator=g)[:topk] for _ in range(M)])
+    wts = torch.rand(M, topk, generator=g).to(torch.bfloat16)
+    out = fused_experts_impl(
+        x.clone(), w1, w2, wts, ids, inplace=False, use_fp8_w8a8=True,
+        w1_scale=w1s, w2_scale=w2s, block_shape=[128, 128],
+    )
+    save(
+        "fused_moe_fp8", x=bits16(x), w1=bits8(w1), w2=bits8(w2), w1s=w1s.numpy(), w2s=w2s.numpy(),
+        ids=ids.numpy(), wts=bits16(wts), out=bits16(out),
+    )
+
+
+# ---------------------------------------------------------------- MLA paged decode (fp32-held bf16 values)
+def gen_mla_decode():
+    from chitu.triton_decode_attention import _mla_attn_kernel, _mla_softmax_reducev
+
+    g = torch.Generator().manual_seed(5)
+    bs, H, C, R, page, pages = 3, 16, 512, 64, 64, 10
+    lens = torch.tensor([1, 77, 200], dtype=torch.int32)  # incl. this token
+    table = torch.tensor([[4, 0, 0, 0], [2, 9, 0, 0], [7, 1, 5, 3]], dtype=torch.int32)
+    cache = (torch.randn(pages, page, C + R, generator=g)).to(torch.bfloat16).float()
+    q_nope = (torch.randn(bs, H, C, generator=g) * 0.3).to(torch.bfloat16).float()
+    q_pe = (torch.randn(bs, H, R, generator=g) * 0.3).to(torch.bfloat16).float()
+    scale = 0.1352
+    splits = 4
+    logits = torch.zeros(bs, H, splits, C + 1)
+    o = torch.zeros(bs, H, C)
+    kv_c, k_pe = cache[..., :C], cache[..., C:]
+    grid = (bs, 1, splits)
+    _mla_attn_kernel.fn[grid](
+        q_nope, q_pe, kv_c, k_pe, table, lens, logits, scale,
+        q_nope.stride(0), q_nope.stride(1), q_pe.stride(0), q_pe.stride(1),
+        kv_c.stride(-2), k_pe.stride(-2), table.stride(0),
+        logits.stride(0), logits.stride(1), logits.stride(2),
+        BLOCK_H=16, BLOCK_N=64, NUM_KV_SPLITS=splits, PAGE_SIZE=page,
+        HEAD_DIM_CKV=C, HEAD_DIM_KPE=R,
+    )
+    _mla_softmax_reducev(logits, o, lens, splits)
+    save(
+        "mla_decode", cache=bits16(cache.to(torch.bfloat16)), q_nope=bits16(q_nope.to(torch.bfloat16)),
+        q_pe=bits16(q_pe.to(torch.bfloat16)), table=table.numpy(), lens=lens.numpy(),
+        scale=np.array([scale], dtype=np.float32), out=o.numpy(),
+    )
+
+
+GENS = {
+    "moe_align": gen_moe_align,
+    "fp8_linear": gen_fp8_linear,
+    "group_quant": gen_group_quant,
+    "append_rope": gen_append_rope,
+    "fused_moe": gen_fused_moe,
+    "mla_decode": gen_mla_decode,
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(GENS)
+    for n in names:
+        print("==", n)
+        GENS[n]()

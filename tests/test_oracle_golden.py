@@ -1,0 +1,195 @@
+"""Pin the CPU oracle against fixtures produced by the REFERENCE's own code
+(tests/golden/gen_golden.py, Triton interpreter) and its documented known-answer vector."""
+
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fp8 as ofp8
+from oracle import kv as okv
+from oracle import moe as omoe
+from oracle import moe_align as oalign
+from tests.util import bf16, bits16, bits8, fp8, golden, max_rel_to_peak, pattern_cache
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture
+def interpreter_casts(monkeypatch):
+    """Make the oracle round like the Triton *interpreter* the fixtures were generated under
+    (its float->fp8e4nv cast is round-half-up with no exponent carry, its float->bf16 cast
+    truncates; triton/runtime/interpreter.py::_convert_float).  With these two casts swapped in,
+    the restatements must reproduce the reference's outputs BIT-EXACTLY; with the default IEEE
+    casts they reproduce what the reference computes on a GPU."""
+    triton = pytest.importorskip("triton")
+    import triton.language as tl
+    from triton.runtime.interpreter import _convert_float
+    from triton._C.libtriton import ir as _ir
+
+    def to_fp8_interp(t):
+        a = t.contiguous().float().numpy()
+        out = _convert_float(a, tl.float32, tl.float8e4nv, _ir.ROUNDING_MODE.RTNE)
+        return torch.from_numpy(np.asarray(out, dtype=np.uint8).reshape(a.shape).copy()).view(torch.float8_e4m3fn)
+
+    def to_out_interp(t, dtype):
+        if dtype != torch.bfloat16:
+            return t.to(dtype)
+        bits = t.contiguous().float().numpy().view(np.uint32) >> 16
+        return torch.from_numpy(bits.astype(np.uint16).view(np.int16).copy()).view(torch.bfloat16).reshape(t.shape)
+
+    monkeypatch.setitem(ofp8.CAST, "fp8", to_fp8_interp)
+    monkeypatch.setitem(ofp8.CAST, "out", to_out_interp)
+
+
+def test_moe_align_docstring_known_answer():
+    # chitu/fused_moe.py:478-487
+    ids = np.array([[2, 3, 4], [1, 2, 4], [1, 3, 4], [1, 2, 3]])
+    s, e, n, c = oalign.moe_align_block_size(ids, 4, 5)
+    # expert 0 is empty (no padding block); experts 1..4 hold the documented rows
+    assert s[:16].tolist() == [3, 6, 9, 12, 0, 4, 10, 12, 1, 7, 11, 12, 2, 5, 8, 12]
+    assert n[0] == 16
+    assert e[:4].tolist() == [1, 2, 3, 4]
+
+
+@pytest.mark.parametrize("case", ["doc", "reftest", "r1_bs16", "skew_b16"])
+def test_moe_align_matches_reference_triton_path(case):
+    g = golden("moe_align")
+    block, E = g[f"{case}_cfg"].tolist()
+    s, e, n, _ = oalign.moe_align_block_size(g[f"{case}_ids"], block, E)
+    assert np.array_equal(s, g[f"{case}_sorted"])
+    assert np.array_equal(e, g[f"{case}_experts"])
+    assert np.array_equal(n, g[f"{case}_npost"])
+
+
+def test_moe_align_c_restatement_matches_numpy():
+    lib_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("oracle/liboracle.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    lib = ctypes.CDLL(lib_path)
+    rng = np.random.default_rng(0)
+    for numel, E, block in [(0, 4, 4), (1, 1, 1), (1000, 256, 64), (128, 256, 16), (4097, 64, 128)]:
+        ids = rng.integers(0, E, size=numel).astype(np.int64)
+        s_ref, e_ref, n_ref, c_ref = oalign.moe_align_block_size(ids, block, E)
+        s = np.full_like(s_ref, numel)
+        e = np.zeros_like(e_ref)
+        n = np.zeros(1, dtype=np.int32)
+        c = np.zeros(E + 1, dtype=np.int32)
+        rc = lib.oracle_moe_align_block_size(
+            ids.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(numel), ctypes.c_int32(E), ctypes.c_int32(block),
+            s.ctypes.data_as(ctypes.c_void_p), e.ctypes.data_as(ctypes.c_void_p),
+            n.ctypes.data_as(ctypes.c_void_p), c.ctypes.data_as(ctypes.c_void_p),
+        )
+        assert rc == 0
+        assert np.array_equal(s, s_ref) and np.array_equal(e, e_ref)
+        assert np.array_equal(n, n_ref) and np.array_equal(c, c_ref)
+
+
+def _assert_codes_match_modulo_interpreter_cast_defect(mine, ref, y):
+    """Codes must be bit-exact except where the Triton *interpreter's* float->fp8e4nv cast (not
+    the reference's GPU behaviour, PTX cvt.rn.satfinite) mis-rounds: (a) a round-up that carries
+    into the next binade loses the exponent increment (124.8 -> 64 instead of 128), (b) exact
+    ties go away from zero instead of to even.  Every mismatch must fall in one of these two
+    classes; the oracle implements IEEE round-to-nearest-even, which is what both the NVIDIA cvt
+    and gfx950's v_cvt_pk_fp8_f32 do."""
+    bad = np.argwhere(mine != ref)
+    assert len(bad) < 0.05 * mine.size
+    for i, j in bad:
+        v_mine = float(fp8(np.array([mine[i, j]], dtype=np.uint8)).float())
+        v_ref = float(fp8(np.array([ref[i, j]], dtype=np.uint8)).float())
+        carry = (mine[i, j] & 0x7) == 0 and abs(v_mine) > abs(y[i, j]) and abs(v_ref) * 2 == abs(v_mine)
+        tie = abs(abs(v_mine - y[i, j]) - abs(v_ref - y[i, j])) == 0.0
+        assert carry or tie, (i, j, y[i, j], v_mine, v_ref)
+
+
+def test_act_quant_matches_reference():
+    g = golden("fp8_linear")
+    x = bf16(g["x"])
+    q, s = ofp8.act_quant_deepseek_v3(x)
+    assert np.array_equal(s.numpy(), g["xs"])  # scales bit-exact
+    y = (x.float().reshape(-1, 128) / s.reshape(-1, 1)).reshape(x.shape).numpy()
+    _assert_codes_match_modulo_interpreter_cast_defect(bits8(q), g["xq"], y)
+
+
+def test_group_quant_matches_reference():
+    g = golden("group_quant")
+    x = bf16(g["x"])
+    q, s = ofp8.per_token_group_quant_fp8(x)
+    assert np.array_equal(s.numpy(), g["s"])
+    y = (x.float().reshape(-1, 128) / s.reshape(-1, 1)).reshape(x.shape).numpy()
+    _assert_codes_match_modulo_interpreter_cast_defect(bits8(q), g["q"], y)
+    assert (bits8(q)[2, :128] == 0).all() and s[2, 0] == np.float32(1e-10) / np.float32(448.0)
+
+
+def test_quant_bit_exact_under_interpreter_casts(interpreter_casts):
+    g = golden("fp8_linear")
+    q, s = ofp8.act_quant_deepseek_v3(bf16(g["x"]))
+    assert np.array_equal(bits8(q), g["xq"]) and np.array_equal(s.numpy(), g["xs"])
+    g = golden("group_quant")
+    q, s = ofp8.per_token_group_quant_fp8(bf16(g["x"]))
+    assert np.array_equal(bits8(q), g["q"]) and np.array_equal(s.numpy(), g["s"])
+
+
+def test_fp8_gemm_bit_exact_under_interpreter_casts(interpreter_casts):
+    g = golden("fp8_linear")
+    c = ofp8.fp8_gemm_deepseek_v3(fp8(g["xq"]), torch.from_numpy(g["xs"]), fp8(g["w"]), torch.from_numpy(g["ws"]))
+    assert np.array_equal(bits16(c), g["c"])
+
+
+def test_fused_moe_bit_exact_under_interpreter_casts(interpreter_casts):
+    g = golden("fused_moe_fp8")
+    out = omoe.fused_experts_fp8(
+        bf16(g["x"]), fp8(g["w1"]), fp8(g["w2"]), bf16(g["wts"]), torch.from_numpy(g["ids"]),
+        torch.from_numpy(g["w1s"]), torch.from_numpy(g["w2s"]),
+    )
+    assert max_rel_to_peak(out, bf16(g["out"])) < 2e-3
+    mism = (bits16(out) != g["out"]).mean()
+    assert mism < 0.02, mism  # fp32 dot summation order inside tl.dot is the only freedom left
+
+
+def test_fp8_gemm_and_dequant():
+    g = golden("fp8_linear")
+    c = ofp8.fp8_gemm_deepseek_v3(fp8(g["xq"]), torch.from_numpy(g["xs"]), fp8(g["w"]), torch.from_numpy(g["ws"]))
+    ref = bf16(g["c"])
+    assert max_rel_to_peak(c, ref) < 8e-3  # one bf16 ulp: the interpreter truncates, we round
+    wd = ofp8.weight_dequant_deepseek_v3(fp8(g["w"]), torch.from_numpy(g["ws"]))
+    assert np.array_equal(bits16(wd), g["w_dequant"])
+
+
+def test_soft_decode_equals_hard_decode_on_finite_codes():
+    codes = torch.arange(256, dtype=torch.uint8)
+    w = codes.view(torch.float8_e4m3fn)
+    s = torch.tensor([[0.0173]])
+    w2 = w.reshape(2, 128)
+    hard = ofp8.weight_dequant_deepseek_v3(w2, s)
+    soft = ofp8.weight_dequant_soft_fp8_deepseek_v3(w2, s)
+    finite = ~torch.isnan(w2.float())
+    assert torch.equal(hard[finite], soft[finite])
+    # NaN codes 0x7F / 0xFF decode to +-480*s in the soft scheme
+    assert torch.allclose(soft[~finite].float().abs(), torch.tensor(480 * 0.0173), rtol=1e-2)
+
+
+def test_append_and_rope():
+    g = golden("append_rope")
+    pages, page, dim = g["cache_shape"].tolist()
+    before = pattern_cache(pages, page, dim)
+    after = okv.append_to_paged_kv_cache(
+        before, torch.from_numpy(g["table"]), bf16(g["kv"]), torch.from_numpy(g["lens"])
+    )
+    expect = before.clone()
+    ch = torch.from_numpy(g["changed"])
+    expect[ch[:, 0], ch[:, 1]] = bf16(g["changed_rows"])
+    assert torch.equal(after, expect)
+    oq, ok = okv.apply_rotary_pos_emb(
+        bf16(g["q"]), bf16(g["k"]), torch.from_numpy(g["cos"]), torch.from_numpy(g["sin"]), "llama"
+    )
+    assert np.array_equal(bits16(oq), g["oq_torch"]) and np.array_equal(bits16(ok), g["ok_torch"])
+    # the reference's Triton RoPE agrees with its torch RoPE to bf16 rounding
+    assert max_rel_to_peak(oq, bf16(g["oq_triton"])) < 1e-2
+
+
+# NB: there is deliberately no default-cast (RNE) comparison against fused_moe_fp8.npz: ~3% of the
+# interpreter's fp8 activation codes are off by 2x (lost exponent carry), which moves that fixture
+# by ~10% of its peak.  The bit-exact test above pins the algorithm; RNE is the GPU behaviour.
