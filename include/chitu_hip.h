@@ -42,6 +42,68 @@ int chitu_hip_moe_align_block_size(const void* topk_ids, int ids_dtype, int64_t 
                                    int32_t* num_tokens_post_pad, int32_t* cumsum,
                                    int32_t fill_sentinels, void* stream);
 
+/* ---- FP8 activation quantisation ---------------------------------------------------
+ * mode 0 replaces act_quant_deepseek_v3 (chitu/ops.py:330-353, kernel
+ *        chitu/triton_kernels.py:193-214): s = max|x|/448, y = x/s, no eps, no clamp.
+ * mode 1 replaces per_token_group_quant_fp8 (chitu/fused_moe.py:713-793, kernel :670-710):
+ *        s = max(max|x|, eps)/448, y = clamp(x/s, +-448).
+ *   x [rows, cols] act_dtype; y_fp8 [rows, cols] e4m3fn; scales [rows, cols/group] f32.
+ * group_size must be 128 and divide cols (the reference asserts this, ops.py:345-348). */
+int chitu_hip_act_quant_fp8(const void* x, int act_dtype, int64_t rows, int64_t cols,
+                            int32_t group_size, int32_t mode, float eps, void* y_fp8,
+                            float* scales, void* stream);
+
+/* ---- FP8 weight de-quantisation -------------------------------------------------------
+ * Replaces weight_dequant_deepseek_v3 (chitu/ops.py:357-392, kernel triton_kernels.py:217-247)
+ * when soft = 0, and weight_dequant_soft_fp8_deepseek_v3 (chitu/ops.py:396-449, kernels
+ * triton_kernels.py:250-287: bit placement * (s * 2^120)) when soft = 1.
+ *   w_fp8 [batch, rows, cols]; scales [batch, ceil(rows/128), ceil(cols/128)] f32;
+ *   y [batch, rows, cols] of out_dtype (0 bf16, 1 f16, 2 f32). */
+int chitu_hip_weight_dequant_fp8(const void* w_fp8, const float* scales, int64_t batch,
+                                 int64_t rows, int64_t cols, int32_t block_size, int32_t soft,
+                                 int out_dtype, void* y, void* stream);
+
+/* ---- FP8 x FP8 block-scaled GEMM (W8A8) --------------------------------------------------
+ * Replaces fp8_gemm_deepseek_v3 (chitu/ops.py:453-483, kernel triton_kernels.py:302-365):
+ *   out[m][n] = sum_kb dot(a[m, kb], b[n, kb]) * a_scale[m, kb] * b_scale[n/128, kb]
+ *   a_fp8 [M, K]; a_scale [M, K/128] f32; b_fp8 [N, K]; b_scale [ceil(N/128), K/128] f32;
+ *   out [M, N] of out_dtype.  K % 128 == 0.  Built for decode (M <= 64 per weight pass).
+ * workspace: optional device scratch for cross-workgroup split-K partials
+ * (needs 8 * M * N * 4 bytes at most); NULL/too small => no cross-workgroup split. */
+int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_scale, const void* b_fp8,
+                                  const float* b_scale, void* out, int out_dtype, int64_t M,
+                                  int64_t N, int64_t K, void* workspace,
+                                  int64_t workspace_bytes, void* stream);
+
+/* ---- FP8-weight x bf16-activation GEMM ("soft fp8") ------------------------------------
+ * Replaces soft_fp8_gemm_deepseek_v3 (chitu/ops.py:487-511, kernel triton_kernels.py:388-508):
+ * weights decoded to bf16 as bits((b&0x80)<<24 | (b&0x7f)<<20) * (b_scale * 2^120), bf16 dot,
+ * fp32 accumulate.  a_bf16 [M, K]; b_fp8 [N, K]; b_scale [ceil(N/128), K/128]; out [M, N]. */
+int chitu_hip_soft_fp8_gemm(const void* a_bf16, const void* b_fp8, const float* b_scale,
+                            void* out, int out_dtype, int64_t M, int64_t N, int64_t K,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- paged KV append ----------------------------------------------------------------------
+ * Replaces append_to_paged_kv_cache (chitu/ops.py:51-91, kernel triton_kernels.py:18-48):
+ *   cache[page_table[b][L_b / page_size]][L_b % page_size] = this_kv[b],  L_b = old_seq_lens[b]
+ *   kv_cache [num_pages, page_size, row_bytes] bytes; page_table [batch, pages_per_seq] i32;
+ *   this_kv [batch, row_bytes]; old_seq_lens [batch] i32.  Out-of-table positions are dropped. */
+int chitu_hip_append_paged_kv(void* kv_cache, int64_t num_pages, int32_t page_size,
+                              int64_t row_bytes, const int32_t* page_table,
+                              int32_t pages_per_seq, const void* this_kv,
+                              const int32_t* old_seq_lens, int32_t batch, void* stream);
+
+/* ---- rotary embedding ---------------------------------------------------------------------
+ * Replaces apply_rotary_pos_emb (chitu/ops.py:311-326; kernels triton_kernels.py:51-190; torch
+ * form ops.py:243-272).  layout 0 = "llama" interleaved (re, im) pairs, 1 = "hf-llama" halves.
+ *   q [batch, q_heads, head_dim], k [batch, k_heads, head_dim] (element strides given),
+ *   cos/sin [batch, head_dim/2] f32; fp32 math, one rounding to act_dtype. */
+int chitu_hip_rope(const void* q, const void* k, void* out_q, void* out_k, const float* cos,
+                   const float* sin, int act_dtype, int32_t batch, int32_t q_heads,
+                   int32_t k_heads, int32_t head_dim, int64_t q_sb, int64_t q_sh, int64_t k_sb,
+                   int64_t k_sh, int64_t oq_sb, int64_t oq_sh, int64_t ok_sb, int64_t ok_sh,
+                   int32_t layout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

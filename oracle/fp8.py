@@ -62,7 +62,7 @@ def _expand_block_scale(s: torch.Tensor, rows: int, cols: int, block: int = BLOC
 def weight_dequant_deepseek_v3(w: torch.Tensor, s: torch.Tensor, out_dtype=torch.bfloat16):
     """chitu/triton_kernels.py:217-247: y = float(x) * s[m//128, n//128] -> out dtype."""
     rows, cols = w.shape[-2], w.shape[-1]
-    return (w.float() * _expand_block_scale(s, rows, cols)).to(out_dtype)
+    return to_out(w.float() * _expand_block_scale(s, rows, cols), out_dtype)
 
 
 def soft_decode_fp8(w: torch.Tensor) -> torch.Tensor:
@@ -79,7 +79,7 @@ def weight_dequant_soft_fp8_deepseek_v3(w: torch.Tensor, s: torch.Tensor, out_dt
     """chitu/triton_kernels.py:265-287 (step 2): y = x_bits * (s * 2^120) -> out dtype."""
     rows, cols = w.shape[-2], w.shape[-1]
     s2 = _expand_block_scale(s, rows, cols) * SOFT_SCALE
-    return (soft_decode_fp8(w) * s2).to(out_dtype)
+    return to_out(soft_decode_fp8(w) * s2, out_dtype)
 
 
 def fp8_gemm_deepseek_v3(a_q, a_s, b_q, b_s, out_dtype=torch.bfloat16):

@@ -1,0 +1,171 @@
+"""HIP fp8 quant / dequant / GEMM vs the oracle and the reference fixtures."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fp8 as ofp8
+from tests.util import bf16, bits16, bits8, fp8, golden, max_rel_to_peak
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-2  # "<= 1e-2 rel for fp8 GEMM"
+
+
+def randw(n, k, g):
+    w = (torch.randn(n, k, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    s = torch.rand((n + 127) // 128, k // 128, generator=g) * 0.02 + 0.01
+    return w, s
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(1, 128), (5, 512), (16, 7168), (3, 2, 256)])
+def test_act_quant_bit_exact(shape, dtype):
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(*shape, generator=g) * 1.7).to(dtype)
+    q_ref, s_ref = ofp8.act_quant_deepseek_v3(x)
+    q, s = ops.act_quant_deepseek_v3(x.cuda())
+    assert q.dtype == torch.float8_e4m3fn and s.shape == s_ref.shape
+    assert np.array_equal(s.cpu().numpy(), s_ref.numpy())
+    assert np.array_equal(bits8(q), bits8(q_ref))
+
+
+def test_act_quant_fixture_scales_and_zero_group():
+    from chitu_amd import fused_moe, ops
+
+    g = golden("fp8_linear")
+    q, s = ops.act_quant_deepseek_v3(bf16(g["x"]).cuda())
+    assert np.array_equal(s.cpu().numpy(), g["xs"])
+    # all-zero group: reference act_quant gives scale 0 and NaN codes (0/0)
+    z = torch.zeros(2, 256, dtype=torch.bfloat16)
+    z[1, 128:] = 1.0
+    q, s = ops.act_quant_deepseek_v3(z.cuda())
+    assert s.cpu()[0, 0] == 0 and torch.isnan(q.cpu().float()[0, :128]).all()
+    assert (q.cpu().float()[1, 128:] == 448).all()
+    # per_token_group_quant (eps + clamp): zero group stays zero, scale eps/448
+    q2, s2 = fused_moe.per_token_group_quant_fp8(z.cuda(), 128)
+    q2r, s2r = ofp8.per_token_group_quant_fp8(z)
+    assert np.array_equal(bits8(q2), bits8(q2r)) and np.array_equal(s2.cpu().numpy(), s2r.numpy())
+    gq = golden("group_quant")
+    q3, s3 = fused_moe.per_token_group_quant_fp8(bf16(gq["x"]).cuda(), 128)
+    q3r, s3r = ofp8.per_token_group_quant_fp8(bf16(gq["x"]))
+    assert np.array_equal(s3.cpu().numpy(), gq["s"]) and np.array_equal(bits8(q3), bits8(q3r))
+
+
+def test_weight_dequant_all_codes_and_shapes():
+    from chitu_amd import ops
+
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        codes = torch.arange(256, dtype=torch.uint8).repeat(128).reshape(128, 256).view(torch.float8_e4m3fn)
+        s = torch.tensor([[0.0173, 0.0291]], dtype=torch.float32)
+        hard = ops.weight_dequant_deepseek_v3(codes.cuda(), s.cuda()).cpu()
+        soft = ops.weight_dequant_soft_fp8_deepseek_v3(codes.cuda(), s.cuda()).cpu()
+        hard_ref = ofp8.weight_dequant_deepseek_v3(codes, s)
+        soft_ref = ofp8.weight_dequant_soft_fp8_deepseek_v3(codes, s)
+        finite = ~torch.isnan(hard_ref.float())
+        assert torch.equal(hard[finite], hard_ref[finite]) and torch.isnan(hard.float()[~finite]).all()
+        assert np.array_equal(bits16(soft), bits16(soft_ref))  # incl. NaN codes -> +-480*s
+        g = torch.Generator().manual_seed(3)
+        w, ws = randw(384, 512, g)  # fixture shape
+        gf = golden("fp8_linear")
+        wd = ops.weight_dequant_deepseek_v3(fp8(gf["w"]).cuda(), torch.from_numpy(gf["ws"]).cuda())
+        assert np.array_equal(bits16(wd), bits16(ofp8.weight_dequant_deepseek_v3(fp8(gf["w"]), torch.from_numpy(gf["ws"]))))
+        # 3-D (stacked experts) and ragged (rows/cols not multiples of 128 / 16)
+        w3 = (torch.randn(3, 200, 136, generator=g) * 0.5).to(torch.float8_e4m3fn)
+        s3 = torch.rand(3, 2, 2, generator=g) * 0.02 + 0.01
+        for fn, ref in ((ops.weight_dequant_deepseek_v3, ofp8.weight_dequant_deepseek_v3),
+                        (ops.weight_dequant_soft_fp8_deepseek_v3, ofp8.weight_dequant_soft_fp8_deepseek_v3)):
+            assert np.array_equal(bits16(fn(w3.cuda(), s3.cuda())), bits16(ref(w3, s3)))
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def test_fp8_gemm_fixture():
+    from chitu_amd import ops
+
+    g = golden("fp8_linear")
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        c = ops.fp8_gemm_deepseek_v3(
+            fp8(g["xq"]).cuda(), torch.from_numpy(g["xs"]).cuda(), fp8(g["w"]).cuda(), torch.from_numpy(g["ws"]).cuda()
+        )
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert c.dtype == torch.bfloat16 and tuple(c.shape) == (5, 384)
+    # fixture was truncated to bf16 by the interpreter: allow one bf16 ulp per element
+    assert max_rel_to_peak(c, bf16(g["c"])) < 8e-3
+    exact = ofp8.fp8_gemm_deepseek_v3(fp8(g["xq"]), torch.from_numpy(g["xs"]), fp8(g["w"]), torch.from_numpy(g["ws"]), torch.float32)
+    assert max_rel_to_peak(c, exact) < 4e-3
+
+
+R1_SHAPES = [(2112, 7168), (3072, 1536), (7168, 2048), (512, 7168), (7168, 256), (4608, 7168), (7168, 2304)]
+
+
+@pytest.mark.parametrize("N,K", R1_SHAPES + [(24, 128), (1000, 384), (129, 256)])
+@pytest.mark.parametrize("M", [1, 3, 16, 17, 32, 50, 70])
+def test_fp8_gemm_vs_oracle(M, N, K):
+    from chitu_amd import ops
+
+    if M > 32 and N * K > 8e6:
+        pytest.skip("large-M cases only on small shapes")
+    g = torch.Generator().manual_seed(M * 131 + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.8).to(torch.bfloat16)
+    w, ws = randw(N, K, g)
+    xq, xs = ofp8.act_quant_deepseek_v3(x)
+    ref = ofp8.fp8_gemm_deepseek_v3(xq, xs, w, ws, torch.float32)
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        c = ops.fp8_gemm_deepseek_v3(xq.cuda(), xs.cuda(), w.cuda(), ws.cuda())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert tuple(c.shape) == (M, N)
+    assert max_rel_to_peak(c, ref) < 5e-3  # bf16 output rounding only
+    assert max_rel_to_peak(c, ref) < REL_TOL
+    # deterministic (no atomics in the split-K path)
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        c2 = ops.fp8_gemm_deepseek_v3(xq.cuda(), xs.cuda(), w.cuda(), ws.cuda())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert torch.equal(c, c2)
+
+
+@pytest.mark.parametrize("N,K", [(2112, 7168), (7168, 256), (136, 384)])
+@pytest.mark.parametrize("M", [1, 16, 20])
+def test_soft_fp8_gemm_vs_oracle(M, N, K):
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.8).to(torch.bfloat16)
+    w, ws = randw(N, K, g)
+    ref = ofp8.soft_fp8_gemm_deepseek_v3(x, w, ws, torch.float32)
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        c = ops.soft_fp8_gemm_deepseek_v3(x.cuda(), w.cuda(), ws.cuda())
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert max_rel_to_peak(c, ref) < 5e-3
+
+
+def test_linearity_property_full_size():
+    """Size-independent property at the R1 wqkv_a size: gemm(a, W) + gemm(b, W) == gemm over
+    stacked rows, and a row scaled by 2 (exact in fp8 scales) doubles the output exactly."""
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    N, K = 2112, 7168
+    x = (torch.randn(4, K, generator=g)).to(torch.bfloat16)
+    w, ws = randw(N, K, g)
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        xq, xs = ops.act_quant_deepseek_v3(x.cuda())
+        full = ops.fp8_gemm_deepseek_v3(xq, xs, w.cuda(), ws.cuda())
+        rows = [ops.fp8_gemm_deepseek_v3(xq[i : i + 1].contiguous(), xs[i : i + 1].contiguous(), w.cuda(), ws.cuda()) for i in range(4)]
+        assert torch.equal(full, torch.cat(rows))  # row results do not depend on the batch
+        dbl = ops.fp8_gemm_deepseek_v3(xq, (xs * 2).contiguous(), w.cuda(), ws.cuda())
+        assert torch.equal(dbl.float(), full.float() * 2)
+    finally:
+        torch.set_default_dtype(torch.float32)

@@ -136,6 +136,8 @@ def test_fp8_gemm_bit_exact_under_interpreter_casts(interpreter_casts):
     g = golden("fp8_linear")
     c = ofp8.fp8_gemm_deepseek_v3(fp8(g["xq"]), torch.from_numpy(g["xs"]), fp8(g["w"]), torch.from_numpy(g["ws"]))
     assert np.array_equal(bits16(c), g["c"])
+    wd = ofp8.weight_dequant_deepseek_v3(fp8(g["w"]), torch.from_numpy(g["ws"]))
+    assert np.array_equal(bits16(wd), g["w_dequant"])
 
 
 def test_fused_moe_bit_exact_under_interpreter_casts(interpreter_casts):
@@ -155,7 +157,8 @@ def test_fp8_gemm_and_dequant():
     ref = bf16(g["c"])
     assert max_rel_to_peak(c, ref) < 8e-3  # one bf16 ulp: the interpreter truncates, we round
     wd = ofp8.weight_dequant_deepseek_v3(fp8(g["w"]), torch.from_numpy(g["ws"]))
-    assert np.array_equal(bits16(wd), g["w_dequant"])
+    d = np.abs(bits16(wd).astype(np.int32) - g["w_dequant"].astype(np.int32))
+    assert d.max() <= 1  # RNE vs the interpreter's truncation: at most one bf16 ulp
 
 
 def test_soft_decode_equals_hard_decode_on_finite_codes():
