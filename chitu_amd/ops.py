@@ -61,6 +61,7 @@ def _weight_dequant(x, s, block_size, soft):
     else:
         assert False, "Weight tensor must have 2 or 3 dimensions"
     require_cuda(x, s)
+    assert x.element_size() == 1 and s.dtype == torch.float32, "fp8 weight + float32 block scales expected"
     y = torch.empty_like(x, dtype=torch.get_default_dtype())
     check(
         _lib.lib().chitu_hip_weight_dequant_fp8(
@@ -87,6 +88,8 @@ def fp8_gemm_deepseek_v3(a: torch.Tensor, a_s: torch.Tensor, b: torch.Tensor, b_
     assert a.is_contiguous() and b.is_contiguous(), "Input tensors must be contiguous"
     assert a_s.is_contiguous() and b_s.is_contiguous(), "Scaling factor tensors must be contiguous"
     require_cuda(a, a_s, b, b_s)
+    assert a.element_size() == 1 and b.element_size() == 1, "fp8 operands expected"
+    assert a_s.dtype == torch.float32 and b_s.dtype == torch.float32, "float32 scales expected"
     K = a.size(-1)
     M = a.numel() // K
     N = b.size(0)
@@ -108,6 +111,7 @@ def soft_fp8_gemm_deepseek_v3(a: torch.Tensor, b: torch.Tensor, b_s: torch.Tenso
     assert b_s.is_contiguous(), "Scaling factor tensor must be contiguous"
     assert a.dtype == torch.bfloat16, "soft-fp8 GEMM takes bf16 activations"
     require_cuda(a, b, b_s)
+    assert b.element_size() == 1 and b_s.dtype == torch.float32
     K = a.size(-1)
     M = a.numel() // K
     N = b.size(0)

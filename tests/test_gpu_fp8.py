@@ -13,8 +13,8 @@ REL_TOL = 1e-2  # "<= 1e-2 rel for fp8 GEMM"
 
 
 def randw(n, k, g):
-    w = (torch.randn(n, k, generator=g) * 0.5).to(torch.float8_e4m3fn)
-    s = torch.rand((n + 127) // 128, k // 128, generator=g) * 0.02 + 0.01
+    w = (torch.randn(n, k, generator=g, dtype=torch.float32) * 0.5).to(torch.float8_e4m3fn)
+    s = torch.rand((n + 127) // 128, k // 128, generator=g, dtype=torch.float32) * 0.02 + 0.01
     return w, s
 
 
@@ -74,8 +74,8 @@ def test_weight_dequant_all_codes_and_shapes():
         wd = ops.weight_dequant_deepseek_v3(fp8(gf["w"]).cuda(), torch.from_numpy(gf["ws"]).cuda())
         assert np.array_equal(bits16(wd), bits16(ofp8.weight_dequant_deepseek_v3(fp8(gf["w"]), torch.from_numpy(gf["ws"]))))
         # 3-D (stacked experts) and ragged (rows/cols not multiples of 128 / 16)
-        w3 = (torch.randn(3, 200, 136, generator=g) * 0.5).to(torch.float8_e4m3fn)
-        s3 = torch.rand(3, 2, 2, generator=g) * 0.02 + 0.01
+        w3 = (torch.randn(3, 200, 136, generator=g, dtype=torch.float32) * 0.5).to(torch.float8_e4m3fn)
+        s3 = torch.rand(3, 2, 2, generator=g, dtype=torch.float32) * 0.02 + 0.01
         for fn, ref in ((ops.weight_dequant_deepseek_v3, ofp8.weight_dequant_deepseek_v3),
                         (ops.weight_dequant_soft_fp8_deepseek_v3, ofp8.weight_dequant_soft_fp8_deepseek_v3)):
             assert np.array_equal(bits16(fn(w3.cuda(), s3.cuda())), bits16(ref(w3, s3)))
