@@ -1,0 +1,454 @@
+// Fused MoE for decode on gfx950: grouped FP8 (W8A8, 128x128 block scales) GEMMs over
+// expert-sorted token slots, SiLU-and-mul + re-quantisation, routed-weight epilogue, top-k sum.
+//
+// Replaces (reference, read-only):
+//   chitu/fused_moe.py:62-307     fused_moe_kernel (Triton grouped GEMM, BLOCK_M=64 tiles)
+//   chitu/fused_moe.py:796-891    invoke_fused_moe_kernel
+//   chitu/fused_moe.py:24-39      SiluAndMul
+//   chitu/fused_moe.py:670-710    _per_token_group_quant_fp8 (between the two GEMMs)
+//   chitu/fused_moe.py:1299-1305  moe_sum
+//
+// Design.  In decode each routed expert sees 1-3 tokens, so the reference's 64-row tiles are
+// >90% padding and its cost is the expert weights, streamed once.  Here the m-tile is 16 sorted
+// slots (one MFMA tile; moe_align is run with block 16) and everything else mirrors the dense
+// weight-streaming GEMM of fp8_gemm.hip: a wave owns 16 weight rows, lanes load 16 B of a row
+// (non-temporal: each weight byte is used once), the same k order is applied to the gathered
+// activation rows, per-128 block scales are folded in fp32 in the reference's order
+// (fused_moe.py:281).  GEMM1 splits K over the waves of a workgroup; GEMM2 (K = moe_inter/tp,
+// two K blocks at TP=8) gives every wave its own 16-row tiles and keeps the 16x256 activation
+// fragment in registers.  Rounding points are the reference's: GEMM outputs -> bf16, silu in
+// fp32 -> bf16, product -> bf16, routed weight multiplied on the fp32 accumulator, top-k sum in
+// fp32 over bf16 values.  No atomics anywhere: results are run-to-run identical.
+#include "common.h"
+
+namespace chitu {
+
+__device__ __forceinline__ long pk_lo(const i32x4& v) {
+    return (long)(((unsigned long long)(uint32_t)v[1] << 32) | (uint32_t)v[0]);
+}
+__device__ __forceinline__ long pk_hi(const i32x4& v) {
+    return (long)(((unsigned long long)(uint32_t)v[3] << 32) | (uint32_t)v[2]);
+}
+
+struct MoeStage {
+    i32x4 w[2];
+    i32x4 x[2];
+    float xs, ws;
+};
+
+__device__ __forceinline__ f32x4 moe_block_dot(const MoeStage& st) {
+    f32x4 blk = f32x4{0.f, 0.f, 0.f, 0.f};
+    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk_lo(st.w[0]), pk_lo(st.x[0]), blk, 0, 0, 0);
+    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk_hi(st.w[0]), pk_hi(st.x[0]), blk, 0, 0, 0);
+    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk_lo(st.w[1]), pk_lo(st.x[1]), blk, 0, 0, 0);
+    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk_hi(st.w[1]), pk_hi(st.x[1]), blk, 0, 0, 0);
+    return blk;
+}
+
+// ---------------------------------------------------------------- GEMM1: x[token] . W1[e]^T
+// grid (n_tiles, max_mblocks); block 64*WK.  out: bf16 [numel, N] (row = sorted slot id).
+template <int WK>
+__global__ __launch_bounds__(64 * WK) void moe_gemm1_kernel(
+    const fp8_t* __restrict__ Xq, const float* __restrict__ Xs, const fp8_t* __restrict__ W,
+    const float* __restrict__ Ws, const int32_t* __restrict__ sorted_ids,
+    const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
+    bf16_t* __restrict__ out, int numel, int topk, int N, int K) {
+    __shared__ float red[WK > 1 ? WK * 256 : 1];
+    const int mb = blockIdx.y;
+    if (mb * 16 >= *num_post_pad) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int KB = K >> 7;
+    const int slot = sorted_ids[mb * 16 + j];
+    const bool valid = slot < numel;
+    const int e = expert_ids[mb];
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e >= 0) {
+        const int kb0 = KB * wave / WK, kb1 = KB * (wave + 1) / WK;
+        const int token = valid ? slot / topk : 0;
+        const fp8_t* xp = Xq + (size_t)token * K + g * 16;
+        const float* xsp = Xs + (size_t)token * KB;
+        const int nrow = min(n0 + j, N - 1);
+        const fp8_t* wp = W + ((size_t)e * N + nrow) * K + g * 16;
+        const float* wsp = Ws + ((size_t)e * ((N + 127) >> 7) + (n0 >> 7)) * KB;
+        auto load = [&](MoeStage& st, int kb) {
+            const int off = kb << 7;
+            st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
+            st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off + 64));
+            st.x[0] = *reinterpret_cast<const i32x4*>(xp + off);
+            st.x[1] = *reinterpret_cast<const i32x4*>(xp + off + 64);
+            st.xs = xsp[kb];
+            st.ws = wsp[kb];
+        };
+        auto compute = [&](const MoeStage& st) {
+            const f32x4 blk = moe_block_dot(st);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * st.xs) * st.ws;
+        };
+        MoeStage a, b;
+        int kb = kb0;
+        if (kb < kb1) load(a, kb);
+        while (kb < kb1) {
+            if (kb + 1 < kb1) load(b, kb + 1);
+            compute(a);
+            ++kb;
+            if (kb >= kb1) break;
+            if (kb + 1 < kb1) load(a, kb + 1);
+            compute(b);
+            ++kb;
+        }
+    }
+    if (WK > 1) {
+        *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WK; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&red[(w * 64 + lane) * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += v[r];
+        }
+    }
+    if (!valid) return;
+    const int n = n0 + g * 4;
+    bf16_t* dst = out + (size_t)slot * N + n;
+    if (n + 3 < N && (N & 3) == 0) {
+        i32x2 o;
+        o[0] = (int)((uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16));
+        o[1] = (int)((uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16));
+        *reinterpret_cast<i32x2*>(dst) = o;
+    } else {
+        for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = f32_to_bf16(acc[r]);
+    }
+}
+
+// ---------------------------------------------------------------- SiLU-and-mul + fp8 requant
+// c1 [rows, 2I] bf16 -> h = bf16(bf16(silu(gate)) * up) -> q [rows, I] e4m3, s [rows, I/128].
+// One 128-wide group per 16 lanes (same shape as act_quant_kernel MODE 1).
+__global__ __launch_bounds__(256) void moe_silu_quant_kernel(const bf16_t* __restrict__ c1,
+                                                             fp8_t* __restrict__ q,
+                                                             float* __restrict__ s, int64_t rows,
+                                                             int I, float eps) {
+    const int lane16 = threadIdx.x & 15;
+    const int gpr = I >> 7;  // groups per row
+    const int64_t n_groups = rows * gpr;
+    int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (; group < n_groups; group += stride) {
+        const int64_t row = group / gpr;
+        const int col = (int)(group % gpr) * 128 + lane16 * 8;
+        const i32x4 graw = *reinterpret_cast<const i32x4*>(c1 + row * 2 * I + col);
+        const i32x4 uraw = *reinterpret_cast<const i32x4*>(c1 + row * 2 * I + I + col);
+        float h[8];
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t gu = (uint32_t)graw[i >> 1], uu = (uint32_t)uraw[i >> 1];
+            const float gv = (i & 1) ? __uint_as_float(gu & 0xffff0000u) : __uint_as_float(gu << 16);
+            const float uv = (i & 1) ? __uint_as_float(uu & 0xffff0000u) : __uint_as_float(uu << 16);
+            const float sl = round_bf16(gv / (1.0f + expf(-gv)));
+            h[i] = round_bf16(sl * uv);
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(h[i]));
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off, 64));
+        amax = __builtin_fmaxf(amax, eps);
+        const float sc = amax / 448.0f;
+        const uint32_t lo = f32x2_to_fp8x2_sat(h[0] / sc, h[1] / sc) | (f32x2_to_fp8x2_sat(h[2] / sc, h[3] / sc) << 16);
+        const uint32_t hi = f32x2_to_fp8x2_sat(h[4] / sc, h[5] / sc) | (f32x2_to_fp8x2_sat(h[6] / sc, h[7] / sc) << 16);
+        i32x2 o;
+        o[0] = (int)lo;
+        o[1] = (int)hi;
+        *reinterpret_cast<i32x2*>(q + row * I + col) = o;
+        if (lane16 == 0) s[group] = sc;
+    }
+}
+
+// ---------------------------------------------------------------- GEMM2: h[slot] . W2[e]^T * w
+// grid (ceil(n_tiles / (4*NT)), max_mblocks); block 256 (4 waves, NT row tiles per wave, no K
+// split).  KB = I/128 is small (2 at TP=8): the whole 16 x I activation fragment stays in
+// registers (KBMAX blocks), only weights stream.
+template <int KBMAX, int NT>
+__global__ __launch_bounds__(256) void moe_gemm2_kernel(
+    const fp8_t* __restrict__ Hq, const float* __restrict__ Hs, const fp8_t* __restrict__ W,
+    const float* __restrict__ Ws, const int32_t* __restrict__ sorted_ids,
+    const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
+    const void* __restrict__ topk_w, int w_dt, bf16_t* __restrict__ out, int numel, int N, int I,
+    int mul_weight) {
+    const int mb = blockIdx.y;
+    if (mb * 16 >= *num_post_pad) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int KB = I >> 7;
+    const int slot = sorted_ids[mb * 16 + j];
+    const bool valid = slot < numel;
+    const int e = expert_ids[mb];
+    const int row = valid ? slot : 0;
+    float rw = 1.0f;
+    if (mul_weight && valid) {
+        if (w_dt == 0) rw = bf16_to_f32(((const bf16_t*)topk_w)[slot]);
+        else if (w_dt == 1) rw = f16_to_f32(((const uint16_t*)topk_w)[slot]);
+        else rw = ((const float*)topk_w)[slot];
+    }
+    i32x4 x[KBMAX][2];
+    float xs[KBMAX];
+    if (e >= 0) {
+        const fp8_t* xp = Hq + (size_t)row * I + g * 16;
+#pragma unroll
+        for (int kb = 0; kb < KBMAX; ++kb) {
+            if (kb < KB) {
+                x[kb][0] = *reinterpret_cast<const i32x4*>(xp + (kb << 7));
+                x[kb][1] = *reinterpret_cast<const i32x4*>(xp + (kb << 7) + 64);
+                xs[kb] = Hs[(size_t)row * KB + kb];
+            }
+        }
+    }
+    const int tile0 = (blockIdx.x * 4 + wave) * NT;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n0 = (tile0 + t) * 16;
+        if (n0 >= N) break;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e >= 0) {
+            const int nrow = min(n0 + j, N - 1);
+            const fp8_t* wp = W + ((size_t)e * N + nrow) * I + g * 16;
+            const float* wsp = Ws + ((size_t)e * ((N + 127) >> 7) + (n0 >> 7)) * KB;
+#pragma unroll
+            for (int kb = 0; kb < KBMAX; ++kb) {
+                if (kb < KB) {
+                    MoeStage st;
+                    st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + (kb << 7)));
+                    st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + (kb << 7) + 64));
+                    st.x[0] = x[kb][0];
+                    st.x[1] = x[kb][1];
+                    const f32x4 blk = moe_block_dot(st);
+                    const float ws = wsp[kb];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * xs[kb]) * ws;
+                }
+            }
+        }
+        if (!valid) continue;
+        const int n = n0 + g * 4;
+        bf16_t* dst = out + (size_t)slot * N + n;
+        if (n + 3 < N && (N & 3) == 0) {
+            i32x2 o;
+            o[0] = (int)((uint32_t)f32_to_bf16(acc[0] * rw) | ((uint32_t)f32_to_bf16(acc[1] * rw) << 16));
+            o[1] = (int)((uint32_t)f32_to_bf16(acc[2] * rw) | ((uint32_t)f32_to_bf16(acc[3] * rw) << 16));
+            *reinterpret_cast<i32x2*>(dst) = o;
+        } else {
+            for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = f32_to_bf16(acc[r] * rw);
+        }
+    }
+}
+
+// Generic-K GEMM2 (any I): reuses the GEMM1 kernel shape with slot-indexed activations.
+template <int WK>
+__global__ __launch_bounds__(64 * WK) void moe_gemm2_generic_kernel(
+    const fp8_t* __restrict__ Hq, const float* __restrict__ Hs, const fp8_t* __restrict__ W,
+    const float* __restrict__ Ws, const int32_t* __restrict__ sorted_ids,
+    const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
+    const void* __restrict__ topk_w, int w_dt, bf16_t* __restrict__ out, int numel, int N, int I,
+    int mul_weight) {
+    __shared__ float red[WK > 1 ? WK * 256 : 1];
+    const int mb = blockIdx.y;
+    if (mb * 16 >= *num_post_pad) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int KB = I >> 7;
+    const int slot = sorted_ids[mb * 16 + j];
+    const bool valid = slot < numel;
+    const int e = expert_ids[mb];
+    const int row = valid ? slot : 0;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e >= 0) {
+        const int kb0 = KB * wave / WK, kb1 = KB * (wave + 1) / WK;
+        const fp8_t* xp = Hq + (size_t)row * I + g * 16;
+        const float* xsp = Hs + (size_t)row * KB;
+        const int nrow = min(n0 + j, N - 1);
+        const fp8_t* wp = W + ((size_t)e * N + nrow) * I + g * 16;
+        const float* wsp = Ws + ((size_t)e * ((N + 127) >> 7) + (n0 >> 7)) * KB;
+        for (int kb = kb0; kb < kb1; ++kb) {
+            MoeStage st;
+            const int off = kb << 7;
+            st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
+            st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off + 64));
+            st.x[0] = *reinterpret_cast<const i32x4*>(xp + off);
+            st.x[1] = *reinterpret_cast<const i32x4*>(xp + off + 64);
+            const f32x4 blk = moe_block_dot(st);
+            const float xs = xsp[kb], ws = wsp[kb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * xs) * ws;
+        }
+    }
+    if (WK > 1) {
+        *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WK; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&red[(w * 64 + lane) * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += v[r];
+        }
+    }
+    if (!valid) return;
+    float rw = 1.0f;
+    if (mul_weight) {
+        if (w_dt == 0) rw = bf16_to_f32(((const bf16_t*)topk_w)[slot]);
+        else if (w_dt == 1) rw = f16_to_f32(((const uint16_t*)topk_w)[slot]);
+        else rw = ((const float*)topk_w)[slot];
+    }
+    const int n = n0 + g * 4;
+    for (int r = 0; r < 4 && n + r < N; ++r) out[(size_t)slot * N + n + r] = f32_to_bf16(acc[r] * rw);
+}
+
+// ---------------------------------------------------------------- top-k sum
+// out[t][n] = bf16( sum_k float(c3[t][k][n]) ), k ascending (fused_moe.py:1299-1305).
+__global__ __launch_bounds__(256) void moe_sum_kernel(const bf16_t* __restrict__ c3,
+                                                      bf16_t* __restrict__ out, int64_t M, int topk,
+                                                      int64_t N) {
+    const int64_t n8 = N >> 3;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < M * n8;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = idx / n8, c = (idx % n8) * 8;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < topk; ++k) {
+            const i32x4 raw = *reinterpret_cast<const i32x4*>(c3 + (t * topk + k) * N + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t u = (uint32_t)raw[i];
+                acc[2 * i] += __uint_as_float(u << 16);
+                acc[2 * i + 1] += __uint_as_float(u & 0xffff0000u);
+            }
+        }
+        i32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o[i] = (int)((uint32_t)f32_to_bf16(acc[2 * i]) | ((uint32_t)f32_to_bf16(acc[2 * i + 1]) << 16));
+        *reinterpret_cast<i32x4*>(out + t * N + c) = o;
+    }
+}
+
+}  // namespace chitu
+
+extern "C" int chitu_hip_moe_gemm1_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
+                                       const float* w1_scale, const int32_t* sorted_token_ids,
+                                       const int32_t* expert_ids,
+                                       const int32_t* num_tokens_post_pad, void* out_bf16,
+                                       int64_t numel, int32_t topk, int64_t N, int64_t K,
+                                       int64_t max_mblocks, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(a_fp8 && a_scale && w1_fp8 && w1_scale && sorted_token_ids && expert_ids);
+    CHITU_REQUIRE(num_tokens_post_pad && out_bf16);
+    CHITU_REQUIRE(numel >= 0 && topk >= 1 && N >= 1 && K >= 128 && max_mblocks >= 0);
+    if (K % 128 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (numel == 0 || max_mblocks == 0) return CHITU_OK;
+    const int n_tiles = (int)((N + 15) / 16);
+    const dim3 grid((unsigned)n_tiles, (unsigned)max_mblocks);
+    const int64_t wgs = (int64_t)n_tiles * (numel < max_mblocks ? numel : max_mblocks);
+    const int KB = (int)(K / 128);
+    int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 4096 ? 2 : 1;
+    while (WK > 1 && WK > KB) WK >>= 1;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(WKV)                                                                              \
+    hipLaunchKernelGGL(moe_gemm1_kernel<WKV>, grid, dim3(64 * WKV), 0, st, (const fp8_t*)a_fp8,  \
+                       a_scale, (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids,    \
+                       num_tokens_post_pad, (bf16_t*)out_bf16, (int)numel, (int)topk, (int)N, (int)K)
+    switch (WK) {
+        case 8: LAUNCH(8); break;
+        case 4: LAUNCH(4); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(1); break;
+    }
+#undef LAUNCH
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_moe_silu_mul_quant_fp8(const void* c1_bf16, int64_t rows,
+                                                int64_t inter_size, float eps, void* q_fp8,
+                                                float* scales, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(c1_bf16 && q_fp8 && scales && rows >= 0 && inter_size >= 128);
+    if (inter_size % 128 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (rows == 0) return CHITU_OK;
+    const int64_t lanes = rows * (inter_size / 128) * 16;
+    int64_t blocks = (lanes + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(moe_silu_quant_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)c1_bf16, (fp8_t*)q_fp8, scales, rows,
+                       (int)inter_size, eps);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, const void* w2_fp8,
+                                       const float* w2_scale, const int32_t* sorted_token_ids,
+                                       const int32_t* expert_ids,
+                                       const int32_t* num_tokens_post_pad, const void* topk_weights,
+                                       int weights_dtype, int32_t mul_routed_weight,
+                                       void* out_bf16, int64_t numel, int64_t N, int64_t inter_size,
+                                       int64_t max_mblocks, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(h_fp8 && h_scale && w2_fp8 && w2_scale && sorted_token_ids && expert_ids);
+    CHITU_REQUIRE(num_tokens_post_pad && out_bf16 && (topk_weights || !mul_routed_weight));
+    CHITU_REQUIRE(numel >= 0 && N >= 1 && inter_size >= 128 && max_mblocks >= 0);
+    CHITU_REQUIRE(weights_dtype >= 0 && weights_dtype <= 2);
+    if (inter_size % 128 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (numel == 0 || max_mblocks == 0) return CHITU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_tiles = (int)((N + 15) / 16);
+    const int KB = (int)(inter_size / 128);
+    if (KB <= 4) {
+        const int64_t mbs = numel < max_mblocks ? numel : max_mblocks;
+#define LAUNCH2(KBM, NTV)                                                                        \
+    hipLaunchKernelGGL((moe_gemm2_kernel<KBM, NTV>),                                             \
+                       dim3((unsigned)((n_tiles + 4 * NTV - 1) / (4 * NTV)), (unsigned)max_mblocks), \
+                       dim3(256), 0, st, (const fp8_t*)h_fp8, h_scale, (const fp8_t*)w2_fp8,     \
+                       w2_scale, sorted_token_ids, expert_ids, num_tokens_post_pad, topk_weights, \
+                       weights_dtype, (bf16_t*)out_bf16, (int)numel, (int)N, (int)inter_size,    \
+                       (int)mul_routed_weight)
+        const bool many = (int64_t)n_tiles * mbs > 8192;
+        if (KB <= 2) {
+            if (many) LAUNCH2(2, 4); else LAUNCH2(2, 2);
+        } else {
+            if (many) LAUNCH2(4, 4); else LAUNCH2(4, 2);
+        }
+#undef LAUNCH2
+    } else {
+        const dim3 grid((unsigned)n_tiles, (unsigned)max_mblocks);
+        const int64_t wgs = (int64_t)n_tiles * (numel < max_mblocks ? numel : max_mblocks);
+        int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 4096 ? 2 : 1;
+        while (WK > 1 && WK > KB) WK >>= 1;
+#define LAUNCHG(WKV)                                                                              \
+    hipLaunchKernelGGL(moe_gemm2_generic_kernel<WKV>, grid, dim3(64 * WKV), 0, st,                \
+                       (const fp8_t*)h_fp8, h_scale, (const fp8_t*)w2_fp8, w2_scale,              \
+                       sorted_token_ids, expert_ids, num_tokens_post_pad, topk_weights,           \
+                       weights_dtype, (bf16_t*)out_bf16, (int)numel, (int)N, (int)inter_size,     \
+                       (int)mul_routed_weight)
+        switch (WK) {
+            case 8: LAUNCHG(8); break;
+            case 4: LAUNCHG(4); break;
+            case 2: LAUNCHG(2); break;
+            default: LAUNCHG(1); break;
+        }
+#undef LAUNCHG
+    }
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_moe_sum(const void* c3_bf16, void* out_bf16, int64_t tokens, int32_t topk,
+                                 int64_t N, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(c3_bf16 && out_bf16 && tokens >= 0 && topk >= 1 && N >= 8);
+    if (N % 8 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (tokens == 0) return CHITU_OK;
+    int64_t blocks = (tokens * (N / 8) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(moe_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)c3_bf16, (bf16_t*)out_bf16, tokens, (int)topk, N);
+    CHITU_RETURN_LAUNCH_STATUS();
+}

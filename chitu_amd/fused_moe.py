@@ -126,3 +126,187 @@ def per_token_group_quant_fp8(
         "per_token_group_quant_fp8",
     )
     return x_q, x_s
+
+
+_MOE_BLOCK_M = 16  # one MFMA tile of sorted slots (the reference's BLOCK_SIZE_M=64 is >90% padding in decode)
+
+
+class SiluAndMul(torch.nn.Module):
+    """x -> silu(x[..., :d]) * x[..., d:]  (chitu/fused_moe.py:24-39).  Kept for API parity; the
+    fused path applies it inside chitu_hip_moe_silu_mul_quant_fp8."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        d = x.shape[-1] // 2
+        return torch.nn.functional.silu(x[..., :d]) * x[..., d:]
+
+
+def fused_experts(
+    hidden_states: torch.Tensor,
+    w1: torch.Tensor,
+    w2: torch.Tensor,
+    topk_weights: torch.Tensor,
+    topk_ids: torch.Tensor,
+    inplace: bool = False,
+    activation: str = "silu",
+    use_fp8_w8a8: bool = False,
+    use_int8_w8a16: bool = False,
+    use_int4_w4a16: bool = False,
+    global_num_experts: int = -1,
+    expert_map: Optional[torch.Tensor] = None,
+    w1_scale: Optional[torch.Tensor] = None,
+    w2_scale: Optional[torch.Tensor] = None,
+    w1_zp: Optional[torch.Tensor] = None,
+    w2_zp: Optional[torch.Tensor] = None,
+    a1_scale: Optional[torch.Tensor] = None,
+    a2_scale: Optional[torch.Tensor] = None,
+    block_shape: Optional[List[int]] = None,
+    soft_fp8: bool = False,
+) -> torch.Tensor:
+    """Same signature as chitu/fused_moe.py:1060-1127.  (The reference's inplace=False branch
+    calls an unregistered torch.ops.vllm op; here both branches work.)"""
+    return fused_experts_impl(
+        hidden_states, w1, w2, topk_weights, topk_ids, inplace, activation, use_fp8_w8a8,
+        use_int8_w8a16, use_int4_w4a16, global_num_experts, expert_map, w1_scale, w2_scale, w1_zp,
+        w2_zp, a1_scale, a2_scale, block_shape, soft_fp8=soft_fp8,
+    )
+
+
+def fused_experts_impl(
+    hidden_states: torch.Tensor,
+    w1: torch.Tensor,
+    w2: torch.Tensor,
+    topk_weights: torch.Tensor,
+    topk_ids: torch.Tensor,
+    inplace: bool = False,
+    activation: str = "silu",
+    use_fp8_w8a8: bool = False,
+    use_int8_w8a16: bool = False,
+    use_int4_w4a16: bool = False,
+    global_num_experts: int = -1,
+    expert_map: Optional[torch.Tensor] = None,
+    w1_scale: Optional[torch.Tensor] = None,
+    w2_scale: Optional[torch.Tensor] = None,
+    w1_zp: Optional[torch.Tensor] = None,
+    w2_zp: Optional[torch.Tensor] = None,
+    a1_scale: Optional[torch.Tensor] = None,
+    a2_scale: Optional[torch.Tensor] = None,
+    block_shape: Optional[List[int]] = None,
+    soft_fp8: bool = False,
+):
+    """out[t] = sum_j w[t,j] * W2[e_tj] . (silu(W1[e_tj] x_t)[:I] * (W1[e_tj] x_t)[I:])
+
+    FP8 W8A8 with [128,128] block scales (the DeepSeek-V3/R1 path, fused_moe.py:1130-1307).
+    Six launches: align(16) -> quant -> grouped GEMM1 -> silu*mul+requant -> grouped GEMM2 (x routed
+    weight) -> top-k sum.  Scratch lives in a persistent workspace (graph-capture safe).
+    """
+    assert hidden_states.shape[1] == w1.shape[2], "Hidden size mismatch"
+    assert topk_weights.shape == topk_ids.shape, "topk shape mismatch"
+    assert hidden_states.is_contiguous(), "Hidden_states must be contiguous"
+    assert w1.is_contiguous(), "Expert weights1 must be contiguous"
+    assert w2.is_contiguous(), "Expert weights2 must be contiguous"
+    assert hidden_states.dtype in [torch.float32, torch.float16, torch.bfloat16]
+    if activation != "silu":
+        raise ValueError(f"Unsupported FusedMoe activation: {activation}")
+    if not use_fp8_w8a8 or soft_fp8 or use_int8_w8a16 or use_int4_w4a16:
+        raise NotImplementedError(
+            "chitu_amd.fused_moe implements the fp8_w8a8 block-scaled path (use_fp8_w8a8=True, "
+            "block_shape=[128,128], soft_fp8=False); other modes are not built yet"
+        )
+    assert block_shape is not None and list(block_shape) == [128, 128], "block_shape must be [128, 128]"
+    assert w1_scale is not None and w2_scale is not None
+    assert a1_scale is None and a2_scale is None, "dynamic per-token-group activation scales only"
+    assert hidden_states.dtype == torch.bfloat16, "bf16 activations (the reference's R1 configuration)"
+    require_cuda(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale)
+    assert w1_scale.is_contiguous() and w2_scale.is_contiguous()
+    assert w1_scale.dtype == torch.float32 and w2_scale.dtype == torch.float32
+
+    num_tokens, K = hidden_states.shape
+    E, N, _ = w1.shape
+    I = N // 2
+    assert w2.shape[0] == E and w2.shape[2] == I, "w2 must be [E, hidden_out, N/2]"
+    Nout = w2.shape[1]
+    if global_num_experts == -1:
+        global_num_experts = E
+    topk = topk_ids.shape[1]
+    dev = hidden_states.device
+    out = hidden_states if inplace else torch.empty_like(hidden_states)
+    if num_tokens == 0:
+        return out
+    numel = num_tokens * topk
+    if not topk_ids.is_contiguous():
+        topk_ids = topk_ids.contiguous()
+    if not topk_weights.is_contiguous():
+        topk_weights = topk_weights.contiguous()
+
+    # ---- scratch carve-up (persistent, 256-B aligned)
+    def rnd(n):
+        return (n + 255) // 256 * 256
+
+    cap = numel + global_num_experts * (_MOE_BLOCK_M - 1)
+    nblk = ceil_div(cap, _MOE_BLOCK_M)
+    KB = K // 128
+    sizes = [
+        ("sorted", cap * 4), ("experts", nblk * 4), ("npost", 4), ("cumsum", (global_num_experts + 1) * 4),
+        ("a1q", num_tokens * K), ("a1s", num_tokens * KB * 4), ("c1", numel * N * 2),
+        ("a2q", numel * I), ("a2s", numel * (I // 128) * 4), ("c3", numel * Nout * 2),
+    ]
+    total = sum(rnd(n) for _, n in sizes)
+    ws = workspace.get(total, dev, "moe")
+    base = ws.data_ptr()
+    off = {}
+    cur = 0
+    for name, n in sizes:
+        off[name] = base + cur
+        cur += rnd(n)
+    import ctypes as _ct
+
+    P = lambda name: _ct.c_void_p(off[name])
+    lib = _lib.lib()
+    st = stream_ptr()
+    max_mblocks = min(nblk, numel)
+
+    check(
+        lib.chitu_hip_moe_align_block_size(
+            ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel), i32(global_num_experts),
+            i32(_MOE_BLOCK_M), P("sorted"), i64(cap), P("experts"), i64(nblk), P("npost"), P("cumsum"),
+            i32(1), st,
+        ),
+        "moe_align_block_size",
+    )
+    experts_ptr = P("experts")
+    if expert_map is not None:
+        ev = _view_i32(ws, off["experts"] - base, nblk)
+        mapped = expert_map.to(torch.int32)[ev.long()].contiguous()
+        ev.copy_(mapped)
+    check(
+        lib.chitu_hip_act_quant_fp8(
+            ptr(hidden_states), float_dtype_code(hidden_states.dtype), i64(num_tokens), i64(K), i32(128),
+            i32(1), f32(1e-10), P("a1q"), P("a1s"), st,
+        ),
+        "moe quant1",
+    )
+    check(
+        lib.chitu_hip_moe_gemm1_fp8(
+            P("a1q"), P("a1s"), ptr(w1), ptr(w1_scale), P("sorted"), experts_ptr, P("npost"), P("c1"),
+            i64(numel), i32(topk), i64(N), i64(K), i64(max_mblocks), st,
+        ),
+        "moe gemm1",
+    )
+    check(
+        lib.chitu_hip_moe_silu_mul_quant_fp8(P("c1"), i64(numel), i64(I), f32(1e-10), P("a2q"), P("a2s"), st),
+        "moe silu_mul_quant",
+    )
+    check(
+        lib.chitu_hip_moe_gemm2_fp8(
+            P("a2q"), P("a2s"), ptr(w2), ptr(w2_scale), P("sorted"), experts_ptr, P("npost"),
+            ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel), i64(Nout),
+            i64(I), i64(max_mblocks), st,
+        ),
+        "moe gemm2",
+    )
+    check(lib.chitu_hip_moe_sum(P("c3"), ptr(out), i64(num_tokens), i32(topk), i64(Nout), st), "moe sum")
+    return out
+
+
+def _view_i32(ws: torch.Tensor, byte_off: int, n: int) -> torch.Tensor:
+    return ws[byte_off : byte_off + 4 * n].view(torch.int32)

@@ -104,6 +104,40 @@ int chitu_hip_rope(const void* q, const void* k, void* out_q, void* out_k, const
                    int64_t k_sh, int64_t oq_sb, int64_t oq_sh, int64_t ok_sb, int64_t ok_sh,
                    int32_t layout, void* stream);
 
+/* ---- fused MoE, fp8 W8A8 with 128x128 block scales (decode) -------------------------------
+ * Together these replace fused_experts_impl (chitu/fused_moe.py:1130-1307): the two
+ * invoke_fused_moe_kernel calls (:796-891, Triton kernel :62-307), SiluAndMul (:24-39), the
+ * activation re-quantisation (:829 -> :713-793) and moe_sum (:1299-1305).  All take the outputs
+ * of chitu_hip_moe_align_block_size run with block_size = 16 (one MFMA tile of sorted slots).
+ *   sorted_token_ids / expert_ids / num_tokens_post_pad: from moe_align (block 16); expert -1
+ *   (expert_map, not on this rank) writes zeros like write_zeros_to_output (:40-59).
+ *   max_mblocks: grid bound, min(len(expert_ids), numel) is always enough.
+ *
+ * gemm1:  c1[slot, :] = bf16( sum_kb dot(a[slot/topk, kb], w1[e, :, kb]) * a_s * w1_s )
+ *   a_fp8 [tokens, K], a_scale [tokens, K/128]; w1 [E, N, K] fp8, w1_scale [E, ceil(N/128), K/128];
+ *   out_bf16 [numel, N] with numel = tokens*topk (row = flat slot id t*topk+k).
+ * silu_mul_quant:  h = bf16(bf16(silu(c1[:, :I])) * c1[:, I:]); per-128 group
+ *   s = max(max|h|, eps)/448, q = clamp(h/s) -> e4m3.   c1 [rows, 2I]; q [rows, I]; scales [rows, I/128].
+ * gemm2:  c3[slot, :] = bf16( (sum_kb dot(h[slot, kb], w2[e, :, kb]) * h_s * w2_s) * topk_w[slot] )
+ *   h_fp8 [numel, I]; w2 [E, N, I]; out [numel, N]; topk_weights [numel] of weights_dtype.
+ * moe_sum: out[t, :] = bf16( sum_k float(c3[t, k, :]) ).
+ */
+int chitu_hip_moe_gemm1_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
+                            const float* w1_scale, const int32_t* sorted_token_ids,
+                            const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                            void* out_bf16, int64_t numel, int32_t topk, int64_t N, int64_t K,
+                            int64_t max_mblocks, void* stream);
+int chitu_hip_moe_silu_mul_quant_fp8(const void* c1_bf16, int64_t rows, int64_t inter_size,
+                                     float eps, void* q_fp8, float* scales, void* stream);
+int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, const void* w2_fp8,
+                            const float* w2_scale, const int32_t* sorted_token_ids,
+                            const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                            const void* topk_weights, int weights_dtype,
+                            int32_t mul_routed_weight, void* out_bf16, int64_t numel, int64_t N,
+                            int64_t inter_size, int64_t max_mblocks, void* stream);
+int chitu_hip_moe_sum(const void* c3_bf16, void* out_bf16, int64_t tokens, int32_t topk, int64_t N,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif
