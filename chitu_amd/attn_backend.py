@@ -1,0 +1,151 @@
+"""Attention backend for gfx950 behind the reference's `AttnBackend` interface.
+
+Reference (read-only): chitu/attn_backend.py -- interface AttnBackend:24-164,
+TritonAttnBackend:687-774 (the MLA decode path the reference runs on non-NVIDIA devices),
+FlashMLABackend:504-572 / FlashInferBackend:575-684 (graph-capturable third-party paths).
+`HipAttnBackend` implements `prepare_metadata_for_decode`, `mla_attn_with_kvcache` and
+`attn_with_kvcache(block_table=...)` with hand-written HIP kernels; the host side only sizes
+the KV split count from the batch (graph-static) and keeps a persistent scratch buffer.
+"""
+
+import ctypes
+from typing import Optional, Union
+
+import torch
+
+from . import _lib, workspace
+from ._lib import check, f32, i32, i64, ptr, require_cuda, stream_ptr
+from .ops import append_to_paged_kv_cache
+
+__all__ = ["AttnBackend", "HipAttnBackend"]
+
+
+class AttnBackend:
+    """Interface (chitu/attn_backend.py:24-164)."""
+
+    def prepare_metadata_for_decode(self, *args, **kwargs):
+        pass
+
+    def attn_varlen_func(self, *args, **kwargs):
+        raise NotImplementedError()
+
+    def attn_with_kvcache(self, *args, **kwargs):
+        raise NotImplementedError()
+
+    def mla_attn_with_kvcache(self, *args, **kwargs):
+        raise NotImplementedError()
+
+
+def _num_cus():
+    try:
+        return torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    except Exception:
+        return 256
+
+
+def choose_num_splits(batch: int, head_blocks: int, max_tiles: int, target_wgs: Optional[int] = None) -> int:
+    """KV splits so that batch*head_blocks*splits workgroups fill the chip (2 per CU), never more
+    splits than 64-token tiles.  Depends only on graph-static quantities (batch, max context)."""
+    if target_wgs is None:
+        target_wgs = 2 * _num_cus()
+    per = max(1, batch * head_blocks)
+    s = max(1, min(max_tiles, (target_wgs + per - 1) // per))
+    return min(s, 64)
+
+
+class HipAttnBackend(AttnBackend):
+    """MLA absorb-mode paged decode (+ GQA paged decode) on hand-written HIP kernels.
+
+    Construction mirrors TritonAttnBackend (attn_backend.py:688-696) but takes the model
+    dimensions explicitly instead of reading hydra globals.
+    """
+
+    def __init__(self, local_n_heads: int = 16, kv_lora_rank: int = 512, qk_rope_head_dim: int = 64,
+                 qk_nope_head_dim: int = 128, max_seq_len: int = 4096):
+        self.local_n_heads = local_n_heads
+        self.kv_lora_rank = kv_lora_rank
+        self.qk_rope_head_dim = qk_rope_head_dim
+        self.qk_nope_head_dim = qk_nope_head_dim
+        self.max_seq_len = max_seq_len
+        self.block_size = None
+        self.num_splits = None
+
+    def prepare_metadata_for_decode(
+        self,
+        cache_seqlens_excl_this_decode,
+        cache_seqlens_incl_this_decode,
+        block_table,
+        block_size,
+        softmax_scale=None,
+    ):
+        """Runs OUTSIDE the captured graph (model.py:540 -> model_deepseek_v3.py:1339).  Unlike
+        FlashInfer's prepare (attn_backend.py:620-637: Python loops with .item() syncs) this does
+        no device work: the split count depends only on the batch size and the table width."""
+        self.block_size = block_size
+        bs = int(cache_seqlens_incl_this_decode.shape[0])
+        max_tiles = max(1, (int(block_table.shape[1]) * int(block_size) + 63) // 64)
+        self.num_splits = choose_num_splits(bs, (self.local_n_heads + 15) // 16, max_tiles)
+
+    def mla_decode(self, q_nope, q_pe, kv_cache, cache_seqlens_incl, block_table, softmax_scale,
+                   num_splits: Optional[int] = None, out: Optional[torch.Tensor] = None):
+        """softmax(scale * (q_nope.c + q_pe.k_pe)) . c over the paged latent cache; no append."""
+        require_cuda(q_nope, q_pe, kv_cache, cache_seqlens_incl, block_table)
+        assert kv_cache.ndim == 3 and kv_cache.is_contiguous()  # (num_blocks, block_size, dim)
+        assert kv_cache.dtype == torch.bfloat16 and q_nope.dtype == torch.bfloat16 and q_pe.dtype == torch.bfloat16
+        assert block_table.dtype == torch.int32 and cache_seqlens_incl.dtype == torch.int32
+        assert block_table.stride(1) == 1 and cache_seqlens_incl.is_contiguous()
+        B, H, C = q_nope.shape
+        R = q_pe.shape[-1]
+        assert kv_cache.shape[-1] == C + R
+
+        def ok(t):
+            return t.stride(-1) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
+
+        if not ok(q_nope):
+            q_nope = q_nope.contiguous()
+        if not ok(q_pe):
+            q_pe = q_pe.contiguous()
+        if num_splits is None:
+            max_tiles = max(1, (int(block_table.shape[1]) * int(kv_cache.shape[1]) + 63) // 64)
+            num_splits = self.num_splits or choose_num_splits(B, (H + 15) // 16, max_tiles)
+        if out is None:
+            out = torch.empty(B, H, C, dtype=torch.bfloat16, device=q_nope.device)
+        need = B * H * num_splits * (C + 1) * 4 if num_splits > 1 else 0
+        ws = workspace.get(max(need, 1), q_nope.device, "mla")
+        check(
+            _lib.lib().chitu_hip_mla_decode(
+                ptr(q_nope), i64(q_nope.stride(0)), i64(q_nope.stride(1)), ptr(q_pe), i64(q_pe.stride(0)),
+                i64(q_pe.stride(1)), ptr(kv_cache), i64(kv_cache.shape[0]), i32(kv_cache.shape[1]),
+                ptr(block_table), i32(block_table.stride(0)), ptr(cache_seqlens_incl), f32(softmax_scale),
+                ptr(out), i32(B), i32(H), i32(C), i32(R), i32(num_splits), ptr(ws), i64(ws.numel()),
+                stream_ptr(),
+            ),
+            "mla_decode",
+        )
+        return out
+
+    def mla_attn_with_kvcache(
+        self,
+        q_nope,
+        q_pe,
+        kv_cache,
+        kv,
+        cache_seqlens_excl_this_decode: Union[(int, torch.Tensor)],
+        cache_seqlens_incl_this_decode: Union[(int, torch.Tensor)],
+        block_table: torch.Tensor,
+        causal=True,
+        window_size=(-1, -1),  # -1 means infinite context window
+        softcap=0.0,  # 0.0 means deactivated
+        softmax_scale=None,
+    ):
+        """Same contract as TritonAttnBackend.mla_attn_with_kvcache (attn_backend.py:707-774):
+        append this token's [kv_c | k_pe] row to its page, then attend over the sequence.
+        Returns [B, 1, H, kv_lora_rank]."""
+        assert window_size == (-1, -1) and softcap == 0.0, "not used by the MLA decode path"
+        if softmax_scale is None:
+            # the reference's default here is accidentally a 1-tuple (attn_backend.py:756-758)
+            softmax_scale = 1.0 / ((self.qk_rope_head_dim + self.qk_nope_head_dim) ** 0.5)
+        append_to_paged_kv_cache(kv_cache, block_table, kv, cache_seqlens_excl_this_decode)
+        B = q_nope.shape[0]
+        o = self.mla_decode(q_nope, q_pe, kv_cache, cache_seqlens_incl_this_decode, block_table, float(softmax_scale))
+        return o.view(B, 1, q_nope.shape[1], -1)

@@ -1,0 +1,181 @@
+"""Paged KV cache manager: host page allocator + persistent device buffers.
+
+Mirrors chitu/cache_manager.py:12-225 (PagedKVCacheManager): same methods, same buffers
+(`curr_seq_lens_gpu_{excl,incl}_this_decode`, `gpu_block_table_buffer`, `paged_kv_cache` /
+`paged_k_cache`+`paged_v_cache`).  Differences, all host-side: the free list is a deque instead
+of `list(set)[0]` (the reference's own TODO, :69), per-step H2D traffic is two small pinned
+copies instead of one per request, and no Timers (their cuda syncs, global_vars.py:132,140,
+would serialise the decode loop).  Device memory layout is unchanged, so the HIP kernels see
+exactly the reference's cache.
+"""
+
+from collections import deque
+from logging import getLogger
+
+import torch
+
+logger = getLogger(__name__)
+_BLOCK_SIZE = 512
+_MAX_SEQ_LEN = 2048
+
+
+class PagedKVCacheManager:
+    def __init__(
+        self,
+        begin_layer_id,
+        end_layer_id,
+        num_hot_req=16,
+        block_size=_BLOCK_SIZE,
+        max_seq_len=_MAX_SEQ_LEN,
+        device="cuda",
+        *,
+        k_shape_per_sample=None,
+        v_shape_per_sample=None,
+        kv_shape_per_sample=None,
+        n_local_kv_heads=None,
+        head_dim=None,
+        dtype=None,
+    ):
+        self.max_blocks_per_req = max_seq_len // block_size + 1
+        self.num_blocks = self.max_blocks_per_req * num_hot_req
+        self.begin_layer_id = begin_layer_id
+        self.end_layer_id = end_layer_id
+        self.num_layers = end_layer_id - begin_layer_id
+        self.k_shape_per_sample = (
+            k_shape_per_sample if k_shape_per_sample is not None else (n_local_kv_heads, head_dim)
+        )
+        self.v_shape_per_sample = (
+            v_shape_per_sample if v_shape_per_sample is not None else (n_local_kv_heads, head_dim)
+        )
+        self.kv_shape_per_sample = kv_shape_per_sample
+        self.block_size = block_size
+        self.max_seq_len = max_seq_len
+        self.device = torch.device(device)
+        self.gpu_block_table = None
+        dtype = dtype or torch.get_default_dtype()
+
+        self.seq_lens = {}
+        self.block_table = {}  # req_id -> [block ids]
+        self.curr_seq_lens = []
+        self.curr_seq_lens_gpu_excl_this_decode = torch.zeros(num_hot_req, dtype=torch.int32, device=self.device)
+        self.curr_seq_lens_gpu_incl_this_decode = torch.zeros(num_hot_req, dtype=torch.int32, device=self.device)
+        self.gpu_block_table_buffer = torch.zeros(
+            (num_hot_req, self.max_blocks_per_req), dtype=torch.int32, device=self.device
+        )
+        pin = self.device.type == "cuda"
+        self._host_lens = torch.zeros(2, num_hot_req, dtype=torch.int32, pin_memory=pin)
+        self._host_table = torch.zeros((num_hot_req, self.max_blocks_per_req), dtype=torch.int32, pin_memory=pin)
+        self.free_blocks = deque(range(self.num_blocks))
+        if self.kv_shape_per_sample is not None:
+            self.paged_kv_cache = torch.zeros(
+                (self.num_layers, self.num_blocks, block_size) + tuple(self.kv_shape_per_sample),
+                device=device, dtype=dtype,
+            )
+        else:
+            self.paged_k_cache = torch.zeros(
+                (self.num_layers, self.num_blocks, block_size) + tuple(self.k_shape_per_sample),
+                device=device, dtype=dtype,
+            )
+            self.paged_v_cache = torch.zeros(
+                (self.num_layers, self.num_blocks, block_size) + tuple(self.v_shape_per_sample),
+                device=device, dtype=dtype,
+            )
+
+    def get_block_size(self):
+        return self.block_size
+
+    # ---- prefill: write whole pages (chitu/cache_manager.py:93-142)
+    def finalize_cache_bylayer_prefill(self, xk, xv, req_ids, varlen, layer_id):
+        for idx, req_id in enumerate(req_ids):
+            n_prepared = (varlen.cpu_lens[idx] + self.block_size - 1) // self.block_size
+            if layer_id == self.begin_layer_id:
+                self.seq_lens[req_id] = varlen.cpu_lens[idx]
+                self.block_table[req_id] = [self.get_free_block() for _ in range(n_prepared)]
+            block_ids = self.block_table[req_id]
+            start_pos = varlen.cpu_prefix_lens[idx]
+            end_pos = varlen.cpu_prefix_lens[idx + 1]
+            li = layer_id - self.begin_layer_id
+            for chunk_id in range(n_prepared):
+                blk = block_ids[chunk_id]
+                n = min(self.block_size, end_pos - start_pos)
+                if self.kv_shape_per_sample is not None:
+                    self.paged_kv_cache[li][blk][:n] = xk[start_pos : start_pos + n]
+                else:
+                    self.paged_k_cache[li][blk][:n] = xk[start_pos : start_pos + n]
+                    self.paged_v_cache[li][blk][:n] = xv[start_pos : start_pos + n]
+                start_pos += n
+
+    def register_sequence(self, req_id, length):
+        """Allocate pages for a sequence of `length` cached tokens without writing data
+        (synthetic benchmarks / tests; prefill normally does this)."""
+        self.seq_lens[req_id] = length
+        n = (length + self.block_size - 1) // self.block_size
+        self.block_table[req_id] = [self.get_free_block() for _ in range(n)]
+
+    def finalize_cache_all_prefill(self, req_ids, varlen):
+        self.curr_varlens = None
+        self.curr_req_ids = None
+
+    def prepare_cache_decode(self, req_ids):
+        n = len(req_ids)
+        seq_lens = [self.seq_lens[r] for r in req_ids]
+        self.curr_seq_lens = seq_lens
+        self._host_lens[0, :n] = torch.tensor(seq_lens, dtype=torch.int32)
+        self._host_lens[1, :n] = self._host_lens[0, :n] + 1
+        self.curr_seq_lens_gpu_excl_this_decode[:n].copy_(self._host_lens[0, :n], non_blocking=True)
+        self.curr_seq_lens_gpu_incl_this_decode[:n].copy_(self._host_lens[1, :n], non_blocking=True)
+
+    def get_free_block(self):
+        if not self.free_blocks:
+            raise Exception("No more free blocks.")  # same behaviour as cache_manager.py:163-164
+        return self.free_blocks.popleft()
+
+    def get_gpu_block_table(self):
+        return self.gpu_block_table
+
+    def get_gpu_seq_lens_excl_this_decode(self):
+        return self.curr_seq_lens_gpu_excl_this_decode[: len(self.curr_seq_lens)]
+
+    def get_gpu_seq_lens_incl_this_decode(self):
+        return self.curr_seq_lens_gpu_incl_this_decode[: len(self.curr_seq_lens)]
+
+    def get_paged_kv_cache(self, layer_id):
+        if self.kv_shape_per_sample is not None:
+            return self.paged_kv_cache[layer_id - self.begin_layer_id]
+        return (
+            self.paged_k_cache[layer_id - self.begin_layer_id],
+            self.paged_v_cache[layer_id - self.begin_layer_id],
+        )
+
+    def free_req_cache_blocks(self, req_id):
+        for block in self.block_table[req_id]:
+            self.free_blocks.append(block)
+        del self.block_table[req_id]
+
+    def prepare_block_table_for_decode(self, req_ids):
+        """Make room for the token this decode step appends, then refresh the device table
+        (chitu/cache_manager.py:196-209).  Page allocation stays on the host, outside the graph."""
+        n = len(req_ids)
+        for req_id in req_ids:
+            if self.seq_lens[req_id] % self.block_size == 0:
+                self.block_table[req_id].append(self.get_free_block())
+        self._host_table[:n].zero_()
+        for idx, req_id in enumerate(req_ids):
+            ids = self.block_table[req_id]
+            self._host_table[idx, : len(ids)] = torch.tensor(ids, dtype=torch.int32)
+        self.gpu_block_table_buffer[:n].copy_(self._host_table[:n], non_blocking=True)
+        self.gpu_block_table = self.gpu_block_table_buffer[:n]
+
+    def finalize_cache_single_decode(self, req_ids):
+        for req_id in req_ids:
+            self.seq_lens[req_id] = self.seq_lens[req_id] + 1
+        self.curr_varlens = None
+        self.curr_req_ids = None
+
+    def finalize_cache_all_decode(self, req_id):
+        assert req_id in self.seq_lens
+        assert req_id in self.block_table
+        del self.seq_lens[req_id]
+        self.free_req_cache_blocks(req_id)
+        self.curr_varlens = None
+        self.curr_req_ids = None

@@ -1,0 +1,265 @@
+// MLA (absorb mode) paged decode attention for gfx950: split-KV flash decoding in latent space.
+//
+// Replaces (reference, read-only):
+//   chitu/triton_decode_attention.py:20-130   _mla_attn_kernel      (stage 1, fixed 4 splits)
+//   chitu/triton_decode_attention.py:185-232  _mla_softmax_reducev  (stage 2, LSE merge)
+//   chitu/attn_backend.py:707-774             TritonAttnBackend.mla_attn_with_kvcache
+//   (and the third-party flash_mla / flashinfer calls at attn_backend.py:561-571, 678-684)
+//
+//   out[b,h,:] = softmax_t( scale * (q_nope[b,h,:] . c[t,:512] + q_pe[b,h,:] . c[t,512:]) ) . c[t,:512]
+// over the first seqlens[b] cached tokens; V *is* the 512-wide latent (the MLA trick), so a KV
+// tile is staged in LDS once and used for both products.
+//
+// Design.  One workgroup (4 waves) = 16 heads x one KV split of one sequence.  Per 64-token
+// tile: coalesced 16-B global loads of the 64 x 576 bf16 rows into LDS (row stride padded to
+// 1168 B => conflict-free ds_read_b128 for the K fragments); QK^T: each wave owns 16 tokens,
+// 18 x v_mfma_f32_16x16x32_bf16 with Q (A operand) held in registers for the whole kernel;
+// online softmax in fp32 with 16-lane shuffles + a 4-wave LDS exchange; P -> bf16 -> LDS;
+// PV: each wave owns 128 latent columns, V^T fragments come straight from the row-major tile
+// with ds_read_b64_tr_b16 (gfx950 transpose read), 16 MFMAs per wave per tile.  Splits are
+// sized on the host from the batch only (graph-static); a split's token range is derived from
+// the device-side sequence length, empty splits publish LSE = -inf.  Stage 2 merges splits.
+#include "common.h"
+
+namespace chitu {
+
+constexpr int kC = 512;        // kv_lora_rank (latent / V width)
+constexpr int kR = 64;         // qk_rope_head_dim
+constexpr int kD = kC + kR;    // cached row width (576)
+constexpr int kTile = 64;      // KV tokens per tile
+constexpr int kRowB = 1168;    // LDS row stride in bytes (1152 + 16 pad)
+constexpr int kPStride = 72;   // P row stride in bf16 elements (64 + 8 pad)
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// grid (num_splits, batch, heads/16); block 256.
+__global__ __launch_bounds__(256, 2) void mla_decode_kernel(
+    const bf16_t* __restrict__ q_nope, int64_t qn_sb, int64_t qn_sh, const bf16_t* __restrict__ q_pe,
+    int64_t qp_sb, int64_t qp_sh, const bf16_t* __restrict__ cache, int64_t num_pages, int page_size,
+    const int32_t* __restrict__ block_table, int table_stride, const int32_t* __restrict__ seqlens,
+    float scale, float* __restrict__ part_o, float* __restrict__ part_lse, bf16_t* __restrict__ out,
+    int H, int num_splits) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* kv_lds = smem;                                             // [64][1168]
+    bf16_t* p_lds = reinterpret_cast<bf16_t*>(smem + kTile * kRowB);   // [16][72]
+    float* red_max = reinterpret_cast<float*>(smem + kTile * kRowB + 16 * kPStride * 2);  // [4][16]
+    float* red_sum = red_max + 64;                                                     // [4][16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int split = blockIdx.x, b = blockIdx.y, hb = blockIdx.z;
+    const int L = seqlens[b];
+    const int n_tiles = (L + kTile - 1) / kTile;
+    const int tile0 = (int)((long)n_tiles * split / num_splits);
+    const int tile1 = (int)((long)n_tiles * (split + 1) / num_splits);
+    const int h0 = hb * 16;
+
+    // Q fragments (A operand): lane holds Q[head h0+j][kk*32 + g*8 .. +8], kk = 0..17
+    s16x8 qf[18];
+    {
+        const int h = min(h0 + j, H - 1);
+        const bf16_t* qn = q_nope + b * qn_sb + h * qn_sh + g * 8;
+        const bf16_t* qp = q_pe + b * qp_sb + h * qp_sh + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) qf[kk] = *reinterpret_cast<const s16x8*>(qn + kk * 32);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) qf[16 + kk] = *reinterpret_cast<const s16x8*>(qp + kk * 32);
+    }
+
+    f32x4 o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m_run[r] = -INFINITY;
+        l_run[r] = 0.f;
+    }
+
+    for (int tile = tile0; tile < tile1; ++tile) {
+        const int t0 = tile * kTile;
+        const int valid = min(kTile, L - t0);
+        int64_t page = block_table[(int64_t)b * table_stride + t0 / page_size];
+        if (page < 0 || page >= num_pages) page = 0;  // corrupt table: stay in bounds
+        const bf16_t* src = cache + (page * page_size + (t0 % page_size)) * (int64_t)kD;
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage the tile: 64 rows x 72 chunks of 16 B
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / 72, col = c % 72;
+            i32x4 v = i32x4{0, 0, 0, 0};
+            if (row < valid) v = *reinterpret_cast<const i32x4*>(src + row * kD + col * 8);
+            *reinterpret_cast<i32x4*>(kv_lds + row * kRowB + col * 16) = v;
+        }
+        __syncthreads();
+
+        // ---- S = Q K^T for this wave's 16 tokens
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const uint8_t* krow = kv_lds + (wave * 16 + j) * kRowB + g * 16;
+#pragma unroll
+            for (int kk = 0; kk < 18; ++kk) {
+                const s16x8 kf = *reinterpret_cast<const s16x8*>(krow + kk * 64);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, s, 0, 0, 0);
+            }
+        }
+        // lane holds S[head 4g+r][token wave*16+j]
+        const bool tok_ok = (wave * 16 + j) < valid;
+        float mx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[r] = tok_ok ? s[r] * scale : -INFINITY;
+            mx[r] = s[r];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) mx[r] = __builtin_fmaxf(mx[r], __shfl_xor(mx[r], off, 64));
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red_max[wave * 16 + g * 4 + r] = mx[r];
+        }
+        __syncthreads();
+        float alpha[4], psum[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hh = g * 4 + r;
+            const float mt = __builtin_fmaxf(__builtin_fmaxf(red_max[hh], red_max[16 + hh]),
+                                             __builtin_fmaxf(red_max[32 + hh], red_max[48 + hh]));
+            const float m_new = __builtin_fmaxf(m_run[r], mt);  // finite: token t0 is always valid
+            alpha[r] = __expf(m_run[r] - m_new);
+            m_run[r] = m_new;
+            const float p = __expf(s[r] - m_new);
+            psum[r] = p;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) psum[r] += __shfl_xor(psum[r], off, 64);
+            p_lds[hh * kPStride + wave * 16 + j] = f32_to_bf16(p);
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red_sum[wave * 16 + g * 4 + r] = psum[r];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[c][r] *= alpha[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hh = g * 4 + r;
+            l_run[r] = l_run[r] * alpha[r] + (red_sum[hh] + red_sum[16 + hh] + red_sum[32 + hh] + red_sum[48 + hh]);
+        }
+
+        // ---- O += P V : this wave owns latent columns [wave*128, wave*128+128)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const s16x8 pf = *reinterpret_cast<const s16x8*>(p_lds + j * kPStride + ks * 32 + g * 8);
+            // transpose-read addressing: lane t of a 16-lane group supplies key row t/4, column chunk t%4
+            const uint8_t* vbase = kv_lds + (ks * 32 + g * 8 + (j >> 2)) * kRowB + (wave * 128 + (j & 3) * 4) * 2;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + c * 32));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + 4 * kRowB + c * 32));
+                s16x8 vf;
+                vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+                vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[c], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds O[head 4g+r][col wave*128 + c*16 + j]
+    const bool empty = tile1 <= tile0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = h0 + g * 4 + r;
+        if (h >= H) continue;
+        const float inv = empty ? 0.f : 1.0f / l_run[r];
+        if (num_splits == 1) {
+            bf16_t* dst = out + ((int64_t)b * H + h) * kC + wave * 128 + j;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dst[c * 16] = f32_to_bf16(o[c][r] * inv);
+        } else {
+            float* dst = part_o + (((int64_t)b * H + h) * num_splits + split) * kC + wave * 128 + j;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) dst[c * 16] = o[c][r] * inv;
+            if (wave == 0 && j == 0)
+                part_lse[((int64_t)b * H + h) * num_splits + split] = empty ? -INFINITY : m_run[r] + __logf(l_run[r]);
+        }
+    }
+}
+
+// Stage 2: out[b,h,:] = sum_s w_s * part_o[b,h,s,:] / sum_s w_s, w_s = exp(lse_s - max lse).
+__global__ __launch_bounds__(128) void mla_merge_kernel(const float* __restrict__ part_o,
+                                                        const float* __restrict__ part_lse,
+                                                        bf16_t* __restrict__ out, int num_splits) {
+    const int64_t bh = blockIdx.x;
+    const float* lse = part_lse + bh * num_splits;
+    float m = -INFINITY;
+    for (int s = 0; s < num_splits; ++s) m = __builtin_fmaxf(m, lse[s]);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float wsum = 0.f;
+    for (int s = 0; s < num_splits; ++s) {
+        const float l = lse[s];
+        if (l == -INFINITY) continue;
+        const float w = __expf(l - m);
+        wsum += w;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + (bh * num_splits + s) * kC + threadIdx.x * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += w * v[i];
+    }
+    const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+    i32x2 o2;
+    o2[0] = (int)((uint32_t)f32_to_bf16(acc[0] * inv) | ((uint32_t)f32_to_bf16(acc[1] * inv) << 16));
+    o2[1] = (int)((uint32_t)f32_to_bf16(acc[2] * inv) | ((uint32_t)f32_to_bf16(acc[3] * inv) << 16));
+    *reinterpret_cast<i32x2*>(out + bh * kC + threadIdx.x * 4) = o2;
+}
+
+}  // namespace chitu
+
+extern "C" int chitu_hip_mla_decode_workspace_bytes(int32_t batch, int32_t heads, int32_t num_splits,
+                                                    int64_t* bytes) {
+    if (!bytes || batch < 0 || heads < 1 || num_splits < 1) return CHITU_ERR_BAD_ARG;
+    *bytes = (int64_t)batch * heads * num_splits * (chitu::kC + 1) * 4;
+    return CHITU_OK;
+}
+
+extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int64_t qn_stride_h,
+                                    const void* q_pe, int64_t qp_stride_b, int64_t qp_stride_h,
+                                    const void* kv_cache, int64_t num_pages, int32_t page_size,
+                                    const int32_t* block_table, int32_t table_stride,
+                                    const int32_t* seqlens, float softmax_scale, void* out_bf16,
+                                    int32_t batch, int32_t heads, int32_t kv_lora_rank,
+                                    int32_t rope_dim, int32_t num_splits, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(q_nope && q_pe && kv_cache && block_table && seqlens && out_bf16);
+    CHITU_REQUIRE(batch >= 0 && heads >= 1 && num_pages >= 1 && table_stride >= 1);
+    if (kv_lora_rank != kC || rope_dim != kR) return CHITU_ERR_UNSUPPORTED;
+    if (page_size < kTile || page_size % kTile != 0) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(num_splits >= 1 && num_splits <= 256);
+    if (batch == 0) return CHITU_OK;
+    float* part_o = nullptr;
+    float* part_lse = nullptr;
+    if (num_splits > 1) {
+        const int64_t need = (int64_t)batch * heads * num_splits * (kC + 1) * 4;
+        CHITU_REQUIRE(workspace && workspace_bytes >= need);
+        part_o = (float*)workspace;
+        part_lse = part_o + (int64_t)batch * heads * num_splits * kC;
+    }
+    const size_t lds = kTile * kRowB + 16 * kPStride * 2 + 2 * 64 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)mla_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)num_splits, (unsigned)batch, (unsigned)((heads + 15) / 16));
+    hipLaunchKernelGGL(mla_decode_kernel, grid, dim3(256), lds, st, (const bf16_t*)q_nope, qn_stride_b,
+                       qn_stride_h, (const bf16_t*)q_pe, qp_stride_b, qp_stride_h, (const bf16_t*)kv_cache,
+                       num_pages, (int)page_size, block_table, (int)table_stride, seqlens, softmax_scale,
+                       part_o, part_lse, (bf16_t*)out_bf16, (int)heads, (int)num_splits);
+    if (num_splits > 1)
+        hipLaunchKernelGGL(mla_merge_kernel, dim3((unsigned)(batch * heads)), dim3(128), 0, st, part_o,
+                           part_lse, (bf16_t*)out_bf16, (int)num_splits);
+    CHITU_RETURN_LAUNCH_STATUS();
+}

@@ -138,6 +138,28 @@ int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, const void*
 int chitu_hip_moe_sum(const void* c3_bf16, void* out_bf16, int64_t tokens, int32_t topk, int64_t N,
                       void* stream);
 
+/* ---- MLA absorb-mode paged decode attention ------------------------------------------------
+ * Replaces mla_decode (chitu/triton_decode_attention.py:259-290: _mla_attn_kernel :20-130 +
+ * _mla_softmax_reducev_kernel :185-232) as called from TritonAttnBackend.mla_attn_with_kvcache
+ * (chitu/attn_backend.py:707-774), and the third-party flash_mla / flashinfer MLA calls
+ * (attn_backend.py:561-571, 678-684):
+ *   out[b,h,:] = softmax_t(scale * (q_nope[b,h,:].c[t,:C] + q_pe[b,h,:].c[t,C:])) . c[t,:C]
+ *   q_nope [batch, heads, C=512] bf16 (element strides given, multiples of 8); q_pe [batch, heads, R=64];
+ *   kv_cache [num_pages, page_size, C+R] bf16 (one layer), page_size % 64 == 0;
+ *   block_table [batch, table_stride] i32; seqlens [batch] i32 = tokens to attend (incl. the
+ *   row appended this step -- append is chitu_hip_append_paged_kv); out [batch, heads, C] bf16.
+ *   num_splits: KV splits per sequence (graph-static; any value >= 1 gives the same result up to
+ *   fp32 rounding).  workspace: >= chitu_hip_mla_decode_workspace_bytes when num_splits > 1. */
+int chitu_hip_mla_decode_workspace_bytes(int32_t batch, int32_t heads, int32_t num_splits,
+                                         int64_t* bytes);
+int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int64_t qn_stride_h,
+                         const void* q_pe, int64_t qp_stride_b, int64_t qp_stride_h,
+                         const void* kv_cache, int64_t num_pages, int32_t page_size,
+                         const int32_t* block_table, int32_t table_stride, const int32_t* seqlens,
+                         float softmax_scale, void* out_bf16, int32_t batch, int32_t heads,
+                         int32_t kv_lora_rank, int32_t rope_dim, int32_t num_splits,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
