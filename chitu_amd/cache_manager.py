@@ -3,7 +3,7 @@
 Mirrors chitu/cache_manager.py:12-225 (PagedKVCacheManager): same methods, same buffers
 (`curr_seq_lens_gpu_{excl,incl}_this_decode`, `gpu_block_table_buffer`, `paged_kv_cache` /
 `paged_k_cache`+`paged_v_cache`).  Differences, all host-side: the free list is a deque instead
-of `list(set)[0]` (the reference's own TODO, :69), per-step H2D traffic is two small pinned
+of `list(set)[0]` (the reference's own TODO, :69), per-step H2D traffic is three small
 copies instead of one per request, and no Timers (their cuda syncs, global_vars.py:132,140,
 would serialise the decode loop).  Device memory layout is unchanged, so the HIP kernels see
 exactly the reference's cache.
@@ -62,9 +62,11 @@ class PagedKVCacheManager:
         self.gpu_block_table_buffer = torch.zeros(
             (num_hot_req, self.max_blocks_per_req), dtype=torch.int32, device=self.device
         )
-        pin = self.device.type == "cuda"
-        self._host_lens = torch.zeros(2, num_hot_req, dtype=torch.int32, pin_memory=pin)
-        self._host_table = torch.zeros((num_hot_req, self.max_blocks_per_req), dtype=torch.int32, pin_memory=pin)
+        # Pageable host staging: copy_() from pageable memory returns only after the runtime has
+        # staged the bytes, so these buffers can be rewritten for the next step while the GPU is
+        # still several (graph-replayed) steps behind the host.
+        self._host_lens = torch.zeros(2, num_hot_req, dtype=torch.int32)
+        self._host_table = torch.zeros((num_hot_req, self.max_blocks_per_req), dtype=torch.int32)
         self.free_blocks = deque(range(self.num_blocks))
         if self.kv_shape_per_sample is not None:
             self.paged_kv_cache = torch.zeros(
@@ -122,8 +124,8 @@ class PagedKVCacheManager:
         self.curr_seq_lens = seq_lens
         self._host_lens[0, :n] = torch.tensor(seq_lens, dtype=torch.int32)
         self._host_lens[1, :n] = self._host_lens[0, :n] + 1
-        self.curr_seq_lens_gpu_excl_this_decode[:n].copy_(self._host_lens[0, :n], non_blocking=True)
-        self.curr_seq_lens_gpu_incl_this_decode[:n].copy_(self._host_lens[1, :n], non_blocking=True)
+        self.curr_seq_lens_gpu_excl_this_decode[:n].copy_(self._host_lens[0, :n])
+        self.curr_seq_lens_gpu_incl_this_decode[:n].copy_(self._host_lens[1, :n])
 
     def get_free_block(self):
         if not self.free_blocks:
@@ -163,7 +165,7 @@ class PagedKVCacheManager:
         for idx, req_id in enumerate(req_ids):
             ids = self.block_table[req_id]
             self._host_table[idx, : len(ids)] = torch.tensor(ids, dtype=torch.int32)
-        self.gpu_block_table_buffer[:n].copy_(self._host_table[:n], non_blocking=True)
+        self.gpu_block_table_buffer[:n].copy_(self._host_table[:n])
         self.gpu_block_table = self.gpu_block_table_buffer[:n]
 
     def finalize_cache_single_decode(self, req_ids):

@@ -1,0 +1,88 @@
+// Per-head projections of MLA "absorb" mode with the FP8 wkv_b de-quantised on the fly.
+//
+// Replaces (reference, read-only) -- executed every layer of every decode step there:
+//   chitu/models/model_deepseek_v3.py:511-531  weight_dequant(wkv_b) -> bf16 tensor in HBM, then
+//                                              einsum("shd,hdc->shc", q_nope, wkv_b[:, :128])
+//   chitu/models/model_deepseek_v3.py:697      einsum("bshc,hdc->bshd", o, wkv_b[:, -128:])
+//   chitu/triton_kernels.py:217-247            weight_dequant_deepseek_v3_kernel (K8)
+// i.e. out[b,h,n] = sum_k x[b,h,k] * bf16(float(W[h,n,k]) * s[block]),  fp32 accumulate, bf16 out.
+// The dequantised value is rounded to bf16 exactly as the reference's materialised tensor is,
+// but it never leaves registers: 2 MB of fp8 is read instead of 2 MB read + 4 MB written + 4 MB
+// re-read per layer.  W is [H, N, K] (head stride given) with K contiguous (the contraction index); for the
+// W_UK half the host keeps a transposed fp8 copy (layout-only preprocessing, 1 MB per layer).
+// One wave per (16 output columns, head, 16 tokens); weights are the MFMA A operand so a lane
+// ends with 4 consecutive output columns of one token.
+#include "common.h"
+
+namespace chitu {
+
+__device__ __forceinline__ s16x8 dequant8_bf16(uint32_t w0, uint32_t w1, float s) {
+    s16x8 r;
+    r[0] = (short)f32_to_bf16(fp8_to_f32<0>(w0) * s);
+    r[1] = (short)f32_to_bf16(fp8_to_f32<1>(w0) * s);
+    r[2] = (short)f32_to_bf16(fp8_to_f32<2>(w0) * s);
+    r[3] = (short)f32_to_bf16(fp8_to_f32<3>(w0) * s);
+    r[4] = (short)f32_to_bf16(fp8_to_f32<0>(w1) * s);
+    r[5] = (short)f32_to_bf16(fp8_to_f32<1>(w1) * s);
+    r[6] = (short)f32_to_bf16(fp8_to_f32<2>(w1) * s);
+    r[7] = (short)f32_to_bf16(fp8_to_f32<3>(w1) * s);
+    return r;
+}
+
+// grid (N/16, H, ceil(batch/16)); block 64.
+__global__ __launch_bounds__(64) void absorb_bmm_kernel(
+    const bf16_t* __restrict__ x, int64_t x_sb, int64_t x_sh, const fp8_t* __restrict__ W, int64_t w_sh,
+    const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sn, int64_t s_sk,
+    bf16_t* __restrict__ out, int64_t o_sb, int64_t o_sh, int batch, int N, int K) {
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16, h = blockIdx.y, m0 = blockIdx.z * 16;
+    const int m = min(m0 + j, batch - 1);
+    const fp8_t* wp = W + (int64_t)h * w_sh + (int64_t)min(n0 + j, N - 1) * K + g * 16;
+    const bf16_t* xp = x + m * x_sb + h * x_sh + g * 16;
+    const float* sp = scale + s_off + h * s_sh + (n0 >> 7) * s_sn;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const i32x4 w = *reinterpret_cast<const i32x4*>(wp + k0);
+        const float s = sp[(k0 >> 7) * s_sk];
+        const s16x8 wa = dequant8_bf16((uint32_t)w[0], (uint32_t)w[1], s);
+        const s16x8 wb = dequant8_bf16((uint32_t)w[2], (uint32_t)w[3], s);
+        const s16x8 xa = *reinterpret_cast<const s16x8*>(xp + k0);
+        const s16x8 xb = *reinterpret_cast<const s16x8*>(xp + k0 + 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xa, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc, 0, 0, 0);
+    }
+    if (m0 + j >= batch) return;
+    const int n = n0 + g * 4;
+    bf16_t* dst = out + (m0 + j) * o_sb + h * o_sh + n;
+    if (n + 3 < N) {
+        i32x2 o;
+        o[0] = (int)((uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16));
+        o[1] = (int)((uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16));
+        *reinterpret_cast<i32x2*>(dst) = o;
+    } else {
+        for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = f32_to_bf16(acc[r]);
+    }
+}
+
+}  // namespace chitu
+
+extern "C" int chitu_hip_absorb_bmm_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
+                                        const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                        int64_t scale_offset,
+                                        int64_t scale_stride_h, int64_t scale_stride_n,
+                                        int64_t scale_stride_k, void* out_bf16, int64_t out_stride_b,
+                                        int64_t out_stride_h, int32_t batch, int32_t heads, int32_t N,
+                                        int32_t K, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && w_fp8 && scale && out_bf16);
+    CHITU_REQUIRE(batch >= 0 && heads >= 1 && N >= 1 && K >= 64 && w_stride_h % 16 == 0);
+    if (K % 64 != 0) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(x_stride_b % 8 == 0 && x_stride_h % 8 == 0 && out_stride_b % 4 == 0 && out_stride_h % 4 == 0);
+    if (batch == 0) return CHITU_OK;
+    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)heads, (unsigned)((batch + 15) / 16));
+    hipLaunchKernelGGL(absorb_bmm_kernel, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+                       x_stride_b, x_stride_h, (const fp8_t*)w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
+                       scale_stride_n, scale_stride_k, (bf16_t*)out_bf16, out_stride_b, out_stride_h,
+                       (int)batch, (int)N, (int)K);
+    CHITU_RETURN_LAUNCH_STATUS();
+}

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_kernel(
 __global__ __launch_bounds__(256) void moe_silu_quant_kernel(const bf16_t* __restrict__ c1,
                                                              fp8_t* __restrict__ q,
                                                              float* __restrict__ s, int64_t rows,
-                                                             int I, float eps) {
+                                                             int I, float eps, int act_rule) {
     const int lane16 = threadIdx.x & 15;
     const int gpr = I >> 7;  // groups per row
     const int64_t n_groups = rows * gpr;
@@ -154,10 +154,18 @@ __global__ __launch_bounds__(256) void moe_silu_quant_kernel(const bf16_t* __res
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off, 64));
-        amax = __builtin_fmaxf(amax, eps);
+        // act_rule: act_quant_deepseek_v3 (no eps, no clamp; triton_kernels.py:210-212) for the
+        // dense / shared-expert MLP; otherwise per_token_group_quant_fp8 (fused_moe.py:701-703).
+        if (!act_rule) amax = __builtin_fmaxf(amax, eps);
         const float sc = amax / 448.0f;
-        const uint32_t lo = f32x2_to_fp8x2_sat(h[0] / sc, h[1] / sc) | (f32x2_to_fp8x2_sat(h[2] / sc, h[3] / sc) << 16);
-        const uint32_t hi = f32x2_to_fp8x2_sat(h[4] / sc, h[5] / sc) | (f32x2_to_fp8x2_sat(h[6] / sc, h[7] / sc) << 16);
+        uint32_t lo, hi;
+        if (act_rule) {
+            lo = f32x2_to_fp8x2(h[0] / sc, h[1] / sc) | (f32x2_to_fp8x2(h[2] / sc, h[3] / sc) << 16);
+            hi = f32x2_to_fp8x2(h[4] / sc, h[5] / sc) | (f32x2_to_fp8x2(h[6] / sc, h[7] / sc) << 16);
+        } else {
+            lo = f32x2_to_fp8x2_sat(h[0] / sc, h[1] / sc) | (f32x2_to_fp8x2_sat(h[2] / sc, h[3] / sc) << 16);
+            hi = f32x2_to_fp8x2_sat(h[4] / sc, h[5] / sc) | (f32x2_to_fp8x2_sat(h[6] / sc, h[7] / sc) << 16);
+        }
         i32x2 o;
         o[0] = (int)lo;
         o[1] = (int)hi;
@@ -370,10 +378,11 @@ extern "C" int chitu_hip_moe_gemm1_fp8(const void* a_fp8, const float* a_scale, 
 }
 
 extern "C" int chitu_hip_moe_silu_mul_quant_fp8(const void* c1_bf16, int64_t rows,
-                                                int64_t inter_size, float eps, void* q_fp8,
-                                                float* scales, void* stream) {
+                                                int64_t inter_size, int32_t quant_mode, float eps,
+                                                void* q_fp8, float* scales, void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(c1_bf16 && q_fp8 && scales && rows >= 0 && inter_size >= 128);
+    CHITU_REQUIRE(quant_mode == 0 || quant_mode == 1);
     if (inter_size % 128 != 0) return CHITU_ERR_UNSUPPORTED;
     if (rows == 0) return CHITU_OK;
     const int64_t lanes = rows * (inter_size / 128) * 16;
@@ -381,7 +390,7 @@ extern "C" int chitu_hip_moe_silu_mul_quant_fp8(const void* c1_bf16, int64_t row
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(moe_silu_quant_kernel, dim3((unsigned)blocks), dim3(256), 0,
                        (hipStream_t)stream, (const bf16_t*)c1_bf16, (fp8_t*)q_fp8, scales, rows,
-                       (int)inter_size, eps);
+                       (int)inter_size, eps, quant_mode == 0 ? 1 : 0);
     CHITU_RETURN_LAUNCH_STATUS();
 }
 

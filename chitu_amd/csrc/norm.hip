@@ -1,0 +1,133 @@
+// RMSNorm for the decode path, optionally fused with the FP8 block quantisation of its output.
+//
+// Replaces (reference, read-only):
+//   chitu/models/model.py:29-78   RMSNorm.forward -> F.rms_norm(x.to(compute_dtype), w, eps).to(dtype)
+//   + the act_quant_deepseek_v3 launch that follows it in linear_deepseek_v3
+//     (chitu/models/model_deepseek_v3.py:98-100, kernel chitu/triton_kernels.py:193-214)
+// Math: y = (x * rsqrt(mean(x^2) + eps)) * w in fp32, one rounding to the output dtype -- this is
+// bit-identical to torch's rms_norm on bf16 input (checked in tests).  The optional second output
+// is the e4m3 quantisation of that *rounded* y (what the reference's next kernel would compute),
+// so the fused form changes no numerics, it only removes a launch and a round trip through HBM.
+// One workgroup per row, 16-B loads, 8 elements per lane per chunk; 16 consecutive lanes own one
+// 128-wide quantisation group, exactly as in quant.hip.
+#include "common.h"
+
+namespace chitu {
+
+constexpr int kNormThreads = 256;
+constexpr int kNormMaxChunks = 4;  // dim <= 256 * 8 * 4 = 8192
+
+// QMODE 0: no quant; 1: act_quant (no eps, no clamp); 2: per_token_group_quant (eps, clamp)
+template <int QMODE>
+__global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(
+    const bf16_t* __restrict__ x, int64_t x_stride, const bf16_t* __restrict__ w,
+    bf16_t* __restrict__ y, int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs,
+    int dim, float eps, float qeps) {
+    __shared__ float red[kNormThreads / 64];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const bf16_t* xr = x + (int64_t)row * x_stride;
+    const int n_chunks = dim >> 3;
+    float v[kNormMaxChunks][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNormMaxChunks; ++i) {
+        const int c = tid + i * kNormThreads;
+        if (c < n_chunks) {
+            const i32x4 raw = *reinterpret_cast<const i32x4*>(xr + c * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t u = (uint32_t)raw[k];
+                v[i][2 * k] = __uint_as_float(u << 16);
+                v[i][2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+                ss += v[i][2 * k] * v[i][2 * k] + v[i][2 * k + 1] * v[i][2 * k + 1];
+            }
+        }
+    }
+    ss = wave_reduce_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float rr = rsqrtf(ss / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < kNormMaxChunks; ++i) {
+        const int c = tid + i * kNormThreads;
+        const bool act = c < n_chunks;
+        float o[8];
+        if (act) {
+            const i32x4 wraw = *reinterpret_cast<const i32x4*>(w + c * 8);
+            uint16_t h[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t u = (uint32_t)wraw[k];
+                h[2 * k] = f32_to_bf16((v[i][2 * k] * rr) * __uint_as_float(u << 16));
+                h[2 * k + 1] = f32_to_bf16((v[i][2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = bf16_to_f32(h[k]);
+            if (y) {
+                i32x4 out;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[k] = (int)((uint32_t)h[2 * k] | ((uint32_t)h[2 * k + 1] << 16));
+                *reinterpret_cast<i32x4*>(y + (int64_t)row * y_stride + c * 8) = out;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = 0.f;
+        }
+        if (QMODE != 0) {
+            // dim % 128 == 0 => a 16-lane group is either fully active or fully idle
+            float amax = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(o[k]));
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off, 64));
+            if (QMODE == 2) amax = __builtin_fmaxf(amax, qeps);
+            const float sc = amax / 448.0f;
+            if (act) {
+                uint32_t lo, hi;
+                if (QMODE == 2) {
+                    lo = f32x2_to_fp8x2_sat(o[0] / sc, o[1] / sc) | (f32x2_to_fp8x2_sat(o[2] / sc, o[3] / sc) << 16);
+                    hi = f32x2_to_fp8x2_sat(o[4] / sc, o[5] / sc) | (f32x2_to_fp8x2_sat(o[6] / sc, o[7] / sc) << 16);
+                } else {
+                    lo = f32x2_to_fp8x2(o[0] / sc, o[1] / sc) | (f32x2_to_fp8x2(o[2] / sc, o[3] / sc) << 16);
+                    hi = f32x2_to_fp8x2(o[4] / sc, o[5] / sc) | (f32x2_to_fp8x2(o[6] / sc, o[7] / sc) << 16);
+                }
+                i32x2 out;
+                out[0] = (int)lo;
+                out[1] = (int)hi;
+                *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + c * 8) = out;
+                if ((tid & 15) == 0) qs[(int64_t)row * (dim >> 7) + (c >> 4)] = sc;
+            }
+        }
+    }
+}
+
+}  // namespace chitu
+
+extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const void* weight_bf16,
+                                 void* y_bf16, int64_t y_row_stride, int64_t rows, int32_t dim,
+                                 float eps, void* q_fp8, float* q_scales, int32_t quant_mode,
+                                 float quant_eps, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && weight_bf16 && rows >= 0 && dim >= 8);
+    CHITU_REQUIRE(y_bf16 || quant_mode != 0);
+    if (dim % 8 != 0 || dim > kNormThreads * 8 * kNormMaxChunks) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(x_row_stride % 8 == 0 && (!y_bf16 || y_row_stride % 8 == 0));
+    if (quant_mode != 0) {
+        CHITU_REQUIRE(q_fp8 && q_scales);
+        if (dim % 128 != 0) return CHITU_ERR_UNSUPPORTED;
+        CHITU_REQUIRE(quant_mode == 1 || quant_mode == 2);
+    }
+    if (rows == 0) return CHITU_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(QM)                                                                               \
+    hipLaunchKernelGGL(rmsnorm_kernel<QM>, dim3((unsigned)rows), dim3(kNormThreads), 0, st,       \
+                       (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)weight_bf16,           \
+                       (bf16_t*)y_bf16, y_row_stride, (fp8_t*)q_fp8, q_scales, (int)dim, eps, quant_eps)
+    if (quant_mode == 0) LAUNCH(0);
+    else if (quant_mode == 1) LAUNCH(1);
+    else LAUNCH(2);
+#undef LAUNCH
+    CHITU_RETURN_LAUNCH_STATUS();
+}

@@ -1,0 +1,395 @@
+"""DeepSeek-V3/R1 decode step on the HIP operator surface (the caller of the hot path).
+
+This is the part of chitu/models/model_deepseek_v3.py that executes per decode token, re-wired
+onto chitu_amd's ops (reference file:line in each docstring): `linear_deepseek_v3:53-106`,
+`AttentionDeepSeekV3._run_linear:475-536` + `decode_forward_paged:672-699` (MLA absorb-without-
+precomp), `MLPDeepSeekV3:703-772`, `GateDeepSeekV3:774-842`, `MoEDeepSeekV3.forward:921-1011`
+(fused path), `TransformerBlockDeepSeekV3.forward:1100-1114`, `_post_layers:1321-1325`, and the
+graph capture of `Transformer.decode` (chitu/models/model.py:538-622).
+
+Sharding is the reference's Megatron TP (chitu/models/model.py:332-370): heads and FFN / expert
+width split across ranks, `wqkv_a`, the gate and the latent KV cache replicated, one all-reduce
+after `wo` and one after the FFN / MoE.  Prefill, checkpoint loading, tokenizer, scheduler are out
+of scope here.
+"""
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import fused_moe, ops
+from . import tensor_parallel as tp
+from .attn_backend import HipAttnBackend
+from .cache_manager import PagedKVCacheManager
+
+FP8 = torch.float8_e4m3fn
+BLOCK = 128
+
+
+@dataclass
+class DeepSeekV3Args:
+    """Fields of chitu/config/models/DeepSeek-R1.yaml:6-29 (defaults = DeepSeek-R1-671B)."""
+
+    vocab_size: int = 129280
+    dim: int = 7168
+    inter_dim: int = 18432
+    moe_inter_dim: int = 2048
+    n_layers: int = 61
+    n_dense_layers: int = 3
+    n_heads: int = 128
+    n_routed_experts: int = 256
+    n_shared_experts: int = 1
+    n_activated_experts: int = 8
+    n_expert_groups: int = 8
+    n_limited_groups: int = 4
+    route_scale: float = 2.5
+    score_func: str = "sigmoid"
+    q_lora_rank: int = 1536
+    kv_lora_rank: int = 512
+    qk_nope_head_dim: int = 128
+    qk_rope_head_dim: int = 64
+    v_head_dim: int = 128
+    rope_theta: float = 10000.0
+    rope_factor: float = 40
+    norm_eps: float = 1e-6
+    gate_bias: Optional[bool] = None  # reference: bias iff dim == 7168 (model_deepseek_v3.py:804-808)
+
+    def has_gate_bias(self):
+        return self.dim == 7168 if self.gate_bias is None else self.gate_bias
+
+
+def compute_softmax_scale(args: DeepSeekV3Args) -> float:
+    """chitu/models/model_deepseek_v3.py:1441-1445."""
+    qk_head_dim = args.qk_nope_head_dim + args.qk_rope_head_dim
+    mscale = 0.1 * math.log(args.rope_factor) + 1.0
+    return (qk_head_dim**-0.5) * mscale * mscale
+
+
+def precompute_freqs_cis(args: DeepSeekV3Args, max_position_embeddings: int):
+    """YaRN-corrected rotary table, returned as (cos, sin) fp32 [pos, rope/2].
+    Restates chitu/models/model_deepseek_v3.py:1353-1438 (same constants: beta 32/1, original
+    context 4096, correction only when the table is longer than that)."""
+    dim, base, factor = args.qk_rope_head_dim, args.rope_theta, args.rope_factor
+    freqs = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+    original = 4096
+    if max_position_embeddings > original:
+
+        def corr_dim(rot):
+            return dim * math.log(original / (rot * 2 * math.pi)) / (2 * math.log(base))
+
+        low = max(math.floor(corr_dim(32)), 0)
+        high = min(math.ceil(corr_dim(1)), dim - 1)
+        if low == high:
+            high += 0.001
+        ramp = torch.clamp((torch.arange(dim // 2, dtype=torch.float32) - low) / (high - low), 0, 1)
+        smooth = 1 - ramp
+        freqs = freqs / factor * (1 - smooth) + freqs * smooth
+    ang = torch.outer(torch.arange(max_position_embeddings).float(), freqs)
+    return torch.cos(ang), torch.sin(ang)
+
+
+def linear_deepseek_v3(x, weight, weight_scale=None, bias=None, x_quant=None):
+    """y = x W^T (chitu/models/model_deepseek_v3.py:53-106, W8A8 branch): quantise x per 128
+    values, block-scaled fp8 GEMM.  `x_quant=(q, s)` skips the quantisation when the producer
+    already emitted it (fused RMSNorm)."""
+    if weight.element_size() > 1:
+        return F.linear(x, weight, bias)
+    assert weight_scale is not None
+    if x_quant is None:
+        shape = x.shape
+        xq, xs = ops.act_quant_deepseek_v3(x.reshape(-1, shape[-1]).contiguous(), BLOCK)
+    else:
+        xq, xs = x_quant
+        shape = xq.shape
+        xq, xs = xq.reshape(-1, shape[-1]), xs.reshape(-1, xs.shape[-1])
+    y = ops.fp8_gemm_deepseek_v3(xq, xs, weight, weight_scale, out_dtype=torch.bfloat16)
+    if bias is not None:
+        y += bias
+    return y.view(*shape[:-1], y.shape[-1])
+
+
+class Fp8Linear(torch.nn.Module):
+    """Weight [out, in] e4m3fn + scale [ceil(out/128), ceil(in/128)] f32
+    (LinearDeepSeekV3 and its parallel variants, model_deepseek_v3.py:108-392)."""
+
+    def __init__(self, in_features, out_features, device=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = torch.nn.Parameter(torch.empty(out_features, in_features, dtype=FP8, device=device), requires_grad=False)
+        self.scale = torch.nn.Parameter(
+            torch.empty((out_features + BLOCK - 1) // BLOCK, (in_features + BLOCK - 1) // BLOCK,
+                        dtype=torch.float32, device=device), requires_grad=False)
+
+    def forward(self, x, x_quant=None):
+        return linear_deepseek_v3(x, self.weight, self.scale, x_quant=x_quant)
+
+
+class RMSNormW(torch.nn.Module):
+    def __init__(self, dim, eps, device=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = torch.nn.Parameter(torch.ones(dim, dtype=torch.bfloat16, device=device), requires_grad=False)
+
+
+class AttentionDeepSeekV3(torch.nn.Module):
+    """MLA, absorb-without-precomp, paged decode (model_deepseek_v3.py:394-703)."""
+
+    def __init__(self, args: DeepSeekV3Args, layer_id, cache, attn_backend, device=None):
+        super().__init__()
+        tp_size = tp.get_tp_size()
+        self.layer_id, self.cache, self.attn_backend = layer_id, cache, attn_backend
+        self.dim = args.dim
+        self.n_local_heads = args.n_heads // tp_size
+        self.q_lora_rank, self.kv_lora_rank = args.q_lora_rank, args.kv_lora_rank
+        self.qk_nope_head_dim, self.qk_rope_head_dim = args.qk_nope_head_dim, args.qk_rope_head_dim
+        self.qk_head_dim = args.qk_nope_head_dim + args.qk_rope_head_dim
+        self.v_head_dim = args.v_head_dim
+        assert self.q_lora_rank > 0 and self.q_lora_rank % BLOCK == 0  # model_deepseek_v3.py:423,477
+        assert self.qk_nope_head_dim == BLOCK and self.v_head_dim == BLOCK, "wkv_b head halves = one 128 block each"
+        H = self.n_local_heads
+        self.wqkv_a = Fp8Linear(args.dim, self.q_lora_rank + self.kv_lora_rank + self.qk_rope_head_dim, device)
+        self.q_norm = RMSNormW(self.q_lora_rank, args.norm_eps, device)
+        self.wq_b = Fp8Linear(self.q_lora_rank, H * self.qk_head_dim, device)
+        self.kv_norm = RMSNormW(self.kv_lora_rank, args.norm_eps, device)
+        self.wkv_b = Fp8Linear(self.kv_lora_rank, H * (self.qk_nope_head_dim + self.v_head_dim), device)
+        self.wo = Fp8Linear(H * self.v_head_dim, args.dim, device)
+        self.softmax_scale = compute_softmax_scale(args)
+        self._w_uk_t = None
+
+    def w_uk_transposed(self):
+        """fp8 copy of W_UK laid out [H, kv_lora, nope] so the absorbed contraction index is
+        contiguous.  Layout-only preprocessing of wkv_b; values and scales untouched."""
+        if self._w_uk_t is None:
+            H = self.n_local_heads
+            w = self.wkv_b.weight.view(torch.uint8).view(H, self.qk_nope_head_dim + self.v_head_dim, self.kv_lora_rank)
+            self._w_uk_t = w[:, : self.qk_nope_head_dim].transpose(1, 2).contiguous().view(FP8)
+        return self._w_uk_t
+
+    def decode_forward_paged(self, x_quant, cos, sin):
+        """x_quant = fp8 (q, s) of attn_norm(x), [bs, dim].  Returns wo(attn) before the all-reduce."""
+        H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
+        bs = x_quant[0].shape[0]
+        q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [bs, q_lora + C + R]
+        q_a = q_a_kv[:, : self.q_lora_rank]
+        _, qq, qs = ops.rms_norm(q_a, self.q_norm.weight, self.q_norm.eps, out_bf16=False, quant="act")
+        q = self.wq_b(None, x_quant=(qq, qs)).view(bs, H, self.qk_head_dim)
+        q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
+        k_pe = q_a_kv[:, self.q_lora_rank + C :]
+        q_pe, k_pe = ops.apply_rotary_pos_emb(q_pe, k_pe, cos, sin, rotary_type="llama")
+        # q_nope' = q_nope . W_UK  (einsum "shd,hdc->shc", :529-531), wkv_b dequantised in registers
+        nblk = C // BLOCK
+        q_abs = ops.absorb_bmm_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0)
+        this_kv = ops.rms_norm(q_a_kv[:, self.q_lora_rank : self.q_lora_rank + C], self.kv_norm.weight, self.kv_norm.eps)
+        this_kv_pe = torch.cat([this_kv, k_pe], dim=-1)
+        o = self.attn_backend.mla_attn_with_kvcache(
+            q_abs, q_pe, self.cache.get_paged_kv_cache(self.layer_id), this_kv_pe.view(bs, 1, 1, -1),
+            cache_seqlens_excl_this_decode=self.cache.get_gpu_seq_lens_excl_this_decode(),
+            cache_seqlens_incl_this_decode=self.cache.get_gpu_seq_lens_incl_this_decode(),
+            block_table=self.cache.get_gpu_block_table(), softmax_scale=self.softmax_scale,
+        ).view(bs, H, C)
+        # out = o . W_UV^T  (einsum "bshc,hdc->bshd", :697)
+        w_uv = self.wkv_b.weight.view(H, self.qk_nope_head_dim + self.v_head_dim, C)[:, self.qk_nope_head_dim :]
+        o = ops.absorb_bmm_fp8(o, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 0, 1)
+        return self.wo(o.reshape(bs, H * self.v_head_dim))
+
+
+class MLPDeepSeekV3(torch.nn.Module):
+    """Dense FFN of the first n_dense_layers (model_deepseek_v3.py:703-772), gate/up merged."""
+
+    def __init__(self, args, device=None):
+        super().__init__()
+        tp_size = tp.get_tp_size()
+        self.inter = args.inter_dim // tp_size
+        self.w1w3 = Fp8Linear(args.dim, 2 * self.inter, device)
+        self.w2 = Fp8Linear(self.inter, args.dim, device)
+
+    def forward(self, x_quant):
+        h = self.w1w3(None, x_quant=x_quant)
+        hq, hs = fused_moe.silu_and_mul_quant(h, mode="act")
+        return self.w2(None, x_quant=(hq, hs))
+
+
+class GateDeepSeekV3(torch.nn.Module):
+    """Router (model_deepseek_v3.py:774-842): bf16 scores, sigmoid/softmax, bias, group-limited
+    top-k, normalise, route_scale."""
+
+    def __init__(self, args, device=None):
+        super().__init__()
+        self.topk, self.n_groups, self.topk_groups = args.n_activated_experts, args.n_expert_groups, args.n_limited_groups
+        self.score_func, self.route_scale = args.score_func, args.route_scale
+        self.weight = torch.nn.Parameter(torch.empty(args.n_routed_experts, args.dim, dtype=torch.bfloat16, device=device), requires_grad=False)
+        self.bias = (torch.nn.Parameter(torch.empty(args.n_routed_experts, dtype=torch.bfloat16, device=device), requires_grad=False)
+                     if args.has_gate_bias() else None)
+
+    def forward(self, x):
+        scores = F.linear(x, self.weight)
+        scores = scores.softmax(dim=-1, dtype=torch.float32) if self.score_func == "softmax" else scores.sigmoid()
+        original_scores = scores
+        if self.bias is not None:
+            scores = scores + self.bias
+        if self.n_groups > 1:
+            scores = scores.view(x.size(0), self.n_groups, -1)
+            group_scores = scores.amax(dim=-1) if self.bias is None else scores.topk(2, dim=-1)[0].sum(dim=-1)
+            indices = group_scores.topk(self.topk_groups, dim=-1)[1]
+            mask = torch.zeros_like(scores[..., 0]).scatter_(1, indices, True)
+            scores = (scores * mask.unsqueeze(-1)).flatten(1)
+        indices = torch.topk(scores, self.topk, dim=-1)[1]
+        weights = original_scores.gather(1, indices)
+        if self.score_func == "sigmoid":
+            weights = weights / weights.sum(dim=-1, keepdim=True)
+        weights = weights * self.route_scale
+        return weights.type_as(x), indices
+
+
+class MoEDeepSeekV3(torch.nn.Module):
+    """Routed + shared experts, fused path (model_deepseek_v3.py:845-1011).  Experts are stacked
+    [n_routed + n_shared, ...] with the shared expert last, every rank holds all experts at 1/tp
+    width (:883-919)."""
+
+    def __init__(self, args, device=None):
+        super().__init__()
+        tp_size = tp.get_tp_size()
+        self.n_routed, self.n_shared = args.n_routed_experts, args.n_shared_experts
+        self.inter = args.moe_inter_dim // tp_size
+        E = self.n_routed + self.n_shared
+        self.gate = GateDeepSeekV3(args, device)
+        self.w1w3_weight = torch.nn.Parameter(torch.empty(E, 2 * self.inter, args.dim, dtype=FP8, device=device), requires_grad=False)
+        self.w1w3_scale = torch.nn.Parameter(torch.empty(E, (2 * self.inter + BLOCK - 1) // BLOCK, args.dim // BLOCK, dtype=torch.float32, device=device), requires_grad=False)
+        self.w2_weight = torch.nn.Parameter(torch.empty(E, args.dim, self.inter, dtype=FP8, device=device), requires_grad=False)
+        self.w2_scale = torch.nn.Parameter(torch.empty(E, args.dim // BLOCK, (self.inter + BLOCK - 1) // BLOCK, dtype=torch.float32, device=device), requires_grad=False)
+
+    def forward(self, x, x_quant):
+        """x: ffn_norm output bf16 [bs, dim] (gate input); x_quant its fp8 form."""
+        weights, indices = self.gate(x)
+        y = None
+        for i in range(self.n_routed, self.n_routed + self.n_shared):
+            h = linear_deepseek_v3(None, self.w1w3_weight[i], self.w1w3_scale[i], x_quant=x_quant)
+            hq, hs = fused_moe.silu_and_mul_quant(h, mode="act")
+            yi = linear_deepseek_v3(None, self.w2_weight[i], self.w2_scale[i], x_quant=(hq, hs))
+            y = yi if y is None else y + yi
+        y1 = fused_moe.fused_experts(
+            x, self.w1w3_weight[: self.n_routed], self.w2_weight[: self.n_routed], topk_weights=weights,
+            topk_ids=indices, use_fp8_w8a8=True, inplace=True, global_num_experts=self.n_routed,
+            w1_scale=self.w1w3_scale[: self.n_routed], w2_scale=self.w2_scale[: self.n_routed],
+            block_shape=[BLOCK, BLOCK], a1_quant=x_quant,
+        )
+        return y1 if y is None else y + y1
+
+
+class TransformerBlockDeepSeekV3(torch.nn.Module):
+    """x += attn(attn_norm(x)); x += ffn(ffn_norm(x))  (model_deepseek_v3.py:1064-1114)."""
+
+    def __init__(self, layer_id, args, cache, attn_backend, device=None):
+        super().__init__()
+        self.attn = AttentionDeepSeekV3(args, layer_id, cache, attn_backend, device)
+        self.is_moe = layer_id >= args.n_dense_layers
+        self.ffn = MoEDeepSeekV3(args, device) if self.is_moe else MLPDeepSeekV3(args, device)
+        self.attn_norm = RMSNormW(args.dim, args.norm_eps, device)
+        self.ffn_norm = RMSNormW(args.dim, args.norm_eps, device)
+
+    def forward(self, x, cos, sin):
+        _, xq, xs = ops.rms_norm(x, self.attn_norm.weight, self.attn_norm.eps, out_bf16=False, quant="act")
+        a = self.attn.decode_forward_paged((xq, xs), cos, sin)
+        x = x + tp.all_reduce(a)
+        if self.is_moe:
+            hn, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=True, quant="group")
+            f = self.ffn(hn, (hq, hs))
+        else:
+            _, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=False, quant="act")
+            f = self.ffn((hq, hs))
+        return x + tp.all_reduce(f)
+
+
+class DeepSeekV3Decoder(torch.nn.Module):
+    """Decode-only transformer: embed -> blocks -> norm -> head -> fp32 logits, with the whole
+    step captured as a hipGraph per batch size (chitu/models/model.py:538-622; no third-party
+    attention gate as at :543-546 -- the HIP backend is capture-safe by construction)."""
+
+    def __init__(self, args: DeepSeekV3Args, cache: PagedKVCacheManager, attn_backend: HipAttnBackend,
+                 max_position_embeddings: int = 4096, device="cuda", layers: Optional[List[int]] = None):
+        super().__init__()
+        self.args, self.cache, self.attn_backend, self.device = args, cache, attn_backend, torch.device(device)
+        self.embed = tp.VocabParallelEmbedding(args.vocab_size, args.dim, dtype=torch.bfloat16).to(device)
+        ids = list(range(args.n_layers)) if layers is None else layers
+        self.layers = torch.nn.ModuleList(TransformerBlockDeepSeekV3(i, args, cache, attn_backend, device) for i in ids)
+        self.norm = RMSNormW(args.dim, args.norm_eps, device)
+        self.head = tp.ColumnParallelLinear(args.dim, args.vocab_size, has_bias=False, gather_output=True,
+                                            dtype=torch.bfloat16).to(device)
+        cos, sin = precompute_freqs_cis(args, max_position_embeddings)
+        self.cos_table, self.sin_table = cos.to(device), sin.to(device)
+        self.graphs, self.static_tokens, self.static_out = {}, {}, {}
+        self.graph_pool = None
+
+    def decode_eager(self, tokens):
+        """tokens [bs] int64 -> logits [bs, vocab] fp32 (decode_single_device, model.py:468-475)."""
+        pos = self.cache.get_gpu_seq_lens_excl_this_decode().long()
+        cos, sin = self.cos_table[pos], self.sin_table[pos]  # prepare_freqs_cis_decode, model.py:429-448
+        h = self.embed(tokens)
+        for layer in self.layers:
+            h = layer(h, cos, sin)
+        h = ops.rms_norm(h, self.norm.weight, self.norm.eps)
+        return self.head(h).float()
+
+    def prepare_decoding_attn(self):
+        """model_deepseek_v3.py:1339-1350 -- outside the graph."""
+        c = self.cache
+        self.attn_backend.prepare_metadata_for_decode(
+            c.get_gpu_seq_lens_excl_this_decode(), c.get_gpu_seq_lens_incl_this_decode(),
+            c.get_gpu_block_table(), c.get_block_size(), softmax_scale=compute_softmax_scale(self.args))
+
+    @torch.inference_mode()
+    def decode(self, tokens, use_graph=True):
+        self.prepare_decoding_attn()
+        bs = tokens.shape[0]
+        if not use_graph:
+            return self.decode_eager(tokens)
+        if bs not in self.graphs:
+            self.static_tokens[bs] = tokens.clone()
+            # Warm-up replicates the graph's side effect (append at position L), which the captured
+            # run then overwrites with the same values.
+            sample = self.decode_eager(self.static_tokens[bs])
+            self.static_out[bs] = torch.zeros_like(sample)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph_pool):
+                self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs]))
+            if self.graph_pool is None:
+                self.graph_pool = g.pool()
+            self.graphs[bs] = g
+        self.static_tokens[bs].copy_(tokens)
+        self.graphs[bs].replay()
+        return self.static_out[bs]
+
+
+# ---------------------------------------------------------------- synthetic weights
+def _fill_fp8(t: torch.Tensor, gen: torch.Generator, std=0.5, chunk=1 << 26):
+    flat = t.view(-1)
+    for i in range(0, flat.numel(), chunk):
+        n = min(chunk, flat.numel() - i)
+        flat[i : i + n].copy_((torch.randn(n, device=t.device, dtype=torch.bfloat16, generator=gen) * std).to(FP8))
+
+
+@torch.no_grad()
+def init_synthetic_(model: torch.nn.Module, seed: int = 0):
+    """fp8 = (randn*0.5) -> e4m3 (never raw bytes: no NaN codes), block scales U(0.01,0.03),
+    bf16 weights randn*0.05, norm weights 1, gate bias small -- SURVEY.md 8(d)."""
+    dev = next(model.parameters()).device
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    for name, p in model.named_parameters():
+        if p.dtype == FP8:
+            _fill_fp8(p.data, gen)
+        elif p.dtype == torch.float32:
+            p.data.copy_(torch.rand(p.shape, device=dev, generator=gen) * 0.02 + 0.01)
+        elif name.endswith("norm.weight"):
+            p.data.fill_(1.0)
+        elif name.endswith("gate.bias"):
+            p.data.copy_((torch.randn(p.shape, device=dev, generator=gen) * 0.01).to(p.dtype))
+        else:
+            flat = p.data.view(-1)
+            for i in range(0, flat.numel(), 1 << 26):
+                n = min(1 << 26, flat.numel() - i)
+                flat[i : i + n].copy_((torch.randn(n, device=dev, generator=gen) * 0.05).to(p.dtype))
+    return model

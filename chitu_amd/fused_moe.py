@@ -161,13 +161,14 @@ def fused_experts(
     a2_scale: Optional[torch.Tensor] = None,
     block_shape: Optional[List[int]] = None,
     soft_fp8: bool = False,
+    a1_quant=None,
 ) -> torch.Tensor:
-    """Same signature as chitu/fused_moe.py:1060-1127.  (The reference's inplace=False branch
+    """Same signature as chitu/fused_moe.py:1060-1127 (+ optional a1_quant, see fused_experts_impl).  (The reference's inplace=False branch
     calls an unregistered torch.ops.vllm op; here both branches work.)"""
     return fused_experts_impl(
         hidden_states, w1, w2, topk_weights, topk_ids, inplace, activation, use_fp8_w8a8,
         use_int8_w8a16, use_int4_w4a16, global_num_experts, expert_map, w1_scale, w2_scale, w1_zp,
-        w2_zp, a1_scale, a2_scale, block_shape, soft_fp8=soft_fp8,
+        w2_zp, a1_scale, a2_scale, block_shape, soft_fp8=soft_fp8, a1_quant=a1_quant,
     )
 
 
@@ -192,12 +193,15 @@ def fused_experts_impl(
     a2_scale: Optional[torch.Tensor] = None,
     block_shape: Optional[List[int]] = None,
     soft_fp8: bool = False,
+    a1_quant=None,
 ):
     """out[t] = sum_j w[t,j] * W2[e_tj] . (silu(W1[e_tj] x_t)[:I] * (W1[e_tj] x_t)[I:])
 
     FP8 W8A8 with [128,128] block scales (the DeepSeek-V3/R1 path, fused_moe.py:1130-1307).
     Six launches: align(16) -> quant -> grouped GEMM1 -> silu*mul+requant -> grouped GEMM2 (x routed
     weight) -> top-k sum.  Scratch lives in a persistent workspace (graph-capture safe).
+    a1_quant=(q, s): the per-128-group fp8 form of hidden_states if the producer (fused RMSNorm)
+    already computed it -- skips the quant launch, numerics unchanged.
     """
     assert hidden_states.shape[1] == w1.shape[2], "Hidden size mismatch"
     assert topk_weights.shape == topk_ids.shape, "topk shape mismatch"
@@ -278,22 +282,29 @@ def fused_experts_impl(
         ev = _view_i32(ws, off["experts"] - base, nblk)
         mapped = expert_map.to(torch.int32)[ev.long()].contiguous()
         ev.copy_(mapped)
-    check(
-        lib.chitu_hip_act_quant_fp8(
-            ptr(hidden_states), float_dtype_code(hidden_states.dtype), i64(num_tokens), i64(K), i32(128),
-            i32(1), f32(1e-10), P("a1q"), P("a1s"), st,
-        ),
-        "moe quant1",
-    )
+    if a1_quant is None:
+        check(
+            lib.chitu_hip_act_quant_fp8(
+                ptr(hidden_states), float_dtype_code(hidden_states.dtype), i64(num_tokens), i64(K), i32(128),
+                i32(1), f32(1e-10), P("a1q"), P("a1s"), st,
+            ),
+            "moe quant1",
+        )
+        a1q_p, a1s_p = P("a1q"), P("a1s")
+    else:
+        aq, as_ = a1_quant
+        assert aq.is_contiguous() and as_.is_contiguous() and aq.numel() == num_tokens * K
+        assert as_.dtype == torch.float32 and as_.numel() == num_tokens * KB
+        a1q_p, a1s_p = ptr(aq), ptr(as_)
     check(
         lib.chitu_hip_moe_gemm1_fp8(
-            P("a1q"), P("a1s"), ptr(w1), ptr(w1_scale), P("sorted"), experts_ptr, P("npost"), P("c1"),
+            a1q_p, a1s_p, ptr(w1), ptr(w1_scale), P("sorted"), experts_ptr, P("npost"), P("c1"),
             i64(numel), i32(topk), i64(N), i64(K), i64(max_mblocks), st,
         ),
         "moe gemm1",
     )
     check(
-        lib.chitu_hip_moe_silu_mul_quant_fp8(P("c1"), i64(numel), i64(I), f32(1e-10), P("a2q"), P("a2s"), st),
+        lib.chitu_hip_moe_silu_mul_quant_fp8(P("c1"), i64(numel), i64(I), i32(1), f32(1e-10), P("a2q"), P("a2s"), st),
         "moe silu_mul_quant",
     )
     check(
@@ -310,3 +321,22 @@ def fused_experts_impl(
 
 def _view_i32(ws: torch.Tensor, byte_off: int, n: int) -> torch.Tensor:
     return ws[byte_off : byte_off + 4 * n].view(torch.int32)
+
+
+def silu_and_mul_quant(x: torch.Tensor, mode: str = "act"):
+    """h = silu(x[..., :d]) * x[..., d:] (SiluAndMul, fused_moe.py:24-39) followed by the 128-group
+    fp8 quantisation the next fp8 GEMM needs.  mode "act": act_quant_deepseek_v3 rule (dense and
+    shared-expert MLPs, model_deepseek_v3.py:771, 936-949); "group": per_token_group_quant_fp8."""
+    require_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    d = x.shape[-1] // 2
+    rows = x.numel() // x.shape[-1]
+    q = torch.empty(*x.shape[:-1], d, dtype=torch.float8_e4m3fn, device=x.device)
+    s = torch.empty(*x.shape[:-1], d // 128, dtype=torch.float32, device=x.device)
+    check(
+        _lib.lib().chitu_hip_moe_silu_mul_quant_fp8(
+            ptr(x), i64(rows), i64(d), i32(0 if mode == "act" else 1), f32(1e-10), ptr(q), ptr(s), stream_ptr()
+        ),
+        "silu_and_mul_quant",
+    )
+    return q, s

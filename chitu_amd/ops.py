@@ -83,8 +83,9 @@ def weight_dequant_soft_fp8_deepseek_v3(x: torch.Tensor, s: torch.Tensor, block_
     return _weight_dequant(x, s, block_size, soft=True)
 
 
-def fp8_gemm_deepseek_v3(a: torch.Tensor, a_s: torch.Tensor, b: torch.Tensor, b_s: torch.Tensor):
-    """c = sum_kb (a_kb . b_kb^T) * a_s[:, kb] * b_s[n//128, kb]   (chitu/ops.py:453-483)."""
+def fp8_gemm_deepseek_v3(a: torch.Tensor, a_s: torch.Tensor, b: torch.Tensor, b_s: torch.Tensor, out_dtype=None):
+    """c = sum_kb (a_kb . b_kb^T) * a_s[:, kb] * b_s[n//128, kb]   (chitu/ops.py:453-483).
+    Output dtype = torch.get_default_dtype() like the reference (:474), unless out_dtype is given."""
     assert a.is_contiguous() and b.is_contiguous(), "Input tensors must be contiguous"
     assert a_s.is_contiguous() and b_s.is_contiguous(), "Scaling factor tensors must be contiguous"
     require_cuda(a, a_s, b, b_s)
@@ -93,7 +94,7 @@ def fp8_gemm_deepseek_v3(a: torch.Tensor, a_s: torch.Tensor, b: torch.Tensor, b_
     K = a.size(-1)
     M = a.numel() // K
     N = b.size(0)
-    c = a.new_empty(*a.size()[:-1], N, dtype=torch.get_default_dtype())
+    c = a.new_empty(*a.size()[:-1], N, dtype=out_dtype or torch.get_default_dtype())
     ws = workspace.get(_GEMM_WS_BYTES, a.device, "gemm")
     check(
         _lib.lib().chitu_hip_fp8_gemm_blockscale(
@@ -198,3 +199,70 @@ def apply_rotary_pos_emb(q, k, cos, sin, rotary_type="hf-llama"):
         "apply_rotary_pos_emb",
     )
     return out_q, out_k
+
+
+# ---- ops on the decode path that the reference runs as torch glue -----------------
+
+
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16: bool = True, quant: str = None):
+    """RMSNorm (chitu/models/model.py:29-78), optionally fused with the FP8 quantisation that the
+    next fp8 linear would run on its output (model_deepseek_v3.py:98-100).
+
+    x [..., dim] bf16 (last dim contiguous, uniform row stride); weight [dim] bf16.
+    quant: None | "act" (act_quant_deepseek_v3) | "group" (per_token_group_quant_fp8, eps 1e-10).
+    Returns y, or (y, q, s) when quant is set (y is None if out_bf16=False).
+    """
+    require_cuda(x, weight)
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+    dim = x.shape[-1]
+    assert x.stride(-1) == 1 and weight.is_contiguous() and weight.numel() == dim
+    x2 = x.reshape(-1, dim) if x.dim() != 2 else x
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    y = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if out_bf16 else None
+    q = s = None
+    mode = 0
+    if quant is not None:
+        mode = {"act": 1, "group": 2}[quant]
+        q = torch.empty(rows, dim, dtype=torch.float8_e4m3fn, device=x.device)
+        s = torch.empty(rows, dim // 128, dtype=torch.float32, device=x.device)
+    check(
+        _lib.lib().chitu_hip_rmsnorm(
+            ptr(x2), i64(x2.stride(0)), ptr(weight), ptr(y), i64(dim), i64(rows), i32(dim), f32(eps),
+            ptr(q), ptr(s), i32(mode), f32(1e-10), stream_ptr(),
+        ),
+        "rms_norm",
+    )
+    if y is not None:
+        y = y.view(*x.shape[:-1], dim)
+    if quant is None:
+        return y
+    return y, q.view(*x.shape[:-1], dim), s.view(*x.shape[:-1], dim // 128)
+
+
+def absorb_bmm_fp8(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, scale_offset: int, scale_stride_h: int,
+                   scale_stride_n: int, scale_stride_k: int) -> torch.Tensor:
+    """out[b,h,n] = sum_k x[b,h,k] * bf16(float(w[h,n,k]) * scale[...])  -- the two absorb einsums of
+    MLA decode (model_deepseek_v3.py:529-531, 697) with wkv_b de-quantised in registers.
+
+    x [B, H, K] bf16 (K contiguous); w [H, N, K] fp8 (dense rows, any head stride); scale: the flat fp32 block-scale
+    tensor of wkv_b, indexed as offset + h*stride_h + (n//128)*stride_n + (k//128)*stride_k.
+    """
+    require_cuda(x, w, scale)
+    assert x.dtype == torch.bfloat16 and w.element_size() == 1 and scale.dtype == torch.float32
+    assert x.dim() == 3 and w.dim() == 3 and x.stride(-1) == 1
+    assert w.stride(2) == 1 and w.stride(1) == w.shape[2], "w rows must be dense; only the head stride is free"
+    B, H, K = x.shape
+    assert w.shape[0] == H and w.shape[2] == K
+    N = w.shape[1]
+    out = torch.empty(B, H, N, dtype=torch.bfloat16, device=x.device)
+    check(
+        _lib.lib().chitu_hip_absorb_bmm_fp8(
+            ptr(x), i64(x.stride(0)), i64(x.stride(1)), ptr(w), i64(w.stride(0)), ptr(scale), i64(scale_offset),
+            i64(scale_stride_h), i64(scale_stride_n), i64(scale_stride_k), ptr(out), i64(out.stride(0)),
+            i64(out.stride(1)), i32(B), i32(H), i32(N), i32(K), stream_ptr(),
+        ),
+        "absorb_bmm_fp8",
+    )
+    return out

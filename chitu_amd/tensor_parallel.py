@@ -1,0 +1,171 @@
+"""Tensor-parallel groups and linears with the reference's `chitu/tensor_parallel.py` surface.
+
+Reference (read-only): chitu/tensor_parallel.py:1-208.  One process per GPU; the process group
+backend string "nccl" IS RCCL on ROCm (collectives run over xGMI and are hipGraph-capturable),
+"gloo" is used by the CPU tests.  `linear_op` stays the GEMM plug point (tensor_parallel.py:50,
+:125): the DeepSeek modules pass the HIP fp8 linear through it.
+
+All collectives go through `all_reduce` / `all_gather_last_dim` below so the decode step has ONE
+place where communication is issued (and where a custom xGMI all-reduce can later replace RCCL).
+"""
+
+__all__ = [
+    "init_tp",
+    "get_tp_group",
+    "get_tp_size",
+    "get_tp_rank",
+    "ColumnParallelLinear",
+    "RowParallelLinear",
+    "VocabParallelEmbedding",
+]
+
+import torch
+import torch.distributed as dist
+
+tp_comm_group = None
+
+
+def generate_tp_rank_list(tp_size: int, pp_size: int):
+    return torch.arange(tp_size * pp_size).reshape(pp_size, tp_size).tolist()
+
+
+def init_tp(tp_size: int, pp_size: int = 1):
+    """Create the TP groups (ranks laid out [pp, tp], tensor_parallel.py:16-27)."""
+    global tp_comm_group
+    rank_list = generate_tp_rank_list(tp_size, pp_size)
+    global_rank = dist.get_rank()
+    for ranks in rank_list:
+        group = dist.new_group(ranks)
+        if global_rank in ranks:
+            tp_comm_group = group
+
+
+def reset_tp():
+    global tp_comm_group
+    tp_comm_group = None
+
+
+def get_tp_group():
+    return tp_comm_group
+
+
+def get_tp_size():
+    return tp_comm_group.size() if tp_comm_group is not None else 1
+
+
+def get_tp_rank():
+    return dist.get_rank(group=get_tp_group()) if tp_comm_group is not None else 0
+
+
+def all_reduce(t: torch.Tensor) -> torch.Tensor:
+    """Sum over the TP group, in place (tensor_parallel.py:166, model_deepseek_v3.py:1011)."""
+    if get_tp_size() > 1:
+        dist.all_reduce(t, group=get_tp_group())
+    return t
+
+
+def all_gather_last_dim(y: torch.Tensor) -> torch.Tensor:
+    """Concatenate the last dimension over TP ranks (tensor_parallel.py:94-102: the reference
+    gathers on a permuted [N/tp, ...] layout so the result is rank-major along the last dim)."""
+    tp = get_tp_size()
+    if tp == 1:
+        return y
+    y_t = y.permute(-1, *range(y.dim() - 1)).contiguous()
+    shape = list(y_t.shape)
+    shape[0] *= tp
+    gathered = y.new_empty(shape)
+    dist.all_gather_into_tensor(gathered, y_t, group=get_tp_group())
+    return gathered.permute(*range(1, y.dim()), 0)
+
+
+class ColumnParallelLinear(torch.nn.Module):
+    """Output-dimension-parallel linear (tensor_parallel.py:42-103)."""
+
+    def __init__(self, in_features, out_features, has_bias=True, gather_output=True, dtype=None,
+                 bias_dtype=None, linear_op=torch.nn.functional.linear):
+        super().__init__()
+        self.tp_group = get_tp_group()
+        self.tp_size = get_tp_size()
+        self.in_features = in_features
+        self.out_features = out_features
+        assert out_features % self.tp_size == 0, "out_features must be divisible by tp_size"
+        self.gather_output = gather_output
+        self.linear_op = linear_op
+        self.weight = torch.nn.Parameter(
+            torch.empty(out_features // self.tp_size, in_features, dtype=dtype), requires_grad=False
+        )
+        if has_bias:
+            self.bias = torch.nn.Parameter(
+                torch.empty(out_features // self.tp_size, dtype=bias_dtype or dtype), requires_grad=False
+            )
+        else:
+            self.bias = None
+
+    def forward(self, x):
+        y = self.linear_op(x, self.weight, self.bias)
+        if self.gather_output and self.tp_size > 1:
+            y = all_gather_last_dim(y)
+        return y
+
+
+class RowParallelLinear(torch.nn.Module):
+    """Input-dimension-parallel linear followed by an all-reduce (tensor_parallel.py:106-169)."""
+
+    def __init__(self, in_features, out_features, has_bias=True, input_is_parallel=False, dtype=None,
+                 bias_dtype=None, linear_op=torch.nn.functional.linear):
+        super().__init__()
+        self.tp_group = get_tp_group()
+        self.tp_size = get_tp_size()
+        self.rank = get_tp_rank()
+        self.in_features = in_features
+        self.out_features = out_features
+        assert in_features % self.tp_size == 0, "in_features must be divisible by tp_size"
+        self.input_is_parallel = input_is_parallel
+        self.linear_op = linear_op
+        self.weight = torch.nn.Parameter(
+            torch.empty(out_features, in_features // self.tp_size, dtype=dtype), requires_grad=False
+        )
+        if has_bias:
+            self.bias = torch.nn.Parameter(torch.empty(out_features, dtype=bias_dtype or dtype), requires_grad=False)
+        else:
+            self.bias = None
+
+    def forward(self, x):
+        if not self.input_is_parallel and self.tp_size > 1:
+            shape = list(x.shape)
+            this_rank_dim = shape[-1] // self.tp_size
+            shape[-1] = self.tp_size
+            shape.append(this_rank_dim)
+            x = x.view(shape).select(-2, self.rank)
+        if self.tp_size > 1:
+            y = self.linear_op(x, self.weight, self.bias if self.rank == 0 else None)
+            all_reduce(y)
+        else:
+            y = self.linear_op(x, self.weight, self.bias)
+        return y
+
+
+class VocabParallelEmbedding(torch.nn.Module):
+    """Vocabulary-sharded embedding: mask, local lookup, all-reduce (tensor_parallel.py:172-208)."""
+
+    def __init__(self, num_embeddings, embedding_dim, dtype=None):
+        super().__init__()
+        self.tp_group = get_tp_group()
+        self.tp_size = get_tp_size()
+        self.rank = get_tp_rank()
+        assert num_embeddings % self.tp_size == 0, "num_embeddings must be divisible by tp_size"
+        self.vocab_start_idx = self.rank * (num_embeddings // self.tp_size)
+        self.vocab_end_idx = self.vocab_start_idx + (num_embeddings // self.tp_size)
+        self.weight = torch.nn.Parameter(
+            torch.empty(num_embeddings // self.tp_size, embedding_dim, dtype=dtype), requires_grad=False
+        )
+
+    def forward(self, x):
+        if self.tp_size > 1:
+            mask = (x < self.vocab_start_idx) | (x >= self.vocab_end_idx)
+            x = torch.where(mask, torch.zeros_like(x), x - self.vocab_start_idx)  # no in-place on the caller's ids
+        y = torch.nn.functional.embedding(x, self.weight)
+        if self.tp_size > 1:
+            y = torch.where(mask.unsqueeze(-1), torch.zeros_like(y), y)
+            all_reduce(y)
+        return y

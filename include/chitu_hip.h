@@ -117,7 +117,9 @@ int chitu_hip_rope(const void* q, const void* k, void* out_q, void* out_k, const
  *   a_fp8 [tokens, K], a_scale [tokens, K/128]; w1 [E, N, K] fp8, w1_scale [E, ceil(N/128), K/128];
  *   out_bf16 [numel, N] with numel = tokens*topk (row = flat slot id t*topk+k).
  * silu_mul_quant:  h = bf16(bf16(silu(c1[:, :I])) * c1[:, I:]); per-128 group
- *   s = max(max|h|, eps)/448, q = clamp(h/s) -> e4m3.   c1 [rows, 2I]; q [rows, I]; scales [rows, I/128].
+ *   s = max(max|h|, eps)/448, q = clamp(h/s) -> e4m3 (quant_mode 1, the MoE rule) or s = max|h|/448,
+ *   q = h/s (quant_mode 0, act_quant_deepseek_v3: dense / shared-expert MLP, model_deepseek_v3.py:936-949).
+ *   c1 [rows, 2I]; q [rows, I]; scales [rows, I/128].
  * gemm2:  c3[slot, :] = bf16( (sum_kb dot(h[slot, kb], w2[e, :, kb]) * h_s * w2_s) * topk_w[slot] )
  *   h_fp8 [numel, I]; w2 [E, N, I]; out [numel, N]; topk_weights [numel] of weights_dtype.
  * moe_sum: out[t, :] = bf16( sum_k float(c3[t, k, :]) ).
@@ -128,7 +130,8 @@ int chitu_hip_moe_gemm1_fp8(const void* a_fp8, const float* a_scale, const void*
                             void* out_bf16, int64_t numel, int32_t topk, int64_t N, int64_t K,
                             int64_t max_mblocks, void* stream);
 int chitu_hip_moe_silu_mul_quant_fp8(const void* c1_bf16, int64_t rows, int64_t inter_size,
-                                     float eps, void* q_fp8, float* scales, void* stream);
+                                     int32_t quant_mode, float eps, void* q_fp8, float* scales,
+                                     void* stream);
 int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, const void* w2_fp8,
                             const float* w2_scale, const int32_t* sorted_token_ids,
                             const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
@@ -159,6 +162,31 @@ int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int64_t qn_str
                          float softmax_scale, void* out_bf16, int32_t batch, int32_t heads,
                          int32_t kv_lora_rank, int32_t rope_dim, int32_t num_splits,
                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- RMSNorm (+ fused FP8 quantisation of its output) ----------------------------------------
+ * Replaces RMSNorm.forward (chitu/models/model.py:29-78: F.rms_norm in fp32, one rounding) and,
+ * when quant_mode != 0, also the act-quant launch of the fp8 linear that consumes it
+ * (chitu/models/model_deepseek_v3.py:98-100).  quant_mode 1 = act_quant_deepseek_v3 rule,
+ * 2 = per_token_group_quant_fp8 rule (eps = quant_eps); the codes are those of the bf16-rounded y.
+ *   x [rows, dim] bf16 (row stride given); weight [dim] bf16; y [rows, dim] bf16 or NULL;
+ *   q_fp8 [rows, dim], q_scales [rows, dim/128] (dim % 128 == 0 when quantising); dim <= 8192. */
+int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const void* weight_bf16,
+                      void* y_bf16, int64_t y_row_stride, int64_t rows, int32_t dim, float eps,
+                      void* q_fp8, float* q_scales, int32_t quant_mode, float quant_eps,
+                      void* stream);
+
+/* ---- MLA absorb projections with in-register FP8 dequant ---------------------------------------
+ * Replaces weight_dequant(wkv_b) + einsum("shd,hdc->shc") / einsum("bshc,hdc->bshd")
+ * (chitu/models/model_deepseek_v3.py:511-531, 697; kernel triton_kernels.py:217-247):
+ *   out[b,h,n] = bf16( sum_k x[b,h,k] * bf16(float(w[h,n,k]) * scale[off + h*sh + (n/128)*sn + (k/128)*sk]) )
+ *   x [batch, heads, K] bf16 (strides in elements, multiples of 8); w [heads, N, K] fp8 with head
+ *   stride w_stride_h elements (so a row-slice of wkv_b can be passed in place); K % 64 == 0;
+ *   out [batch, heads, N] bf16 (strides multiples of 4). */
+int chitu_hip_absorb_bmm_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
+                             const void* w_fp8, int64_t w_stride_h, const float* scale,
+                             int64_t scale_offset, int64_t scale_stride_h, int64_t scale_stride_n, int64_t scale_stride_k,
+                             void* out_bf16, int64_t out_stride_b, int64_t out_stride_h,
+                             int32_t batch, int32_t heads, int32_t N, int32_t K, void* stream);
 
 #ifdef __cplusplus
 }
