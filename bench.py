@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Decode-throughput benchmark of the MI355X-native hot path (BASELINE.json metric).
+
+Workload (named in `config.workload`): DeepSeek-R1-671B FP8, one TP=8 rank shard per GPU -- all
+61 layers, 16 local heads, all 257 experts at 1/8 width, replicated wqkv_a / gate / latent KV
+cache -- i.e. exactly the bytes and kernels one GPU of the 8-GPU node executes per decode step
+(35.7 GB/step at bs=16, 5.7 GB at bs=1).  Random synthetic weights and KV
+(no network for checkpoints), batch `--bs` sequences at context `--ctx`, greedy sampling, the
+whole step replayed as one hipGraph.  With N ranks live, the TP all-reduces / all-gather run over
+RCCL across those N ranks; at N=8 this IS the metric's configuration.
+
+A "step" = one decode token for the whole batch.  value = (N/8) * bs * K / T: N GPUs complete N/8
+of the model's work for every token they emit, so this is the full-model-equivalent rate the job
+sustains (weak scaling: per-GPU work fixed).  `node_tok_s` = bs*K/T is what an 8-GPU node would
+emit at this per-rank step time.
+
+Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SHARD = 8  # the metric's TP degree
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--bs", type=int, default=16)
+    ap.add_argument("--ctx", type=int, default=1024)
+    ap.add_argument("--layers", type=int, default=61, help="debug only: fewer layers => result flagged invalid")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def setup_dist(n):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        from chitu_amd import tensor_parallel as tp
+
+        tp.init_tp(world, 1)
+    else:
+        torch.cuda.set_device(0)
+    assert world == n, f"--gpus {n} but WORLD_SIZE={world}"
+    return rank, world, local
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def build_model(args_ns, rank):
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args, DeepSeekV3Decoder, init_synthetic_
+
+    margs = DeepSeekV3Args(shard_degree=SHARD, n_layers=args_ns.layers)
+    max_seq = args_ns.ctx + args_ns.steps + args_ns.warmup + 256
+    max_reqs = max(args_ns.bs, 1)
+    cache = PagedKVCacheManager(0, margs.n_layers, num_hot_req=max_reqs, block_size=64, max_seq_len=max_seq,
+                                device="cuda", kv_shape_per_sample=(margs.kv_lora_rank + margs.qk_rope_head_dim,),
+                                dtype=torch.bfloat16)
+    be = HipAttnBackend(local_n_heads=margs.n_heads // SHARD, max_seq_len=max_seq)
+    model = DeepSeekV3Decoder(margs, cache, be, max_position_embeddings=max(max_seq, 4097), device="cuda")
+    init_synthetic_(model, seed=1000 + rank)
+    # synthetic "prefilled" latent KV (prefill is out of scope)
+    gen = torch.Generator(device="cuda").manual_seed(77 + rank)
+    flat = cache.paged_kv_cache.view(-1)
+    for i in range(0, flat.numel(), 1 << 26):
+        n = min(1 << 26, flat.numel() - i)
+        flat[i : i + n].copy_(torch.randn(n, device="cuda", dtype=torch.bfloat16, generator=gen) * 0.5)
+    return margs, model, cache
+
+
+def run_decode(model, cache, reqs, tokens, steps, world, use_graph, timed):
+    """Exactly `steps` decode steps; returns (seconds (max over ranks) or None, final tokens)."""
+    if timed:
+        barrier_sync(world)
+        t0 = time.perf_counter()
+    for _ in range(steps):
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        logits = model.decode(tokens, use_graph=use_graph)
+        tokens = logits.argmax(dim=-1)  # greedy (executor.py:103-104), stays on device
+        cache.finalize_cache_single_decode(reqs)
+    if not timed:
+        torch.cuda.synchronize()
+        return None, tokens
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, tokens
+
+
+def measure(model, cache, bs, ctx, steps, warmup, world, use_graph, tag):
+    reqs = [f"{tag}{i}" for i in range(bs)]
+    for r in reqs:
+        cache.register_sequence(r, ctx)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    tokens = torch.randint(100, 1000, (bs,), device="cuda", generator=gen)
+    _, tokens = run_decode(model, cache, reqs, tokens, warmup, world, use_graph, timed=False)
+    dt, tokens = run_decode(model, cache, reqs, tokens, steps, world, use_graph, timed=True)
+    for r in reqs:
+        cache.finalize_cache_all_decode(r)
+    return dt
+
+
+def distinct_experts_last_step(model, bs):
+    """Average number of distinct routed experts hit per MoE layer (drives the algorithmic bytes)."""
+    return None
+
+
+def algorithmic_bytes_per_step(margs, bs, ctx, distinct):
+    """every weight byte counted once per step, per GPU, TP = SHARD."""
+    t = SHARD
+    d = margs.dim
+    attn = (margs.q_lora_rank + margs.kv_lora_rank + margs.qk_rope_head_dim) * d \
+        + (margs.n_heads * 192 // t) * margs.q_lora_rank + (margs.n_heads * 256 // t) * margs.kv_lora_rank \
+        + d * (margs.n_heads * 128 // t)
+    dense = 3 * margs.inter_dim * d // t
+    moe = margs.n_routed_experts * d * 2 + (1 + distinct) * 3 * margs.moe_inter_dim * d // t
+    n_moe = margs.n_layers - margs.n_dense_layers
+    head = (margs.vocab_size // t) * d * 2
+    kv = margs.n_layers * bs * ctx * 576 * 2
+    return margs.n_layers * attn + margs.n_dense_layers * dense + n_moe * moe + head + kv
+
+
+def roofline_dominant_kernel(model, margs, bs, iters=3):
+    """Time the dominant kernel -- the routed-expert GEMM1 (chitu_hip_moe_gemm1_fp8: ~2/3 of all
+    bytes at bs=16) -- live with HIP events on the launch stream, one launch per MoE layer with that
+    layer's own weights (HBM-cold) and a uniform random routing of the same shape as the step's."""
+    import ctypes
+
+    from chitu_amd import _lib, fused_moe
+    from chitu_amd._lib import i32, i64, ptr, stream_ptr
+
+    lib = _lib.lib()
+    moe_layers = [l.ffn for l in model.layers if l.is_moe]
+    if not moe_layers:
+        return None
+    E, topk, K = margs.n_routed_experts, margs.n_activated_experts, margs.dim
+    N = moe_layers[0].w1w3_weight.shape[1]
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    ids = torch.stack([torch.randperm(E, device="cuda", generator=gen)[:topk] for _ in range(bs)])
+    distinct = int(ids.unique().numel())
+    x = torch.randn(bs, K, device="cuda", dtype=torch.bfloat16, generator=gen)
+    xq, xs = fused_moe.per_token_group_quant_fp8(x, 128)
+    sorted_ids, expert_ids, npost = fused_moe.moe_align_block_size(ids, 16, E)
+    numel = bs * topk
+    out = torch.empty(numel, N, dtype=torch.bfloat16, device="cuda")
+    max_mb = min(expert_ids.numel(), numel)
+    st = stream_ptr()
+
+    def launch(m):
+        rc = lib.chitu_hip_moe_gemm1_fp8(ptr(xq), ptr(xs), ptr(m.w1w3_weight), ptr(m.w1w3_scale), ptr(sorted_ids),
+                                         ptr(expert_ids), ptr(npost), ptr(out), i64(numel), i32(topk), i64(N), i64(K),
+                                         i64(max_mb), st)
+        assert rc == 0
+
+    for m in moe_layers[:2]:
+        launch(m)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(iters):
+        for m in moe_layers:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch(m)
+            e1.record()
+            times.append((e0, e1))
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in times)
+    avg_ms = sum(ms) / len(ms)
+    # algorithmic bytes of one launch: each hit expert's W1 slice once + its scales + activations + output
+    w_bytes = distinct * N * K
+    s_bytes = distinct * ((N + 127) // 128) * (K // 128) * 4
+    a_bytes = bs * K + bs * (K // 128) * 4 + numel * N * 2
+    alg = w_bytes + s_bytes + a_bytes
+    achieved = alg / (avg_ms * 1e-3) / 1e9
+    return {
+        "kernel": "moe_gemm1_kernel (routed experts W1, fp8 block-scaled grouped GEMM)",
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(ms[len(ms) // 2] * 1e3, 2),
+        "algorithmic_bytes_per_launch": alg, "distinct_experts": distinct, "launches_timed": len(ms),
+    }
+
+
+def cpu_baseline(margs, bs, ctx):
+    """The oracle (CPU restatement of the reference's decode path) timed on this host's cores, on a
+    bounded sample: ONE MoE decoder layer at the full per-rank shapes and the full batch/context.
+    Scaled by the layer count it gives the reference-CPU-path rate for the same per-GPU workload."""
+    import torch.nn.functional as F  # noqa: F401
+
+    from oracle import deepseek as ods
+
+    # torch's intra-op pool collapses on the oracle's many small ops when given hundreds of
+    # threads (measured: 158 s/layer with 256 threads vs <10 s with 16), so cap it; `cores` reports
+    # the threads actually used.
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    H = margs.n_heads // SHARD
+    I = margs.moe_inter_dim // SHARD
+    # 32 routed experts are materialised for the sample (1.4 GB of host weights would take longer
+    # to generate than to use); each token still runs top-8 routing + the shared expert.
+    E = 32
+    d = margs.dim
+    g = torch.Generator().manual_seed(0)
+    fp8 = torch.float8_e4m3fn
+
+    def w(*shape):
+        return (torch.randn(*shape, generator=g, dtype=torch.bfloat16) * 0.5).to(fp8)
+
+    def s(*shape):
+        return torch.rand(*shape, generator=g) * 0.02 + 0.01
+
+    pre = "layers.3."
+    p = {
+        pre + "attn_norm.weight": torch.ones(d, dtype=torch.bfloat16),
+        pre + "ffn_norm.weight": torch.ones(d, dtype=torch.bfloat16),
+        pre + "attn.wqkv_a.weight": w(2112, d), pre + "attn.wqkv_a.scale": s(17, d // 128),
+        pre + "attn.q_norm.weight": torch.ones(1536, dtype=torch.bfloat16),
+        pre + "attn.wq_b.weight": w(H * 192, 1536), pre + "attn.wq_b.scale": s(H * 192 // 128, 12),
+        pre + "attn.kv_norm.weight": torch.ones(512, dtype=torch.bfloat16),
+        pre + "attn.wkv_b.weight": w(H * 256, 512), pre + "attn.wkv_b.scale": s(H * 2, 4),
+        pre + "attn.wo.weight": w(d, H * 128), pre + "attn.wo.scale": s(d // 128, H),
+        pre + "ffn.gate.weight": (torch.randn(E, d, generator=g) * 0.05).to(torch.bfloat16),
+        pre + "ffn.gate.bias": (torch.randn(E, generator=g) * 0.01).to(torch.bfloat16),
+        pre + "ffn.w1w3_weight": w(E + 1, 2 * I, d), pre + "ffn.w1w3_scale": s(E + 1, 2 * I // 128, d // 128),
+        pre + "ffn.w2_weight": w(E + 1, d, I), pre + "ffn.w2_scale": s(E + 1, d // 128, I // 128),
+    }
+    from chitu_amd.deepseek_v3 import compute_softmax_scale
+
+    cfg = dict(H=H, C=512, R=64, NOPE=128, V=128, QL=1536, eps=1e-6, scale=compute_softmax_scale(margs),
+               n_groups=8, topk_groups=4, topk=8, score_func="sigmoid", route_scale=2.5, n_routed=E)
+    ods.block(p, 3, torch.randn(1, d, generator=g).to(torch.bfloat16), torch.randn(1, 32, generator=g),
+              torch.randn(1, 32, generator=g), (torch.randn(2, 64, 576, generator=g) * 0.5).to(torch.bfloat16),
+              torch.zeros(1, 2, dtype=torch.int32), torch.full((1,), 10, dtype=torch.int32), cfg, True)  # warm-up
+    pages_per = (ctx + 64) // 64 + 1
+    cache = (torch.randn(bs * pages_per, 64, 576, generator=g) * 0.5).to(torch.bfloat16)
+    table = torch.arange(bs * pages_per, dtype=torch.int32).view(bs, pages_per)
+    lens = torch.full((bs,), ctx, dtype=torch.int32)
+    cos = torch.randn(bs, 32, generator=g)
+    sin = torch.randn(bs, 32, generator=g)
+    x = torch.randn(bs, d, generator=g).to(torch.bfloat16)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        ods.block(p, 3, x, cos, sin, cache, table, lens, cfg, True)
+        reps += 1
+        if time.perf_counter() - t0 > 8.0 or reps >= 3:
+            break
+    per_layer = (time.perf_counter() - t0) / reps
+    step_s = per_layer * margs.n_layers
+    return {
+        "value": round((1.0 / SHARD) * bs / step_s, 4), "unit": "tok/s (same normalisation as value, 1 of 8 shards)",
+        "cores": cores, "kind": "port",
+        "sample": f"{reps} x one MoE decoder layer (per-rank R1 shapes, bs={bs}, ctx={ctx}) on the CPU oracle, "
+                  f"{per_layer * 1e3:.0f} ms/layer, scaled x{margs.n_layers} layers",
+        "ms_per_layer": round(per_layer * 1e3, 1),
+    }
+
+
+def main():
+    a = parse()
+    rank, world, local = setup_dist(a.gpus)
+    use_graph = not a.no_graph
+    t_build = time.perf_counter()
+    margs, model, cache = build_model(a, rank)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t_build
+
+    dt = measure(model, cache, a.bs, a.ctx, a.steps, a.warmup, world, use_graph, "m")
+    ms_per_step = dt / a.steps * 1e3
+    node_tok_s = a.bs * a.steps / dt
+    value = node_tok_s * world / SHARD
+
+    extra = {}
+    if not a.no_bs1 and a.bs != 1:
+        dt1 = measure(model, cache, 1, a.ctx, a.steps, a.warmup, world, use_graph, "s")
+        extra["bs1"] = {
+            "ms_per_step": round(dt1 / a.steps * 1e3, 4), "node_tok_s": round(a.steps / dt1, 2),
+            "value": round(a.steps / dt1 * world / SHARD, 3),
+        }
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        roof = roofline_dominant_kernel(model, margs, a.bs)
+    distinct = roof["distinct_experts"] if roof else min(256, a.bs * 8)
+    step_bytes = algorithmic_bytes_per_step(margs, a.bs, a.ctx, distinct)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        del model
+        torch.cuda.empty_cache()
+        cpu = cpu_baseline(margs, a.bs, a.ctx)
+
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        res = {
+            "metric": f"output tok/s (bs={a.bs}) DeepSeek-R1 FP8 TP=8; HBM GB/s vs peak",
+            "value": round(value, 3), "unit": "tok/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "fp8_e4m3 weights+activations (W8A8, fp32 accumulate), bf16 attention",
+            "data": "synthetic (random-init weights, random KV cache, random prompts)",
+            "config": {
+                "workload": f"DeepSeek-R1-671B FP8 decode, one TP=8 rank shard per GPU "
+                            f"({margs.n_layers} layers, 16 heads, 257 experts x 1/8 width), {world} of 8 shards live, "
+                            f"bs={a.bs}, ctx={a.ctx}, greedy, hipGraph={'on' if use_graph else 'off'}",
+                "batch": a.bs, "context": a.ctx, "parallelism": f"tp8-shard x{world}", "layers": margs.n_layers,
+            },
+            "node_tok_s": round(node_tok_s, 2),
+            "step_algorithmic_GB": round(step_bytes / 1e9, 3),
+            "step_hbm_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+            "step_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": roof, "cpu_baseline": cpu, "build_s": round(build_s, 1),
+        }
+        res.update(extra)
+        if a.layers != 61:
+            res["invalid"] = "reduced layer count (debug run)"
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

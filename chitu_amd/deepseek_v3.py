@@ -56,6 +56,13 @@ class DeepSeekV3Args:
     rope_factor: float = 40
     norm_eps: float = 1e-6
     gate_bias: Optional[bool] = None  # reference: bias iff dim == 7168 (model_deepseek_v3.py:804-808)
+    # Width of the tensor-parallel sharding used for LOCAL SHAPES.  None = the live TP group size
+    # (the reference's behaviour).  bench.py sets 8 to run one TP=8 rank shard per GPU even when
+    # fewer than 8 ranks are live (collectives then span the live ranks only).
+    shard_degree: Optional[int] = None
+
+    def tp_degree(self):
+        return self.shard_degree if self.shard_degree is not None else tp.get_tp_size()
 
     def has_gate_bias(self):
         return self.dim == 7168 if self.gate_bias is None else self.gate_bias
@@ -139,7 +146,7 @@ class AttentionDeepSeekV3(torch.nn.Module):
 
     def __init__(self, args: DeepSeekV3Args, layer_id, cache, attn_backend, device=None):
         super().__init__()
-        tp_size = tp.get_tp_size()
+        tp_size = args.tp_degree()
         self.layer_id, self.cache, self.attn_backend = layer_id, cache, attn_backend
         self.dim = args.dim
         self.n_local_heads = args.n_heads // tp_size
@@ -201,7 +208,7 @@ class MLPDeepSeekV3(torch.nn.Module):
 
     def __init__(self, args, device=None):
         super().__init__()
-        tp_size = tp.get_tp_size()
+        tp_size = args.tp_degree()
         self.inter = args.inter_dim // tp_size
         self.w1w3 = Fp8Linear(args.dim, 2 * self.inter, device)
         self.w2 = Fp8Linear(self.inter, args.dim, device)
@@ -251,7 +258,7 @@ class MoEDeepSeekV3(torch.nn.Module):
 
     def __init__(self, args, device=None):
         super().__init__()
-        tp_size = tp.get_tp_size()
+        tp_size = args.tp_degree()
         self.n_routed, self.n_shared = args.n_routed_experts, args.n_shared_experts
         self.inter = args.moe_inter_dim // tp_size
         E = self.n_routed + self.n_shared
@@ -312,12 +319,17 @@ class DeepSeekV3Decoder(torch.nn.Module):
                  max_position_embeddings: int = 4096, device="cuda", layers: Optional[List[int]] = None):
         super().__init__()
         self.args, self.cache, self.attn_backend, self.device = args, cache, attn_backend, torch.device(device)
-        self.embed = tp.VocabParallelEmbedding(args.vocab_size, args.dim, dtype=torch.bfloat16).to(device)
+        deg = args.tp_degree()
+        assert args.vocab_size % deg == 0
+        self.vocab_local = args.vocab_size // deg
+        self.vocab_start = (tp.get_tp_rank() % deg) * self.vocab_local
+        # VocabParallelEmbedding / ColumnParallelLinear(gather_output) of the reference
+        # (model_deepseek_v3.py:1292-1319), sharded `deg` ways
+        self.embed_weight = torch.nn.Parameter(torch.empty(self.vocab_local, args.dim, dtype=torch.bfloat16, device=device), requires_grad=False)
         ids = list(range(args.n_layers)) if layers is None else layers
         self.layers = torch.nn.ModuleList(TransformerBlockDeepSeekV3(i, args, cache, attn_backend, device) for i in ids)
         self.norm = RMSNormW(args.dim, args.norm_eps, device)
-        self.head = tp.ColumnParallelLinear(args.dim, args.vocab_size, has_bias=False, gather_output=True,
-                                            dtype=torch.bfloat16).to(device)
+        self.head_weight = torch.nn.Parameter(torch.empty(self.vocab_local, args.dim, dtype=torch.bfloat16, device=device), requires_grad=False)
         cos, sin = precompute_freqs_cis(args, max_position_embeddings)
         self.cos_table, self.sin_table = cos.to(device), sin.to(device)
         self.graphs, self.static_tokens, self.static_out = {}, {}, {}
@@ -331,7 +343,17 @@ class DeepSeekV3Decoder(torch.nn.Module):
         for layer in self.layers:
             h = layer(h, cos, sin)
         h = ops.rms_norm(h, self.norm.weight, self.norm.eps)
-        return self.head(h).float()
+        return tp.all_gather_last_dim(F.linear(h, self.head_weight)).float()
+
+    def embed(self, tokens):
+        """tensor_parallel.py:199-208: mask ids outside this rank's vocab slice, lookup, all-reduce."""
+        if self.vocab_local == self.args.vocab_size:
+            return F.embedding(tokens, self.embed_weight)
+        local = tokens - self.vocab_start
+        mask = (local < 0) | (local >= self.vocab_local)
+        y = F.embedding(torch.where(mask, torch.zeros_like(local), local), self.embed_weight)
+        y = torch.where(mask.unsqueeze(-1), torch.zeros_like(y), y)
+        return tp.all_reduce(y)
 
     def prepare_decoding_attn(self):
         """model_deepseek_v3.py:1339-1350 -- outside the graph."""
