@@ -64,7 +64,71 @@ __global__ __launch_bounds__(64) void absorb_bmm_kernel(
     }
 }
 
+// Same product for N == 128 (the W_UV half: one head = one 128-wide quantisation group of wo's
+// input), fused with act_quant_deepseek_v3 of the bf16-rounded result (the launch that precedes the
+// wo GEMM in linear_deepseek_v3, model_deepseek_v3.py:98-100).  grid (H, ceil(batch/16)); block 512:
+// wave w owns output columns [16w, 16w+16), the per-(token, head) max goes through LDS.
+__global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
+    const bf16_t* __restrict__ x, int64_t x_sb, int64_t x_sh, const fp8_t* __restrict__ W, int64_t w_sh,
+    const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sk, fp8_t* __restrict__ q,
+    float* __restrict__ qs, int batch, int H, int K) {
+    __shared__ float red[8][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, m0 = blockIdx.y * 16;
+    const int m = min(m0 + j, batch - 1);
+    const fp8_t* wp = W + (int64_t)h * w_sh + (int64_t)(wave * 16 + j) * K + g * 16;
+    const bf16_t* xp = x + m * x_sb + h * x_sh + g * 16;
+    const float* sp = scale + s_off + h * s_sh;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const i32x4 w = *reinterpret_cast<const i32x4*>(wp + k0);
+        const float s = sp[(k0 >> 7) * s_sk];
+        const s16x8 wa = dequant8_bf16((uint32_t)w[0], (uint32_t)w[1], s);
+        const s16x8 wb = dequant8_bf16((uint32_t)w[2], (uint32_t)w[3], s);
+        const s16x8 xa = *reinterpret_cast<const s16x8*>(xp + k0);
+        const s16x8 xb = *reinterpret_cast<const s16x8*>(xp + k0 + 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xa, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc, 0, 0, 0);
+    }
+    float v[4], amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = round_bf16(acc[r]);
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v[r]));
+    }
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
+    if (g == 0) red[wave][j] = amax;
+    __syncthreads();
+    amax = red[0][j];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) amax = __builtin_fmaxf(amax, red[w][j]);
+    const float sc = amax / 448.0f;
+    if (m0 + j >= batch) return;
+    const uint32_t packed = f32x2_to_fp8x2(v[0] / sc, v[1] / sc) | (f32x2_to_fp8x2(v[2] / sc, v[3] / sc) << 16);
+    *reinterpret_cast<uint32_t*>(q + ((int64_t)(m0 + j) * H + h) * 128 + wave * 16 + g * 4) = packed;
+    if (wave == 0 && g == 0) qs[(int64_t)(m0 + j) * H + h] = sc;
+}
+
 }  // namespace chitu
+
+extern "C" int chitu_hip_absorb_uv_quant_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
+                                             const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                             int64_t scale_offset, int64_t scale_stride_h,
+                                             int64_t scale_stride_k, void* q_fp8, float* q_scales,
+                                             int32_t batch, int32_t heads, int32_t K, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && w_fp8 && scale && q_fp8 && q_scales);
+    CHITU_REQUIRE(batch >= 0 && heads >= 1 && K >= 64 && w_stride_h % 16 == 0);
+    if (K % 64 != 0) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(x_stride_b % 8 == 0 && x_stride_h % 8 == 0);
+    if (batch == 0) return CHITU_OK;
+    hipLaunchKernelGGL(absorb_uv_quant_kernel, dim3((unsigned)heads, (unsigned)((batch + 15) / 16)), dim3(512), 0,
+                       (hipStream_t)stream, (const bf16_t*)x_bf16, x_stride_b, x_stride_h, (const fp8_t*)w_fp8,
+                       w_stride_h, scale, scale_offset, scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales,
+                       (int)batch, (int)heads, (int)K);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int chitu_hip_absorb_bmm_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
                                         const void* w_fp8, int64_t w_stride_h, const float* scale,

@@ -1,0 +1,239 @@
+// MoE router for decode on gfx950: skinny bf16 GEMM (scores) + one fused routing kernel.
+//
+// Replaces (reference, read-only) GateDeepSeekV3.forward, chitu/models/model_deepseek_v3.py:810-842,
+// which runs as ~17 small torch launches per layer (F.linear, sigmoid, + bias, view, topk(2), sum,
+// topk(groups), zeros_like, scatter_, mul, flatten, topk(k), gather, sum, div, mul, type_as):
+//   scores = sigmoid(x W^T) (bf16) | softmax(x W^T) (fp32);  s' = scores + bias
+//   group score = sum of the group's top-2 s' (bias present) or its max (no bias)
+//   keep the top `topk_groups` groups, zero the rest; pick the top-k experts of s'
+//   weights = scores[idx]  (/ their sum for sigmoid)  * route_scale  -> x.dtype
+// Rounding points mirror torch's: every bf16 tensor op rounds once (sigmoid, +bias, top-2 sum,
+// weight sum, division, scaling).  Ties are broken towards the LOWER index (torch.topk leaves tie
+// order unspecified), which makes routing deterministic.
+//
+// The score GEMM is the same weight-streaming shape as fp8_gemm.hip with bf16 weights as the MFMA A
+// operand; N = n_experts is tiny (16 row tiles), so K is split across workgroups and the fp32
+// partials are summed, in order, by the routing kernel itself (no separate reduce launch).  The same
+// GEMM entry point serves the LM head (N = vocab/tp, no split).
+#include "common.h"
+#include "gemm_common.h"
+
+namespace chitu {
+
+// ---------------------------------------------------------------- skinny bf16 GEMM
+// out[m][n] = sum_k x[m][k] * w[n][k]; k-block = 64 elements (128 B of a weight row).
+template <int MT, int WK>
+__global__ __launch_bounds__(64 * WK) void bf16_gemm_kernel(const bf16_t* __restrict__ X,
+                                                            const bf16_t* __restrict__ W,
+                                                            void* __restrict__ out, int out_dt,
+                                                            float* __restrict__ partial, int M, int N,
+                                                            int K, int S, int m_base) {
+    __shared__ float red[WK > 1 ? WK * MT * 256 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int KB = K >> 6;
+    const int T = S * WK;
+    const int t = blockIdx.y * WK + wave;
+    const int kb0 = (int)((long)KB * t / T), kb1 = (int)((long)KB * (t + 1) / T);
+    const bf16_t* wp = W + (size_t)min(n0 + j, N - 1) * K + g * 8;
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xp[mt] = X + (size_t)min(m_base + mt * 16 + j, M - 1) * K + g * 8;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int off = kb << 6;
+        const s16x8 w0 = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp + off));
+        const s16x8 w1 = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp + off + 32));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const s16x8 x0 = *reinterpret_cast<const s16x8*>(xp[mt] + off);
+            const s16x8 x1 = *reinterpret_cast<const s16x8*>(xp[mt] + off + 32);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc[mt], 0, 0, 0);
+        }
+    }
+    gemm_epilogue<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
+}
+
+// ---------------------------------------------------------------- fused routing
+__device__ __forceinline__ float bf16r(float v) { return round_bf16(v); }
+
+// One workgroup per token; thread e owns expert e (blockDim = E rounded up to 64, E <= 1024).
+// logits: bf16 [M, E] (S == 0) or fp32 partials [S, M, E] to be summed here.
+// SIGMOID=1: bf16 score pipeline (DeepSeek-V3); 0: fp32 softmax pipeline (DeepSeek-V2).
+template <int SIGMOID>
+__global__ __launch_bounds__(1024) void gate_route_kernel(
+    const void* __restrict__ logits, int S, int M, int E, const bf16_t* __restrict__ bias, int n_groups,
+    int topk_groups, int topk, float route_scale, bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids,
+    int out_stride, int extra_id, float extra_w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sc = lds;             // [E] selection score s'
+    float* red = lds + E;        // [32] wave partials
+    float* gsc = lds + E + 32;   // [n_groups] group scores
+    float* wsel = lds + E + 32 + 64;  // [topk] selected original scores
+    const int t = blockIdx.x, e = threadIdx.x, lane = e & 63, wave = e >> 6;
+    const int nw = blockDim.x >> 6;
+    const bool act = e < E;
+
+    float logit = -INFINITY;
+    if (act) {
+        if (S == 0) {
+            logit = bf16_to_f32(((const bf16_t*)logits)[(int64_t)t * E + e]);
+        } else {
+            float a = 0.f;
+            for (int s = 0; s < S; ++s) a += ((const float*)logits)[((int64_t)s * M + t) * E + e];
+            logit = bf16r(a);  // F.linear output in bf16 (model_deepseek_v3.py:820)
+        }
+    }
+    float orig;  // original_scores
+    if (SIGMOID) {
+        orig = act ? bf16r(1.0f / (1.0f + expf(-logit))) : 0.f;
+    } else {
+        float m = wave_reduce_max(logit);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+        for (int w = 1; w < nw; ++w) m = __builtin_fmaxf(m, red[w]);
+        __syncthreads();
+        const float ex = act ? expf(logit - m) : 0.f;
+        float sum = wave_reduce_sum(ex);
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        sum = 0.f;
+        for (int w = 0; w < nw; ++w) sum += red[w];
+        __syncthreads();
+        orig = ex / sum;  // softmax(dim=-1, dtype=float32)
+    }
+    float sel = orig;
+    if (bias && act) sel = SIGMOID ? bf16r(orig + bf16_to_f32(bias[e])) : orig + bf16_to_f32(bias[e]);
+    if (act) sc[e] = sel;
+    __syncthreads();
+
+    if (n_groups > 1) {
+        const int gs = E / n_groups;
+        if (e < n_groups) {
+            float m1 = -INFINITY, m2 = -INFINITY;
+            for (int i = 0; i < gs; ++i) {
+                const float v = sc[e * gs + i];
+                if (v > m1) { m2 = m1; m1 = v; }
+                else if (v > m2) m2 = v;
+            }
+            // bias: topk(2).sum (bf16 add); no bias: amax  (model_deepseek_v3.py:827-831)
+            gsc[e] = bias ? (SIGMOID ? bf16r(m1 + m2) : m1 + m2) : m1;
+        }
+        __syncthreads();
+        if (act) {
+            const int grp = e / gs;
+            const float mine = gsc[grp];
+            int rank = 0;
+            for (int g2 = 0; g2 < n_groups; ++g2) {
+                const float o = gsc[g2];
+                rank += (o > mine) || (o == mine && g2 < grp);
+            }
+            if (rank >= topk_groups) sel = 0.f;  // scores * mask
+        }
+        __syncthreads();
+        if (act) sc[e] = sel;
+        __syncthreads();
+    }
+    int rank = 0;
+    if (act) {
+        for (int i = 0; i < E; ++i) {
+            const float o = sc[i];
+            rank += (o > sel) || (o == sel && i < e);
+        }
+        if (rank < topk) {
+            out_ids[(int64_t)t * out_stride + rank] = e;
+            wsel[rank] = orig;
+        }
+    }
+    __syncthreads();
+    if (e < topk) {
+        float w = wsel[e];
+        if (SIGMOID) {
+            float sum = 0.f;
+            for (int i = 0; i < topk; ++i) sum += wsel[i];
+            w = bf16r(w / bf16r(sum));          // weights /= weights.sum(-1, keepdim=True)
+            w = bf16r(w * route_scale);         // weights *= route_scale
+        } else {
+            w = w * route_scale;                // fp32, then type_as(x)
+        }
+        out_w[(int64_t)t * out_stride + e] = f32_to_bf16(w);
+    }
+    if (e == 0 && extra_id >= 0) {  // optional always-on (shared) expert appended as slot `topk`
+        out_ids[(int64_t)t * out_stride + topk] = extra_id;
+        out_w[(int64_t)t * out_stride + topk] = f32_to_bf16(extra_w);
+    }
+}
+
+}  // namespace chitu
+
+extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void* out, int out_dtype,
+                                   int64_t M, int64_t N, int64_t K, int32_t num_splits,
+                                   float* partials, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && w_bf16 && M >= 0 && N >= 1 && K >= 64 && N < (1 << 30) && K < (1 << 30));
+    CHITU_REQUIRE(num_splits >= 1 && num_splits <= 64);
+    CHITU_REQUIRE(num_splits > 1 ? partials != nullptr : (out != nullptr && out_dtype >= 0 && out_dtype <= 2));
+    if (K % 64 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (M == 0) return CHITU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int KB = (int)(K / 64);
+    const int tiles = (int)((N + 15) / 16);
+    if (num_splits > KB) return CHITU_ERR_BAD_ARG;
+    const int S = num_splits;
+    int WK = 8;
+    while (WK > 1 && (WK * S > KB || (int64_t)tiles * S * WK > 4096)) WK >>= 1;
+    const dim3 grid((unsigned)tiles, (unsigned)S);
+#define LAUNCH(MT, WKV)                                                                            \
+    hipLaunchKernelGGL((bf16_gemm_kernel<MT, WKV>), grid, dim3(64 * WKV), 0, st, (const bf16_t*)x_bf16, \
+                       (const bf16_t*)w_bf16, out, out_dtype, partials, (int)M, (int)N, (int)K, S, mbase)
+#define LAUNCH_WK(MT)                      \
+    switch (WK) {                          \
+        case 8: LAUNCH(MT, 8); break;      \
+        case 4: LAUNCH(MT, 4); break;      \
+        case 2: LAUNCH(MT, 2); break;      \
+        default: LAUNCH(MT, 1); break;     \
+    }
+    for (int64_t mb = 0; mb < M; mb += 32) {
+        const int mbase = (int)mb;
+        if (M - mb <= 16) { LAUNCH_WK(1) } else { LAUNCH_WK(2) }
+    }
+#undef LAUNCH_WK
+#undef LAUNCH
+    // num_splits > 1: partials [S][M][N] are left for the consumer (chitu_hip_gate_route) to sum.
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, int64_t tokens,
+                                    int32_t num_experts, const void* bias_bf16, int32_t n_groups,
+                                    int32_t topk_groups, int32_t topk, int32_t score_func,
+                                    float route_scale, void* out_weights_bf16, int64_t* out_ids,
+                                    int32_t out_stride, int32_t extra_expert_id, float extra_weight,
+                                    void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(logits && out_weights_bf16 && out_ids && tokens >= 0);
+    CHITU_REQUIRE(num_experts >= 1 && num_experts <= 1024 && topk >= 1 && topk <= num_experts && topk <= 64);
+    CHITU_REQUIRE(n_groups >= 1 && n_groups <= 64 && num_experts % n_groups == 0);
+    CHITU_REQUIRE(topk_groups >= 1 && topk_groups <= n_groups && num_partials >= 0);
+    CHITU_REQUIRE(out_stride >= topk + (extra_expert_id >= 0 ? 1 : 0));
+    CHITU_REQUIRE(score_func == 0 || score_func == 1);
+    if (tokens == 0) return CHITU_OK;
+    const int threads = ((num_experts + 63) / 64) * 64;
+    const size_t lds = sizeof(float) * (size_t)(num_experts + 32 + 64 + 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (score_func == 1)
+        hipLaunchKernelGGL(gate_route_kernel<1>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
+                           (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
+                           (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
+                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight);
+    else
+        hipLaunchKernelGGL(gate_route_kernel<0>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
+                           (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
+                           (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
+                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight);
+    CHITU_RETURN_LAUNCH_STATUS();
+}

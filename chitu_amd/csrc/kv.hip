@@ -78,7 +78,96 @@ __global__ __launch_bounds__(256) void rope_kernel(
     }
 }
 
+// MLA decode "KV prep": for each sequence, kv_norm(kv_c) and RoPE(k_pe) are written straight into
+// the token's page row (no intermediate [kv | pe] tensor, no separate append), and RoPE is applied
+// to q_pe in place.  Replaces four launches of the reference's decode_forward_paged
+// (chitu/models/model_deepseek_v3.py:493-500 apply_rotary_pos_emb, :684 kv_norm, :686 torch.cat,
+// attn_backend.py:720-722 append_to_paged_kv_cache) with identical arithmetic:
+// RMSNorm in fp32 with one bf16 rounding, RoPE products rounded separately.
+// One workgroup (256 threads) per sequence: wave 0 = norm (512 = 64 lanes x 8), wave 1 = k_pe,
+// waves 2-3 = q_pe.  kv_lora_rank 512 / rope 64 (the MLA cache row is 576 wide).
+__global__ __launch_bounds__(256) void mla_kv_prep_kernel(
+    const bf16_t* __restrict__ kv_in, int64_t kv_stride, bf16_t* __restrict__ q_pe, int64_t q_sb, int64_t q_sh,
+    int H, const float* __restrict__ cos, const float* __restrict__ sin, const bf16_t* __restrict__ norm_w,
+    float eps, bf16_t* __restrict__ cache, int64_t num_pages, int page_size, const int32_t* __restrict__ table,
+    int pages_per_seq, const int32_t* __restrict__ old_lens) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const bf16_t* src = kv_in + (int64_t)b * kv_stride;
+    const float* cb = cos + (int64_t)b * 32;
+    const float* sb = sin + (int64_t)b * 32;
+    bf16_t* row = nullptr;
+    {
+        const int L = old_lens[b];
+        const int pidx = L / page_size;
+        if (L >= 0 && pidx < pages_per_seq) {
+            const int64_t page = table[(int64_t)b * pages_per_seq + pidx];
+            if (page >= 0 && page < num_pages) row = cache + (page * page_size + (L % page_size)) * 576;
+        }
+    }
+    if (wave == 0) {
+        const i32x4 raw = *reinterpret_cast<const i32x4*>(src + lane * 8);
+        float v[8], ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)raw[k];
+            v[2 * k] = __uint_as_float(u << 16);
+            v[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ss += v[k] * v[k];
+        ss = wave_reduce_sum(ss);
+        const float rr = rsqrtf(ss / 512.0f + eps);
+        const i32x4 wraw = *reinterpret_cast<const i32x4*>(norm_w + lane * 8);
+        i32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)wraw[k];
+            const uint16_t lo = f32_to_bf16((v[2 * k] * rr) * __uint_as_float(u << 16));
+            const uint16_t hi = f32_to_bf16((v[2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
+            o[k] = (int)((uint32_t)lo | ((uint32_t)hi << 16));
+        }
+        if (row) *reinterpret_cast<i32x4*>(row + lane * 8) = o;
+    } else if (wave == 1) {
+        if (lane < 32 && row) {
+            const float x0 = bf16_to_f32(src[512 + 2 * lane]), x1 = bf16_to_f32(src[512 + 2 * lane + 1]);
+            const float c = cb[lane], s = sb[lane];
+            const uint32_t pk = (uint32_t)f32_to_bf16(x0 * c - x1 * s) | ((uint32_t)f32_to_bf16(x1 * c + x0 * s) << 16);
+            *reinterpret_cast<uint32_t*>(row + 512 + 2 * lane) = pk;
+        }
+    } else {
+        for (int idx = tid - 128; idx < H * 32; idx += 128) {
+            const int h = idx >> 5, i = idx & 31;
+            bf16_t* p = q_pe + b * q_sb + h * q_sh + 2 * i;
+            const float x0 = bf16_to_f32(p[0]), x1 = bf16_to_f32(p[1]);
+            const float c = cb[i], s = sb[i];
+            const uint32_t pk = (uint32_t)f32_to_bf16(x0 * c - x1 * s) | ((uint32_t)f32_to_bf16(x1 * c + x0 * s) << 16);
+            *reinterpret_cast<uint32_t*>(p) = pk;
+        }
+    }
+}
+
 }  // namespace chitu
+
+extern "C" int chitu_hip_mla_kv_prep(const void* kv_in_bf16, int64_t kv_row_stride, void* q_pe_bf16,
+                                     int64_t q_stride_b, int64_t q_stride_h, int32_t heads,
+                                     const float* cos, const float* sin, const void* kv_norm_weight_bf16,
+                                     float eps, void* kv_cache, int64_t num_pages, int32_t page_size,
+                                     const int32_t* page_table, int32_t pages_per_seq,
+                                     const int32_t* old_seq_lens, int32_t batch, int32_t kv_lora_rank,
+                                     int32_t rope_dim, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(kv_in_bf16 && q_pe_bf16 && cos && sin && kv_norm_weight_bf16 && kv_cache && page_table && old_seq_lens);
+    CHITU_REQUIRE(batch >= 0 && heads >= 1 && num_pages >= 1 && page_size >= 1 && pages_per_seq >= 1);
+    if (kv_lora_rank != 512 || rope_dim != 64) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(kv_row_stride % 8 == 0 && q_stride_b % 2 == 0 && q_stride_h % 2 == 0);
+    if (batch == 0) return CHITU_OK;
+    hipLaunchKernelGGL(mla_kv_prep_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)kv_in_bf16, kv_row_stride, (bf16_t*)q_pe_bf16, q_stride_b, q_stride_h,
+                       (int)heads, cos, sin, (const bf16_t*)kv_norm_weight_bf16, eps, (bf16_t*)kv_cache, num_pages,
+                       (int)page_size, page_table, (int)pages_per_seq, old_seq_lens);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
 
 extern "C" int chitu_hip_append_paged_kv(void* kv_cache, int64_t num_pages, int32_t page_size,
                                          int64_t row_bytes, const int32_t* page_table,

@@ -4,6 +4,7 @@
 //   chitu/models/model.py:29-78   RMSNorm.forward -> F.rms_norm(x.to(compute_dtype), w, eps).to(dtype)
 //   + the act_quant_deepseek_v3 launch that follows it in linear_deepseek_v3
 //     (chitu/models/model_deepseek_v3.py:98-100, kernel chitu/triton_kernels.py:193-214)
+// Optional residual: x <- bf16(x + add) first (also written to sum_out).
 // Math: y = (x * rsqrt(mean(x^2) + eps)) * w in fp32, one rounding to the output dtype -- this is
 // bit-identical to torch's rms_norm on bf16 input (checked in tests).  The optional second output
 // is the e4m3 quantisation of that *rounded* y (what the reference's next kernel would compute),
@@ -20,7 +21,8 @@ constexpr int kNormMaxChunks = 4;  // dim <= 256 * 8 * 4 = 8192
 // QMODE 0: no quant; 1: act_quant (no eps, no clamp); 2: per_token_group_quant (eps, clamp)
 template <int QMODE>
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(
-    const bf16_t* __restrict__ x, int64_t x_stride, const bf16_t* __restrict__ w,
+    const bf16_t* __restrict__ x, int64_t x_stride, const bf16_t* __restrict__ add,
+    int64_t add_stride, bf16_t* __restrict__ sum_out, int64_t sum_stride, const bf16_t* __restrict__ w,
     bf16_t* __restrict__ y, int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs,
     int dim, float eps, float qeps) {
     __shared__ float red[kNormThreads / 64];
@@ -40,8 +42,25 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(
                 const uint32_t u = (uint32_t)raw[k];
                 v[i][2 * k] = __uint_as_float(u << 16);
                 v[i][2 * k + 1] = __uint_as_float(u & 0xffff0000u);
-                ss += v[i][2 * k] * v[i][2 * k] + v[i][2 * k + 1] * v[i][2 * k + 1];
             }
+            if (add) {
+                // residual: x <- bf16(x + add), the reference's `x = x + attn(...)` in bf16
+                // (model_deepseek_v3.py:1107-1113), folded into the norm that consumes it
+                const i32x4 araw = *reinterpret_cast<const i32x4*>(add + (int64_t)row * add_stride + c * 8);
+                i32x4 sraw;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t u = (uint32_t)araw[k];
+                    const uint16_t lo = f32_to_bf16(v[i][2 * k] + __uint_as_float(u << 16));
+                    const uint16_t hi = f32_to_bf16(v[i][2 * k + 1] + __uint_as_float(u & 0xffff0000u));
+                    v[i][2 * k] = bf16_to_f32(lo);
+                    v[i][2 * k + 1] = bf16_to_f32(hi);
+                    sraw[k] = (int)((uint32_t)lo | ((uint32_t)hi << 16));
+                }
+                if (sum_out) *reinterpret_cast<i32x4*>(sum_out + (int64_t)row * sum_stride + c * 8) = sraw;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ss += v[i][k] * v[i][k];
         }
     }
     ss = wave_reduce_sum(ss);
@@ -105,15 +124,17 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(
 
 }  // namespace chitu
 
-extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const void* weight_bf16,
-                                 void* y_bf16, int64_t y_row_stride, int64_t rows, int32_t dim,
-                                 float eps, void* q_fp8, float* q_scales, int32_t quant_mode,
-                                 float quant_eps, void* stream) {
+extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
+                                 int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                 const void* weight_bf16, void* y_bf16, int64_t y_row_stride,
+                                 int64_t rows, int32_t dim, float eps, void* q_fp8, float* q_scales,
+                                 int32_t quant_mode, float quant_eps, void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(x_bf16 && weight_bf16 && rows >= 0 && dim >= 8);
     CHITU_REQUIRE(y_bf16 || quant_mode != 0);
     if (dim % 8 != 0 || dim > kNormThreads * 8 * kNormMaxChunks) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(x_row_stride % 8 == 0 && (!y_bf16 || y_row_stride % 8 == 0));
+    CHITU_REQUIRE((!add_bf16 || add_row_stride % 8 == 0) && (!sum_out_bf16 || (add_bf16 && sum_row_stride % 8 == 0)));
     if (quant_mode != 0) {
         CHITU_REQUIRE(q_fp8 && q_scales);
         if (dim % 128 != 0) return CHITU_ERR_UNSUPPORTED;
@@ -123,7 +144,8 @@ extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(QM)                                                                               \
     hipLaunchKernelGGL(rmsnorm_kernel<QM>, dim3((unsigned)rows), dim3(kNormThreads), 0, st,       \
-                       (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)weight_bf16,           \
+                       (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)add_bf16, add_row_stride, \
+                       (bf16_t*)sum_out_bf16, sum_row_stride, (const bf16_t*)weight_bf16,         \
                        (bf16_t*)y_bf16, y_row_stride, (fp8_t*)q_fp8, q_scales, (int)dim, eps, quant_eps)
     if (quant_mode == 0) LAUNCH(0);
     else if (quant_mode == 1) LAUNCH(1);

@@ -176,31 +176,32 @@ class AttentionDeepSeekV3(torch.nn.Module):
         return self._w_uk_t
 
     def decode_forward_paged(self, x_quant, cos, sin):
-        """x_quant = fp8 (q, s) of attn_norm(x), [bs, dim].  Returns wo(attn) before the all-reduce."""
+        """x_quant = fp8 (q, s) of attn_norm(x), [bs, dim].  Returns wo(attn) before the all-reduce.
+
+        9 launches (the reference's decode_forward_paged + _run_linear issue ~25): wqkv_a GEMM,
+        q_norm+quant, wq_b GEMM, [kv_norm + RoPE + page append], W_UK absorb, MLA decode (+ merge),
+        [W_UV absorb + quant], wo GEMM."""
         H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
         bs = x_quant[0].shape[0]
+        cache = self.cache
         q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [bs, q_lora + C + R]
-        q_a = q_a_kv[:, : self.q_lora_rank]
-        _, qq, qs = ops.rms_norm(q_a, self.q_norm.weight, self.q_norm.eps, out_bf16=False, quant="act")
+        _, qq, qs = ops.rms_norm(q_a_kv[:, : self.q_lora_rank], self.q_norm.weight, self.q_norm.eps,
+                                 out_bf16=False, quant="act")
         q = self.wq_b(None, x_quant=(qq, qs)).view(bs, H, self.qk_head_dim)
         q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
-        k_pe = q_a_kv[:, self.q_lora_rank + C :]
-        q_pe, k_pe = ops.apply_rotary_pos_emb(q_pe, k_pe, cos, sin, rotary_type="llama")
+        kv_cache = cache.get_paged_kv_cache(self.layer_id)
+        # this token's [kv_norm(kv_c) | rope(k_pe)] row goes straight into its page; q_pe rotated in place
+        ops.mla_kv_prep(q_a_kv[:, self.q_lora_rank :], q_pe, cos, sin, self.kv_norm.weight, self.kv_norm.eps,
+                        kv_cache, cache.get_gpu_block_table(), cache.get_gpu_seq_lens_excl_this_decode())
         # q_nope' = q_nope . W_UK  (einsum "shd,hdc->shc", :529-531), wkv_b dequantised in registers
         nblk = C // BLOCK
         q_abs = ops.absorb_bmm_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0)
-        this_kv = ops.rms_norm(q_a_kv[:, self.q_lora_rank : self.q_lora_rank + C], self.kv_norm.weight, self.kv_norm.eps)
-        this_kv_pe = torch.cat([this_kv, k_pe], dim=-1)
-        o = self.attn_backend.mla_attn_with_kvcache(
-            q_abs, q_pe, self.cache.get_paged_kv_cache(self.layer_id), this_kv_pe.view(bs, 1, 1, -1),
-            cache_seqlens_excl_this_decode=self.cache.get_gpu_seq_lens_excl_this_decode(),
-            cache_seqlens_incl_this_decode=self.cache.get_gpu_seq_lens_incl_this_decode(),
-            block_table=self.cache.get_gpu_block_table(), softmax_scale=self.softmax_scale,
-        ).view(bs, H, C)
-        # out = o . W_UV^T  (einsum "bshc,hdc->bshd", :697)
+        o = self.attn_backend.mla_decode(q_abs, q_pe, kv_cache, cache.get_gpu_seq_lens_incl_this_decode(),
+                                         cache.get_gpu_block_table(), self.softmax_scale)
+        # out = o . W_UV^T  (einsum "bshc,hdc->bshd", :697) + the act-quant of wo's input
         w_uv = self.wkv_b.weight.view(H, self.qk_nope_head_dim + self.v_head_dim, C)[:, self.qk_nope_head_dim :]
-        o = ops.absorb_bmm_fp8(o, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 0, 1)
-        return self.wo(o.reshape(bs, H * self.v_head_dim))
+        oq, os_ = ops.absorb_uv_quant_fp8(o, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1)
+        return self.wo(None, x_quant=(oq, os_))
 
 
 class MLPDeepSeekV3(torch.nn.Module):
@@ -231,24 +232,10 @@ class GateDeepSeekV3(torch.nn.Module):
         self.bias = (torch.nn.Parameter(torch.empty(args.n_routed_experts, dtype=torch.bfloat16, device=device), requires_grad=False)
                      if args.has_gate_bias() else None)
 
-    def forward(self, x):
-        scores = F.linear(x, self.weight)
-        scores = scores.softmax(dim=-1, dtype=torch.float32) if self.score_func == "softmax" else scores.sigmoid()
-        original_scores = scores
-        if self.bias is not None:
-            scores = scores + self.bias
-        if self.n_groups > 1:
-            scores = scores.view(x.size(0), self.n_groups, -1)
-            group_scores = scores.amax(dim=-1) if self.bias is None else scores.topk(2, dim=-1)[0].sum(dim=-1)
-            indices = group_scores.topk(self.topk_groups, dim=-1)[1]
-            mask = torch.zeros_like(scores[..., 0]).scatter_(1, indices, True)
-            scores = (scores * mask.unsqueeze(-1)).flatten(1)
-        indices = torch.topk(scores, self.topk, dim=-1)[1]
-        weights = original_scores.gather(1, indices)
-        if self.score_func == "sigmoid":
-            weights = weights / weights.sum(dim=-1, keepdim=True)
-        weights = weights * self.route_scale
-        return weights.type_as(x), indices
+    def forward(self, x, extra_expert_id: int = -1):
+        """(weights [bs, topk(+1)] bf16, indices int64).  Two HIP launches (ops.gate_deepseek_v3)."""
+        return ops.gate_deepseek_v3(x, self.weight, self.bias, self.n_groups, self.topk_groups, self.topk,
+                                    self.score_func, self.route_scale, extra_expert_id=extra_expert_id)
 
 
 class MoEDeepSeekV3(torch.nn.Module):
@@ -269,19 +256,31 @@ class MoEDeepSeekV3(torch.nn.Module):
         self.w2_scale = torch.nn.Parameter(torch.empty(E, args.dim // BLOCK, (self.inter + BLOCK - 1) // BLOCK, dtype=torch.float32, device=device), requires_grad=False)
 
     def forward(self, x, x_quant):
-        """x: ffn_norm output bf16 [bs, dim] (gate input); x_quant its fp8 form."""
+        """x: ffn_norm output bf16 [bs, dim] (gate input); x_quant its fp8 (per-group) form.
+
+        With one shared expert (R1/V3) it is routed as slot `topk` with weight 1 and runs inside the
+        same grouped GEMMs as the routed experts: its 16 tokens form one full MFMA tile and four
+        launches disappear.  Only difference to the reference (:936-949, 1010): shared + routed are
+        summed in fp32 and rounded once instead of bf16 + bf16."""
+        nr, ns = self.n_routed, self.n_shared
+        if ns == 1:
+            weights, indices = self.gate(x, extra_expert_id=nr)
+            return fused_moe.fused_experts(
+                x, self.w1w3_weight, self.w2_weight, topk_weights=weights, topk_ids=indices, use_fp8_w8a8=True,
+                inplace=True, global_num_experts=nr + ns, w1_scale=self.w1w3_scale, w2_scale=self.w2_scale,
+                block_shape=[BLOCK, BLOCK], a1_quant=x_quant,
+            )
         weights, indices = self.gate(x)
         y = None
-        for i in range(self.n_routed, self.n_routed + self.n_shared):
+        for i in range(nr, nr + ns):
             h = linear_deepseek_v3(None, self.w1w3_weight[i], self.w1w3_scale[i], x_quant=x_quant)
             hq, hs = fused_moe.silu_and_mul_quant(h, mode="act")
             yi = linear_deepseek_v3(None, self.w2_weight[i], self.w2_scale[i], x_quant=(hq, hs))
             y = yi if y is None else y + yi
         y1 = fused_moe.fused_experts(
-            x, self.w1w3_weight[: self.n_routed], self.w2_weight[: self.n_routed], topk_weights=weights,
-            topk_ids=indices, use_fp8_w8a8=True, inplace=True, global_num_experts=self.n_routed,
-            w1_scale=self.w1w3_scale[: self.n_routed], w2_scale=self.w2_scale[: self.n_routed],
-            block_shape=[BLOCK, BLOCK], a1_quant=x_quant,
+            x, self.w1w3_weight[:nr], self.w2_weight[:nr], topk_weights=weights, topk_ids=indices,
+            use_fp8_w8a8=True, inplace=True, global_num_experts=nr, w1_scale=self.w1w3_scale[:nr],
+            w2_scale=self.w2_scale[:nr], block_shape=[BLOCK, BLOCK], a1_quant=x_quant,
         )
         return y1 if y is None else y + y1
 
@@ -297,17 +296,23 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
         self.attn_norm = RMSNormW(args.dim, args.norm_eps, device)
         self.ffn_norm = RMSNormW(args.dim, args.norm_eps, device)
 
-    def forward(self, x, cos, sin):
-        _, xq, xs = ops.rms_norm(x, self.attn_norm.weight, self.attn_norm.eps, out_bf16=False, quant="act")
-        a = self.attn.decode_forward_paged((xq, xs), cos, sin)
-        x = x + tp.all_reduce(a)
+    def forward(self, x, pending, cos, sin):
+        """(x, pending) -> (x', pending'): the residual stream is x + pending; every residual add is
+        folded into the RMSNorm that consumes the sum (ops.rms_norm(add=...)), so a layer is
+        norm, attention, norm, ffn with no separate add launches (reference: :1107-1113)."""
+        if pending is None:
+            _, xq, xs = ops.rms_norm(x, self.attn_norm.weight, self.attn_norm.eps, out_bf16=False, quant="act")
+        else:
+            x, _, xq, xs = ops.rms_norm(x, self.attn_norm.weight, self.attn_norm.eps, out_bf16=False, quant="act",
+                                        add=pending)
+        a = tp.all_reduce(self.attn.decode_forward_paged((xq, xs), cos, sin))
         if self.is_moe:
-            hn, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=True, quant="group")
+            x, hn, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=True, quant="group", add=a)
             f = self.ffn(hn, (hq, hs))
         else:
-            _, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=False, quant="act")
+            x, _, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=False, quant="act", add=a)
             f = self.ffn((hq, hs))
-        return x + tp.all_reduce(f)
+        return x, tp.all_reduce(f)
 
 
 class DeepSeekV3Decoder(torch.nn.Module):
@@ -339,11 +344,12 @@ class DeepSeekV3Decoder(torch.nn.Module):
         """tokens [bs] int64 -> logits [bs, vocab] fp32 (decode_single_device, model.py:468-475)."""
         pos = self.cache.get_gpu_seq_lens_excl_this_decode().long()
         cos, sin = self.cos_table[pos], self.sin_table[pos]  # prepare_freqs_cis_decode, model.py:429-448
-        h = self.embed(tokens)
+        h, pending = self.embed(tokens), None
         for layer in self.layers:
-            h = layer(h, cos, sin)
-        h = ops.rms_norm(h, self.norm.weight, self.norm.eps)
-        return tp.all_gather_last_dim(F.linear(h, self.head_weight)).float()
+            h, pending = layer(h, pending, cos, sin)
+        h = ops.rms_norm(h, self.norm.weight, self.norm.eps, add=pending)[1] if pending is not None else \
+            ops.rms_norm(h, self.norm.weight, self.norm.eps)
+        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()  # bf16 logits -> fp32 (model.py:475)
 
     def embed(self, tokens):
         """tensor_parallel.py:199-208: mask ids outside this rank's vocab slice, lookup, all-reduce."""

@@ -204,13 +204,17 @@ def apply_rotary_pos_emb(q, k, cos, sin, rotary_type="hf-llama"):
 # ---- ops on the decode path that the reference runs as torch glue -----------------
 
 
-def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16: bool = True, quant: str = None):
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16: bool = True, quant: str = None,
+             add: torch.Tensor = None):
     """RMSNorm (chitu/models/model.py:29-78), optionally fused with the FP8 quantisation that the
     next fp8 linear would run on its output (model_deepseek_v3.py:98-100).
 
     x [..., dim] bf16 (last dim contiguous, uniform row stride); weight [dim] bf16.
     quant: None | "act" (act_quant_deepseek_v3) | "group" (per_token_group_quant_fp8, eps 1e-10).
-    Returns y, or (y, q, s) when quant is set (y is None if out_bf16=False).
+    add: optional residual branch; the kernel first forms x_new = bf16(x + add) (the reference's
+    `x = x + attn(...)`, model_deepseek_v3.py:1107-1113) and normalises that.
+    Returns y, or (y, q, s) when quant is set (y is None if out_bf16=False); with `add`, x_new is
+    prepended: (x_new, y) / (x_new, y, q, s).
     """
     require_cuda(x, weight)
     assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
@@ -220,6 +224,13 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
     if x2.stride(-1) != 1:
         x2 = x2.contiguous()
     rows = x2.shape[0]
+    a2 = sum_out = None
+    if add is not None:
+        assert add.dtype == torch.bfloat16 and add.shape == x.shape
+        a2 = add.reshape(-1, dim)
+        if a2.stride(-1) != 1:
+            a2 = a2.contiguous()
+        sum_out = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
     y = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if out_bf16 else None
     q = s = None
     mode = 0
@@ -229,16 +240,18 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
         s = torch.empty(rows, dim // 128, dtype=torch.float32, device=x.device)
     check(
         _lib.lib().chitu_hip_rmsnorm(
-            ptr(x2), i64(x2.stride(0)), ptr(weight), ptr(y), i64(dim), i64(rows), i32(dim), f32(eps),
+            ptr(x2), i64(x2.stride(0)), ptr(a2), i64(a2.stride(0) if a2 is not None else 0), ptr(sum_out), i64(dim),
+            ptr(weight), ptr(y), i64(dim), i64(rows), i32(dim), f32(eps),
             ptr(q), ptr(s), i32(mode), f32(1e-10), stream_ptr(),
         ),
         "rms_norm",
     )
     if y is not None:
         y = y.view(*x.shape[:-1], dim)
-    if quant is None:
-        return y
-    return y, q.view(*x.shape[:-1], dim), s.view(*x.shape[:-1], dim // 128)
+    res = (y,) if quant is None else (y, q.view(*x.shape[:-1], dim), s.view(*x.shape[:-1], dim // 128))
+    if add is not None:
+        res = (sum_out.view(x.shape),) + res
+    return res[0] if len(res) == 1 else res
 
 
 def absorb_bmm_fp8(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, scale_offset: int, scale_stride_h: int,
@@ -266,3 +279,95 @@ def absorb_bmm_fp8(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, scale_
         "absorb_bmm_fp8",
     )
     return out
+
+
+def bf16_linear(x: torch.Tensor, weight: torch.Tensor, out_dtype=None) -> torch.Tensor:
+    """F.linear(x, weight) for bf16 weights at decode batch sizes (weight-streaming skinny GEMM)."""
+    require_cuda(x, weight)
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+    assert x.is_contiguous() and weight.is_contiguous()
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = weight.shape[0]
+    out = torch.empty(*x.shape[:-1], N, dtype=out_dtype or torch.bfloat16, device=x.device)
+    check(
+        _lib.lib().chitu_hip_bf16_gemm(ptr(x), ptr(weight), ptr(out), float_dtype_code(out.dtype), i64(M), i64(N),
+                                       i64(K), i32(1), ptr(None), stream_ptr()),
+        "bf16_linear",
+    )
+    return out
+
+
+_GATE_SPLITS = 16
+
+
+def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale,
+                     extra_expert_id: int = -1, extra_weight: float = 1.0):
+    """GateDeepSeekV3.forward (chitu/models/model_deepseek_v3.py:810-842) in two launches:
+    split-K skinny GEMM for the scores, then one fused routing kernel.  Returns (weights bf16
+    [M, topk(+1)], indices int64 [M, topk(+1)]); the optional extra slot routes every token to
+    `extra_expert_id` with weight `extra_weight` (shared expert)."""
+    require_cuda(x, weight)
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous() and weight.is_contiguous()
+    M, K = x.shape
+    E = weight.shape[0]
+    splits = _GATE_SPLITS if K % (64 * _GATE_SPLITS) == 0 else 1
+    cols = topk + (1 if extra_expert_id >= 0 else 0)
+    w_out = torch.empty(M, cols, dtype=torch.bfloat16, device=x.device)
+    ids = torch.empty(M, cols, dtype=torch.int64, device=x.device)
+    lib = _lib.lib()
+    if splits > 1:
+        part = torch.empty(splits, M, E, dtype=torch.float32, device=x.device)
+        check(lib.chitu_hip_bf16_gemm(ptr(x), ptr(weight), ptr(None), i32(0), i64(M), i64(E), i64(K), i32(splits),
+                                      ptr(part), stream_ptr()), "gate scores")
+        logits, nparts = part, splits
+    else:
+        logits = bf16_linear(x, weight)
+        nparts = 0
+    check(
+        lib.chitu_hip_gate_route(ptr(logits), i32(nparts), i64(M), i32(E), ptr(bias), i32(n_groups), i32(topk_groups),
+                                 i32(topk), i32(1 if score_func == "sigmoid" else 0), f32(route_scale), ptr(w_out),
+                                 ptr(ids), i32(cols), i32(extra_expert_id), f32(extra_weight), stream_ptr()),
+        "gate_route",
+    )
+    return w_out, ids
+
+
+def mla_kv_prep(kv_in, q_pe, cos, sin, kv_norm_weight, eps, kv_cache, page_table, old_seq_lens):
+    """kv_norm + RoPE(q_pe in place, k_pe) + paged append in one launch (see chitu_hip_mla_kv_prep).
+    kv_in [bs, 576] (row-strided view of wqkv_a's output), q_pe [bs, H, 64] view, rotated in place."""
+    require_cuda(kv_in, q_pe, cos, sin, kv_norm_weight, kv_cache, page_table, old_seq_lens)
+    assert kv_in.dtype == torch.bfloat16 and q_pe.dtype == torch.bfloat16 and kv_cache.dtype == torch.bfloat16
+    assert kv_in.shape[-1] == 576 and kv_in.stride(-1) == 1 and q_pe.stride(-1) == 1 and q_pe.shape[-1] == 64
+    assert kv_cache.is_contiguous() and kv_cache.shape[-1] == 576 and page_table.is_contiguous()
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+    bs = kv_in.shape[0]
+    check(
+        _lib.lib().chitu_hip_mla_kv_prep(
+            ptr(kv_in), i64(kv_in.stride(0)), ptr(q_pe), i64(q_pe.stride(0)), i64(q_pe.stride(1)), i32(q_pe.shape[1]),
+            ptr(cos), ptr(sin), ptr(kv_norm_weight), f32(eps), ptr(kv_cache), i64(kv_cache.shape[0]),
+            i32(kv_cache.shape[1]), ptr(page_table), i32(page_table.shape[1]), ptr(old_seq_lens), i32(bs), i32(512),
+            i32(64), stream_ptr(),
+        ),
+        "mla_kv_prep",
+    )
+
+
+def absorb_uv_quant_fp8(x, w, scale, scale_offset, scale_stride_h, scale_stride_k):
+    """absorb_bmm_fp8 for the W_UV half (N = 128) + act_quant of its bf16 result: returns
+    (q [B, H*128] e4m3fn, s [B, H] f32), the input of the wo fp8 GEMM."""
+    require_cuda(x, w, scale)
+    assert x.dtype == torch.bfloat16 and w.element_size() == 1 and scale.dtype == torch.float32
+    assert x.dim() == 3 and w.dim() == 3 and x.stride(-1) == 1 and w.shape[1] == 128
+    assert w.stride(2) == 1 and w.stride(1) == w.shape[2]
+    B, H, K = x.shape
+    q = torch.empty(B, H * 128, dtype=torch.float8_e4m3fn, device=x.device)
+    s = torch.empty(B, H, dtype=torch.float32, device=x.device)
+    check(
+        _lib.lib().chitu_hip_absorb_uv_quant_fp8(
+            ptr(x), i64(x.stride(0)), i64(x.stride(1)), ptr(w), i64(w.stride(0)), ptr(scale), i64(scale_offset),
+            i64(scale_stride_h), i64(scale_stride_k), ptr(q), ptr(s), i32(B), i32(H), i32(K), stream_ptr(),
+        ),
+        "absorb_uv_quant_fp8",
+    )
+    return q, s

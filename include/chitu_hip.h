@@ -168,12 +168,15 @@ int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int64_t qn_str
  * when quant_mode != 0, also the act-quant launch of the fp8 linear that consumes it
  * (chitu/models/model_deepseek_v3.py:98-100).  quant_mode 1 = act_quant_deepseek_v3 rule,
  * 2 = per_token_group_quant_fp8 rule (eps = quant_eps); the codes are those of the bf16-rounded y.
+ *   add_bf16 (optional): residual branch folded in first, x <- bf16(x + add) -- the reference's
+ *   `x = x + attn(...)` / `x = x + ffn(...)` (model_deepseek_v3.py:1107-1113); sum_out receives it.
  *   x [rows, dim] bf16 (row stride given); weight [dim] bf16; y [rows, dim] bf16 or NULL;
  *   q_fp8 [rows, dim], q_scales [rows, dim/128] (dim % 128 == 0 when quantising); dim <= 8192. */
-int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const void* weight_bf16,
-                      void* y_bf16, int64_t y_row_stride, int64_t rows, int32_t dim, float eps,
-                      void* q_fp8, float* q_scales, int32_t quant_mode, float quant_eps,
-                      void* stream);
+int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
+                      int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                      const void* weight_bf16, void* y_bf16, int64_t y_row_stride, int64_t rows,
+                      int32_t dim, float eps, void* q_fp8, float* q_scales, int32_t quant_mode,
+                      float quant_eps, void* stream);
 
 /* ---- MLA absorb projections with in-register FP8 dequant ---------------------------------------
  * Replaces weight_dequant(wkv_b) + einsum("shd,hdc->shc") / einsum("bshc,hdc->bshd")
@@ -187,6 +190,58 @@ int chitu_hip_absorb_bmm_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_s
                              int64_t scale_offset, int64_t scale_stride_h, int64_t scale_stride_n, int64_t scale_stride_k,
                              void* out_bf16, int64_t out_stride_b, int64_t out_stride_h,
                              int32_t batch, int32_t heads, int32_t N, int32_t K, void* stream);
+
+/* ---- skinny bf16 GEMM (router scores, LM head) ---------------------------------------------
+ * Replaces the F.linear calls on bf16 weights on the decode path: gate scores
+ * (chitu/models/model_deepseek_v3.py:820) and the LM head (tensor_parallel.py:93, model.py:468-475).
+ *   out[m][n] = sum_k x[m][k] * w[n][k];  x [M, K] bf16, w [N, K] bf16, K % 64 == 0.
+ *   num_splits == 1: out [M, N] of out_dtype is written.  num_splits > 1 (tiny N): K is split across
+ *   workgroups and fp32 partials [num_splits, M, N] are written to `partials` for the consumer
+ *   (chitu_hip_gate_route sums them in order); `out` is ignored. */
+int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void* out, int out_dtype, int64_t M,
+                        int64_t N, int64_t K, int32_t num_splits, float* partials, void* stream);
+
+/* ---- fused MoE routing ------------------------------------------------------------------------
+ * Replaces everything after the score GEMM in GateDeepSeekV3.forward
+ * (chitu/models/model_deepseek_v3.py:821-842; ~16 torch launches): score function, bias, group-limited
+ * top-k, weight gather / normalise / scale.  Ties go to the lower index (torch.topk: unspecified).
+ *   logits: bf16 [tokens, E] when num_partials == 0, else fp32 [num_partials, tokens, E] summed here
+ *   and rounded to bf16 like F.linear's output.  bias_bf16 [E] or NULL.  score_func 1 = sigmoid
+ *   (bf16 pipeline, weights normalised), 0 = softmax (fp32 pipeline).
+ *   out_weights_bf16 / out_ids (int64) [tokens, out_stride]: slots 0..topk-1 sorted by descending
+ *   selection score; if extra_expert_id >= 0, slot `topk` = (extra_expert_id, extra_weight) -- used to
+ *   run the always-on shared expert (stacked last, model_deepseek_v3.py:883-919) through the same
+ *   grouped GEMMs as the routed ones. */
+int chitu_hip_gate_route(const void* logits, int32_t num_partials, int64_t tokens, int32_t num_experts,
+                         const void* bias_bf16, int32_t n_groups, int32_t topk_groups, int32_t topk,
+                         int32_t score_func, float route_scale, void* out_weights_bf16,
+                         int64_t* out_ids, int32_t out_stride, int32_t extra_expert_id,
+                         float extra_weight, void* stream);
+
+/* ---- MLA decode KV prep (kv_norm + RoPE + append, fused) ------------------------------------
+ * Replaces four launches of AttentionDeepSeekV3.decode_forward_paged: apply_rotary_pos_emb on
+ * (q_pe, k_pe) (chitu/models/model_deepseek_v3.py:493-500), kv_norm (:684), torch.cat (:686) and
+ * append_to_paged_kv_cache (attn_backend.py:720-722).  Same arithmetic as the separate ops.
+ *   kv_in_bf16: row b holds [kv_c (512) | k_pe (64)] (the tail of wqkv_a's output), row stride given;
+ *   q_pe_bf16 [batch, heads, 64] rotated IN PLACE (strides in elements); cos/sin [batch, 32] f32;
+ *   kv_cache [num_pages, page_size, 576] bf16: row (page_table[b][L/page], L%page), L = old_seq_lens[b],
+ *   receives [rmsnorm(kv_c) * w | rope(k_pe)]. */
+int chitu_hip_mla_kv_prep(const void* kv_in_bf16, int64_t kv_row_stride, void* q_pe_bf16,
+                          int64_t q_stride_b, int64_t q_stride_h, int32_t heads, const float* cos,
+                          const float* sin, const void* kv_norm_weight_bf16, float eps, void* kv_cache,
+                          int64_t num_pages, int32_t page_size, const int32_t* page_table,
+                          int32_t pages_per_seq, const int32_t* old_seq_lens, int32_t batch,
+                          int32_t kv_lora_rank, int32_t rope_dim, void* stream);
+
+/* ---- W_UV absorb projection fused with the FP8 quantisation of wo's input ---------------------
+ * chitu_hip_absorb_bmm_fp8 for N = 128 (einsum "bshc,hdc->bshd", model_deepseek_v3.py:697) followed by
+ * act_quant_deepseek_v3 of the bf16-rounded result (model_deepseek_v3.py:98-100 inside wo):
+ *   q_fp8 [batch, heads*128] e4m3, q_scales [batch, heads] (one 128-group per head). */
+int chitu_hip_absorb_uv_quant_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
+                                  const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                  int64_t scale_offset, int64_t scale_stride_h, int64_t scale_stride_k,
+                                  void* q_fp8, float* q_scales, int32_t batch, int32_t heads, int32_t K,
+                                  void* stream);
 
 #ifdef __cplusplus
 }

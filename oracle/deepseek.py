@@ -24,11 +24,18 @@ def rms_norm(x, w, eps):
 
 def gate(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale):
     """model_deepseek_v3.py:810-842 verbatim semantics (bf16 scores, torch.topk tie-breaking)."""
-    scores = F.linear(x, weight)
+    return gate_from_logits(F.linear(x, weight), bias, n_groups, topk_groups, topk, score_func, route_scale)
+
+
+def gate_from_logits(logits, bias, n_groups, topk_groups, topk, score_func, route_scale, return_masked=False):
+    """Everything after `scores = linear(x, self.weight)` (model_deepseek_v3.py:821-842)."""
+    x = logits
+    scores = logits
     scores = scores.softmax(dim=-1, dtype=torch.float32) if score_func == "softmax" else scores.sigmoid()
     original = scores
     if bias is not None:
         scores = scores + bias
+    pre_mask, group_scores = scores, None
     if n_groups > 1:
         scores = scores.view(x.size(0), n_groups, -1)
         group_scores = scores.amax(dim=-1) if bias is None else scores.topk(2, dim=-1)[0].sum(dim=-1)
@@ -40,6 +47,9 @@ def gate(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale):
     if score_func == "sigmoid":
         weights = weights / weights.sum(dim=-1, keepdim=True)
     weights = weights * route_scale
+    if return_masked:
+        return weights.type_as(x), indices, dict(masked=scores, original=original, pre_mask=pre_mask,
+                                                 group_scores=group_scores)
     return weights.type_as(x), indices
 
 
