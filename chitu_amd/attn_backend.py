@@ -44,10 +44,15 @@ def _num_cus():
 
 
 def choose_num_splits(batch: int, head_blocks: int, max_tiles: int, target_wgs: Optional[int] = None) -> int:
-    """KV splits so that batch*head_blocks*splits workgroups fill the chip (2 per CU), never more
-    splits than 64-token tiles.  Depends only on graph-static quantities (batch, max context)."""
+    """KV splits so that batch*head_blocks*splits workgroups fill the chip once (the decode kernel
+    runs one 96 KB-LDS workgroup per CU), never more splits than 64-token tiles.  Depends only on
+    graph-static quantities (batch, max context)."""
+    import os
+
+    if os.environ.get("CHITU_MLA_SPLITS"):
+        return max(1, min(max_tiles, int(os.environ["CHITU_MLA_SPLITS"])))  # tuning knob
     if target_wgs is None:
-        target_wgs = 2 * _num_cus()
+        target_wgs = _num_cus()
     per = max(1, batch * head_blocks)
     s = max(1, min(max_tiles, (target_wgs + per - 1) // per))
     return min(s, 64)

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64) void absorb_bmm_kernel(
 // input), fused with act_quant_deepseek_v3 of the bf16-rounded result (the launch that precedes the
 // wo GEMM in linear_deepseek_v3, model_deepseek_v3.py:98-100).  grid (H, ceil(batch/16)); block 512:
 // wave w owns output columns [16w, 16w+16), the per-(token, head) max goes through LDS.
+template <int KC>  // K / 64 when known at compile time (8 for kv_lora_rank 512), 0 = runtime loop
 __global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
     const bf16_t* __restrict__ x, int64_t x_sb, int64_t x_sh, const fp8_t* __restrict__ W, int64_t w_sh,
     const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sk, fp8_t* __restrict__ q,
@@ -80,15 +81,35 @@ __global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
     const bf16_t* xp = x + m * x_sb + h * x_sh + g * 16;
     const float* sp = scale + s_off + h * s_sh;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 64) {
-        const i32x4 w = *reinterpret_cast<const i32x4*>(wp + k0);
-        const float s = sp[(k0 >> 7) * s_sk];
-        const s16x8 wa = dequant8_bf16((uint32_t)w[0], (uint32_t)w[1], s);
-        const s16x8 wb = dequant8_bf16((uint32_t)w[2], (uint32_t)w[3], s);
-        const s16x8 xa = *reinterpret_cast<const s16x8*>(xp + k0);
-        const s16x8 xb = *reinterpret_cast<const s16x8*>(xp + k0 + 8);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xa, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc, 0, 0, 0);
+    if (KC > 0) {
+        // all loads of the K loop issued up front (one HBM round trip instead of KC)
+        constexpr int KA = KC > 0 ? KC : 1;  // (zero-length arrays are not allowed in device code)
+        i32x4 w[KA];
+        s16x8 xa[KA], xb[KA];
+        float sv[KA];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            w[c] = *reinterpret_cast<const i32x4*>(wp + c * 64);
+            sv[c] = sp[(c >> 1) * s_sk];
+            xa[c] = *reinterpret_cast<const s16x8*>(xp + c * 64);
+            xb[c] = *reinterpret_cast<const s16x8*>(xp + c * 64 + 8);
+        }
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dequant8_bf16((uint32_t)w[c][0], (uint32_t)w[c][1], sv[c]), xa[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dequant8_bf16((uint32_t)w[c][2], (uint32_t)w[c][3], sv[c]), xb[c], acc, 0, 0, 0);
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const i32x4 w = *reinterpret_cast<const i32x4*>(wp + k0);
+            const float s = sp[(k0 >> 7) * s_sk];
+            const s16x8 wa = dequant8_bf16((uint32_t)w[0], (uint32_t)w[1], s);
+            const s16x8 wb = dequant8_bf16((uint32_t)w[2], (uint32_t)w[3], s);
+            const s16x8 xa = *reinterpret_cast<const s16x8*>(xp + k0);
+            const s16x8 xb = *reinterpret_cast<const s16x8*>(xp + k0 + 8);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xa, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, xb, acc, 0, 0, 0);
+        }
     }
     float v[4], amax = 0.f;
 #pragma unroll
@@ -123,10 +144,15 @@ extern "C" int chitu_hip_absorb_uv_quant_fp8(const void* x_bf16, int64_t x_strid
     if (K % 64 != 0) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(x_stride_b % 8 == 0 && x_stride_h % 8 == 0);
     if (batch == 0) return CHITU_OK;
-    hipLaunchKernelGGL(absorb_uv_quant_kernel, dim3((unsigned)heads, (unsigned)((batch + 15) / 16)), dim3(512), 0,
-                       (hipStream_t)stream, (const bf16_t*)x_bf16, x_stride_b, x_stride_h, (const fp8_t*)w_fp8,
-                       w_stride_h, scale, scale_offset, scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales,
-                       (int)batch, (int)heads, (int)K);
+    const dim3 grid((unsigned)heads, (unsigned)((batch + 15) / 16));
+    if (K == 512)
+        hipLaunchKernelGGL(absorb_uv_quant_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+                           x_stride_b, x_stride_h, (const fp8_t*)w_fp8, w_stride_h, scale, scale_offset,
+                           scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales, (int)batch, (int)heads, (int)K);
+    else
+        hipLaunchKernelGGL(absorb_uv_quant_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+                           x_stride_b, x_stride_h, (const fp8_t*)w_fp8, w_stride_h, scale, scale_offset,
+                           scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales, (int)batch, (int)heads, (int)K);
     CHITU_RETURN_LAUNCH_STATUS();
 }
 

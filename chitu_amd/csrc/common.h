@@ -86,6 +86,27 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
     return v;
 }
 
+// Reductions inside each 16-lane DPP row (lanes 16r..16r+15) on the VALU: 4 row-rotate steps,
+// every lane ends with the row's result.  (__shfl_xor lowers to ds_bpermute = an LDS round trip.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_reduce_max(float v) {
+    v = __builtin_fmaxf(v, dpp_row<0x128>(v));  // row_ror:8
+    v = __builtin_fmaxf(v, dpp_row<0x124>(v));  // row_ror:4
+    v = __builtin_fmaxf(v, dpp_row<0x122>(v));  // row_ror:2
+    v = __builtin_fmaxf(v, dpp_row<0x121>(v));  // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float row16_reduce_sum(float v) {
+    v += dpp_row<0x128>(v);
+    v += dpp_row<0x124>(v);
+    v += dpp_row<0x122>(v);
+    v += dpp_row<0x121>(v);
+    return v;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 static inline int ceil_div_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -99,17 +99,21 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
         }
     };
 
-    GemmStage<MT> a, b;
-    int kb = kb0;
-    if (kb < kb1) load(a, kb);
-    while (kb < kb1) {
-        if (kb + 1 < kb1) load(b, kb + 1);
-        compute(a);
-        ++kb;
-        if (kb >= kb1) break;
-        if (kb + 1 < kb1) load(a, kb + 1);
-        compute(b);
-        ++kb;
+    // D-deep register ring: D K-blocks (2 KB of weights each) are in flight per wave while one is
+    // consumed -- HBM latency under load is ~2-4 us, so 2 stages capped a wave at ~1.5 GB/s.
+    constexpr int D = MT >= 4 ? 2 : 4;
+    GemmStage<MT> ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (kb0 + d < kb1) load(ring[d], kb0 + d);
+    for (int kb = kb0; kb < kb1; kb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (kb + d < kb1) {
+                compute(ring[d]);
+                if (kb + d + D < kb1) load(ring[d], kb + d + D);
+            }
+        }
     }
 
     gemm_epilogue<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);

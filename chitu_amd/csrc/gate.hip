@@ -83,8 +83,16 @@ __global__ __launch_bounds__(1024) void gate_route_kernel(
         if (S == 0) {
             logit = bf16_to_f32(((const bf16_t*)logits)[(int64_t)t * E + e]);
         } else {
+            // 8 partial loads in flight at a time (a plain `for s < S` loop waits for each load)
             float a = 0.f;
-            for (int s = 0; s < S; ++s) a += ((const float*)logits)[((int64_t)s * M + t) * E + e];
+            for (int s0 = 0; s0 < S; s0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    v[i] = (s0 + i < S) ? ((const float*)logits)[((int64_t)(s0 + i) * M + t) * E + e] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a += v[i];
+            }
             logit = bf16r(a);  // F.linear output in bf16 (model_deepseek_v3.py:820)
         }
     }
@@ -114,7 +122,22 @@ __global__ __launch_bounds__(1024) void gate_route_kernel(
 
     if (n_groups > 1) {
         const int gs = E / n_groups;
-        if (e < n_groups) {
+        if (gs == 32 || gs == 64) {
+            // group = half a wave (or a wave): top-2 by shuffles instead of a serial LDS scan
+            const float v = act ? sel : -INFINITY;
+            float m1 = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+                if (off < gs) m1 = __builtin_fmaxf(m1, __shfl_xor(m1, off, 64));
+            const unsigned long long gmask = gs == 64 ? ~0ull : (0xffffffffull << (lane & 32));
+            const int n_max = __popcll(__ballot(v == m1) & gmask);
+            float m2 = v < m1 ? v : -INFINITY;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+                if (off < gs) m2 = __builtin_fmaxf(m2, __shfl_xor(m2, off, 64));
+            if (n_max >= 2) m2 = m1;
+            if (act && (e % gs) == 0) gsc[e / gs] = bias ? (SIGMOID ? bf16r(m1 + m2) : m1 + m2) : m1;
+        } else if (e < n_groups) {
             float m1 = -INFINITY, m2 = -INFINITY;
             for (int i = 0; i < gs; ++i) {
                 const float v = sc[e * gs + i];
@@ -141,7 +164,18 @@ __global__ __launch_bounds__(1024) void gate_route_kernel(
     }
     int rank = 0;
     if (act) {
-        for (int i = 0; i < E; ++i) {
+        // rank among all experts: wide broadcast LDS reads, 16 in flight (a scalar loop costs one
+        // LDS round trip per expert: ~10 us for 256 experts)
+        const int e4 = E & ~3;
+#pragma unroll 16
+        for (int i = 0; i < e4; i += 4) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(&sc[i]);
+            rank += (o[0] > sel) || (o[0] == sel && i < e);
+            rank += (o[1] > sel) || (o[1] == sel && i + 1 < e);
+            rank += (o[2] > sel) || (o[2] == sel && i + 2 < e);
+            rank += (o[3] > sel) || (o[3] == sel && i + 3 < e);
+        }
+        for (int i = e4; i < E; ++i) {
             const float o = sc[i];
             rank += (o > sel) || (o == sel && i < e);
         }

@@ -11,15 +11,16 @@
 // tile is staged in LDS once and used for both products.
 //
 // Design.  One workgroup (4 waves) = 16 heads x one KV split of one sequence.  Per 64-token
-// tile: coalesced 16-B global loads of the 64 x 576 bf16 rows into LDS (row stride padded to
-// 1168 B => conflict-free ds_read_b128 for the K fragments); QK^T: each wave owns 16 tokens,
-// 18 x v_mfma_f32_16x16x32_bf16 with Q (A operand) held in registers for the whole kernel;
+// tile: coalesced 16-B global loads of the 64 x 576 bf16 rows, register-staged one tile ahead,
+// into LDS (row stride padded to 1168 B for the ds_read_b128 K fragments); QK^T: each wave owns
+// 16 tokens, 18 x v_mfma_f32_16x16x32_bf16 with Q (A operand) read from its own LDS copy;
 // online softmax in fp32 with 16-lane shuffles + a 4-wave LDS exchange; P -> bf16 -> LDS;
 // PV: each wave owns 128 latent columns, V^T fragments come straight from the row-major tile
 // with ds_read_b64_tr_b16 (gfx950 transpose read), 16 MFMAs per wave per tile.  Splits are
 // sized on the host from the batch only (graph-static); a split's token range is derived from
 // the device-side sequence length, empty splits publish LSE = -inf.  Stage 2 merges splits.
 #include "common.h"
+#include <stdlib.h>
 
 namespace chitu {
 
@@ -29,21 +30,27 @@ constexpr int kD = kC + kR;    // cached row width (576)
 constexpr int kTile = 64;      // KV tokens per tile
 constexpr int kRowB = 1168;    // LDS row stride in bytes (1152 + 16 pad)
 constexpr int kPStride = 72;   // P row stride in bf16 elements (64 + 8 pad)
+constexpr int kMaxTilesLds = 512;  // page ids cached in LDS per split (32k tokens)
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-// grid (num_splits, batch, heads/16); block 256.
-__global__ __launch_bounds__(256, 2) void mla_decode_kernel(
+// grid (num_splits, batch, heads/16); block 256, one workgroup per CU (96 KB LDS).
+// Per-tile pipeline (register-staged, one tile ahead): the 18 x 16 B per thread of tile t+1 are
+// in flight while tile t is multiplied, so a CU is bound by its share of HBM bandwidth
+// (~74 KB / tile) rather than by load latency + compute in series.
+__global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     const bf16_t* __restrict__ q_nope, int64_t qn_sb, int64_t qn_sh, const bf16_t* __restrict__ q_pe,
     int64_t qp_sb, int64_t qp_sh, const bf16_t* __restrict__ cache, int64_t num_pages, int page_size,
     const int32_t* __restrict__ block_table, int table_stride, const int32_t* __restrict__ seqlens,
     float scale, float* __restrict__ part_o, float* __restrict__ part_lse, bf16_t* __restrict__ out,
-    int H, int num_splits) {
+    int H, int num_splits, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* kv_lds = smem;                                             // [64][1168]
-    bf16_t* p_lds = reinterpret_cast<bf16_t*>(smem + kTile * kRowB);   // [16][72]
-    float* red_max = reinterpret_cast<float*>(smem + kTile * kRowB + 16 * kPStride * 2);  // [4][16]
-    float* red_sum = red_max + 64;                                                     // [4][16]
+    uint8_t* kv_lds = smem;                                   // [64][1168]
+    uint8_t* q_lds = smem + kTile * kRowB;                    // [16][1168]
+    bf16_t* p_lds = reinterpret_cast<bf16_t*>(q_lds + 16 * kRowB);  // [16][72]
+    float* red_max = reinterpret_cast<float*>(q_lds + 16 * kRowB + 16 * kPStride * 2);  // [4][16]
+    float* red_sum = red_max + 64;                                                      // [4][16]
+    int* pages_lds = reinterpret_cast<int*>(red_sum + 64);                              // [kMaxTilesLds]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -53,17 +60,41 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
     const int tile0 = (int)((long)n_tiles * split / num_splits);
     const int tile1 = (int)((long)n_tiles * (split + 1) / num_splits);
     const int h0 = hb * 16;
+    const int32_t* tbl = block_table + (int64_t)b * table_stride;
 
-    // Q fragments (A operand): lane holds Q[head h0+j][kk*32 + g*8 .. +8], kk = 0..17
-    s16x8 qf[18];
-    {
-        const int h = min(h0 + j, H - 1);
-        const bf16_t* qn = q_nope + b * qn_sb + h * qn_sh + g * 8;
-        const bf16_t* qp = q_pe + b * qp_sb + h * qp_sh + g * 8;
+    // this split's page ids -> LDS once (a per-tile table lookup is a dependent global load on the
+    // critical path of every tile)
+    const bool pages_in_lds = (tile1 - tile0) <= kMaxTilesLds;
+    if (pages_in_lds) {
+        for (int i = tid; i < tile1 - tile0; i += 256) pages_lds[i] = tbl[((tile0 + i) * kTile) / page_size];
+        __syncthreads();
+    }
+    auto tile_src = [&](int tile) -> const bf16_t* {
+        const int t0 = tile * kTile;
+        int64_t page = pages_in_lds ? pages_lds[tile - tile0] : tbl[t0 / page_size];
+        if (page < 0 || page >= num_pages) page = 0;  // corrupt table: stay in bounds
+        return cache + (page * page_size + (t0 % page_size)) * (int64_t)kD;
+    };
+    // this thread's 18 chunks of a tile: chunk c = tid + i*256 -> (row, col)
+    i32x4 pf[18];
+    auto issue = [&](const bf16_t* src, int valid) {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) qf[kk] = *reinterpret_cast<const s16x8*>(qn + kk * 32);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[16 + kk] = *reinterpret_cast<const s16x8*>(qp + kk * 32);
+        for (int i = 0; i < 18; ++i) {
+            const int c = tid + i * 256;
+            const int row = c / 72, col = c % 72;
+            pf[i] = i32x4{0, 0, 0, 0};  // rows past the sequence end are staged as zeros
+            if (row < valid && !(dbg & 1)) pf[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(src + row * kD + col * 8));
+        }
+    };
+    if (tile0 < tile1) issue(tile_src(tile0), min(kTile, L - tile0 * kTile));
+
+    // Q -> LDS (A operand of QK^T; 16 heads x 576, same padded stride as the KV rows)
+    for (int c = tid; c < 16 * 72; c += 256) {
+        const int row = c / 72, col = c % 72;
+        const int h = min(h0 + row, H - 1);
+        const bf16_t* src = col < 64 ? q_nope + b * qn_sb + h * qn_sh + col * 8
+                                     : q_pe + b * qp_sb + h * qp_sh + (col - 64) * 8;
+        *reinterpret_cast<i32x4*>(q_lds + row * kRowB + col * 16) = *reinterpret_cast<const i32x4*>(src);
     }
 
     f32x4 o[8];
@@ -77,42 +108,41 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
     }
 
     for (int tile = tile0; tile < tile1; ++tile) {
-        const int t0 = tile * kTile;
-        const int valid = min(kTile, L - t0);
-        int64_t page = block_table[(int64_t)b * table_stride + t0 / page_size];
-        if (page < 0 || page >= num_pages) page = 0;  // corrupt table: stay in bounds
-        const bf16_t* src = cache + (page * page_size + (t0 % page_size)) * (int64_t)kD;
-        __syncthreads();  // previous tile fully consumed
-        // ---- stage the tile: 64 rows x 72 chunks of 16 B
+        const int valid = min(kTile, L - tile * kTile);
+        const bf16_t* next_src = (tile + 1 < tile1) ? tile_src(tile + 1) : nullptr;
+        __syncthreads();  // previous tile fully consumed (and Q staged, first time round)
+        if (!(dbg & 16)) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             const int c = tid + i * 256;
-            const int row = c / 72, col = c % 72;
-            i32x4 v = i32x4{0, 0, 0, 0};
-            if (row < valid) v = *reinterpret_cast<const i32x4*>(src + row * kD + col * 8);
-            *reinterpret_cast<i32x4*>(kv_lds + row * kRowB + col * 16) = v;
+            *reinterpret_cast<i32x4*>(kv_lds + (c / 72) * kRowB + (c % 72) * 16) = pf[i];
+        }
         }
         __syncthreads();
+        if (next_src) issue(next_src, min(kTile, L - (tile + 1) * kTile));
 
-        // ---- S = Q K^T for this wave's 16 tokens
-        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
+        // ---- S = Q K^T for this wave's 16 tokens (two accumulators: no 18-deep dependent chain)
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!(dbg & 2)) {
             const uint8_t* krow = kv_lds + (wave * 16 + j) * kRowB + g * 16;
+            const uint8_t* qrow = q_lds + j * kRowB + g * 16;
 #pragma unroll
-            for (int kk = 0; kk < 18; ++kk) {
-                const s16x8 kf = *reinterpret_cast<const s16x8*>(krow + kk * 64);
-                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], kf, s, 0, 0, 0);
+            for (int kk = 0; kk < 18; kk += 2) {
+                const s16x8 q0 = *reinterpret_cast<const s16x8*>(qrow + kk * 64);
+                const s16x8 k0 = *reinterpret_cast<const s16x8*>(krow + kk * 64);
+                const s16x8 q1 = *reinterpret_cast<const s16x8*>(qrow + kk * 64 + 64);
+                const s16x8 k1 = *reinterpret_cast<const s16x8*>(krow + kk * 64 + 64);
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, k0, s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, k1, s1, 0, 0, 0);
             }
         }
         // lane holds S[head 4g+r][token wave*16+j]
         const bool tok_ok = (wave * 16 + j) < valid;
-        float mx[4];
+        float sv[4], mx[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            s[r] = tok_ok ? s[r] * scale : -INFINITY;
-            mx[r] = s[r];
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mx[r] = __builtin_fmaxf(mx[r], __shfl_xor(mx[r], off, 64));
+            sv[r] = tok_ok ? (s0[r] + s1[r]) * scale : -INFINITY;
+            mx[r] = row16_reduce_max(sv[r]);
         }
         if (j == 0) {
 #pragma unroll
@@ -125,13 +155,11 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
             const int hh = g * 4 + r;
             const float mt = __builtin_fmaxf(__builtin_fmaxf(red_max[hh], red_max[16 + hh]),
                                              __builtin_fmaxf(red_max[32 + hh], red_max[48 + hh]));
-            const float m_new = __builtin_fmaxf(m_run[r], mt);  // finite: token t0 is always valid
+            const float m_new = __builtin_fmaxf(m_run[r], mt);  // finite: the tile's first token is valid
             alpha[r] = __expf(m_run[r] - m_new);
             m_run[r] = m_new;
-            const float p = __expf(s[r] - m_new);
-            psum[r] = p;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) psum[r] += __shfl_xor(psum[r], off, 64);
+            const float p = __expf(sv[r] - m_new);
+            psum[r] = row16_reduce_sum(p);
             p_lds[hh * kPStride + wave * 16 + j] = f32_to_bf16(p);
         }
         if (j == 0) {
@@ -150,9 +178,10 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
         }
 
         // ---- O += P V : this wave owns latent columns [wave*128, wave*128+128)
+        if (!(dbg & 8))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const s16x8 pf = *reinterpret_cast<const s16x8*>(p_lds + j * kPStride + ks * 32 + g * 8);
+            const s16x8 pfrag = *reinterpret_cast<const s16x8*>(p_lds + j * kPStride + ks * 32 + g * 8);
             // transpose-read addressing: lane t of a 16-lane group supplies key row t/4, column chunk t%4
             const uint8_t* vbase = kv_lds + (ks * 32 + g * 8 + (j >> 2)) * kRowB + (wave * 128 + (j & 3) * 4) * 2;
 #pragma unroll
@@ -162,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void mla_decode_kernel(
                 s16x8 vf;
                 vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
                 vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[c], 0, 0, 0);
+                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfrag, vf, o[c], 0, 0, 0);
             }
         }
     }
@@ -198,14 +227,23 @@ __global__ __launch_bounds__(128) void mla_merge_kernel(const float* __restrict_
     for (int s = 0; s < num_splits; ++s) m = __builtin_fmaxf(m, lse[s]);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float wsum = 0.f;
-    for (int s = 0; s < num_splits; ++s) {
-        const float l = lse[s];
-        if (l == -INFINITY) continue;
-        const float w = __expf(l - m);
-        wsum += w;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + (bh * num_splits + s) * kC + threadIdx.x * 4);
+    for (int s0 = 0; s0 < num_splits; s0 += 8) {  // 8 partial rows in flight
+        f32x4 v[8];
+        float w[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += w * v[i];
+        for (int i = 0; i < 8; ++i) {
+            const int s = s0 + i;
+            const float l = s < num_splits ? lse[s] : -INFINITY;
+            w[i] = l == -INFINITY ? 0.f : __expf(l - m);
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (w[i] != 0.f) v[i] = *reinterpret_cast<const f32x4*>(part_o + (bh * num_splits + s) * kC + threadIdx.x * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            wsum += w[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += w[i] * v[i][k];
+        }
     }
     const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
     i32x2 o2;
@@ -246,18 +284,19 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
         part_o = (float*)workspace;
         part_lse = part_o + (int64_t)batch * heads * num_splits * kC;
     }
-    const size_t lds = kTile * kRowB + 16 * kPStride * 2 + 2 * 64 * sizeof(float);
+    const size_t lds = (kTile + 16) * kRowB + 16 * kPStride * 2 + 2 * 64 * sizeof(float) + kMaxTilesLds * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)mla_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
+    static const int dbg = getenv("CHITU_MLA_DBG") ? atoi(getenv("CHITU_MLA_DBG")) : 0;  // profiling aid: skip phases
     const dim3 grid((unsigned)num_splits, (unsigned)batch, (unsigned)((heads + 15) / 16));
     hipLaunchKernelGGL(mla_decode_kernel, grid, dim3(256), lds, st, (const bf16_t*)q_nope, qn_stride_b,
                        qn_stride_h, (const bf16_t*)q_pe, qp_stride_b, qp_stride_h, (const bf16_t*)kv_cache,
                        num_pages, (int)page_size, block_table, (int)table_stride, seqlens, softmax_scale,
-                       part_o, part_lse, (bf16_t*)out_bf16, (int)heads, (int)num_splits);
+                       part_o, part_lse, (bf16_t*)out_bf16, (int)heads, (int)num_splits, dbg);
     if (num_splits > 1)
         hipLaunchKernelGGL(mla_merge_kernel, dim3((unsigned)(batch * heads)), dim3(128), 0, st, part_o,
                            part_lse, (bf16_t*)out_bf16, (int)num_splits);

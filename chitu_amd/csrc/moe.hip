@@ -20,6 +20,7 @@
 // fp32 -> bf16, product -> bf16, routed weight multiplied on the fp32 accumulator, top-k sum in
 // fp32 over bf16 values.  No atomics anywhere: results are run-to-run identical.
 #include "common.h"
+#include <stdlib.h>
 
 namespace chitu {
 
@@ -86,17 +87,20 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * st.xs) * st.ws;
         };
-        MoeStage a, b;
-        int kb = kb0;
-        if (kb < kb1) load(a, kb);
-        while (kb < kb1) {
-            if (kb + 1 < kb1) load(b, kb + 1);
-            compute(a);
-            ++kb;
-            if (kb >= kb1) break;
-            if (kb + 1 < kb1) load(a, kb + 1);
-            compute(b);
-            ++kb;
+        // D-deep register ring (see fp8_gemm.hip): D x 2 KB of expert weights in flight per wave.
+        constexpr int D = 4;
+        MoeStage ring[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (kb0 + d < kb1) load(ring[d], kb0 + d);
+        for (int kb = kb0; kb < kb1; kb += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (kb + d < kb1) {
+                    compute(ring[d]);
+                    if (kb + d + D < kb1) load(ring[d], kb + d + D);
+                }
+            }
         }
     }
     if (WK > 1) {
@@ -361,6 +365,7 @@ extern "C" int chitu_hip_moe_gemm1_fp8(const void* a_fp8, const float* a_scale, 
     const int64_t wgs = (int64_t)n_tiles * (numel < max_mblocks ? numel : max_mblocks);
     const int KB = (int)(K / 128);
     int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 4096 ? 2 : 1;
+    if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);  // tuning knob (tools/bench_kernels.py)
     while (WK > 1 && WK > KB) WK >>= 1;
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(WKV)                                                                              \
