@@ -1,0 +1,118 @@
+"""TEST-ONLY: run chitu_amd.deepseek_v3's wiring on CPU by swapping every HIP op for the oracle.
+
+The product has no CPU path (ops raise on CPU tensors).  To exercise the *host-side* logic of the
+decode step -- module wiring, shapes, residual/pending handling, tensor-parallel sharding and the
+placement of collectives -- without a GPU, the world-size-2 gloo tests monkeypatch the op entry
+points with oracle-backed implementations.  Nothing outside tests/ imports this file.
+"""
+
+import torch
+import torch.nn.functional as F
+
+from oracle import deepseek as ods
+from oracle import fp8 as ofp8
+from oracle import kv as okv
+from oracle import mla as omla
+from oracle import moe as omoe
+
+
+def rms_norm(x, weight, eps=1e-6, out_bf16=True, quant=None, add=None):
+    res = ()
+    if add is not None:
+        x = x + add
+        res = (x,)
+    y = F.rms_norm(x, (x.shape[-1],), weight, eps).to(x.dtype)
+    if quant is None:
+        out = res + (y,)
+        return out[0] if len(out) == 1 else out
+    q, s = (ofp8.act_quant_deepseek_v3 if quant == "act" else ofp8.per_token_group_quant_fp8)(y.contiguous())
+    return res + ((y if out_bf16 else None), q, s)
+
+
+def act_quant_deepseek_v3(x, block_size=128):
+    return ofp8.act_quant_deepseek_v3(x, block_size)
+
+
+def fp8_gemm_deepseek_v3(a, a_s, b, b_s, out_dtype=None):
+    return ofp8.fp8_gemm_deepseek_v3(a, a_s, b, b_s, out_dtype or torch.bfloat16)
+
+
+def mla_kv_prep(kv_in, q_pe, cos, sin, kv_norm_weight, eps, kv_cache, page_table, old_seq_lens):
+    qo, ko = okv.apply_rotary_pos_emb(q_pe, kv_in[:, 512:], cos, sin, "llama")
+    q_pe.copy_(qo)
+    kvn = F.rms_norm(kv_in[:, :512], (512,), kv_norm_weight, eps).to(kv_in.dtype)
+    new = okv.append_to_paged_kv_cache(kv_cache, page_table, torch.cat([kvn, ko], -1), old_seq_lens)
+    kv_cache.copy_(new)
+
+
+def _dequant_heads(w, scale, off, sh, sn, sk):
+    H, N, K = w.shape
+    out = torch.empty(H, N, K, dtype=torch.bfloat16)
+    flat = scale.reshape(-1)
+    for h in range(H):
+        for nb in range((N + 127) // 128):
+            for kb in range((K + 127) // 128):
+                s = flat[off + h * sh + nb * sn + kb * sk]
+                blk = w[h, nb * 128 : (nb + 1) * 128, kb * 128 : (kb + 1) * 128].float() * s
+                out[h, nb * 128 : (nb + 1) * 128, kb * 128 : (kb + 1) * 128] = blk.to(torch.bfloat16)
+    return out
+
+
+def absorb_bmm_fp8(x, w, scale, scale_offset, sh, sn, sk):
+    wd = _dequant_heads(w, scale, scale_offset, sh, sn, sk)
+    return torch.einsum("bhk,hnk->bhn", x.float(), wd.float()).to(torch.bfloat16)
+
+
+def absorb_uv_quant_fp8(x, w, scale, scale_offset, sh, sk):
+    y = absorb_bmm_fp8(x, w, scale, scale_offset, sh, 0, sk).reshape(x.shape[0], -1)
+    return ofp8.act_quant_deepseek_v3(y.contiguous())
+
+
+def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale, extra_expert_id=-1,
+                     extra_weight=1.0):
+    w, i = ods.gate(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale)
+    if extra_expert_id >= 0:
+        w = torch.cat([w, torch.full((w.shape[0], 1), extra_weight, dtype=w.dtype)], 1)
+        i = torch.cat([i, torch.full((i.shape[0], 1), extra_expert_id, dtype=i.dtype)], 1)
+    return w, i
+
+
+def bf16_linear(x, weight, out_dtype=None):
+    return F.linear(x, weight).to(out_dtype or torch.bfloat16)
+
+
+def fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace=False, use_fp8_w8a8=False,
+                  global_num_experts=-1, w1_scale=None, w2_scale=None, block_shape=None, a1_quant=None, **kw):
+    out = omoe.fused_experts_fp8(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale)
+    if inplace:
+        hidden_states.copy_(out)
+        return hidden_states
+    return out
+
+
+def silu_and_mul_quant(x, mode="act"):
+    d = x.shape[-1] // 2
+    h = F.silu(x[..., :d]) * x[..., d:]
+    return (ofp8.act_quant_deepseek_v3 if mode == "act" else ofp8.per_token_group_quant_fp8)(h.contiguous())
+
+
+class CpuAttnBackend:
+    def __init__(self, local_n_heads):
+        self.local_n_heads = local_n_heads
+
+    def prepare_metadata_for_decode(self, *a, **k):
+        pass
+
+    def mla_decode(self, q_nope, q_pe, kv_cache, lens_incl, block_table, softmax_scale, **kw):
+        return omla.mla_decode(q_nope, q_pe, kv_cache, block_table, lens_incl, softmax_scale).to(torch.bfloat16)
+
+
+def install(monkeypatch_setattr):
+    """monkeypatch_setattr(obj, name, value) -- e.g. pytest's monkeypatch.setattr or plain setattr."""
+    from chitu_amd import fused_moe, ops
+
+    for name in ("rms_norm", "act_quant_deepseek_v3", "fp8_gemm_deepseek_v3", "mla_kv_prep", "absorb_bmm_fp8",
+                 "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear"):
+        monkeypatch_setattr(ops, name, globals()[name])
+    monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)
+    monkeypatch_setattr(fused_moe, "silu_and_mul_quant", silu_and_mul_quant)

@@ -1,0 +1,225 @@
+"""Multi-process (gloo, world_size 2, CPU) tests of the tensor-parallel path.
+
+1. chitu_amd.tensor_parallel layers vs an unsharded reference (same checks the reference would need
+   for chitu/tensor_parallel.py:42-208).
+2. The DeepSeek-V3 decode step wiring under TP=2: shard a tiny model with the reference's rules
+   (chitu/models/model.py:332-370 + model_deepseek_v3.py:1167-1288: heads / FFN width split, wqkv_a,
+   gate and KV cache replicated, gate|up halves chunked separately), run chitu_amd.deepseek_v3 on
+   each rank with the HIP ops swapped for the oracle (tests/cpu_ops_shim.py), and compare the
+   all-reduced result with the single-rank run.
+"""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(fn, world, *args):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] == "ok", r
+    return results
+
+
+def _entry(fn, rank, world, port, q, *args):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from chitu_amd import tensor_parallel as tp
+
+        tp.init_tp(world, 1)
+        fn(rank, world, *args)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "fail: " + repr(e) + traceback.format_exc()))
+
+
+def _tp_layers(rank, world):
+    from chitu_amd import tensor_parallel as tp
+
+    assert tp.get_tp_size() == world and tp.get_tp_rank() == rank
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5, 64, generator=g)
+    w_col = torch.randn(48, 64, generator=g)
+    b_col = torch.randn(48, generator=g)
+    w_row = torch.randn(32, 64, generator=g)
+    b_row = torch.randn(32, generator=g)
+    emb = torch.randn(40, 16, generator=g)
+
+    col = tp.ColumnParallelLinear(64, 48, has_bias=True, gather_output=True, dtype=torch.float32)
+    n = 48 // world
+    col.weight.data.copy_(w_col[rank * n : (rank + 1) * n])
+    col.bias.data.copy_(b_col[rank * n : (rank + 1) * n])
+    assert torch.allclose(col(x), torch.nn.functional.linear(x, w_col, b_col), atol=1e-5)
+
+    row = tp.RowParallelLinear(64, 32, has_bias=True, input_is_parallel=False, dtype=torch.float32)
+    k = 64 // world
+    row.weight.data.copy_(w_row[:, rank * k : (rank + 1) * k])
+    row.bias.data.copy_(b_row)
+    assert torch.allclose(row(x), torch.nn.functional.linear(x, w_row, b_row), atol=1e-4)
+
+    e = tp.VocabParallelEmbedding(40, 16, dtype=torch.float32)
+    v = 40 // world
+    e.weight.data.copy_(emb[rank * v : (rank + 1) * v])
+    ids = torch.tensor([[0, 39, 20], [19, 21, 5]])
+    ids_copy = ids.clone()
+    assert torch.allclose(e(ids), torch.nn.functional.embedding(ids, emb))
+    assert torch.equal(ids, ids_copy)  # caller's ids untouched (the reference mutates them in place)
+
+    y = torch.arange(6.0).view(2, 3) + 100 * rank
+    gth = tp.all_gather_last_dim(y)
+    assert gth.shape == (2, 3 * world) and torch.equal(gth[:, 3 * rank : 3 * rank + 3], y)
+
+
+def test_tp_layers_world2():
+    _run(_tp_layers, 2)
+
+
+def _tiny_args():
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args
+
+    return DeepSeekV3Args(vocab_size=256, dim=256, inter_dim=512, moe_inter_dim=256, n_layers=2, n_dense_layers=1,
+                          n_heads=16, n_routed_experts=8, n_shared_experts=1, n_activated_experts=2, n_expert_groups=2,
+                          n_limited_groups=1, q_lora_rank=128, gate_bias=True)
+
+
+def _build_cpu_model(args, seed=0):
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.deepseek_v3 import DeepSeekV3Decoder
+    from tests import cpu_ops_shim
+
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=2, block_size=64, max_seq_len=128, device="cpu",
+                                kv_shape_per_sample=(576,), dtype=torch.bfloat16)
+    model = DeepSeekV3Decoder(args, cache, cpu_ops_shim.CpuAttnBackend(args.n_heads), max_position_embeddings=256,
+                              device="cpu")
+    return model, cache
+
+
+def _full_state(args):
+    """Deterministic TP=1 parameters (fp8 weights via bf16 randn, scales U(0.01,0.03))."""
+    import copy
+
+    a1 = copy.copy(args)
+    a1.shard_degree = 1
+    model, _ = _build_cpu_model(a1)
+    g = torch.Generator().manual_seed(123)
+    sd = {}
+    for k, p in model.named_parameters():
+        if p.dtype == torch.float8_e4m3fn:
+            sd[k] = (torch.randn(p.shape, generator=g) * 0.5).to(torch.float8_e4m3fn)
+        elif p.dtype == torch.float32:
+            sd[k] = torch.rand(p.shape, generator=g) * 0.02 + 0.01
+        elif k.endswith("norm.weight"):
+            sd[k] = torch.ones(p.shape, dtype=p.dtype)
+        else:
+            sd[k] = (torch.randn(p.shape, generator=g) * 0.05).to(p.dtype)
+    return sd
+
+
+def _shard(sd, args, rank, world):
+    """Megatron-style chunking as in chitu/models/model.py:332-370."""
+    H = args.n_heads
+    out = {}
+    for k, v in sd.items():
+        def rows(t, n_units):  # split dim -2 (or 0) into `world` contiguous chunks
+            c = t.shape[-2] // world
+            return t[..., rank * c : (rank + 1) * c, :].contiguous()
+
+        def cols(t):
+            c = t.shape[-1] // world
+            return t[..., rank * c : (rank + 1) * c].contiguous()
+
+        def halves_rows(t):  # [.., 2I, K] = [gate | up]: chunk each half separately
+            i = t.shape[-2] // 2
+            return torch.cat([rows(t[..., :i, :], 0), rows(t[..., i:, :], 0)], dim=-2).contiguous()
+
+        if any(s in k for s in ("wq_b.", "wkv_b.")):
+            out[k] = rows(v, H)
+        elif "wo." in k or ".w2.weight" in k or ".w2.scale" in k or "w2_weight" in k or "w2_scale" in k:
+            out[k] = cols(v)
+        elif "w1w3" in k:
+            out[k] = halves_rows(v)
+        elif k in ("embed_weight", "head_weight"):
+            c = v.shape[0] // world
+            out[k] = v[rank * c : (rank + 1) * c].contiguous()
+        else:
+            out[k] = v.clone()
+    return out
+
+
+def _decode_tp(rank, world):
+    import copy
+
+    from tests import cpu_ops_shim
+
+    cpu_ops_shim.install(setattr)
+    args = _tiny_args()
+    full = _full_state(args)
+    a = copy.copy(args)
+    a.shard_degree = None  # live TP group size
+    model, cache = _build_cpu_model(a)
+    sharded = _shard(full, args, rank, world)
+    for k, p in model.named_parameters():
+        assert p.shape == sharded[k].shape, (k, p.shape, sharded[k].shape)
+        p.data.copy_(sharded[k])
+    reqs = ["a", "b"]
+    g = torch.Generator().manual_seed(9)
+    for r, n in zip(reqs, (5, 64)):
+        cache.register_sequence(r, n)
+        for blk in cache.block_table[r]:
+            cache.paged_kv_cache[:, blk] = (torch.randn(args.n_layers, 64, 576, generator=g) * 0.5).to(torch.bfloat16)
+    tokens = torch.tensor([3, 200])
+    outs = []
+    for _ in range(2):
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        with torch.inference_mode():
+            logits = model.decode(tokens, use_graph=False)
+        assert logits.shape == (2, args.vocab_size) and logits.dtype == torch.float32
+        outs.append(logits.clone())
+        tokens = logits.argmax(-1)
+        cache.finalize_cache_single_decode(reqs)
+    # every rank must hold identical logits (all-gathered) and an identical replicated KV cache
+    for t in outs + [cache.paged_kv_cache.float()]:
+        ref = t.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(ref, t)
+    if rank == 0:
+        torch.save({"logits": outs}, os.environ["TP_OUT"] + f".w{world}")
+
+
+def test_decode_step_tp2_matches_tp1(tmp_path):
+    base = str(tmp_path / "tp")
+    os.environ["TP_OUT"] = base
+    _run(_decode_tp, 1)
+    _run(_decode_tp, 2)
+    l1 = torch.load(base + ".w1")["logits"]
+    l2 = torch.load(base + ".w2")["logits"]
+    for a, b in zip(l1, l2):
+        err = ((a - b).abs().max() / a.abs().max()).item()
+        assert err < 5e-2, err  # bf16 partial sums are rounded per rank before the all-reduce
