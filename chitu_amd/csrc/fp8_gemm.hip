@@ -7,15 +7,12 @@
 //
 // Design (not a translation of the Triton tiling): at M <= 64 the op is a stream of the
 // [N,K] e4m3 weight matrix, read exactly once, so the kernel is built around the weight
-// load.  One wave owns 16 weight rows x a contiguous range of 128-wide K blocks.  Each lane
-// loads 16 B of one row (`row = n0 + lane%16`, `k = kb*128 + c*64 + (lane/16)*16`), i.e. a
-// wave-load covers 16 rows x 64 B and two of them cover the 128-B lines of a K block.
-// Those 16 B are two MFMA A-fragments of v_mfma_f32_16x16x32_fp8_fp8 (weights = A, so a
-// lane ends up with 4 consecutive output columns of one token -> one 8-B bf16 store).  The
-// dot product is order-free in k, so the k-permutation implied by the 16-B load is simply
-// applied to the activation fragment as well (same addressing on the [M,K] fp8 matrix,
-// which is L2-resident).  Per K block the 4 MFMAs accumulate into a fresh register and the
-// result is folded in as (dot * a_s) * b_s in fp32 -- the reference's order
+// load.  One wave owns 16 weight rows x a contiguous range of 128-wide K blocks.  Each
+// wave-load takes a whole 128-B line from each of 8 rows (gemm_common.h "full-line" layout:
+// 6.5+ TB/s vs 5.1 for 64 B from each of 16 rows); the lane's 16 B are two MFMA A-fragments of
+// v_mfma_f32_16x16x32_fp8_fp8 (weights = A), the matching activation fragments come from the
+// L2-resident [M,K] fp8 matrix with the same k order.  Per K block the MFMAs accumulate into
+// fresh registers and the result is folded in as (dot * a_s) * b_s in fp32 -- the reference's order
 // (triton_kernels.py:357).  K is split over the waves of a workgroup (LDS reduce) and, when
 // N is too small to fill 256 CUs, over S workgroups (fp32 partials + a tiny ordered reduce
 // kernel): deterministic, no atomics.
@@ -35,12 +32,11 @@ __device__ __forceinline__ mfma_ab_t pack_hi(const i32x4& v) {
 
 template <int MT>
 struct GemmStage {
-    i32x4 w[2];
+    W8Frag w;
     i32x4 x[MT][2];
     float xs[MT];
     float ws;
 };
-
 
 // ---------------------------------------------------------------- W8A8 block-scaled
 template <int MT, int WK>
@@ -58,8 +54,8 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
     const int t = blockIdx.y * WK + wave;
     const int kb0 = (int)((long)KB * t / T), kb1 = (int)((long)KB * (t + 1) / T);
 
-    const int nrow = min(n0 + j, N - 1);
-    const fp8_t* wp = W + (size_t)nrow * K + g * 16;
+    const fp8_t *wp0, *wp1;
+    w8_lane_ptrs(W, n0, N, K, j, g, wp0, wp1);
     const float* wsp = WS + (size_t)(n0 >> 7) * KB;
     const fp8_t* xp[MT];
     const float* xsp[MT];
@@ -76,8 +72,8 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
 
     auto load = [&](GemmStage<MT>& st, int kb) {
         const int off = kb << 7;
-        st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
-        st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off + 64));
+        st.w.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + off));
+        st.w.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + off));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             st.x[mt][0] = *reinterpret_cast<const i32x4*>(xp[mt] + off);
@@ -89,18 +85,13 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
     auto compute = [&](const GemmStage<MT>& st) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            f32x4 blk = f32x4{0.f, 0.f, 0.f, 0.f};
-            blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack_lo(st.w[0]), pack_lo(st.x[mt][0]), blk, 0, 0, 0);
-            blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack_hi(st.w[0]), pack_hi(st.x[mt][0]), blk, 0, 0, 0);
-            blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack_lo(st.w[1]), pack_lo(st.x[mt][1]), blk, 0, 0, 0);
-            blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack_hi(st.w[1]), pack_hi(st.x[mt][1]), blk, 0, 0, 0);
+            const f32x4 blk = w8a8_block_dot(st.w, st.x[mt][0], st.x[mt][1]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mt][r] += (blk[r] * st.xs[mt]) * st.ws;
         }
     };
 
-    // D-deep register ring: D K-blocks (2 KB of weights each) are in flight per wave while one is
-    // consumed -- HBM latency under load is ~2-4 us, so 2 stages capped a wave at ~1.5 GB/s.
+    // D-deep register ring: D K-blocks (2 KB of weights each) in flight per wave while one is consumed.
     constexpr int D = MT >= 4 ? 2 : 4;
     GemmStage<MT> ring[D];
 #pragma unroll
@@ -116,7 +107,7 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
         }
     }
 
-    gemm_epilogue<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
+    gemm_epilogue_v2<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
 }
 
 // out[m][n] = sum_s partial[s][m][n] in s order, then cast.

@@ -63,6 +63,110 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT], float* red, void
 }
 
 
+// ---- full-line ("pattern 2") FP8 weight tile -------------------------------------------------
+// Measured on MI355X (tools/probe_stream.hip): a wave-load that takes 64 B from each of 16 rows
+// streams at <= 5.1 TB/s, one that takes a whole 128-B line from each of 8 rows at 6.5-6.8 TB/s
+// (= a linear stream).  So a lane (j = lane%16, g = lane/16) loads 16 B of weight row
+// n0 + 8*half + j/2 at byte ((j%2)*4 + g)*16 of the 128-wide K block: 8 lanes cover one row's line.
+// MFMA A-row j then holds only half of weight row j/2 (even j: K bytes 0-63, odd j: 64-127), so the
+// block dot is taken with TWO activation fragments -- x[0..63] (valid on even A-rows) and x[64..127]
+// (valid on odd A-rows) -- and the halves are added in-lane: C rows 4g+{0,2} come from the "even"
+// product, 4g+{1,3} from the "odd" one, i.e. out row 2g + {0,1} = e[0]+o[1], e[2]+o[3].  Twice the
+// MFMAs (they have ~10x headroom here), full-line HBM reads, no cross-lane traffic.
+struct W8Frag {
+    i32x4 w[2];  // rows half 0 (n0 + j/2) and half 1 (n0 + 8 + j/2)
+};
+
+__device__ __forceinline__ long frag_lo(const i32x4& v) {
+    return (long)(((unsigned long long)(uint32_t)v[1] << 32) | (uint32_t)v[0]);
+}
+__device__ __forceinline__ long frag_hi(const i32x4& v) {
+    return (long)(((unsigned long long)(uint32_t)v[3] << 32) | (uint32_t)v[2]);
+}
+
+// lane's weight pointer for K block 0: W + row*K + ((j&1)*4 + g)*16, rows clamped to n_rows-1
+__device__ __forceinline__ void w8_lane_ptrs(const fp8_t* Wbase, int n0, int n_rows, int K, int j, int g,
+                                             const fp8_t*& p0, const fp8_t*& p1) {
+    const int off = ((j & 1) * 4 + g) * 16;
+    p0 = Wbase + (size_t)min(n0 + (j >> 1), n_rows - 1) * K + off;
+    p1 = Wbase + (size_t)min(n0 + 8 + (j >> 1), n_rows - 1) * K + off;
+}
+
+// Block dot of one 16-row x 128-K weight tile with one 16-token activation tile.
+// x0 / x1: the lane's 16 B of x[token j][kb*128 + g*16 ..] and x[token j][kb*128 + 64 + g*16 ..].
+// Returns {row 2g, row 2g+1, row 8+2g, row 8+2g+1} of (n0 + .) for token j.
+__device__ __forceinline__ f32x4 w8a8_block_dot(const W8Frag& f, const i32x4& x0, const i32x4& x1) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 e0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(f.w[0]), frag_lo(x0), z, 0, 0, 0);
+    f32x4 o0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(f.w[0]), frag_lo(x1), z, 0, 0, 0);
+    f32x4 e1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(f.w[1]), frag_lo(x0), z, 0, 0, 0);
+    f32x4 o1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(f.w[1]), frag_lo(x1), z, 0, 0, 0);
+    e0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(f.w[0]), frag_hi(x0), e0, 0, 0, 0);
+    o0 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(f.w[0]), frag_hi(x1), o0, 0, 0, 0);
+    e1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(f.w[1]), frag_hi(x0), e1, 0, 0, 0);
+    o1 = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(f.w[1]), frag_hi(x1), o1, 0, 0, 0);
+    return f32x4{e0[0] + o0[1], e0[2] + o0[3], e1[0] + o1[1], e1[2] + o1[3]};
+}
+
+// output column of accumulator element e (0..3) for lane group g, tile base n0
+__device__ __forceinline__ int w8_out_col(int n0, int g, int e) { return n0 + (e >> 1) * 8 + 2 * g + (e & 1); }
+
+// Epilogue for the full-line layout: K-split reduce over the workgroup's waves (LDS, fixed order),
+// then per token two 2-column stores (columns 2g,2g+1 and 8+2g,8+2g+1 of the tile).
+template <int MT, int WK>
+__device__ __forceinline__ void gemm_epilogue_v2(f32x4 (&acc)[MT], float* red, void* out, int out_dt,
+                                                 float* partial, int M, int N, int S, int m_base, int n0) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    auto store = [&](int mt, const f32x4& v) {
+        const int m = m_base + mt * 16 + j;
+        if (m >= M) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = n0 + h * 8 + 2 * g;
+            const float a = v[2 * h], b = v[2 * h + 1];
+            if (S > 1) {
+                float* dst = partial + ((size_t)blockIdx.y * M + m) * N + n;
+                if (n < N) dst[0] = a;
+                if (n + 1 < N) dst[1] = b;
+            } else if (out_dt == 2) {
+                float* dst = (float*)out + (size_t)m * N + n;
+                if (n < N) dst[0] = a;
+                if (n + 1 < N) dst[1] = b;
+            } else {
+                uint16_t* dst = (uint16_t*)out + (size_t)m * N + n;
+                const uint16_t ha = out_dt == 0 ? f32_to_bf16(a) : f32_to_f16(a);
+                const uint16_t hb = out_dt == 0 ? f32_to_bf16(b) : f32_to_f16(b);
+                if (n + 1 < N && (N & 1) == 0) *reinterpret_cast<uint32_t*>(dst) = (uint32_t)ha | ((uint32_t)hb << 16);
+                else {
+                    if (n < N) dst[0] = ha;
+                    if (n + 1 < N) dst[1] = hb;
+                }
+            }
+        }
+    };
+    if (WK > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<f32x4*>(&red[((wave * MT + mt) * 64 + lane) * 4]) = acc[mt];
+        __syncthreads();
+        for (int mt = wave; mt < MT; mt += WK) {
+            f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&red[((w * MT + mt) * 64 + lane) * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] += v[r];
+            }
+            store(mt, sum);
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) store(mt, acc[mt]);
+    }
+}
+
 // out[m][n] = sum_s partial[s][m][n] (s ascending), cast to out_dt.  Defined in fp8_gemm.hip.
 void launch_splitk_reduce(const float* partial, void* out, int out_dt, int S, int64_t MN, hipStream_t st);
 

@@ -11,39 +11,45 @@
 // Design.  In decode each routed expert sees 1-3 tokens, so the reference's 64-row tiles are
 // >90% padding and its cost is the expert weights, streamed once.  Here the m-tile is 16 sorted
 // slots (one MFMA tile; moe_align is run with block 16) and everything else mirrors the dense
-// weight-streaming GEMM of fp8_gemm.hip: a wave owns 16 weight rows, lanes load 16 B of a row
-// (non-temporal: each weight byte is used once), the same k order is applied to the gathered
-// activation rows, per-128 block scales are folded in fp32 in the reference's order
+// weight-streaming GEMM of fp8_gemm.hip: a wave owns 16 weight rows, every wave-load takes whole
+// 128-B lines (gemm_common.h full-line layout; non-temporal: each weight byte is used once), the
+// same k order is applied to the gathered activation rows, per-128 block scales are folded in fp32
+// in the reference's order
 // (fused_moe.py:281).  GEMM1 splits K over the waves of a workgroup; GEMM2 (K = moe_inter/tp,
 // two K blocks at TP=8) gives every wave its own 16-row tiles and keeps the 16x256 activation
 // fragment in registers.  Rounding points are the reference's: GEMM outputs -> bf16, silu in
 // fp32 -> bf16, product -> bf16, routed weight multiplied on the fp32 accumulator, top-k sum in
 // fp32 over bf16 values.  No atomics anywhere: results are run-to-run identical.
 #include "common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 
 namespace chitu {
 
-__device__ __forceinline__ long pk_lo(const i32x4& v) {
-    return (long)(((unsigned long long)(uint32_t)v[1] << 32) | (uint32_t)v[0]);
-}
-__device__ __forceinline__ long pk_hi(const i32x4& v) {
-    return (long)(((unsigned long long)(uint32_t)v[3] << 32) | (uint32_t)v[2]);
-}
-
 struct MoeStage {
-    i32x4 w[2];
+    W8Frag w;
     i32x4 x[2];
     float xs, ws;
 };
 
-__device__ __forceinline__ f32x4 moe_block_dot(const MoeStage& st) {
-    f32x4 blk = f32x4{0.f, 0.f, 0.f, 0.f};
-    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk_lo(st.w[0]), pk_lo(st.x[0]), blk, 0, 0, 0);
-    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk_hi(st.w[0]), pk_hi(st.x[0]), blk, 0, 0, 0);
-    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk_lo(st.w[1]), pk_lo(st.x[1]), blk, 0, 0, 0);
-    blk = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pk_hi(st.w[1]), pk_hi(st.x[1]), blk, 0, 0, 0);
-    return blk;
+// write one lane's 4 results (tile columns 2g,2g+1,8+2g,8+2g+1 of token slot) as bf16, scaled by rw
+__device__ __forceinline__ void moe_store_tile(bf16_t* out_row, int n0, int g, int N, const f32x4& acc, float rw) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int n = n0 + h * 8 + 2 * g;
+        const uint16_t a = f32_to_bf16(acc[2 * h] * rw), b = f32_to_bf16(acc[2 * h + 1] * rw);
+        if (n + 1 < N && (N & 1) == 0) *reinterpret_cast<uint32_t*>(out_row + n) = (uint32_t)a | ((uint32_t)b << 16);
+        else {
+            if (n < N) out_row[n] = a;
+            if (n + 1 < N) out_row[n + 1] = b;
+        }
+    }
+}
+
+__device__ __forceinline__ float moe_routed_weight(const void* topk_w, int w_dt, int slot) {
+    if (w_dt == 0) return bf16_to_f32(((const bf16_t*)topk_w)[slot]);
+    if (w_dt == 1) return f16_to_f32(((const uint16_t*)topk_w)[slot]);
+    return ((const float*)topk_w)[slot];
 }
 
 // ---------------------------------------------------------------- GEMM1: x[token] . W1[e]^T
@@ -70,20 +76,20 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_kernel(
         const int token = valid ? slot / topk : 0;
         const fp8_t* xp = Xq + (size_t)token * K + g * 16;
         const float* xsp = Xs + (size_t)token * KB;
-        const int nrow = min(n0 + j, N - 1);
-        const fp8_t* wp = W + ((size_t)e * N + nrow) * K + g * 16;
+        const fp8_t *wp0, *wp1;
+        w8_lane_ptrs(W + (size_t)e * N * K, n0, N, K, j, g, wp0, wp1);
         const float* wsp = Ws + ((size_t)e * ((N + 127) >> 7) + (n0 >> 7)) * KB;
         auto load = [&](MoeStage& st, int kb) {
             const int off = kb << 7;
-            st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
-            st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off + 64));
+            st.w.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + off));
+            st.w.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + off));
             st.x[0] = *reinterpret_cast<const i32x4*>(xp + off);
             st.x[1] = *reinterpret_cast<const i32x4*>(xp + off + 64);
             st.xs = xsp[kb];
             st.ws = wsp[kb];
         };
         auto compute = [&](const MoeStage& st) {
-            const f32x4 blk = moe_block_dot(st);
+            const f32x4 blk = w8a8_block_dot(st.w, st.x[0], st.x[1]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * st.xs) * st.ws;
         };
@@ -116,16 +122,7 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_kernel(
         }
     }
     if (!valid) return;
-    const int n = n0 + g * 4;
-    bf16_t* dst = out + (size_t)slot * N + n;
-    if (n + 3 < N && (N & 3) == 0) {
-        i32x2 o;
-        o[0] = (int)((uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16));
-        o[1] = (int)((uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16));
-        *reinterpret_cast<i32x2*>(dst) = o;
-    } else {
-        for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = f32_to_bf16(acc[r]);
-    }
+    moe_store_tile(out + (size_t)slot * N, n0, g, N, acc, 1.0f);
 }
 
 // ---------------------------------------------------------------- SiLU-and-mul + fp8 requant
@@ -198,12 +195,7 @@ __global__ __launch_bounds__(256) void moe_gemm2_kernel(
     const bool valid = slot < numel;
     const int e = expert_ids[mb];
     const int row = valid ? slot : 0;
-    float rw = 1.0f;
-    if (mul_weight && valid) {
-        if (w_dt == 0) rw = bf16_to_f32(((const bf16_t*)topk_w)[slot]);
-        else if (w_dt == 1) rw = f16_to_f32(((const uint16_t*)topk_w)[slot]);
-        else rw = ((const float*)topk_w)[slot];
-    }
+    const float rw = (mul_weight && valid) ? moe_routed_weight(topk_w, w_dt, slot) : 1.0f;
     i32x4 x[KBMAX][2];
     float xs[KBMAX];
     if (e >= 0) {
@@ -218,41 +210,43 @@ __global__ __launch_bounds__(256) void moe_gemm2_kernel(
         }
     }
     const int tile0 = (blockIdx.x * 4 + wave) * NT;
+    // all NT tiles' weights are requested before the first is consumed
+    W8Frag wf[NT][KBMAX];
+    if (e >= 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n0 = (tile0 + t) * 16;
+            if (n0 < N) {
+                const fp8_t *wp0, *wp1;
+                w8_lane_ptrs(W + (size_t)e * N * I, n0, N, I, j, g, wp0, wp1);
+#pragma unroll
+                for (int kb = 0; kb < KBMAX; ++kb) {
+                    if (kb < KB) {
+                        wf[t][kb].w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + (kb << 7)));
+                        wf[t][kb].w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + (kb << 7)));
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n0 = (tile0 + t) * 16;
         if (n0 >= N) break;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         if (e >= 0) {
-            const int nrow = min(n0 + j, N - 1);
-            const fp8_t* wp = W + ((size_t)e * N + nrow) * I + g * 16;
             const float* wsp = Ws + ((size_t)e * ((N + 127) >> 7) + (n0 >> 7)) * KB;
 #pragma unroll
             for (int kb = 0; kb < KBMAX; ++kb) {
                 if (kb < KB) {
-                    MoeStage st;
-                    st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + (kb << 7)));
-                    st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + (kb << 7) + 64));
-                    st.x[0] = x[kb][0];
-                    st.x[1] = x[kb][1];
-                    const f32x4 blk = moe_block_dot(st);
+                    const f32x4 blk = w8a8_block_dot(wf[t][kb], x[kb][0], x[kb][1]);
                     const float ws = wsp[kb];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * xs[kb]) * ws;
                 }
             }
         }
-        if (!valid) continue;
-        const int n = n0 + g * 4;
-        bf16_t* dst = out + (size_t)slot * N + n;
-        if (n + 3 < N && (N & 3) == 0) {
-            i32x2 o;
-            o[0] = (int)((uint32_t)f32_to_bf16(acc[0] * rw) | ((uint32_t)f32_to_bf16(acc[1] * rw) << 16));
-            o[1] = (int)((uint32_t)f32_to_bf16(acc[2] * rw) | ((uint32_t)f32_to_bf16(acc[3] * rw) << 16));
-            *reinterpret_cast<i32x2*>(dst) = o;
-        } else {
-            for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = f32_to_bf16(acc[r] * rw);
-        }
+        if (valid) moe_store_tile(out + (size_t)slot * N, n0, g, N, acc, rw);
     }
 }
 
@@ -280,17 +274,17 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm2_generic_kernel(
         const int kb0 = KB * wave / WK, kb1 = KB * (wave + 1) / WK;
         const fp8_t* xp = Hq + (size_t)row * I + g * 16;
         const float* xsp = Hs + (size_t)row * KB;
-        const int nrow = min(n0 + j, N - 1);
-        const fp8_t* wp = W + ((size_t)e * N + nrow) * I + g * 16;
+        const fp8_t *wp0, *wp1;
+        w8_lane_ptrs(W + (size_t)e * N * I, n0, N, I, j, g, wp0, wp1);
         const float* wsp = Ws + ((size_t)e * ((N + 127) >> 7) + (n0 >> 7)) * KB;
         for (int kb = kb0; kb < kb1; ++kb) {
-            MoeStage st;
             const int off = kb << 7;
-            st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
-            st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off + 64));
-            st.x[0] = *reinterpret_cast<const i32x4*>(xp + off);
-            st.x[1] = *reinterpret_cast<const i32x4*>(xp + off + 64);
-            const f32x4 blk = moe_block_dot(st);
+            W8Frag f;
+            f.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + off));
+            f.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + off));
+            const i32x4 x0 = *reinterpret_cast<const i32x4*>(xp + off);
+            const i32x4 x1 = *reinterpret_cast<const i32x4*>(xp + off + 64);
+            const f32x4 blk = w8a8_block_dot(f, x0, x1);
             const float xs = xsp[kb], ws = wsp[kb];
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * xs) * ws;
@@ -309,14 +303,8 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm2_generic_kernel(
         }
     }
     if (!valid) return;
-    float rw = 1.0f;
-    if (mul_weight) {
-        if (w_dt == 0) rw = bf16_to_f32(((const bf16_t*)topk_w)[slot]);
-        else if (w_dt == 1) rw = f16_to_f32(((const uint16_t*)topk_w)[slot]);
-        else rw = ((const float*)topk_w)[slot];
-    }
-    const int n = n0 + g * 4;
-    for (int r = 0; r < 4 && n + r < N; ++r) out[(size_t)slot * N + n + r] = f32_to_bf16(acc[r] * rw);
+    const float rw = mul_weight ? moe_routed_weight(topk_w, w_dt, slot) : 1.0f;
+    moe_store_tile(out + (size_t)slot * N, n0, g, N, acc, rw);
 }
 
 // ---------------------------------------------------------------- top-k sum
