@@ -165,10 +165,13 @@ def roofline_dominant_kernel(model, margs, bs, iters=3):
     moe_layers = [l.ffn for l in model.layers if l.is_moe]
     if not moe_layers:
         return None
-    E, topk, K = margs.n_routed_experts, margs.n_activated_experts, margs.dim
+    # same launch shape as the decode step: top-8 routed (uniform random routing) + the shared
+    # expert as slot 9 (MoEDeepSeekV3.forward), E = 257 stacked experts
+    E, topk, K = margs.n_routed_experts + margs.n_shared_experts, margs.n_activated_experts + 1, margs.dim
     N = moe_layers[0].w1w3_weight.shape[1]
     gen = torch.Generator(device="cuda").manual_seed(1)
-    ids = torch.stack([torch.randperm(E, device="cuda", generator=gen)[:topk] for _ in range(bs)])
+    ids = torch.stack([torch.randperm(E - 1, device="cuda", generator=gen)[:topk - 1] for _ in range(bs)])
+    ids = torch.cat([ids, torch.full((bs, 1), E - 1, device="cuda", dtype=ids.dtype)], dim=1).contiguous()
     distinct = int(ids.unique().numel())
     x = torch.randn(bs, K, device="cuda", dtype=torch.bfloat16, generator=gen)
     xq, xs = fused_moe.per_token_group_quant_fp8(x, 128)
@@ -204,10 +207,19 @@ def roofline_dominant_kernel(model, margs, bs, iters=3):
     a_bytes = bs * K + bs * (K // 128) * 4 + numel * N * 2
     alg = w_bytes + s_bytes + a_bytes
     achieved = alg / (avg_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the committed PMC pass (profiles/r01_pmc_moe_gemm.json: FETCH_SIZE,
+    # doubled per MI355X_MICROARCH.md), scaled by the number of distinct experts of THIS launch.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_moe_gemm.json")))["moe_gemm1_kernel<1>"]
+        traffic = int(pmc["hbm_read_bytes_per_launch"] * distinct / pmc["distinct_experts"])
+    except Exception:
+        pass
     return {
         "kernel": "moe_gemm1_kernel (routed experts W1, fp8 block-scaled grouped GEMM)",
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "traffic_source": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction), profiles/r01_pmc_moe_gemm.json, scaled to this launch's distinct experts",
         "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(ms[len(ms) // 2] * 1e3, 2),
         "algorithmic_bytes_per_launch": alg, "distinct_experts": distinct, "launches_timed": len(ms),
     }
@@ -313,7 +325,7 @@ def main():
     roof = None
     if rank == 0 and not a.no_roofline:
         roof = roofline_dominant_kernel(model, margs, a.bs)
-    distinct = roof["distinct_experts"] if roof else min(256, a.bs * 8)
+    distinct = (roof["distinct_experts"] - 1) if roof else min(256, a.bs * 8)  # routed only; shared counted in the formula
     step_bytes = algorithmic_bytes_per_step(margs, a.bs, a.ctx, distinct)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

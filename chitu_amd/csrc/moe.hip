@@ -352,7 +352,9 @@ extern "C" int chitu_hip_moe_gemm1_fp8(const void* a_fp8, const float* a_scale, 
     const dim3 grid((unsigned)n_tiles, (unsigned)max_mblocks);
     const int64_t wgs = (int64_t)n_tiles * (numel < max_mblocks ? numel : max_mblocks);
     const int KB = (int)(K / 128);
-    int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 4096 ? 2 : 1;
+    // measured (tools/bench_kernels.py, full-line loads): one wave per tile is fastest once the
+    // grid alone fills the chip (>= 2048 waves); below that K is split over the workgroup's waves
+    int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 2048 ? 2 : 1;
     if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);  // tuning knob (tools/bench_kernels.py)
     while (WK > 1 && WK > KB) WK >>= 1;
     hipStream_t st = (hipStream_t)stream;
