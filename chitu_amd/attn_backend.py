@@ -154,3 +154,66 @@ class HipAttnBackend(AttnBackend):
         B = q_nope.shape[0]
         o = self.mla_decode(q_nope, q_pe, kv_cache, cache_seqlens_incl_this_decode, block_table, float(softmax_scale))
         return o.view(B, 1, q_nope.shape[1], -1)
+
+    # ------------------------------------------------------------------ non-MLA (GQA / MHA) paged decode
+    def attn_with_kvcache(
+        self,
+        q,
+        k_cache,
+        v_cache,
+        k=None,
+        v=None,
+        cache_seqlens: Optional[Union[(int, torch.Tensor)]] = None,
+        cache_leftpad: Optional[torch.Tensor] = None,
+        block_table: Optional[torch.Tensor] = None,
+        causal=False,
+        window_size=(-1, -1),
+        softcap=0.0,
+        softmax_scale=None,
+        num_splits: Optional[int] = None,
+    ):
+        """Paged single-token attention with in-place append, the contract of
+        AttnBackend.attn_with_kvcache (chitu/attn_backend.py:92-164) as FlashAttnBackend implements
+        it (:208-243): if k/v are given they are written at position cache_seqlens[b] of each
+        sequence's pages, then q attends to cache_seqlens[b] + 1 tokens.
+
+        q [bs, 1, Hq, 128]; k_cache / v_cache [pages, page_size, Hkv, 128]; k / v [bs, 1, Hkv, 128];
+        cache_seqlens [bs] int32 (excluding this token); block_table [bs, max_pages] int32.
+        Returns [bs, 1, Hq, 128].  (RefAttnBackend rejects block_table, :473 -- this is the paged path.)
+        """
+        assert block_table is not None, "HipAttnBackend.attn_with_kvcache is the paged path"
+        assert cache_leftpad is None and window_size == (-1, -1) and softcap == 0.0
+        assert q.dim() == 4 and q.shape[1] == 1, "decode: one query token per sequence"
+        require_cuda(q, k_cache, v_cache, cache_seqlens, block_table)
+        assert q.dtype == torch.bfloat16 and k_cache.dtype == torch.bfloat16 and v_cache.dtype == torch.bfloat16
+        assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == v_cache.shape
+        assert cache_seqlens.dtype == torch.int32 and block_table.dtype == torch.int32 and block_table.stride(1) == 1
+        bs, _, Hq, D = q.shape
+        Hkv = k_cache.shape[2]
+        if softmax_scale is None:
+            softmax_scale = D ** -0.5
+        seqlens = cache_seqlens
+        if k is not None:
+            assert v is not None
+            append_to_paged_kv_cache(k_cache, block_table, k.contiguous(), cache_seqlens)
+            append_to_paged_kv_cache(v_cache, block_table, v.contiguous(), cache_seqlens)
+            seqlens = cache_seqlens + 1
+        q3 = q.view(bs, Hq, D)
+        if not (q3.stride(-1) == 1 and q3.stride(0) % 8 == 0 and q3.stride(1) % 8 == 0 and q3.data_ptr() % 16 == 0):
+            q3 = q3.contiguous()
+        if num_splits is None:
+            max_steps = max(1, int(block_table.shape[1]) * int(k_cache.shape[1]) // 16)
+            num_splits = max(1, min(max_steps, 64, (4 * _num_cus()) // max(1, bs * Hkv)))
+        out = torch.empty(bs, Hq, D, dtype=torch.bfloat16, device=q.device)
+        need = bs * Hq * num_splits * (D + 1) * 4 if num_splits > 1 else 1
+        ws = workspace.get(need, q.device, "gqa")
+        check(
+            _lib.lib().chitu_hip_gqa_decode(
+                ptr(q3), i64(q3.stride(0)), i64(q3.stride(1)), ptr(k_cache), ptr(v_cache), i64(k_cache.shape[0]),
+                i32(k_cache.shape[1]), i32(Hkv), ptr(block_table), i32(block_table.stride(0)), ptr(seqlens),
+                f32(softmax_scale), ptr(out), i32(bs), i32(Hq), i32(D), i32(num_splits), ptr(ws), i64(ws.numel()),
+                stream_ptr(),
+            ),
+            "gqa_decode",
+        )
+        return out.view(bs, 1, Hq, D)

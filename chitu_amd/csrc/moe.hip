@@ -53,26 +53,31 @@ __device__ __forceinline__ float moe_routed_weight(const void* topk_w, int w_dt,
 }
 
 // ---------------------------------------------------------------- GEMM1: x[token] . W1[e]^T
-// grid (n_tiles, max_mblocks); block 64*WK.  out: bf16 [numel, N] (row = sorted slot id).
-template <int WK>
-__global__ __launch_bounds__(64 * WK) void moe_gemm1_kernel(
+// grid (n_tiles / NW, max_mblocks); block 64*WK*NW: NW waves own neighbouring 16-row tiles of the same
+// m-block (their activation fragments are the same addresses at about the same time -> L1 hits),
+// WK waves split K.  out: bf16 [numel, N] (row = sorted slot id).
+template <int WK, int NW, int D>
+__global__ __launch_bounds__(64 * WK * NW) void moe_gemm1_kernel(
     const fp8_t* __restrict__ Xq, const float* __restrict__ Xs, const fp8_t* __restrict__ W,
     const float* __restrict__ Ws, const int32_t* __restrict__ sorted_ids,
     const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
     bf16_t* __restrict__ out, int numel, int topk, int N, int K) {
+    static_assert(WK == 1 || NW == 1, "either split K or tile N inside a workgroup");
     __shared__ float red[WK > 1 ? WK * 256 : 1];
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = (NW > 1 ? blockIdx.x * NW + wave : blockIdx.x) * 16;
+    if (NW > 1 && n0 >= N) return;
     const int KB = K >> 7;
     const int slot = sorted_ids[mb * 16 + j];
     const bool valid = slot < numel;
     const int e = expert_ids[mb];
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (e >= 0) {
-        const int kb0 = KB * wave / WK, kb1 = KB * (wave + 1) / WK;
+        const int kw = NW > 1 ? 0 : wave;
+        const int kb0 = KB * kw / WK, kb1 = KB * (kw + 1) / WK;
         const int token = valid ? slot / topk : 0;
         const fp8_t* xp = Xq + (size_t)token * K + g * 16;
         const float* xsp = Xs + (size_t)token * KB;
@@ -94,7 +99,6 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_kernel(
             for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * st.xs) * st.ws;
         };
         // D-deep register ring (see fp8_gemm.hip): D x 2 KB of expert weights in flight per wave.
-        constexpr int D = 4;
         MoeStage ring[D];
 #pragma unroll
         for (int d = 0; d < D; ++d)
@@ -355,19 +359,28 @@ extern "C" int chitu_hip_moe_gemm1_fp8(const void* a_fp8, const float* a_scale, 
     // measured (tools/bench_kernels.py, full-line loads): one wave per tile is fastest once the
     // grid alone fills the chip (>= 2048 waves); below that K is split over the workgroup's waves
     int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 2048 ? 2 : 1;
-    if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);  // tuning knob (tools/bench_kernels.py)
+    int NW = 1, D = 3;  // sweep on MI355X: D=3 5.7 TB/s, D=2 5.4, D=4 5.2; NW>1 (shared L1 activations) loses 5-20%
+    if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);  // tuning knobs (tools/bench_kernels.py)
+    if (const char* ov = getenv("CHITU_MOE_GEMM1_NW")) NW = atoi(ov);
+    if (const char* ov = getenv("CHITU_MOE_GEMM1_D")) D = atoi(ov);
     while (WK > 1 && WK > KB) WK >>= 1;
+    if (WK > 1) NW = 1;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(WKV)                                                                              \
-    hipLaunchKernelGGL(moe_gemm1_kernel<WKV>, grid, dim3(64 * WKV), 0, st, (const fp8_t*)a_fp8,  \
-                       a_scale, (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids,    \
-                       num_tokens_post_pad, (bf16_t*)out_bf16, (int)numel, (int)topk, (int)N, (int)K)
-    switch (WK) {
-        case 8: LAUNCH(8); break;
-        case 4: LAUNCH(4); break;
-        case 2: LAUNCH(2); break;
-        default: LAUNCH(1); break;
-    }
+#define LAUNCH(WKV, NWV, DV)                                                                          \
+    hipLaunchKernelGGL((moe_gemm1_kernel<WKV, NWV, DV>), dim3((unsigned)((n_tiles + NWV - 1) / NWV), (unsigned)max_mblocks), \
+                       dim3(64 * WKV * NWV), 0, st, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)w1_fp8, w1_scale, \
+                       sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)out_bf16, (int)numel,  \
+                       (int)topk, (int)N, (int)K)
+    if (WK == 8) LAUNCH(8, 1, 4);
+    else if (WK == 4) LAUNCH(4, 1, 4);
+    else if (WK == 2) LAUNCH(2, 1, 4);
+    else if (NW == 4 && D == 2) LAUNCH(1, 4, 2);
+    else if (NW == 4) LAUNCH(1, 4, 4);
+    else if (NW == 2 && D == 2) LAUNCH(1, 2, 2);
+    else if (NW == 2) LAUNCH(1, 2, 4);
+    else if (D == 2) LAUNCH(1, 1, 2);
+    else if (D == 4) LAUNCH(1, 1, 4);
+    else LAUNCH(1, 1, 3);
 #undef LAUNCH
     CHITU_RETURN_LAUNCH_STATUS();
 }

@@ -31,11 +31,13 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(
     const bf16_t* xr = x + (int64_t)row * x_stride;
     const int n_chunks = dim >> 3;
     float v[kNormMaxChunks][8];
+    i32x4 wreg[kNormMaxChunks];  // norm weights requested together with x: one memory round trip
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < kNormMaxChunks; ++i) {
         const int c = tid + i * kNormThreads;
         if (c < n_chunks) {
+            wreg[i] = *reinterpret_cast<const i32x4*>(w + c * 8);
             const i32x4 raw = *reinterpret_cast<const i32x4*>(xr + c * 8);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(
         const bool act = c < n_chunks;
         float o[8];
         if (act) {
-            const i32x4 wraw = *reinterpret_cast<const i32x4*>(w + c * 8);
+            const i32x4 wraw = wreg[i];
             uint16_t h[8];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

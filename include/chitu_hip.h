@@ -243,6 +243,35 @@ int chitu_hip_absorb_uv_quant_fp8(const void* x_bf16, int64_t x_stride_b, int64_
                                   void* q_fp8, float* q_scales, int32_t batch, int32_t heads, int32_t K,
                                   void* stream);
 
+/* ---- INT8 W8A8 linear (per-token activations x per-output-channel weights) --------------------
+ * Replaces quant_act (chitu/quantize/w8a8.py:18-26) and the closed w8a8gemm.mm / w8a8gemv.mv behind
+ * W8A8Linear.forward (chitu/quantize/w8a8.py:97-132; contract pinned by test/pytest/test_w8a8.py:13-48).
+ *   quant_act_int8: s[row] = clamp(max|x[row]|, 1e-5)/127, q = int8(round_half_even(x/s)).
+ *   w8a8_int8_gemm: out[m][n] = (sum_k a[m][k]*b[n][k] exact in i32) * a_scale[m] * b_scale[n] (+ bias[n]);
+ *   a_int8 [M, K], b_int8 [N, K] (K % 128 == 0), scales f32, bias optional (bias_dtype), out of out_dtype. */
+int chitu_hip_quant_act_int8(const void* x, int act_dtype, int64_t rows, int64_t cols, void* q_int8,
+                             float* scales, void* stream);
+int chitu_hip_w8a8_int8_gemm(const void* a_int8, const float* a_scale, const void* b_int8,
+                             const float* b_scale, const void* bias, int bias_dtype, void* out,
+                             int out_dtype, int64_t M, int64_t N, int64_t K, void* stream);
+
+/* ---- GQA / MHA paged decode attention (head_dim 128) ------------------------------------------
+ * Replaces the third-party flash_attn.flash_attn_with_kvcache call behind
+ * FlashAttnBackend.attn_with_kvcache (chitu/attn_backend.py:208-243; contract :92-164) on the paged,
+ * single-query path used by Attention.decode_forward_paged (chitu/models/model.py:167-198):
+ *   out[b,h,:] = softmax_t(scale * q[b,h,:].K[t, h/(Hq/Hkv), :]) . V[t, h/(Hq/Hkv), :],  t < seqlens[b]
+ *   q [batch, q_heads, 128] bf16 (element strides, multiples of 8); k_cache / v_cache
+ *   [num_pages, page_size, kv_heads, 128] bf16, page_size % 16 == 0; block_table [batch, table_stride] i32;
+ *   seqlens [batch] i32 = tokens to attend INCLUDING the row appended this step (append =
+ *   chitu_hip_append_paged_kv on each cache); out [batch, q_heads, 128] bf16; q_heads/kv_heads <= 16.
+ *   workspace >= batch*q_heads*num_splits*129*4 bytes when num_splits > 1. */
+int chitu_hip_gqa_decode(const void* q_bf16, int64_t q_stride_b, int64_t q_stride_h, const void* k_cache,
+                         const void* v_cache, int64_t num_pages, int32_t page_size, int32_t kv_heads,
+                         const int32_t* block_table, int32_t table_stride, const int32_t* seqlens,
+                         float softmax_scale, void* out_bf16, int32_t batch, int32_t q_heads,
+                         int32_t head_dim, int32_t num_splits, void* workspace, int64_t workspace_bytes,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif
