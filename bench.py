@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--bs", type=int, default=16)
     ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--layers", type=int, default=61, help="debug only: fewer layers => result flagged invalid")
+    ap.add_argument("--router-std", type=float, default=None, help="debug only: synthetic router weight std (result flagged invalid)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,7 +87,7 @@ def build_model(args_ns, rank):
                                 dtype=torch.bfloat16)
     be = HipAttnBackend(local_n_heads=margs.n_heads // SHARD, max_seq_len=max_seq)
     model = DeepSeekV3Decoder(margs, cache, be, max_position_embeddings=max(max_seq, 4097), device="cuda")
-    init_synthetic_(model, seed=1000 + rank)
+    init_synthetic_(model, seed=1000 + rank, router_std=getattr(args_ns, 'router_std', None))
     # synthetic "prefilled" latent KV (prefill is out of scope)
     gen = torch.Generator(device="cuda").manual_seed(77 + rank)
     flat = cache.paged_kv_cache.view(-1)
@@ -132,9 +133,31 @@ def measure(model, cache, bs, ctx, steps, warmup, world, use_graph, tag):
     return dt
 
 
-def distinct_experts_last_step(model, bs):
-    """Average number of distinct routed experts hit per MoE layer (drives the algorithmic bytes)."""
-    return None
+def capture_step_routing(model, cache, bs, ctx):
+    """One eager decode step on fresh sequences with a hook on every router: returns the
+    [bs, topk+1] expert ids each MoE layer actually routed (shared expert = last column)."""
+    from chitu_amd.deepseek_v3 import GateDeepSeekV3
+
+    rec = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: rec.append(o[1].clone()))
+             for m in model.modules() if isinstance(m, GateDeepSeekV3)]
+    reqs = [f"route{i}" for i in range(bs)]
+    for r in reqs:
+        cache.register_sequence(r, ctx)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    tokens = torch.randint(100, 1000, (bs,), device="cuda", generator=gen)
+    for _ in range(2):  # second step: tokens are the model's own greedy picks, as in the timed run
+        rec.clear()
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        tokens = model.decode(tokens, use_graph=False).argmax(dim=-1)
+        cache.finalize_cache_single_decode(reqs)
+    torch.cuda.synchronize()
+    for h in hooks:
+        h.remove()
+    for r in reqs:
+        cache.finalize_cache_all_decode(r)
+    return rec
 
 
 def algorithmic_bytes_per_step(margs, bs, ctx, distinct):
@@ -152,12 +175,11 @@ def algorithmic_bytes_per_step(margs, bs, ctx, distinct):
     return margs.n_layers * attn + margs.n_dense_layers * dense + n_moe * moe + head + kv
 
 
-def roofline_dominant_kernel(model, margs, bs, iters=3):
+def roofline_dominant_kernel(model, cache, margs, bs, ctx, iters=3):
     """Time the dominant kernel -- the routed-expert GEMM1 (chitu_hip_moe_gemm1_fp8: ~2/3 of all
-    bytes at bs=16) -- live with HIP events on the launch stream, one launch per MoE layer with that
-    layer's own weights (HBM-cold) and a uniform random routing of the same shape as the step's."""
-    import ctypes
-
+    bytes at bs=16) -- live with HIP events on the launch stream: one launch per MoE layer with that
+    layer's own weights (HBM-cold) and the expert ids that layer really routed in a decode step
+    (capture_step_routing), i.e. the same launches the timed step's graph replays."""
     from chitu_amd import _lib, fused_moe
     from chitu_amd._lib import i32, i64, ptr, stream_ptr
 
@@ -165,50 +187,53 @@ def roofline_dominant_kernel(model, margs, bs, iters=3):
     moe_layers = [l.ffn for l in model.layers if l.is_moe]
     if not moe_layers:
         return None
-    # same launch shape as the decode step: top-8 routed (uniform random routing) + the shared
-    # expert as slot 9 (MoEDeepSeekV3.forward), E = 257 stacked experts
-    E, topk, K = margs.n_routed_experts + margs.n_shared_experts, margs.n_activated_experts + 1, margs.dim
+    routing = capture_step_routing(model, cache, bs, ctx)
+    assert len(routing) == len(moe_layers)
+    E, K = margs.n_routed_experts + margs.n_shared_experts, margs.dim
     N = moe_layers[0].w1w3_weight.shape[1]
+    topk = routing[0].shape[1]
+    numel = bs * topk
     gen = torch.Generator(device="cuda").manual_seed(1)
-    ids = torch.stack([torch.randperm(E - 1, device="cuda", generator=gen)[:topk - 1] for _ in range(bs)])
-    ids = torch.cat([ids, torch.full((bs, 1), E - 1, device="cuda", dtype=ids.dtype)], dim=1).contiguous()
-    distinct = int(ids.unique().numel())
     x = torch.randn(bs, K, device="cuda", dtype=torch.bfloat16, generator=gen)
     xq, xs = fused_moe.per_token_group_quant_fp8(x, 128)
-    sorted_ids, expert_ids, npost = fused_moe.moe_align_block_size(ids, 16, E)
-    numel = bs * topk
     out = torch.empty(numel, N, dtype=torch.bfloat16, device="cuda")
-    max_mb = min(expert_ids.numel(), numel)
+    plans = []
+    for ids in routing:
+        sorted_ids, expert_ids, npost = fused_moe.moe_align_block_size(ids.contiguous(), 16, E)
+        plans.append((sorted_ids, expert_ids, npost, int(ids.unique().numel())))
     st = stream_ptr()
 
-    def launch(m):
+    def launch(m, plan):
+        sorted_ids, expert_ids, npost, _ = plan
         rc = lib.chitu_hip_moe_gemm1_fp8(ptr(xq), ptr(xs), ptr(m.w1w3_weight), ptr(m.w1w3_scale), ptr(sorted_ids),
                                          ptr(expert_ids), ptr(npost), ptr(out), i64(numel), i32(topk), i64(N), i64(K),
-                                         i64(max_mb), st)
+                                         i64(min(expert_ids.numel(), numel)), st)
         assert rc == 0
 
-    for m in moe_layers[:2]:
-        launch(m)
+    for m, pl in list(zip(moe_layers, plans))[:2]:
+        launch(m, pl)
     torch.cuda.synchronize()
     times = []
     for _ in range(iters):
-        for m in moe_layers:
+        for m, pl in zip(moe_layers, plans):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            launch(m)
+            launch(m, pl)
             e1.record()
             times.append((e0, e1))
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in times)
     avg_ms = sum(ms) / len(ms)
-    # algorithmic bytes of one launch: each hit expert's W1 slice once + its scales + activations + output
+    # algorithmic bytes of the average launch: each hit expert's W1 slice once + its scales +
+    # activations + output
+    distinct = sum(pl[3] for pl in plans) / len(plans)
     w_bytes = distinct * N * K
     s_bytes = distinct * ((N + 127) // 128) * (K // 128) * 4
     a_bytes = bs * K + bs * (K // 128) * 4 + numel * N * 2
     alg = w_bytes + s_bytes + a_bytes
     achieved = alg / (avg_ms * 1e-3) / 1e9
     # HBM traffic per launch from the committed PMC pass (profiles/r01_pmc_moe_gemm.json: FETCH_SIZE,
-    # doubled per MI355X_MICROARCH.md), scaled by the number of distinct experts of THIS launch.
+    # doubled per MI355X_MICROARCH.md), scaled by the distinct experts of the average launch.
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_moe_gemm.json")))["moe_gemm1_kernel<1>"]
@@ -221,7 +246,10 @@ def roofline_dominant_kernel(model, margs, bs, iters=3):
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "traffic_source": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction), profiles/r01_pmc_moe_gemm.json, scaled to this launch's distinct experts",
         "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(ms[len(ms) // 2] * 1e3, 2),
-        "algorithmic_bytes_per_launch": alg, "distinct_experts": distinct, "launches_timed": len(ms),
+        "algorithmic_bytes_per_launch": int(alg), "distinct_experts": round(distinct, 2),
+        "distinct_experts_min_max": [min(pl[3] for pl in plans), max(pl[3] for pl in plans)],
+        "routing": "expert ids of a real decode step of this model, per layer (shared expert included)",
+        "launches_timed": len(ms),
     }
 
 
@@ -324,7 +352,7 @@ def main():
 
     roof = None
     if rank == 0 and not a.no_roofline:
-        roof = roofline_dominant_kernel(model, margs, a.bs)
+        roof = roofline_dominant_kernel(model, cache, margs, a.bs, a.ctx)
     distinct = (roof["distinct_experts"] - 1) if roof else min(256, a.bs * 8)  # routed only; shared counted in the formula
     step_bytes = algorithmic_bytes_per_step(margs, a.bs, a.ctx, distinct)
     cpu = None
@@ -355,8 +383,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "build_s": round(build_s, 1),
         }
         res.update(extra)
-        if a.layers != 61:
-            res["invalid"] = "reduced layer count (debug run)"
+        if a.layers != 61 or a.router_std is not None:
+            res["invalid"] = "debug run (reduced layer count or non-default synthetic router)"
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

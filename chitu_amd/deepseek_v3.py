@@ -401,9 +401,10 @@ def _fill_fp8(t: torch.Tensor, gen: torch.Generator, std=0.5, chunk=1 << 26):
 
 
 @torch.no_grad()
-def init_synthetic_(model: torch.nn.Module, seed: int = 0):
+def init_synthetic_(model: torch.nn.Module, seed: int = 0, router_std: float = None):
     """fp8 = (randn*0.5) -> e4m3 (never raw bytes: no NaN codes), block scales U(0.01,0.03),
-    bf16 weights randn*0.05, norm weights 1, gate bias small -- SURVEY.md 8(d)."""
+    bf16 weights randn*0.05, norm weights 1, gate bias small, router weights randn/sqrt(dim)
+    (unit-variance logits => near-uniform routing) -- SURVEY.md 8(d)."""
     dev = next(model.parameters()).device
     gen = torch.Generator(device=dev).manual_seed(seed)
     for name, p in model.named_parameters():
@@ -415,6 +416,12 @@ def init_synthetic_(model: torch.nn.Module, seed: int = 0):
             p.data.fill_(1.0)
         elif name.endswith("gate.bias"):
             p.data.copy_((torch.randn(p.shape, device=dev, generator=gen) * 0.01).to(p.dtype))
+        elif name.endswith("gate.weight"):
+            # router logits ~ N(0, 1): with the generic 0.05 the sigmoid scores saturate, the top-k is
+            # decided by the (token-independent) bias and every token picks the same experts, which
+            # under-counts the expert bytes a balanced router (R1's is) streams per step
+            std = p.shape[-1] ** -0.5 if router_std is None else router_std
+            p.data.copy_((torch.randn(p.shape, device=dev, generator=gen) * std).to(p.dtype))
         else:
             flat = p.data.view(-1)
             for i in range(0, flat.numel(), 1 << 26):

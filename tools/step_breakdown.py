@@ -1,13 +1,16 @@
 #!/usr/bin/env python3
 """Per-decode-step kernel breakdown from a rocprofv3 rocpd .db of `bench.py --steps K`.
-Usage: python tools/step_breakdown.py <db> <timed_steps> [moe_layers_per_step=58]"""
+Usage: python tools/step_breakdown.py <db> <timed_steps> [moe_layers_per_step=58] [tail_aligns=3*moe_layers]
+tail_aligns = moe_align launches bench.py issues AFTER the timed steps (roofline leg: two eager
+routing-capture steps + one align per layer for the launch plans); run bench.py with --no-bs1."""
 import sqlite3, sys
 db, steps = sys.argv[1], int(sys.argv[2])
 nmoe = int(sys.argv[3]) if len(sys.argv) > 3 else 58
 con = sqlite3.connect(db)
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
 al = [i for i, r in enumerate(rows) if "moe_align_kernel" in r[0]]
-first, last = al[-1 - nmoe * steps], al[-1]   # last align call belongs to bench.py's roofline leg
+tail = int(sys.argv[4]) if len(sys.argv) > 4 else 3 * nmoe
+first, last = al[-tail - nmoe * steps], al[-tail]
 t0, t1 = rows[first][1], rows[last][1]
 sel = [r for r in rows if t0 <= r[1] < t1]
 agg = {}
