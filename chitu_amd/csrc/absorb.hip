@@ -126,7 +126,16 @@ __global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
     for (int w = 1; w < 8; ++w) amax = __builtin_fmaxf(amax, red[w][j]);
     const float sc = amax / 448.0f;
     if (m0 + j >= batch) return;
-    const uint32_t packed = f32x2_to_fp8x2(v[0] / sc, v[1] / sc) | (f32x2_to_fp8x2(v[2] / sc, v[3] / sc) << 16);
+    float t[4];
+    if (__builtin_amdgcn_ballot_w64(!group_div_fast(sc)) == 0) {
+        const float r = group_rcp(sc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = group_div(v[k], sc, r);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = v[k] / sc;
+    }
+    const uint32_t packed = f32x2_to_fp8x2(t[0], t[1]) | (f32x2_to_fp8x2(t[2], t[3]) << 16);
     *reinterpret_cast<uint32_t*>(q + ((int64_t)(m0 + j) * H + h) * 128 + wave * 16 + g * 4) = packed;
     if (wave == 0 && g == 0) qs[(int64_t)(m0 + j) * H + h] = sc;
 }

@@ -40,8 +40,16 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
     return __uint_as_float(((uint32_t)v) << 16);
 }
 
-// Round-to-nearest-even, NaN preserved (same as torch's float->bfloat16).
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+// Round-to-nearest-even (torch's float->bfloat16) on gfx950's v_cvt_pk_bf16_f32; the integer
+// emulation (kept as f32_to_bf16_sw, checked against the instruction by chitu_hip_selftest_arith)
+// costs 5 VALU ops per value, which is what the small norm/quant kernels are made of.
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hwbf16x2));
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(f32x2_to_bf16x2(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ bf16_t f32_to_bf16_sw(float f) {
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
     u += 0x7fffu + ((u >> 16) & 1u);
@@ -73,6 +81,44 @@ __device__ __forceinline__ uint32_t f32x2_to_fp8x2_sat(float a, float b) {
     a = __builtin_fminf(__builtin_fmaxf(a, -448.f), 448.f);
     b = __builtin_fminf(__builtin_fmaxf(b, -448.f), 448.f);
     return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+
+// x / sc for many x sharing one divisor (a quantisation group's scale): IEEE-exact quotient from a
+// refined reciprocal and one residual correction (3 FMAs per element instead of the ~10-instruction
+// v_div_scale/v_div_fmas/v_div_fixup sequence).  Exactness needs sc, the quotient and the residual
+// (|x| * 2^-24) in the normal range: callers test group_div_fast(sc) wave-uniformly and use plain division otherwise (zero /
+// denormal / NaN scales, e.g. the reference's 0/0 = NaN for an all-zero group).
+__device__ __forceinline__ bool group_div_fast(float sc) { return sc >= 0x1p-60f && sc <= 0x1p60f; }
+__device__ __forceinline__ float group_rcp(float sc) {
+    const float r0 = __builtin_amdgcn_rcpf(sc);
+    return __builtin_fmaf(__builtin_fmaf(-sc, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float group_div(float x, float sc, float r) {
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, sc, x), r, q);
+}
+
+// 8 values of one lane -> 8 e4m3 bytes of v / sc (SAT: clamped to +-448 first).
+template <bool SAT>
+__device__ __forceinline__ i32x2 quant8_fp8(const float (&v)[8], float sc) {
+    float t[8];
+    if (__builtin_amdgcn_ballot_w64(!group_div_fast(sc)) == 0) {
+        const float r = group_rcp(sc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = group_div(v[k], sc, r);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = v[k] / sc;
+    }
+    i32x2 o;
+    if (SAT) {
+        o[0] = (int)(f32x2_to_fp8x2_sat(t[0], t[1]) | (f32x2_to_fp8x2_sat(t[2], t[3]) << 16));
+        o[1] = (int)(f32x2_to_fp8x2_sat(t[4], t[5]) | (f32x2_to_fp8x2_sat(t[6], t[7]) << 16));
+    } else {
+        o[0] = (int)(f32x2_to_fp8x2(t[0], t[1]) | (f32x2_to_fp8x2(t[2], t[3]) << 16));
+        o[1] = (int)(f32x2_to_fp8x2(t[4], t[5]) | (f32x2_to_fp8x2(t[6], t[7]) << 16));
+    }
+    return o;
 }
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {

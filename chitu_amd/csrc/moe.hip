@@ -157,23 +157,12 @@ __global__ __launch_bounds__(256) void moe_silu_quant_kernel(const bf16_t* __res
             h[i] = round_bf16(sl * uv);
             amax = __builtin_fmaxf(amax, __builtin_fabsf(h[i]));
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off, 64));
+        amax = row16_reduce_max(amax);
         // act_rule: act_quant_deepseek_v3 (no eps, no clamp; triton_kernels.py:210-212) for the
         // dense / shared-expert MLP; otherwise per_token_group_quant_fp8 (fused_moe.py:701-703).
         if (!act_rule) amax = __builtin_fmaxf(amax, eps);
         const float sc = amax / 448.0f;
-        uint32_t lo, hi;
-        if (act_rule) {
-            lo = f32x2_to_fp8x2(h[0] / sc, h[1] / sc) | (f32x2_to_fp8x2(h[2] / sc, h[3] / sc) << 16);
-            hi = f32x2_to_fp8x2(h[4] / sc, h[5] / sc) | (f32x2_to_fp8x2(h[6] / sc, h[7] / sc) << 16);
-        } else {
-            lo = f32x2_to_fp8x2_sat(h[0] / sc, h[1] / sc) | (f32x2_to_fp8x2_sat(h[2] / sc, h[3] / sc) << 16);
-            hi = f32x2_to_fp8x2_sat(h[4] / sc, h[5] / sc) | (f32x2_to_fp8x2_sat(h[6] / sc, h[7] / sc) << 16);
-        }
-        i32x2 o;
-        o[0] = (int)lo;
-        o[1] = (int)hi;
+        const i32x2 o = act_rule ? quant8_fp8<false>(h, sc) : quant8_fp8<true>(h, sc);
         *reinterpret_cast<i32x2*>(q + row * I + col) = o;
         if (lane16 == 0) s[group] = sc;
     }

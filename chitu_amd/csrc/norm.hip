@@ -18,51 +18,66 @@ namespace chitu {
 constexpr int kNormThreads = 256;
 constexpr int kNormMaxChunks = 4;  // dim <= 256 * 8 * 4 = 8192
 
-// QMODE 0: no quant; 1: act_quant (no eps, no clamp); 2: per_token_group_quant (eps, clamp)
-template <int QMODE>
+// QMODE 0: no quant; 1: act_quant (no eps, no clamp); 2: per_token_group_quant (eps, clamp).
+// ADD: residual input present.  Every load of the row (x, add, weights) is issued before the first
+// use, straight-line (chunk indices are clamped, not branched on): one memory round trip, not one
+// per chunk.  sum_out may alias x or add (in-place residual): it is only written after all loads.
+template <int QMODE, bool ADD>
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(
-    const bf16_t* __restrict__ x, int64_t x_stride, const bf16_t* __restrict__ add,
-    int64_t add_stride, bf16_t* __restrict__ sum_out, int64_t sum_stride, const bf16_t* __restrict__ w,
-    bf16_t* __restrict__ y, int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs,
-    int dim, float eps, float qeps) {
+    const bf16_t* x, int64_t x_stride, const bf16_t* add, int64_t add_stride, bf16_t* sum_out,
+    int64_t sum_stride, const bf16_t* __restrict__ w, bf16_t* y, int64_t y_stride,
+    fp8_t* __restrict__ q, float* __restrict__ qs, int dim, float eps, float qeps) {
     __shared__ float red[kNormThreads / 64];
     const int row = blockIdx.x;
     const int tid = threadIdx.x;
     const bf16_t* xr = x + (int64_t)row * x_stride;
     const int n_chunks = dim >> 3;
+    i32x4 xraw[kNormMaxChunks], araw[kNormMaxChunks], wreg[kNormMaxChunks];
+#pragma unroll
+    for (int i = 0; i < kNormMaxChunks; ++i) {
+        const int c = min(tid + i * kNormThreads, n_chunks - 1);
+        xraw[i] = *reinterpret_cast<const i32x4*>(xr + c * 8);
+        if (ADD) araw[i] = *reinterpret_cast<const i32x4*>(add + (int64_t)row * add_stride + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < kNormMaxChunks; ++i) {
+        const int c = min(tid + i * kNormThreads, n_chunks - 1);
+        wreg[i] = *reinterpret_cast<const i32x4*>(w + c * 8);
+    }
     float v[kNormMaxChunks][8];
-    i32x4 wreg[kNormMaxChunks];  // norm weights requested together with x: one memory round trip
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < kNormMaxChunks; ++i) {
-        const int c = tid + i * kNormThreads;
-        if (c < n_chunks) {
-            wreg[i] = *reinterpret_cast<const i32x4*>(w + c * 8);
-            const i32x4 raw = *reinterpret_cast<const i32x4*>(xr + c * 8);
+        const bool act = tid + i * kNormThreads < n_chunks;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)xraw[i][k];
+            v[i][2 * k] = __uint_as_float(u << 16);
+            v[i][2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        }
+        if (ADD) {
+            // residual: x <- bf16(x + add), the reference's `x = x + attn(...)` in bf16
+            // (model_deepseek_v3.py:1107-1113), folded into the norm that consumes it
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const uint32_t u = (uint32_t)raw[k];
-                v[i][2 * k] = __uint_as_float(u << 16);
-                v[i][2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+                const uint32_t u = (uint32_t)araw[i][k];
+                const uint32_t s2 = f32x2_to_bf16x2(v[i][2 * k] + __uint_as_float(u << 16),
+                                                    v[i][2 * k + 1] + __uint_as_float(u & 0xffff0000u));
+                v[i][2 * k] = __uint_as_float(s2 << 16);
+                v[i][2 * k + 1] = __uint_as_float(s2 & 0xffff0000u);
+                araw[i][k] = (int)s2;
             }
-            if (add) {
-                // residual: x <- bf16(x + add), the reference's `x = x + attn(...)` in bf16
-                // (model_deepseek_v3.py:1107-1113), folded into the norm that consumes it
-                const i32x4 araw = *reinterpret_cast<const i32x4*>(add + (int64_t)row * add_stride + c * 8);
-                i32x4 sraw;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t u = (uint32_t)araw[k];
-                    const uint16_t lo = f32_to_bf16(v[i][2 * k] + __uint_as_float(u << 16));
-                    const uint16_t hi = f32_to_bf16(v[i][2 * k + 1] + __uint_as_float(u & 0xffff0000u));
-                    v[i][2 * k] = bf16_to_f32(lo);
-                    v[i][2 * k + 1] = bf16_to_f32(hi);
-                    sraw[k] = (int)((uint32_t)lo | ((uint32_t)hi << 16));
-                }
-                if (sum_out) *reinterpret_cast<i32x4*>(sum_out + (int64_t)row * sum_stride + c * 8) = sraw;
-            }
+        }
+        if (act) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) ss += v[i][k] * v[i][k];
+        }
+    }
+    if (ADD && sum_out) {
+#pragma unroll
+        for (int i = 0; i < kNormMaxChunks; ++i) {
+            const int c = tid + i * kNormThreads;
+            if (c < n_chunks) *reinterpret_cast<i32x4*>(sum_out + (int64_t)row * sum_stride + c * 8) = araw[i];
         }
     }
     ss = wave_reduce_sum(ss);
@@ -75,49 +90,28 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(
         const int c = tid + i * kNormThreads;
         const bool act = c < n_chunks;
         float o[8];
-        if (act) {
-            const i32x4 wraw = wreg[i];
-            uint16_t h[8];
+        i32x4 out;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t u = (uint32_t)wraw[k];
-                h[2 * k] = f32_to_bf16((v[i][2 * k] * rr) * __uint_as_float(u << 16));
-                h[2 * k + 1] = f32_to_bf16((v[i][2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = bf16_to_f32(h[k]);
-            if (y) {
-                i32x4 out;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) out[k] = (int)((uint32_t)h[2 * k] | ((uint32_t)h[2 * k + 1] << 16));
-                *reinterpret_cast<i32x4*>(y + (int64_t)row * y_stride + c * 8) = out;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] = 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)wreg[i][k];
+            const uint32_t h2 = f32x2_to_bf16x2((v[i][2 * k] * rr) * __uint_as_float(u << 16),
+                                                (v[i][2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
+            out[k] = (int)h2;
+            o[2 * k] = act ? __uint_as_float(h2 << 16) : 0.f;
+            o[2 * k + 1] = act ? __uint_as_float(h2 & 0xffff0000u) : 0.f;
         }
+        if (y && act) *reinterpret_cast<i32x4*>(y + (int64_t)row * y_stride + c * 8) = out;
         if (QMODE != 0) {
             // dim % 128 == 0 => a 16-lane group is either fully active or fully idle
             float amax = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(o[k]));
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off, 64));
+            amax = row16_reduce_max(amax);
             if (QMODE == 2) amax = __builtin_fmaxf(amax, qeps);
             const float sc = amax / 448.0f;
+            const i32x2 packed = quant8_fp8<QMODE == 2>(o, act ? sc : 1.0f);
             if (act) {
-                uint32_t lo, hi;
-                if (QMODE == 2) {
-                    lo = f32x2_to_fp8x2_sat(o[0] / sc, o[1] / sc) | (f32x2_to_fp8x2_sat(o[2] / sc, o[3] / sc) << 16);
-                    hi = f32x2_to_fp8x2_sat(o[4] / sc, o[5] / sc) | (f32x2_to_fp8x2_sat(o[6] / sc, o[7] / sc) << 16);
-                } else {
-                    lo = f32x2_to_fp8x2(o[0] / sc, o[1] / sc) | (f32x2_to_fp8x2(o[2] / sc, o[3] / sc) << 16);
-                    hi = f32x2_to_fp8x2(o[4] / sc, o[5] / sc) | (f32x2_to_fp8x2(o[6] / sc, o[7] / sc) << 16);
-                }
-                i32x2 out;
-                out[0] = (int)lo;
-                out[1] = (int)hi;
-                *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + c * 8) = out;
+                *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + c * 8) = packed;
                 if ((tid & 15) == 0) qs[(int64_t)row * (dim >> 7) + (c >> 4)] = sc;
             }
         }
@@ -144,14 +138,20 @@ extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const
     }
     if (rows == 0) return CHITU_OK;
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(QM)                                                                               \
-    hipLaunchKernelGGL(rmsnorm_kernel<QM>, dim3((unsigned)rows), dim3(kNormThreads), 0, st,       \
+#define LAUNCH(QM, AD)                                                                           \
+    hipLaunchKernelGGL((rmsnorm_kernel<QM, AD>), dim3((unsigned)rows), dim3(kNormThreads), 0, st, \
                        (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)add_bf16, add_row_stride, \
                        (bf16_t*)sum_out_bf16, sum_row_stride, (const bf16_t*)weight_bf16,         \
                        (bf16_t*)y_bf16, y_row_stride, (fp8_t*)q_fp8, q_scales, (int)dim, eps, quant_eps)
-    if (quant_mode == 0) LAUNCH(0);
-    else if (quant_mode == 1) LAUNCH(1);
-    else LAUNCH(2);
+    if (add_bf16) {
+        if (quant_mode == 0) LAUNCH(0, true);
+        else if (quant_mode == 1) LAUNCH(1, true);
+        else LAUNCH(2, true);
+    } else {
+        if (quant_mode == 0) LAUNCH(0, false);
+        else if (quant_mode == 1) LAUNCH(1, false);
+        else LAUNCH(2, false);
+    }
 #undef LAUNCH
     CHITU_RETURN_LAUNCH_STATUS();
 }

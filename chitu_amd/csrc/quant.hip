@@ -66,21 +66,10 @@ __global__ __launch_bounds__(256) void act_quant_kernel(const T* __restrict__ x,
 #pragma unroll
         for (int i = 0; i < 8; ++i) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[i]));
         // NaN inputs: fmaxf drops NaN like tl.max's default propagate_nan=NONE.
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off, 64));
+        amax = row16_reduce_max(amax);
         if (MODE == 1) amax = __builtin_fmaxf(amax, eps);
         const float sc = amax / 448.0f;
-        uint32_t lo, hi;
-        if (MODE == 1) {
-            lo = f32x2_to_fp8x2_sat(v[0] / sc, v[1] / sc) | (f32x2_to_fp8x2_sat(v[2] / sc, v[3] / sc) << 16);
-            hi = f32x2_to_fp8x2_sat(v[4] / sc, v[5] / sc) | (f32x2_to_fp8x2_sat(v[6] / sc, v[7] / sc) << 16);
-        } else {
-            lo = f32x2_to_fp8x2(v[0] / sc, v[1] / sc) | (f32x2_to_fp8x2(v[2] / sc, v[3] / sc) << 16);
-            hi = f32x2_to_fp8x2(v[4] / sc, v[5] / sc) | (f32x2_to_fp8x2(v[6] / sc, v[7] / sc) << 16);
-        }
-        i32x2 out;
-        out[0] = (int)lo;
-        out[1] = (int)hi;
+        const i32x2 out = quant8_fp8<MODE == 1>(v, sc);
         *reinterpret_cast<i32x2*>(y + group * 128 + lane16 * 8) = out;
         if (lane16 == 0) s[group] = sc;
     }
@@ -223,5 +212,36 @@ extern "C" int chitu_hip_weight_dequant_fp8(const void* w_fp8, const float* scal
         else return CHITU_ERR_UNSUPPORTED;
     }
 #undef LAUNCH
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+// ---- arithmetic self-test (tests/test_gpu_fp8.py): the two shortcuts every quantising kernel
+// relies on, checked on the device against their slow definitions over caller-supplied operands.
+namespace chitu {
+__global__ __launch_bounds__(256) void selftest_arith_kernel(const float* __restrict__ num, const float* __restrict__ den,
+                                                             int64_t n, unsigned long long* __restrict__ bad) {
+    unsigned long long b0 = 0, b1 = 0, b2 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float x = num[i], d = den[i];
+        if (group_div_fast(d)) {
+            const float fast = group_div(x, d, group_rcp(d)), slow = x / d;
+            b0 += __float_as_uint(fast) != __float_as_uint(slow);
+            b1 += f32x2_to_fp8x2_sat(fast, fast) != f32x2_to_fp8x2_sat(slow, slow);
+        }
+        b2 += f32_to_bf16(x) != f32_to_bf16_sw(x) && x == x;
+    }
+    if (b0) atomicAdd(bad + 0, b0);
+    if (b1) atomicAdd(bad + 1, b1);
+    if (b2) atomicAdd(bad + 2, b2);
+}
+}  // namespace chitu
+
+extern "C" int chitu_hip_selftest_arith(const float* num, const float* den, int64_t n, uint64_t* mismatches,
+                                        void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(num && den && mismatches && n >= 0);
+    if (n == 0) return CHITU_OK;
+    hipLaunchKernelGGL(selftest_arith_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, num, den, n,
+                       (unsigned long long*)mismatches);
     CHITU_RETURN_LAUNCH_STATUS();
 }

@@ -141,6 +141,17 @@ int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, const void*
 int chitu_hip_moe_sum(const void* c3_bf16, void* out_bf16, int64_t tokens, int32_t topk, int64_t N,
                       void* stream);
 
+/* ---- arithmetic self-test ----------------------------------------------------------------------
+ * The quantising kernels divide a group's values by its scale with a refined-reciprocal +
+ * residual-correction sequence instead of the IEEE division expansion, and round to bf16 with
+ * v_cvt_pk_bf16_f32 instead of integer arithmetic.  This entry checks both on the device, element
+ * by element, against the slow definitions: mismatches[0] += #(fast quotient != num/den bitwise),
+ * [1] += #(their e4m3 encodings differ), [2] += #(hardware bf16 != software RNE), over the pairs
+ * whose divisor is in the fast path's range [2^-60, 2^60] (callers keep |num/den| and |num| * 2^-24
+ * inside the normal range, as the kernels' |x| <= 448 * scale does).  mismatches: 3 x u64, caller-zeroed. */
+int chitu_hip_selftest_arith(const float* num, const float* den, int64_t n, uint64_t* mismatches,
+                             void* stream);
+
 /* ---- MLA absorb-mode paged decode attention ------------------------------------------------
  * Replaces mla_decode (chitu/triton_decode_attention.py:259-290: _mla_attn_kernel :20-130 +
  * _mla_softmax_reducev_kernel :185-232) as called from TritonAttnBackend.mla_attn_with_kvcache

@@ -169,3 +169,36 @@ def test_linearity_property_full_size():
         assert torch.equal(dbl.float(), full.float() * 2)
     finally:
         torch.set_default_dtype(torch.float32)
+
+
+def test_arithmetic_shortcuts_selftest():
+    """The quantising kernels' group division (refined reciprocal + residual correction) and the
+    hardware bf16 rounding against their slow definitions, on the device, over 48M operand pairs:
+    quantisation-shaped (|x| <= amax, d = amax/448), bf16-grid operands (where exact ties of the
+    e4m3 rounding live) and wide-range random floats."""
+    import ctypes
+
+    from chitu_amd import _lib
+    from chitu_amd._lib import i64, ptr, stream_ptr
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    n = 1 << 24
+    bad = torch.zeros(3, dtype=torch.int64, device="cuda")
+    cases = []
+    amax = torch.rand(n, device="cuda", generator=g) * 8 + 1e-3
+    cases.append(((torch.rand(n, device="cuda", generator=g) * 2 - 1) * amax, amax / 448.0))
+    xb = (torch.randn(n, device="cuda", generator=g) * 3).to(torch.bfloat16).float()
+    ab = (torch.rand(n, device="cuda", generator=g) * 6 + 0.01).to(torch.bfloat16).float()
+    cases.append((xb, ab / 448.0))
+    # wide dynamic range, quotient kept inside the normal range (the kernels' |x| <= amax = 448 d)
+    ed = torch.randint(-55, 55, (n,), device="cuda", generator=g).float()
+    ex = ed + torch.randint(-30, 30, (n,), device="cuda", generator=g).float()
+    cases.append((torch.randn(n, device="cuda", generator=g) * torch.exp2(ex),
+                  (torch.rand(n, device="cuda", generator=g) + 0.5) * torch.exp2(ed)))
+    for k, (num, den) in enumerate(cases):
+        bad.zero_()
+        rc = _lib.lib().chitu_hip_selftest_arith(ptr(num.contiguous()), ptr(den.contiguous()), i64(n), ptr(bad), stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        f32_mismatch, fp8_mismatch, bf16_mismatch = bad.tolist()
+        assert fp8_mismatch == 0 and bf16_mismatch == 0 and f32_mismatch == 0, (k, bad.tolist())
