@@ -92,8 +92,13 @@ class HipAttnBackend(AttnBackend):
         self.num_splits = choose_num_splits(bs, (self.local_n_heads + 15) // 16, max_tiles)
 
     def mla_decode(self, q_nope, q_pe, kv_cache, cache_seqlens_incl, block_table, softmax_scale,
-                   num_splits: Optional[int] = None, out: Optional[torch.Tensor] = None):
-        """softmax(scale * (q_nope.c + q_pe.k_pe)) . c over the paged latent cache; no append."""
+                   num_splits: Optional[int] = None, out: Optional[torch.Tensor] = None,
+                   return_partials: bool = False):
+        """softmax(scale * (q_nope.c + q_pe.k_pe)) . c over the paged latent cache; no append.
+
+        return_partials=True (fused consumer, ops.mla_merge_absorb_uv_quant_fp8): when the KV range is
+        split, skip the merge pass and return (workspace, num_splits) instead of the output; with a
+        single split the output tensor is returned as usual."""
         require_cuda(q_nope, q_pe, kv_cache, cache_seqlens_incl, block_table)
         assert kv_cache.ndim == 3 and kv_cache.is_contiguous()  # (num_blocks, block_size, dim)
         assert kv_cache.dtype == torch.bfloat16 and q_nope.dtype == torch.bfloat16 and q_pe.dtype == torch.bfloat16
@@ -113,7 +118,8 @@ class HipAttnBackend(AttnBackend):
         if num_splits is None:
             max_tiles = max(1, (int(block_table.shape[1]) * int(kv_cache.shape[1]) + 63) // 64)
             num_splits = self.num_splits or choose_num_splits(B, (H + 15) // 16, max_tiles)
-        if out is None:
+        partials = return_partials and num_splits > 1
+        if out is None and not partials:
             out = torch.empty(B, H, C, dtype=torch.bfloat16, device=q_nope.device)
         need = B * H * num_splits * (C + 1) * 4 if num_splits > 1 else 0
         ws = workspace.get(max(need, 1), q_nope.device, "mla")
@@ -122,12 +128,12 @@ class HipAttnBackend(AttnBackend):
                 ptr(q_nope), i64(q_nope.stride(0)), i64(q_nope.stride(1)), ptr(q_pe), i64(q_pe.stride(0)),
                 i64(q_pe.stride(1)), ptr(kv_cache), i64(kv_cache.shape[0]), i32(kv_cache.shape[1]),
                 ptr(block_table), i32(block_table.stride(0)), ptr(cache_seqlens_incl), f32(softmax_scale),
-                ptr(out), i32(B), i32(H), i32(C), i32(R), i32(num_splits), ptr(ws), i64(ws.numel()),
-                stream_ptr(),
+                ptr(None if partials else out), i32(B), i32(H), i32(C), i32(R), i32(num_splits), ptr(ws),
+                i64(ws.numel()), stream_ptr(),
             ),
             "mla_decode",
         )
-        return out
+        return (ws, num_splits) if partials else out
 
     def mla_attn_with_kvcache(
         self,

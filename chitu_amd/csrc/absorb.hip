@@ -140,6 +140,94 @@ __global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
     if (wave == 0 && g == 0) qs[(int64_t)(m0 + j) * H + h] = sc;
 }
 
+// MLA split-KV merge + W_UV projection + act_quant in one launch (small batches): replaces
+// mla_merge_kernel (mla_decode.hip) followed by absorb_uv_quant_kernel, same arithmetic and rounding
+// points (merged o -> bf16, projection -> bf16, e4m3 group quantisation), two dependent launches and
+// the o round trip less.  grid (H, batch); block 512: thread t merges latent column t of (b, h)
+// into LDS while the 64 KB W_UV[h] tile (requested first) is in flight; wave w then owns output
+// columns [16w, 16w+16).  The MFMA tile's 16 token columns all carry token b (LDS broadcast).
+__global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
+    const float* __restrict__ part_o, const float* __restrict__ part_lse, int S, const fp8_t* __restrict__ W,
+    int64_t w_sh, const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sk,
+    fp8_t* __restrict__ q, float* __restrict__ qs, int H) {
+    constexpr int K = 512, KC = 8;
+    __shared__ __attribute__((aligned(16))) bf16_t xs[K];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int64_t bh = (int64_t)b * H + h;
+    const fp8_t* wp = W + (int64_t)h * w_sh + (int64_t)(wave * 16 + j) * K + g * 16;
+    const float* sp = scale + s_off + h * s_sh;
+    i32x4 w[KC];
+    float sv[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        w[c] = *reinterpret_cast<const i32x4*>(wp + c * 64);
+        sv[c] = sp[(c >> 1) * s_sk];
+    }
+    // ---- merge: out[t] = sum_s w_s * part_o[bh, s, t] / sum_s w_s, w_s = exp(lse_s - max lse)
+    {
+        const float* lse = part_lse + bh * S;
+        float m = -INFINITY;
+        for (int s = 0; s < S; ++s) m = __builtin_fmaxf(m, lse[s]);
+        float acc = 0.f, wsum = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 8) {  // 8 partial rows in flight
+            float v[8], ws[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int s = s0 + i;
+                const float l = s < S ? lse[s] : -INFINITY;
+                ws[i] = l == -INFINITY ? 0.f : __expf(l - m);
+                v[i] = 0.f;
+                if (ws[i] != 0.f) v[i] = part_o[(bh * S + s) * K + tid];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                wsum += ws[i];
+                acc += ws[i] * v[i];
+            }
+        }
+        const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+        xs[tid] = f32_to_bf16(acc * inv);
+    }
+    __syncthreads();
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const s16x8 xa = *reinterpret_cast<const s16x8*>(&xs[c * 64 + g * 16]);
+        const s16x8 xb = *reinterpret_cast<const s16x8*>(&xs[c * 64 + g * 16 + 8]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dequant8_bf16((uint32_t)w[c][0], (uint32_t)w[c][1], sv[c]), xa, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dequant8_bf16((uint32_t)w[c][2], (uint32_t)w[c][3], sv[c]), xb, acc, 0, 0, 0);
+    }
+    float v[4], amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = round_bf16(acc[r]);
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v[r]));
+    }
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = red[0];
+#pragma unroll
+    for (int w8 = 1; w8 < 8; ++w8) amax = __builtin_fmaxf(amax, red[w8]);
+    const float sc = amax / 448.0f;
+    float t[4];
+    if (__builtin_amdgcn_ballot_w64(!group_div_fast(sc)) == 0) {
+        const float r = group_rcp(sc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = group_div(v[k], sc, r);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = v[k] / sc;
+    }
+    if (j != 0) return;
+    const uint32_t packed = f32x2_to_fp8x2(t[0], t[1]) | (f32x2_to_fp8x2(t[2], t[3]) << 16);
+    *reinterpret_cast<uint32_t*>(q + bh * 128 + wave * 16 + g * 4) = packed;
+    if (wave == 0 && g == 0) qs[bh] = sc;
+}
+
 }  // namespace chitu
 
 extern "C" int chitu_hip_absorb_uv_quant_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
@@ -183,5 +271,24 @@ extern "C" int chitu_hip_absorb_bmm_fp8(const void* x_bf16, int64_t x_stride_b, 
                        x_stride_b, x_stride_h, (const fp8_t*)w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
                        scale_stride_n, scale_stride_k, (bf16_t*)out_bf16, out_stride_b, out_stride_h,
                        (int)batch, (int)N, (int)K);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, int32_t num_splits,
+                                                       const void* w_fp8, int64_t w_stride_h,
+                                                       const float* scale, int64_t scale_offset,
+                                                       int64_t scale_stride_h, int64_t scale_stride_k,
+                                                       void* q_fp8, float* q_scales, int32_t batch,
+                                                       int32_t heads, int32_t K, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(workspace && w_fp8 && scale && q_fp8 && q_scales);
+    CHITU_REQUIRE(batch >= 0 && heads >= 1 && num_splits >= 2 && num_splits <= 256 && w_stride_h % 16 == 0);
+    if (K != 512) return CHITU_ERR_UNSUPPORTED;
+    if (batch == 0) return CHITU_OK;
+    const float* part_o = (const float*)workspace;
+    const float* part_lse = part_o + (int64_t)batch * heads * num_splits * 512;
+    hipLaunchKernelGGL(mla_merge_uv_quant_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(512), 0,
+                       (hipStream_t)stream, part_o, part_lse, (int)num_splits, (const fp8_t*)w_fp8, w_stride_h,
+                       scale, scale_offset, scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales, (int)heads);
     CHITU_RETURN_LAUNCH_STATUS();
 }

@@ -270,7 +270,8 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
                                     int32_t rope_dim, int32_t num_splits, void* workspace,
                                     int64_t workspace_bytes, void* stream) {
     using namespace chitu;
-    CHITU_REQUIRE(q_nope && q_pe && kv_cache && block_table && seqlens && out_bf16);
+    CHITU_REQUIRE(q_nope && q_pe && kv_cache && block_table && seqlens);
+    CHITU_REQUIRE(out_bf16 || num_splits > 1);  // no out: leave the split partials for a fused consumer
     CHITU_REQUIRE(batch >= 0 && heads >= 1 && num_pages >= 1 && table_stride >= 1);
     if (kv_lora_rank != kC || rope_dim != kR) return CHITU_ERR_UNSUPPORTED;
     if (page_size < kTile || page_size % kTile != 0) return CHITU_ERR_UNSUPPORTED;
@@ -297,7 +298,7 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
                        qn_stride_h, (const bf16_t*)q_pe, qp_stride_b, qp_stride_h, (const bf16_t*)kv_cache,
                        num_pages, (int)page_size, block_table, (int)table_stride, seqlens, softmax_scale,
                        part_o, part_lse, (bf16_t*)out_bf16, (int)heads, (int)num_splits, dbg);
-    if (num_splits > 1)
+    if (num_splits > 1 && out_bf16)
         hipLaunchKernelGGL(mla_merge_kernel, dim3((unsigned)(batch * heads)), dim3(128), 0, st, part_o,
                            part_lse, (bf16_t*)out_bf16, (int)num_splits);
     CHITU_RETURN_LAUNCH_STATUS();

@@ -196,11 +196,16 @@ class AttentionDeepSeekV3(torch.nn.Module):
         # q_nope' = q_nope . W_UK  (einsum "shd,hdc->shc", :529-531), wkv_b dequantised in registers
         nblk = C // BLOCK
         q_abs = ops.absorb_bmm_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0)
+        # small batches: the split-KV merge runs inside the W_UV projection kernel
+        fuse_merge = bs <= 32 and C == 512
         o = self.attn_backend.mla_decode(q_abs, q_pe, kv_cache, cache.get_gpu_seq_lens_incl_this_decode(),
-                                         cache.get_gpu_block_table(), self.softmax_scale)
+                                         cache.get_gpu_block_table(), self.softmax_scale, return_partials=fuse_merge)
         # out = o . W_UV^T  (einsum "bshc,hdc->bshd", :697) + the act-quant of wo's input
         w_uv = self.wkv_b.weight.view(H, self.qk_nope_head_dim + self.v_head_dim, C)[:, self.qk_nope_head_dim :]
-        oq, os_ = ops.absorb_uv_quant_fp8(o, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1)
+        if isinstance(o, tuple):
+            oq, os_ = ops.mla_merge_absorb_uv_quant_fp8(o[0], o[1], bs, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1)
+        else:
+            oq, os_ = ops.absorb_uv_quant_fp8(o, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1)
         return self.wo(None, x_quant=(oq, os_))
 
 

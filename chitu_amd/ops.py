@@ -353,6 +353,27 @@ def mla_kv_prep(kv_in, q_pe, cos, sin, kv_norm_weight, eps, kv_cache, page_table
     )
 
 
+def mla_merge_absorb_uv_quant_fp8(partials, num_splits, batch, w, scale, scale_offset, scale_stride_h, scale_stride_k):
+    """Split-KV merge of the MLA partials + absorb_uv_quant_fp8 in one launch (one workgroup per
+    (head, token), meant for decode batches up to a few dozen tokens).  partials: the workspace
+    returned by HipAttnBackend.mla_decode(return_partials=True)."""
+    require_cuda(partials, w, scale)
+    assert w.element_size() == 1 and scale.dtype == torch.float32 and w.dim() == 3 and w.shape[1] == 128
+    assert w.stride(2) == 1 and w.stride(1) == w.shape[2] and w.shape[2] == 512 and num_splits >= 2
+    H = w.shape[0]
+    assert partials.numel() * partials.element_size() >= batch * H * num_splits * 513 * 4
+    q = torch.empty(batch, H * 128, dtype=torch.float8_e4m3fn, device=w.device)
+    s = torch.empty(batch, H, dtype=torch.float32, device=w.device)
+    check(
+        _lib.lib().chitu_hip_mla_merge_absorb_uv_quant_fp8(
+            ptr(partials), i32(num_splits), ptr(w), i64(w.stride(0)), ptr(scale), i64(scale_offset),
+            i64(scale_stride_h), i64(scale_stride_k), ptr(q), ptr(s), i32(batch), i32(H), i32(512), stream_ptr(),
+        ),
+        "mla_merge_absorb_uv_quant_fp8",
+    )
+    return q, s
+
+
 def absorb_uv_quant_fp8(x, w, scale, scale_offset, scale_stride_h, scale_stride_k):
     """absorb_bmm_fp8 for the W_UV half (N = 128) + act_quant of its bf16 result: returns
     (q [B, H*128] e4m3fn, s [B, H] f32), the input of the wo fp8 GEMM."""

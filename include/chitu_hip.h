@@ -163,7 +163,10 @@ int chitu_hip_selftest_arith(const float* num, const float* den, int64_t n, uint
  *   block_table [batch, table_stride] i32; seqlens [batch] i32 = tokens to attend (incl. the
  *   row appended this step -- append is chitu_hip_append_paged_kv); out [batch, heads, C] bf16.
  *   num_splits: KV splits per sequence (graph-static; any value >= 1 gives the same result up to
- *   fp32 rounding).  workspace: >= chitu_hip_mla_decode_workspace_bytes when num_splits > 1. */
+ *   fp32 rounding).  workspace: >= chitu_hip_mla_decode_workspace_bytes when num_splits > 1;
+ *   it then holds part_o [batch, heads, num_splits, C] f32 followed by part_lse [batch, heads,
+ *   num_splits] f32.  out_bf16 == NULL (num_splits > 1 only): skip the merge pass and leave the
+ *   partials for chitu_hip_mla_merge_absorb_uv_quant_fp8. */
 int chitu_hip_mla_decode_workspace_bytes(int32_t batch, int32_t heads, int32_t num_splits,
                                          int64_t* bytes);
 int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int64_t qn_stride_h,
@@ -173,6 +176,17 @@ int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int64_t qn_str
                          float softmax_scale, void* out_bf16, int32_t batch, int32_t heads,
                          int32_t kv_lora_rank, int32_t rope_dim, int32_t num_splits,
                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Split-KV merge + W_UV projection (model_deepseek_v3.py:697) + act_quant of wo's input in one
+ * launch, for small batches (one workgroup per (head, token)): the same arithmetic and rounding
+ * points as chitu_hip_mla_decode's merge pass followed by chitu_hip_absorb_uv_quant_fp8.
+ * workspace: as left by chitu_hip_mla_decode(out_bf16 = NULL) with the same batch/heads/num_splits
+ * (>= 2); weight/scale arguments as chitu_hip_absorb_uv_quant_fp8; K must be 512. */
+int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, int32_t num_splits,
+                                            const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                            int64_t scale_offset, int64_t scale_stride_h,
+                                            int64_t scale_stride_k, void* q_fp8, float* q_scales,
+                                            int32_t batch, int32_t heads, int32_t K, void* stream);
 
 /* ---- RMSNorm (+ fused FP8 quantisation of its output) ----------------------------------------
  * Replaces RMSNorm.forward (chitu/models/model.py:29-78: F.rms_norm in fp32, one rounding) and,

@@ -308,3 +308,28 @@ def test_absorb_uv_quant_equals_absorb_then_act_quant(bs):
     q_ref, s_ref = ops.act_quant_deepseek_v3(y.contiguous())
     q, s = ops.absorb_uv_quant_fp8(o, w_uv, sc, 4, 8, 1)
     assert np.array_equal(bits8(q), bits8(q_ref)) and torch.equal(s, s_ref)
+
+
+@pytest.mark.parametrize("bs,lens,splits", [(1, [1000], 17), (16, [1024] * 16, 16), (5, [1, 64, 65, 700, 130], 2), (3, [10, 20, 30], 4)])
+def test_merge_folded_into_uv_projection_is_bit_identical(bs, lens, splits):
+    """chitu_hip_mla_decode(out=NULL) + chitu_hip_mla_merge_absorb_uv_quant_fp8 ==
+    chitu_hip_mla_decode (with its merge pass) + chitu_hip_absorb_uv_quant_fp8, including splits
+    that see no token (lse = -inf)."""
+    from chitu_amd import ops
+    from chitu_amd.attn_backend import HipAttnBackend
+    from tests.test_gpu_mla import make_case
+
+    H, C = 16, 512
+    q_nope, q_pe, cache, table, lens_t = make_case(bs, H, lens, pages=sum((l + 63) // 64 for l in lens) + 2, seed=bs)
+    g = torch.Generator().manual_seed(bs + 90)
+    wkv_b = (torch.randn(H * 256, C, generator=g) * 0.5).to(torch.float8_e4m3fn).cuda()
+    sc = (torch.rand(H * 2, C // 128, generator=g) * 0.02 + 0.01).cuda()
+    w_uv = wkv_b.view(H, 256, C)[:, 128:]
+    be = HipAttnBackend(local_n_heads=H)
+    args = (q_nope.cuda(), q_pe.cuda(), cache.cuda(), lens_t.cuda(), table.cuda(), 0.1)
+    o = be.mla_decode(*args, num_splits=splits)
+    q_ref, s_ref = ops.absorb_uv_quant_fp8(o, w_uv, sc, 4, 8, 1)
+    part = be.mla_decode(*args, num_splits=splits, return_partials=True)
+    assert isinstance(part, tuple) and part[1] == splits
+    q, s = ops.mla_merge_absorb_uv_quant_fp8(part[0], splits, bs, w_uv, sc, 4, 8, 1)
+    assert np.array_equal(bits8(q), bits8(q_ref)) and torch.equal(s, s_ref)
