@@ -29,13 +29,29 @@ __device__ __forceinline__ s16x8 dequant8_bf16(uint32_t w0, uint32_t w1, float s
     return r;
 }
 
-// grid (N/16, H, ceil(batch/16)); block 64.
+// grid (N/16 [+1], H, ceil(batch/16)); block 64.  The optional extra block column (rope != null)
+// rotates q_pe[b, h, :64] in place for the tile's 16 tokens (the q half of mla_kv_prep_kernel,
+// same arithmetic): it needs wq_b's output just like the absorb itself, so it rides in this launch.
 __global__ __launch_bounds__(64) void absorb_bmm_kernel(
     const bf16_t* __restrict__ x, int64_t x_sb, int64_t x_sh, const fp8_t* __restrict__ W, int64_t w_sh,
     const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sn, int64_t s_sk,
-    bf16_t* __restrict__ out, int64_t o_sb, int64_t o_sh, int batch, int N, int K) {
+    bf16_t* __restrict__ out, int64_t o_sb, int64_t o_sh, int batch, int N, int K, bf16_t* __restrict__ q_pe,
+    int64_t p_sb, int64_t p_sh, const float* __restrict__ cos, const float* __restrict__ sin) {
     const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16, h = blockIdx.y, m0 = blockIdx.z * 16;
+    if (n0 >= N) {
+#pragma clang fp contract(off)
+        for (int idx = lane; idx < 16 * 32; idx += 64) {
+            const int b = m0 + (idx >> 5), i = idx & 31;
+            if (b >= batch) break;
+            bf16_t* p = q_pe + b * p_sb + h * p_sh + 2 * i;
+            const uint32_t raw = *reinterpret_cast<const uint32_t*>(p);
+            const float x0 = __uint_as_float(raw << 16), x1 = __uint_as_float(raw & 0xffff0000u);
+            const float c = cos[(int64_t)b * 32 + i], s = sin[(int64_t)b * 32 + i];
+            *reinterpret_cast<uint32_t*>(p) = f32x2_to_bf16x2(x0 * c - x1 * s, x1 * c + x0 * s);
+        }
+        return;
+    }
     const int m = min(m0 + j, batch - 1);
     const fp8_t* wp = W + (int64_t)h * w_sh + (int64_t)min(n0 + j, N - 1) * K + g * 16;
     const bf16_t* xp = x + m * x_sb + h * x_sh + g * 16;
@@ -230,6 +246,18 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
 
 }  // namespace chitu
 
+static int launch_absorb_bmm(const void* x, int64_t x_sb, int64_t x_sh, const void* w, int64_t w_sh, const float* scale,
+                             int64_t s_off, int64_t s_sh, int64_t s_sn, int64_t s_sk, void* out, int64_t o_sb,
+                             int64_t o_sh, int batch, int heads, int N, int K, void* q_pe, int64_t p_sb, int64_t p_sh,
+                             const float* cos, const float* sin, void* stream) {
+    using namespace chitu;
+    const dim3 grid((unsigned)((N + 15) / 16 + (q_pe ? 1 : 0)), (unsigned)heads, (unsigned)((batch + 15) / 16));
+    hipLaunchKernelGGL(absorb_bmm_kernel, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, x_sb, x_sh,
+                       (const fp8_t*)w, w_sh, scale, s_off, s_sh, s_sn, s_sk, (bf16_t*)out, o_sb, o_sh, batch, N, K,
+                       (bf16_t*)q_pe, p_sb, p_sh, cos, sin);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int chitu_hip_absorb_uv_quant_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
                                              const void* w_fp8, int64_t w_stride_h, const float* scale,
                                              int64_t scale_offset, int64_t scale_stride_h,
@@ -266,11 +294,29 @@ extern "C" int chitu_hip_absorb_bmm_fp8(const void* x_bf16, int64_t x_stride_b, 
     if (K % 64 != 0) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(x_stride_b % 8 == 0 && x_stride_h % 8 == 0 && out_stride_b % 4 == 0 && out_stride_h % 4 == 0);
     if (batch == 0) return CHITU_OK;
-    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)heads, (unsigned)((batch + 15) / 16));
-    hipLaunchKernelGGL(absorb_bmm_kernel, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
-                       x_stride_b, x_stride_h, (const fp8_t*)w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
-                       scale_stride_n, scale_stride_k, (bf16_t*)out_bf16, out_stride_b, out_stride_h,
-                       (int)batch, (int)N, (int)K);
+    return launch_absorb_bmm(x_bf16, x_stride_b, x_stride_h, w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
+                             scale_stride_n, scale_stride_k, out_bf16, out_stride_b, out_stride_h, batch, heads, N, K,
+                             nullptr, 0, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int chitu_hip_absorb_bmm_rope_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
+                                             const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                             int64_t scale_offset, int64_t scale_stride_h,
+                                             int64_t scale_stride_n, int64_t scale_stride_k, void* out_bf16,
+                                             int64_t out_stride_b, int64_t out_stride_h, int32_t batch,
+                                             int32_t heads, int32_t N, int32_t K, void* q_pe_bf16,
+                                             int64_t q_pe_stride_b, int64_t q_pe_stride_h, const float* cos,
+                                             const float* sin, int32_t rope_dim, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && w_fp8 && scale && out_bf16 && q_pe_bf16 && cos && sin);
+    CHITU_REQUIRE(batch >= 0 && heads >= 1 && N >= 1 && K >= 64 && w_stride_h % 16 == 0);
+    if (K % 64 != 0 || rope_dim != 64) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(x_stride_b % 8 == 0 && x_stride_h % 8 == 0 && out_stride_b % 4 == 0 && out_stride_h % 4 == 0);
+    CHITU_REQUIRE(q_pe_stride_b % 2 == 0 && q_pe_stride_h % 2 == 0);
+    if (batch == 0) return CHITU_OK;
+    return launch_absorb_bmm(x_bf16, x_stride_b, x_stride_h, w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
+                             scale_stride_n, scale_stride_k, out_bf16, out_stride_b, out_stride_h, batch, heads, N, K,
+                             q_pe_bf16, q_pe_stride_b, q_pe_stride_h, cos, sin, stream);
     CHITU_RETURN_LAUNCH_STATUS();
 }
 

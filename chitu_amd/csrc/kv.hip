@@ -6,6 +6,7 @@
 //   chitu/triton_kernels.py:51-190    rotary_embedding_kernel_hf_llama / _llama
 //   chitu/ops.py:51-91, 124-326       launchers + torch RoPE
 #include "common.h"
+#include "norm_common.h"
 
 namespace chitu {
 
@@ -147,6 +148,73 @@ __global__ __launch_bounds__(256) void mla_kv_prep_kernel(
     }
 }
 
+// kv_norm(kv_c) + RoPE(k_pe) of one token written straight into its page row (waves 0 and 1 of a
+// workgroup); src = [kv_c (512) | k_pe (64)].
+__device__ __forceinline__ void mla_kv_row(int b, const bf16_t* src, const bf16_t* __restrict__ kv_norm_w, float kv_eps,
+                                           const float* __restrict__ cos, const float* __restrict__ sin,
+                                           bf16_t* __restrict__ cache, int64_t num_pages, int page_size,
+                                           const int32_t* __restrict__ table, int pages_per_seq,
+                                           const int32_t* __restrict__ old_lens) {
+#pragma clang fp contract(off)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (wave > 1) return;
+    bf16_t* row = nullptr;
+    {
+        const int L = old_lens[b];
+        const int pidx = L / page_size;
+        if (L >= 0 && pidx < pages_per_seq) {
+            const int64_t page = table[(int64_t)b * pages_per_seq + pidx];
+            if (page >= 0 && page < num_pages) row = cache + (page * page_size + (L % page_size)) * 576;
+        }
+    }
+    if (wave == 0) {
+        const i32x4 raw = *reinterpret_cast<const i32x4*>(src + lane * 8);
+        const i32x4 wraw = *reinterpret_cast<const i32x4*>(kv_norm_w + lane * 8);
+        float v[8], ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)raw[k];
+            v[2 * k] = __uint_as_float(u << 16);
+            v[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ss += v[k] * v[k];
+        ss = wave_reduce_sum(ss);
+        const float rr = rsqrtf(ss / 512.0f + kv_eps);
+        i32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)wraw[k];
+            o[k] = (int)f32x2_to_bf16x2((v[2 * k] * rr) * __uint_as_float(u << 16),
+                                        (v[2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
+        }
+        if (row) *reinterpret_cast<i32x4*>(row + lane * 8) = o;
+    } else if (lane < 32 && row) {
+        const float x0 = bf16_to_f32(src[512 + 2 * lane]), x1 = bf16_to_f32(src[512 + 2 * lane + 1]);
+        const float c = cos[(int64_t)b * 32 + lane], s = sin[(int64_t)b * 32 + lane];
+        *reinterpret_cast<uint32_t*>(row + 512 + 2 * lane) = f32x2_to_bf16x2(x0 * c - x1 * s, x1 * c + x0 * s);
+    }
+}
+
+// Everything that consumes wqkv_a's output row [q_a (q_lora) | kv_c (512) | k_pe (64)] in ONE launch:
+//   blockIdx.y == 0: q_norm + act_quant of q_a  -> the fp8 input of the wq_b GEMM (rmsnorm_row)
+//   blockIdx.y == 1: kv_norm(kv_c) and RoPE(k_pe) written straight into the token's page row
+// (the two parts of mla_kv_prep_kernel that do not need wq_b's output; q_pe is rotated by the
+// W_UK absorb launch, absorb.hip).  Same arithmetic as chitu_hip_rmsnorm + chitu_hip_mla_kv_prep.
+__global__ __launch_bounds__(256) void mla_qkv_post_kernel(
+    const bf16_t* qkv, int64_t row_stride, int q_lora, const bf16_t* __restrict__ q_norm_w, float q_eps,
+    fp8_t* __restrict__ q_fp8, float* __restrict__ q_scales, const bf16_t* __restrict__ kv_norm_w, float kv_eps,
+    const float* __restrict__ cos, const float* __restrict__ sin, bf16_t* __restrict__ cache, int64_t num_pages,
+    int page_size, const int32_t* __restrict__ table, int pages_per_seq, const int32_t* __restrict__ old_lens) {
+    const int b = blockIdx.x;
+    if (blockIdx.y == 0)
+        rmsnorm_row<1, false>(b, qkv, row_stride, nullptr, 0, nullptr, 0, q_norm_w, nullptr, 0, q_fp8, q_scales, q_lora,
+                              q_eps, 0.f);
+    else
+        mla_kv_row(b, qkv + (int64_t)b * row_stride + q_lora, kv_norm_w, kv_eps, cos, sin, cache, num_pages, page_size,
+                   table, pages_per_seq, old_lens);
+}
+
 }  // namespace chitu
 
 extern "C" int chitu_hip_mla_kv_prep(const void* kv_in_bf16, int64_t kv_row_stride, void* q_pe_bf16,
@@ -208,5 +276,27 @@ extern "C" int chitu_hip_rope(const void* q, const void* k, void* out_q, void* o
     else if (act_dtype == 2) LAUNCH(float);
     else return CHITU_ERR_UNSUPPORTED;
 #undef LAUNCH
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_mla_qkv_post(const void* qkv_a_bf16, int64_t row_stride, int32_t q_lora_rank,
+                                      const void* q_norm_weight_bf16, float q_eps, void* q_fp8, float* q_scales,
+                                      const void* kv_norm_weight_bf16, float kv_eps, const float* cos,
+                                      const float* sin, void* kv_cache, int64_t num_pages, int32_t page_size,
+                                      const int32_t* page_table, int32_t pages_per_seq,
+                                      const int32_t* old_seq_lens, int32_t batch, int32_t kv_lora_rank,
+                                      int32_t rope_dim, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(qkv_a_bf16 && q_norm_weight_bf16 && q_fp8 && q_scales && kv_norm_weight_bf16 && cos && sin);
+    CHITU_REQUIRE(kv_cache && page_table && old_seq_lens);
+    CHITU_REQUIRE(batch >= 0 && num_pages >= 1 && page_size >= 1 && pages_per_seq >= 1 && q_lora_rank >= 128);
+    if (kv_lora_rank != 512 || rope_dim != 64) return CHITU_ERR_UNSUPPORTED;
+    if (q_lora_rank % 128 != 0 || q_lora_rank > kNormThreads * 8 * kNormMaxChunks) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(row_stride % 8 == 0 && row_stride >= q_lora_rank + 576);
+    if (batch == 0) return CHITU_OK;
+    hipLaunchKernelGGL(mla_qkv_post_kernel, dim3((unsigned)batch, 2), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)qkv_a_bf16, row_stride, (int)q_lora_rank, (const bf16_t*)q_norm_weight_bf16, q_eps,
+                       (fp8_t*)q_fp8, q_scales, (const bf16_t*)kv_norm_weight_bf16, kv_eps, cos, sin, (bf16_t*)kv_cache,
+                       num_pages, (int)page_size, page_table, (int)pages_per_seq, old_seq_lens);
     CHITU_RETURN_LAUNCH_STATUS();
 }

@@ -1,0 +1,110 @@
+// RMSNorm row body shared by norm.hip (chitu_hip_rmsnorm) and kv.hip (the fused MLA q_norm / kv
+// kernel): one 256-thread workgroup normalises one row.  See norm.hip for the contract.
+#pragma once
+#include "common.h"
+
+namespace chitu {
+
+constexpr int kNormThreads = 256;
+constexpr int kNormMaxChunks = 4;  // dim <= 256 * 8 * 4 = 8192
+
+// QMODE 0: no quant; 1: act_quant (no eps, no clamp); 2: per_token_group_quant (eps, clamp).
+// ADD: residual input present.  Every load of the row (x, add, weights) is issued before the first
+// use, straight-line (chunk indices are clamped, not branched on): one memory round trip, not one
+// per chunk.  sum_out may alias x or add (in-place residual): it is only written after all loads.
+template <int QMODE, bool ADD>
+__device__ __forceinline__ void rmsnorm_row(
+    const int row, const bf16_t* x, int64_t x_stride, const bf16_t* add, int64_t add_stride, bf16_t* sum_out,
+    int64_t sum_stride, const bf16_t* __restrict__ w, bf16_t* y, int64_t y_stride,
+    fp8_t* __restrict__ q, float* __restrict__ qs, int dim, float eps, float qeps) {
+    __shared__ float red[kNormThreads / 64];
+    const int tid = threadIdx.x;
+    const bf16_t* xr = x + (int64_t)row * x_stride;
+    const int n_chunks = dim >> 3;
+    i32x4 xraw[kNormMaxChunks], araw[kNormMaxChunks], wreg[kNormMaxChunks];
+#pragma unroll
+    for (int i = 0; i < kNormMaxChunks; ++i) {
+        const int c = min(tid + i * kNormThreads, n_chunks - 1);
+        xraw[i] = *reinterpret_cast<const i32x4*>(xr + c * 8);
+        if (ADD) araw[i] = *reinterpret_cast<const i32x4*>(add + (int64_t)row * add_stride + c * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < kNormMaxChunks; ++i) {
+        const int c = min(tid + i * kNormThreads, n_chunks - 1);
+        wreg[i] = *reinterpret_cast<const i32x4*>(w + c * 8);
+    }
+    float v[kNormMaxChunks][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNormMaxChunks; ++i) {
+        const bool act = tid + i * kNormThreads < n_chunks;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)xraw[i][k];
+            v[i][2 * k] = __uint_as_float(u << 16);
+            v[i][2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        }
+        if (ADD) {
+            // residual: x <- bf16(x + add), the reference's `x = x + attn(...)` in bf16
+            // (model_deepseek_v3.py:1107-1113), folded into the norm that consumes it
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t u = (uint32_t)araw[i][k];
+                const uint32_t s2 = f32x2_to_bf16x2(v[i][2 * k] + __uint_as_float(u << 16),
+                                                    v[i][2 * k + 1] + __uint_as_float(u & 0xffff0000u));
+                v[i][2 * k] = __uint_as_float(s2 << 16);
+                v[i][2 * k + 1] = __uint_as_float(s2 & 0xffff0000u);
+                araw[i][k] = (int)s2;
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ss += v[i][k] * v[i][k];
+        }
+    }
+    if (ADD && sum_out) {
+#pragma unroll
+        for (int i = 0; i < kNormMaxChunks; ++i) {
+            const int c = tid + i * kNormThreads;
+            if (c < n_chunks) *reinterpret_cast<i32x4*>(sum_out + (int64_t)row * sum_stride + c * 8) = araw[i];
+        }
+    }
+    ss = wave_reduce_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = red[0] + red[1] + red[2] + red[3];
+    const float rr = rsqrtf(ss / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < kNormMaxChunks; ++i) {
+        const int c = tid + i * kNormThreads;
+        const bool act = c < n_chunks;
+        float o[8];
+        i32x4 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)wreg[i][k];
+            const uint32_t h2 = f32x2_to_bf16x2((v[i][2 * k] * rr) * __uint_as_float(u << 16),
+                                                (v[i][2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
+            out[k] = (int)h2;
+            o[2 * k] = act ? __uint_as_float(h2 << 16) : 0.f;
+            o[2 * k + 1] = act ? __uint_as_float(h2 & 0xffff0000u) : 0.f;
+        }
+        if (y && act) *reinterpret_cast<i32x4*>(y + (int64_t)row * y_stride + c * 8) = out;
+        if (QMODE != 0) {
+            // dim % 128 == 0 => a 16-lane group is either fully active or fully idle
+            float amax = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(o[k]));
+            amax = row16_reduce_max(amax);
+            if (QMODE == 2) amax = __builtin_fmaxf(amax, qeps);
+            const float sc = amax / 448.0f;
+            const i32x2 packed = quant8_fp8<QMODE == 2>(o, act ? sc : 1.0f);
+            if (act) {
+                *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + c * 8) = packed;
+                if ((tid & 15) == 0) qs[(int64_t)row * (dim >> 7) + (c >> 4)] = sc;
+            }
+        }
+    }
+}
+
+}  // namespace chitu

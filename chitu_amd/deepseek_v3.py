@@ -178,24 +178,24 @@ class AttentionDeepSeekV3(torch.nn.Module):
     def decode_forward_paged(self, x_quant, cos, sin):
         """x_quant = fp8 (q, s) of attn_norm(x), [bs, dim].  Returns wo(attn) before the all-reduce.
 
-        9 launches (the reference's decode_forward_paged + _run_linear issue ~25): wqkv_a GEMM,
-        q_norm+quant, wq_b GEMM, [kv_norm + RoPE + page append], W_UK absorb, MLA decode (+ merge),
-        [W_UV absorb + quant], wo GEMM."""
+        7 launches (the reference's decode_forward_paged + _run_linear issue ~25): wqkv_a GEMM,
+        [q_norm + quant | kv_norm + RoPE(k_pe) + page append], wq_b GEMM, [W_UK absorb | RoPE(q_pe)],
+        MLA decode, [split merge + W_UV absorb + quant], wo GEMM."""
         H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
         bs = x_quant[0].shape[0]
         cache = self.cache
         q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [bs, q_lora + C + R]
-        _, qq, qs = ops.rms_norm(q_a_kv[:, : self.q_lora_rank], self.q_norm.weight, self.q_norm.eps,
-                                 out_bf16=False, quant="act")
+        kv_cache = cache.get_paged_kv_cache(self.layer_id)
+        # q_norm + quant, and this token's [kv_norm(kv_c) | rope(k_pe)] row straight into its page
+        qq, qs = ops.mla_qkv_post(q_a_kv, self.q_lora_rank, self.q_norm.weight, self.q_norm.eps, self.kv_norm.weight,
+                                  self.kv_norm.eps, cos, sin, kv_cache, cache.get_gpu_block_table(),
+                                  cache.get_gpu_seq_lens_excl_this_decode())
         q = self.wq_b(None, x_quant=(qq, qs)).view(bs, H, self.qk_head_dim)
         q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
-        kv_cache = cache.get_paged_kv_cache(self.layer_id)
-        # this token's [kv_norm(kv_c) | rope(k_pe)] row goes straight into its page; q_pe rotated in place
-        ops.mla_kv_prep(q_a_kv[:, self.q_lora_rank :], q_pe, cos, sin, self.kv_norm.weight, self.kv_norm.eps,
-                        kv_cache, cache.get_gpu_block_table(), cache.get_gpu_seq_lens_excl_this_decode())
-        # q_nope' = q_nope . W_UK  (einsum "shd,hdc->shc", :529-531), wkv_b dequantised in registers
+        # q_nope' = q_nope . W_UK  (einsum "shd,hdc->shc", :529-531), wkv_b dequantised in registers;
+        # q_pe rotated in place by the same launch
         nblk = C // BLOCK
-        q_abs = ops.absorb_bmm_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0)
+        q_abs = ops.absorb_bmm_rope_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0, q_pe, cos, sin)
         # small batches: the split-KV merge runs inside the W_UV projection kernel
         fuse_merge = bs <= 32 and C == 512
         o = self.attn_backend.mla_decode(q_abs, q_pe, kv_cache, cache.get_gpu_seq_lens_incl_this_decode(),

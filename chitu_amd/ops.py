@@ -374,6 +374,53 @@ def mla_merge_absorb_uv_quant_fp8(partials, num_splits, batch, w, scale, scale_o
     return q, s
 
 
+def mla_qkv_post(q_a_kv, q_lora_rank, q_norm_weight, q_eps, kv_norm_weight, kv_eps, cos, sin, kv_cache, page_table,
+                 old_seq_lens):
+    """One launch for everything that reads wqkv_a's output [bs, q_lora + 512 + 64]: q_norm + act_quant
+    (returns (q_fp8, q_scales), the wq_b GEMM input) and kv_norm + RoPE(k_pe) + page append.  q_pe is
+    rotated later by absorb_bmm_rope_fp8."""
+    require_cuda(q_a_kv, q_norm_weight, kv_norm_weight, cos, sin, kv_cache, page_table, old_seq_lens)
+    assert q_a_kv.dtype == torch.bfloat16 and q_a_kv.dim() == 2 and q_a_kv.stride(1) == 1
+    assert q_a_kv.shape[1] == q_lora_rank + 576 and kv_cache.dtype == torch.bfloat16 and kv_cache.shape[-1] == 576
+    assert kv_cache.is_contiguous() and page_table.is_contiguous() and page_table.dtype == torch.int32
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and old_seq_lens.dtype == torch.int32
+    bs = q_a_kv.shape[0]
+    q = torch.empty(bs, q_lora_rank, dtype=torch.float8_e4m3fn, device=q_a_kv.device)
+    s = torch.empty(bs, q_lora_rank // 128, dtype=torch.float32, device=q_a_kv.device)
+    check(
+        _lib.lib().chitu_hip_mla_qkv_post(
+            ptr(q_a_kv), i64(q_a_kv.stride(0)), i32(q_lora_rank), ptr(q_norm_weight), f32(q_eps), ptr(q), ptr(s),
+            ptr(kv_norm_weight), f32(kv_eps), ptr(cos), ptr(sin), ptr(kv_cache), i64(kv_cache.shape[0]),
+            i32(kv_cache.shape[1]), ptr(page_table), i32(page_table.shape[1]), ptr(old_seq_lens), i32(bs), i32(512),
+            i32(64), stream_ptr(),
+        ),
+        "mla_qkv_post",
+    )
+    return q, s
+
+
+def absorb_bmm_rope_fp8(x, w, scale, scale_offset, scale_stride_h, scale_stride_n, scale_stride_k, q_pe, cos, sin):
+    """absorb_bmm_fp8 + in-place RoPE of q_pe [B, H, 64] in the same launch."""
+    require_cuda(x, w, scale, q_pe, cos, sin)
+    assert x.dtype == torch.bfloat16 and w.element_size() == 1 and scale.dtype == torch.float32
+    assert x.dim() == 3 and w.dim() == 3 and x.stride(-1) == 1 and w.stride(2) == 1 and w.stride(1) == w.shape[2]
+    assert q_pe.dtype == torch.bfloat16 and q_pe.shape[-1] == 64 and q_pe.stride(-1) == 1
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+    B, H, K = x.shape
+    N = w.shape[1]
+    out = torch.empty(B, H, N, dtype=torch.bfloat16, device=x.device)
+    check(
+        _lib.lib().chitu_hip_absorb_bmm_rope_fp8(
+            ptr(x), i64(x.stride(0)), i64(x.stride(1)), ptr(w), i64(w.stride(0)), ptr(scale), i64(scale_offset),
+            i64(scale_stride_h), i64(scale_stride_n), i64(scale_stride_k), ptr(out), i64(out.stride(0)),
+            i64(out.stride(1)), i32(B), i32(H), i32(N), i32(K), ptr(q_pe), i64(q_pe.stride(0)), i64(q_pe.stride(1)),
+            ptr(cos), ptr(sin), i32(64), stream_ptr(),
+        ),
+        "absorb_bmm_rope_fp8",
+    )
+    return out
+
+
 def absorb_uv_quant_fp8(x, w, scale, scale_offset, scale_stride_h, scale_stride_k):
     """absorb_bmm_fp8 for the W_UV half (N = 128) + act_quant of its bf16 result: returns
     (q [B, H*128] e4m3fn, s [B, H] f32), the input of the wo fp8 GEMM."""

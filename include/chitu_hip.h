@@ -216,6 +216,17 @@ int chitu_hip_absorb_bmm_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_s
                              void* out_bf16, int64_t out_stride_b, int64_t out_stride_h,
                              int32_t batch, int32_t heads, int32_t N, int32_t K, void* stream);
 
+/* chitu_hip_absorb_bmm_fp8 plus, in the same launch, RoPE applied IN PLACE to q_pe [batch, heads, 64]
+ * (interleaved pairs, cos/sin [batch, 32] f32; the q half of chitu_hip_mla_kv_prep, same arithmetic):
+ * both consume wq_b's output, so they share one launch on the decode path. */
+int chitu_hip_absorb_bmm_rope_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
+                                  const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                  int64_t scale_offset, int64_t scale_stride_h, int64_t scale_stride_n,
+                                  int64_t scale_stride_k, void* out_bf16, int64_t out_stride_b,
+                                  int64_t out_stride_h, int32_t batch, int32_t heads, int32_t N, int32_t K,
+                                  void* q_pe_bf16, int64_t q_pe_stride_b, int64_t q_pe_stride_h,
+                                  const float* cos, const float* sin, int32_t rope_dim, void* stream);
+
 /* ---- skinny bf16 GEMM (router scores, LM head) ---------------------------------------------
  * Replaces the F.linear calls on bf16 weights on the decode path: gate scores
  * (chitu/models/model_deepseek_v3.py:820) and the LM head (tensor_parallel.py:93, model.py:468-475).
@@ -257,6 +268,19 @@ int chitu_hip_mla_kv_prep(const void* kv_in_bf16, int64_t kv_row_stride, void* q
                           int64_t num_pages, int32_t page_size, const int32_t* page_table,
                           int32_t pages_per_seq, const int32_t* old_seq_lens, int32_t batch,
                           int32_t kv_lora_rank, int32_t rope_dim, void* stream);
+
+/* Everything that consumes wqkv_a's output row [q_a (q_lora_rank) | kv_c (512) | k_pe (64)] in one
+ * launch: q_norm + act_quant of q_a (= chitu_hip_rmsnorm quant_mode 1 -> q_fp8 [batch, q_lora_rank],
+ * q_scales [batch, q_lora_rank/128], the input of the wq_b GEMM; model_deepseek_v3.py:480-487) and the
+ * kv half of chitu_hip_mla_kv_prep (kv_norm + RoPE(k_pe) + page append).  q_pe is NOT rotated here
+ * (it does not exist yet): use chitu_hip_absorb_bmm_rope_fp8 after wq_b. */
+int chitu_hip_mla_qkv_post(const void* qkv_a_bf16, int64_t row_stride, int32_t q_lora_rank,
+                           const void* q_norm_weight_bf16, float q_eps, void* q_fp8, float* q_scales,
+                           const void* kv_norm_weight_bf16, float kv_eps, const float* cos,
+                           const float* sin, void* kv_cache, int64_t num_pages, int32_t page_size,
+                           const int32_t* page_table, int32_t pages_per_seq,
+                           const int32_t* old_seq_lens, int32_t batch, int32_t kv_lora_rank,
+                           int32_t rope_dim, void* stream);
 
 /* ---- W_UV absorb projection fused with the FP8 quantisation of wo's input ---------------------
  * chitu_hip_absorb_bmm_fp8 for N = 128 (einsum "bshc,hdc->bshd", model_deepseek_v3.py:697) followed by

@@ -45,6 +45,22 @@ def mla_kv_prep(kv_in, q_pe, cos, sin, kv_norm_weight, eps, kv_cache, page_table
     kv_cache.copy_(new)
 
 
+def mla_qkv_post(q_a_kv, q_lora_rank, q_norm_weight, q_eps, kv_norm_weight, kv_eps, cos, sin, kv_cache, page_table,
+                 old_seq_lens):
+    _, qq, qs = rms_norm(q_a_kv[:, :q_lora_rank], q_norm_weight, q_eps, out_bf16=False, quant="act")
+    kv_in = q_a_kv[:, q_lora_rank:]
+    _, ko = okv.apply_rotary_pos_emb(kv_in[:, None, 512:].expand(-1, 1, -1), kv_in[:, 512:], cos, sin, "llama")
+    kvn = F.rms_norm(kv_in[:, :512], (512,), kv_norm_weight, kv_eps).to(kv_in.dtype)
+    kv_cache.copy_(okv.append_to_paged_kv_cache(kv_cache, page_table, torch.cat([kvn, ko], -1), old_seq_lens))
+    return qq, qs
+
+
+def absorb_bmm_rope_fp8(x, w, scale, scale_offset, sh, sn, sk, q_pe, cos, sin):
+    qo, _ = okv.apply_rotary_pos_emb(q_pe, q_pe[:, 0], cos, sin, "llama")
+    q_pe.copy_(qo)
+    return absorb_bmm_fp8(x, w, scale, scale_offset, sh, sn, sk)
+
+
 def _dequant_heads(w, scale, off, sh, sn, sk):
     H, N, K = w.shape
     out = torch.empty(H, N, K, dtype=torch.bfloat16)
@@ -112,7 +128,7 @@ def install(monkeypatch_setattr):
     from chitu_amd import fused_moe, ops
 
     for name in ("rms_norm", "act_quant_deepseek_v3", "fp8_gemm_deepseek_v3", "mla_kv_prep", "absorb_bmm_fp8",
-                 "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear"):
+                 "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear", "mla_qkv_post", "absorb_bmm_rope_fp8"):
         monkeypatch_setattr(ops, name, globals()[name])
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)
     monkeypatch_setattr(fused_moe, "silu_and_mul_quant", silu_and_mul_quant)

@@ -333,3 +333,36 @@ def test_merge_folded_into_uv_projection_is_bit_identical(bs, lens, splits):
     assert isinstance(part, tuple) and part[1] == splits
     q, s = ops.mla_merge_absorb_uv_quant_fp8(part[0], splits, bs, w_uv, sc, 4, 8, 1)
     assert np.array_equal(bits8(q), bits8(q_ref)) and torch.equal(s, s_ref)
+
+
+@pytest.mark.parametrize("bs", [1, 5, 16, 21])
+def test_qkv_post_and_absorb_rope_equal_the_separate_launches(bs):
+    """mla_qkv_post + absorb_bmm_rope_fp8 == rms_norm(quant) + mla_kv_prep + absorb_bmm_fp8, bit for bit
+    (cache pages, fp8 q_a, scales, rotated q_pe, absorbed q_nope)."""
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(50 + bs)
+    H, C = 16, 512
+    q_a_kv = torch.randn(bs, 1536 + 576, generator=g).to(torch.bfloat16).cuda()
+    q = torch.randn(bs, H, 192, generator=g).to(torch.bfloat16).cuda()
+    cos, sin = torch.randn(bs, 32, generator=g).cuda(), torch.randn(bs, 32, generator=g).cuda()
+    wq = (torch.rand(1536, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    wn = (torch.rand(512, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    pages = 2 * bs + 2
+    cache = torch.randn(pages, 64, 576, generator=g).to(torch.bfloat16).cuda()
+    table = torch.stack([torch.randperm(pages, generator=g)[:2] for _ in range(bs)]).to(torch.int32).cuda()
+    lens = torch.tensor([(37 * i + (63 if i % 2 else 64)) % 128 for i in range(bs)], dtype=torch.int32).cuda()
+    w_uk_t = (torch.randn(H, C, 128, generator=g) * 0.5).to(torch.float8_e4m3fn).cuda()
+    sc = (torch.rand(H * 2, C // 128, generator=g) * 0.02 + 0.01).cuda()
+    # separate launches
+    _, qq_ref, qs_ref = ops.rms_norm(q_a_kv[:, :1536], wq, 1e-6, out_bf16=False, quant="act")
+    q1, cache1 = q.clone(), cache.clone()
+    ops.mla_kv_prep(q_a_kv[:, 1536:], q1[..., 128:], cos, sin, wn, 1e-6, cache1, table, lens)
+    abs_ref = ops.absorb_bmm_fp8(q1[..., :128], w_uk_t, sc, 0, 8, 1, 0)
+    # fused pair
+    q2, cache2 = q.clone(), cache.clone()
+    qq, qs = ops.mla_qkv_post(q_a_kv, 1536, wq, 1e-6, wn, 1e-6, cos, sin, cache2, table, lens)
+    ab = ops.absorb_bmm_rope_fp8(q2[..., :128], w_uk_t, sc, 0, 8, 1, 0, q2[..., 128:], cos, sin)
+    assert np.array_equal(bits8(qq), bits8(qq_ref)) and torch.equal(qs, qs_ref)
+    assert torch.equal(cache2, cache1)
+    assert torch.equal(q2, q1) and torch.equal(ab, abs_ref)
