@@ -16,6 +16,7 @@
 // partials are summed, in order, by the routing kernel itself (no separate reduce launch).  The same
 // GEMM entry point serves the LM head (N = vocab/tp, no split).
 #include "common.h"
+#include <stdlib.h>
 #include "gemm_common.h"
 
 namespace chitu {
@@ -203,6 +204,131 @@ __global__ __launch_bounds__(1024) void gate_route_kernel(
     }
 }
 
+// ---------------------------------------------------------------- fused routing, fast path
+// Same function as gate_route_kernel<1> (sigmoid scores, bf16 pipeline) for the shapes DeepSeek-V3/R1
+// use: group size 32 or 64, at most 64 = waves x topk final candidates, <= 16 logit partials.
+// Scores are bf16 values, so (score, lower-index-wins) packs into one unique 32-bit key
+//   key = ordered16(score) << 16 | (0xffff - e)
+// and every selection becomes integer maxima: group top-2 by DPP row reductions, the top-k by
+// topk rounds of a wave-wide max per wave followed by one rank pass over the <= 64 wave winners --
+// ~300 VALU ops and 2 barriers instead of a 256-way rank loop (~1400 ops) and 6 barriers.  All
+// global loads (partials, bias) are issued up front, straight-line.
+__device__ __forceinline__ uint32_t score_key(float v, int e) {
+    const uint32_t b = __float_as_uint(v) >> 16;
+    return ((b ^ ((b & 0x8000u) ? 0xffffu : 0x8000u)) << 16) | (0xffffu - (uint32_t)e);
+}
+__device__ __forceinline__ float key_score(uint32_t k) {
+    const uint32_t o = k >> 16;
+    return __uint_as_float((o ^ ((o & 0x8000u) ? 0x8000u : 0xffffu)) << 16);
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t row16_max_u32(uint32_t v) {
+    v = max(v, dpp_u32<0x128>(v));
+    v = max(v, dpp_u32<0x124>(v));
+    v = max(v, dpp_u32<0x122>(v));
+    v = max(v, dpp_u32<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32_uniform(uint32_t v) {
+    v = row16_max_u32(v);
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+template <int GS>  // experts per group: 32 or 64 (or 0 = ungrouped)
+__global__ __launch_bounds__(1024) void gate_route_fast_kernel(
+    const void* __restrict__ logits, int S, int M, int E, const bf16_t* __restrict__ bias, int n_groups,
+    int topk_groups, int topk, float route_scale, bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids,
+    int out_stride, int extra_id, float extra_w) {
+    __shared__ float orig_lds[1024];
+    __shared__ float gsc[32];
+    __shared__ __attribute__((aligned(16))) uint32_t cand[64];
+    __shared__ float wsel[64];
+    const int t = blockIdx.x, e = threadIdx.x, lane = e & 63, wave = e >> 6;
+    const int nw = blockDim.x >> 6;
+    const bool act = e < E;
+    const int ec = act ? e : E - 1;
+    // ---- all global loads up front
+    float logit;
+    if (S == 0) {
+        logit = bf16_to_f32(((const bf16_t*)logits)[(int64_t)t * E + ec]);
+    } else {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = ((const float*)logits)[((int64_t)min(i, S - 1) * M + t) * E + ec];
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += i < S ? v[i] : 0.f;
+        logit = bf16r(a);  // F.linear output in bf16 (model_deepseek_v3.py:820)
+    }
+    const float bv = bias ? bf16_to_f32(bias[ec]) : 0.f;
+    const float orig = bf16r(1.0f / (1.0f + expf(-logit)));  // original_scores
+    float sel = bias ? bf16r(orig + bv) : orig;
+    orig_lds[e] = orig;
+    uint32_t key = act ? score_key(sel, e) : 0u;
+    if (GS > 0) {
+        // group score = sum of the group's top-2 (bias) or its max (no bias), :827-831
+        uint32_t k1 = row16_max_u32(key);
+        k1 = max(k1, (uint32_t)__shfl_xor((int)k1, 16, 64));
+        if (GS == 64) k1 = max(k1, (uint32_t)__shfl_xor((int)k1, 32, 64));
+        uint32_t k2 = row16_max_u32(key == k1 ? 0u : key);
+        k2 = max(k2, (uint32_t)__shfl_xor((int)k2, 16, 64));
+        if (GS == 64) k2 = max(k2, (uint32_t)__shfl_xor((int)k2, 32, 64));
+        const float m1 = key_score(k1), m2 = key_score(k2);
+        if (act && (e % GS) == 0) gsc[e / GS] = bias ? bf16r(m1 + m2) : m1;
+        __syncthreads();
+        const int grp = ec / GS;
+        const float mine = gsc[grp];
+        int rank = 0;
+        for (int g2 = 0; g2 < n_groups; ++g2) {
+            const float o = gsc[g2];
+            rank += (o > mine) || (o == mine && g2 < grp);
+        }
+        if (rank >= topk_groups) sel = 0.f;  // scores * mask
+        key = act ? score_key(sel, e) : 0u;
+    }
+    // ---- this wave's topk best keys, one per lane (lane r keeps the r-th)
+    uint32_t mine_k = 0u;
+    for (int r = 0; r < topk; ++r) {
+        const uint32_t m = wave_max_u32_uniform(key);
+        if (lane == r) mine_k = m;
+        if (key == m) key = 0u;
+    }
+    if (lane < topk) cand[wave * topk + lane] = mine_k;
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- rank the nw * topk (<= 64) wave winners; keys are unique, 0 = empty slot
+    const int nc = nw * topk;
+    const uint32_t ck = lane < nc ? cand[lane] : 0u;
+    int rank = 0;
+    for (int i = 0; i < nc; i += 4) {
+        const i32x4 o = *reinterpret_cast<const i32x4*>(&cand[i]);
+        rank += ((uint32_t)o[0] > ck) + ((uint32_t)o[1] > ck) + ((uint32_t)o[2] > ck) + ((uint32_t)o[3] > ck);
+    }
+    if (lane < nc && ck != 0u && rank < topk) {
+        const int we = 0xffff - (int)(ck & 0xffffu);
+        out_ids[(int64_t)t * out_stride + rank] = we;
+        wsel[rank] = orig_lds[we];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-local LDS hand-off (wsel)
+    __builtin_amdgcn_wave_barrier();
+    if (lane < topk) {
+        float sum = 0.f;
+        for (int i = 0; i < topk; ++i) sum += wsel[i];
+        float w = bf16r(wsel[lane] / bf16r(sum));  // weights /= weights.sum(-1, keepdim=True)
+        w = bf16r(w * route_scale);                // weights *= route_scale
+        out_w[(int64_t)t * out_stride + lane] = f32_to_bf16(w);
+    }
+    if (lane == 0 && extra_id >= 0) {  // optional always-on (shared) expert appended as slot `topk`
+        out_ids[(int64_t)t * out_stride + topk] = extra_id;
+        out_w[(int64_t)t * out_stride + topk] = f32_to_bf16(extra_w);
+    }
+}
+
 }  // namespace chitu
 
 extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void* out, int out_dtype,
@@ -259,6 +385,22 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
     const int threads = ((num_experts + 63) / 64) * 64;
     const size_t lds = sizeof(float) * (size_t)(num_experts + 32 + 64 + 64);
     hipStream_t st = (hipStream_t)stream;
+    const int gs = n_groups > 1 ? num_experts / n_groups : 0;
+    const bool fast = score_func == 1 && (gs == 0 || gs == 32 || gs == 64) && num_partials <= 16 &&
+                      (threads / 64) * topk <= 64 && ((threads / 64) * topk) % 4 == 0 && n_groups <= 32 &&
+                      !getenv("CHITU_GATE_SLOW");
+    if (fast) {
+#define LAUNCHF(GSV)                                                                                         \
+    hipLaunchKernelGGL(gate_route_fast_kernel<GSV>, dim3((unsigned)tokens), dim3(threads), 0, st, logits,   \
+                       (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16, (int)n_groups, \
+                       (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16, out_ids,         \
+                       (int)out_stride, (int)extra_expert_id, extra_weight)
+        if (gs == 32) LAUNCHF(32);
+        else if (gs == 64) LAUNCHF(64);
+        else LAUNCHF(0);
+#undef LAUNCHF
+        CHITU_RETURN_LAUNCH_STATUS();
+    }
     if (score_func == 1)
         hipLaunchKernelGGL(gate_route_kernel<1>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
                            (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,

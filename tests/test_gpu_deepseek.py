@@ -366,3 +366,39 @@ def test_qkv_post_and_absorb_rope_equal_the_separate_launches(bs):
     assert np.array_equal(bits8(qq), bits8(qq_ref)) and torch.equal(qs, qs_ref)
     assert torch.equal(cache2, cache1)
     assert torch.equal(q2, q1) and torch.equal(ab, abs_ref)
+
+
+@pytest.mark.parametrize("E,groups,topk,S,bias", [(256, (8, 4), 8, 16, True), (256, (8, 4), 8, 0, True), (256, (4, 2), 8, 3, True),
+                                                  (256, (8, 4), 8, 16, False), (128, (1, 1), 6, 5, True), (64, (2, 1), 4, 0, True)])
+def test_gate_route_fast_path_equals_generic_kernel(E, groups, topk, S, bias, monkeypatch):
+    """The key-based routing kernel and the generic rank-loop kernel are the same function, on
+    tie-heavy inputs too (coarse logits => many equal bf16 scores; the tie rule is lower index first)."""
+    from chitu_amd import _lib
+    from chitu_amd._lib import f32, i32, i64, ptr, stream_ptr
+
+    M = 37
+    g = torch.Generator().manual_seed(E + S + topk)
+    for coarse in (False, True):
+        if S == 0:
+            logits = torch.randn(M, E, generator=g) * 2
+            logits = ((logits * 2).round() / 2 if coarse else logits).to(torch.bfloat16).cuda()
+        else:
+            part = torch.randn(S, M, E, generator=g)
+            logits = ((part * 4).round() / 4 if coarse else part).float().cuda()
+        b = ((torch.randn(E, generator=g) * (0.25 if coarse else 0.05)).to(torch.bfloat16).cuda()) if bias else None
+        outs = []
+        for slow in (False, True):
+            if slow:
+                monkeypatch.setenv("CHITU_GATE_SLOW", "1")
+            else:
+                monkeypatch.delenv("CHITU_GATE_SLOW", raising=False)
+            w = torch.zeros(M, topk + 1, dtype=torch.bfloat16, device="cuda")
+            ids = torch.zeros(M, topk + 1, dtype=torch.int64, device="cuda")
+            rc = _lib.lib().chitu_hip_gate_route(ptr(logits), i32(S), i64(M), i32(E), ptr(b), i32(groups[0]), i32(groups[1]),
+                                                 i32(topk), i32(1), f32(2.5), ptr(w), ptr(ids), i32(topk + 1), i32(E),
+                                                 f32(1.0), stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            outs.append((w.cpu(), ids.cpu()))
+        assert torch.equal(outs[0][1], outs[1][1])
+        assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
