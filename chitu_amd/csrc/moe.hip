@@ -78,7 +78,10 @@ __global__ __launch_bounds__(64 * WK * NW) void moe_gemm1_kernel(
     if (e >= 0) {
         const int kw = NW > 1 ? 0 : wave;
         const int kb0 = KB * kw / WK, kb1 = KB * (kw + 1) / WK;
-        const int token = valid ? slot / topk : 0;
+        // padded slots read the tile's first token (always valid) instead of token 0: the wave's
+        // activation loads then touch only the rows of tokens this expert really has
+        const int slot0 = __builtin_amdgcn_readfirstlane(slot);
+        const int token = (valid ? slot : min(slot0, numel - 1)) / topk;
         const fp8_t* xp = Xq + (size_t)token * K + g * 16;
         const float* xsp = Xs + (size_t)token * KB;
         const fp8_t *wp0, *wp1;
