@@ -39,7 +39,7 @@ struct GemmStage {
 };
 
 // ---------------------------------------------------------------- W8A8 block-scaled
-template <int MT, int WK>
+template <int MT, int WK, bool DEEP = false>
 __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
     const fp8_t* __restrict__ X, const float* __restrict__ XS, const fp8_t* __restrict__ W,
     const float* __restrict__ WS, void* __restrict__ out, int out_dt, float* __restrict__ partial,
@@ -92,7 +92,9 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
     };
 
     // D-deep register ring: D K-blocks (2 KB of weights each) in flight per wave while one is consumed.
-    constexpr int D = MT >= 4 ? 2 : 4;
+    // DEEP (single token tile, 5-8 K blocks per wave): the wave's whole K range is requested at once,
+    // one HBM round trip instead of two -- these launches are latency-, not bandwidth-bound.
+    constexpr int D = DEEP ? 8 : MT >= 4 ? 2 : 4;
     GemmStage<MT> ring[D];
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -248,8 +250,14 @@ extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_s
         const int rem = (int)(M - mb);
         const int mbase = (int)mb;
         if (rem <= 16) {
-            DISPATCH_WK(fp8_gemm_kernel, 1, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale,
-                        out, out_dtype, partial, (int)M, (int)N, (int)K, plan.S, mbase)
+            const int per_wave = (int)(K / 128) / (plan.WK * plan.S);
+            if (plan.WK == 8 && per_wave > 4 && per_wave <= 8)
+                hipLaunchKernelGGL((fp8_gemm_kernel<1, 8, true>), grid, dim3(512), 0, st, (const fp8_t*)a_fp8, a_scale,
+                                   (const fp8_t*)b_fp8, b_scale, out, out_dtype, partial, (int)M, (int)N, (int)K,
+                                   plan.S, mbase);
+            else
+                DISPATCH_WK(fp8_gemm_kernel, 1, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale,
+                            out, out_dtype, partial, (int)M, (int)N, (int)K, plan.S, mbase)
         } else if (rem <= 32) {
             DISPATCH_WK(fp8_gemm_kernel, 2, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale,
                         out, out_dtype, partial, (int)M, (int)N, (int)K, plan.S, mbase)
