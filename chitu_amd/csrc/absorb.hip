@@ -182,25 +182,30 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
         sv[c] = sp[(c >> 1) * s_sk];
     }
     // ---- merge: out[t] = sum_s w_s * part_o[bh, s, t] / sum_s w_s, w_s = exp(lse_s - max lse)
+    // (same operation order as mla_merge_kernel).  Lane s of every wave holds lse_s / w_s; the
+    // partial rows are requested 16 at a time, not one round trip per row.
     {
         const float* lse = part_lse + bh * S;
         float m = -INFINITY;
-        for (int s = 0; s < S; ++s) m = __builtin_fmaxf(m, lse[s]);
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const float l = s0 + lane < S ? lse[s0 + lane] : -INFINITY;
+            m = __builtin_fmaxf(m, wave_reduce_max(l));
+        }
         float acc = 0.f, wsum = 0.f;
-        for (int s0 = 0; s0 < S; s0 += 8) {  // 8 partial rows in flight
-            float v[8], ws[8];
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const float l = s0 + lane < S ? lse[s0 + lane] : -INFINITY;
+            const float wl = l == -INFINITY ? 0.f : __expf(l - m);
+            const int n = min(64, S - s0);
+            for (int i0 = 0; i0 < n; i0 += 16) {
+                float v[16];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int s = s0 + i;
-                const float l = s < S ? lse[s] : -INFINITY;
-                ws[i] = l == -INFINITY ? 0.f : __expf(l - m);
-                v[i] = 0.f;
-                if (ws[i] != 0.f) v[i] = part_o[(bh * S + s) * K + tid];
-            }
+                for (int i = 0; i < 16; ++i) v[i] = part_o[(bh * S + s0 + min(i0 + i, n - 1)) * K + tid];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                wsum += ws[i];
-                acc += ws[i] * v[i];
+                for (int i = 0; i < 16; ++i) {
+                    const float ws = i0 + i < n ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (i0 + i) & 63)) : 0.f;
+                    wsum += ws;
+                    acc += ws * (ws != 0.f ? v[i] : 0.f);
+                }
             }
         }
         const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;

@@ -64,16 +64,17 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
 
     // this split's page ids -> LDS once (a per-tile table lookup is a dependent global load on the
     // critical path of every tile)
+    // The FIRST tile's page id is read directly (one dependent load) so its KV loads leave as early
+    // as possible -- with one tile per split, the usual decode shape, that chain is the kernel; the
+    // LDS copy for the following tiles is filled in the shadow of those loads.
     const bool pages_in_lds = (tile1 - tile0) <= kMaxTilesLds;
-    if (pages_in_lds) {
-        for (int i = tid; i < tile1 - tile0; i += 256) pages_lds[i] = tbl[((tile0 + i) * kTile) / page_size];
-        __syncthreads();
-    }
-    auto tile_src = [&](int tile) -> const bf16_t* {
-        const int t0 = tile * kTile;
-        int64_t page = pages_in_lds ? pages_lds[tile - tile0] : tbl[t0 / page_size];
+    auto page_src = [&](int64_t page, int t0) -> const bf16_t* {
         if (page < 0 || page >= num_pages) page = 0;  // corrupt table: stay in bounds
         return cache + (page * page_size + (t0 % page_size)) * (int64_t)kD;
+    };
+    auto tile_src = [&](int tile) -> const bf16_t* {
+        const int t0 = tile * kTile;
+        return page_src(pages_in_lds ? pages_lds[tile - tile0] : tbl[t0 / page_size], t0);
     };
     // this thread's 18 chunks of a tile: chunk c = tid + i*256 -> (row, col)
     i32x4 pf[18];
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
             if (row < valid && !(dbg & 1)) pf[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(src + row * kD + col * 8));
         }
     };
-    if (tile0 < tile1) issue(tile_src(tile0), min(kTile, L - tile0 * kTile));
+    if (tile0 < tile1) issue(page_src(tbl[(tile0 * kTile) / page_size], tile0 * kTile), min(kTile, L - tile0 * kTile));
+    if (pages_in_lds)  // visible to all waves after the loop's first barrier
+        for (int i = tid; i < tile1 - tile0; i += 256) pages_lds[i] = tbl[((tile0 + i) * kTile) / page_size];
 
     // Q -> LDS (A operand of QK^T; 16 heads x 576, same padded stride as the KV rows)
     for (int c = tid; c < 16 * 72; c += 256) {
@@ -109,7 +112,6 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
 
     for (int tile = tile0; tile < tile1; ++tile) {
         const int valid = min(kTile, L - tile * kTile);
-        const bf16_t* next_src = (tile + 1 < tile1) ? tile_src(tile + 1) : nullptr;
         __syncthreads();  // previous tile fully consumed (and Q staged, first time round)
         if (!(dbg & 16)) {
 #pragma unroll
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         }
         }
         __syncthreads();
-        if (next_src) issue(next_src, min(kTile, L - (tile + 1) * kTile));
+        if (tile + 1 < tile1) issue(tile_src(tile + 1), min(kTile, L - (tile + 1) * kTile));
 
         // ---- S = Q K^T for this wave's 16 tokens (two accumulators: no 18-deep dependent chain)
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -198,22 +200,39 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
 
     // ---- epilogue: lane holds O[head 4g+r][col wave*128 + c*16 + j]
     const bool empty = tile1 <= tile0;
+    if (num_splits == 1) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int h = h0 + g * 4 + r;
-        if (h >= H) continue;
-        const float inv = empty ? 0.f : 1.0f / l_run[r];
-        if (num_splits == 1) {
+        for (int r = 0; r < 4; ++r) {
+            const int h = h0 + g * 4 + r;
+            if (h >= H) continue;
+            const float inv = empty ? 0.f : 1.0f / l_run[r];
             bf16_t* dst = out + ((int64_t)b * H + h) * kC + wave * 128 + j;
 #pragma unroll
             for (int c = 0; c < 8; ++c) dst[c * 16] = f32_to_bf16(o[c][r] * inv);
-        } else {
-            float* dst = part_o + (((int64_t)b * H + h) * num_splits + split) * kC + wave * 128 + j;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) dst[c * 16] = o[c][r] * inv;
-            if (wave == 0 && j == 0)
-                part_lse[((int64_t)b * H + h) * num_splits + split] = empty ? -INFINITY : m_run[r] + __logf(l_run[r]);
         }
+        return;
+    }
+    // split partials: transposed through LDS (the KV tile is dead) so every thread stores 16-B
+    // pieces of whole rows instead of 32 scattered dwords
+    __syncthreads();
+    float* o_lds = reinterpret_cast<float*>(kv_lds);  // [16][512] f32 = 32 KB
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float inv = empty ? 0.f : 1.0f / l_run[r];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o_lds[(g * 4 + r) * kC + wave * 128 + c * 16 + j] = o[c][r] * inv;
+        const int h = h0 + g * 4 + r;
+        if (wave == 0 && j == 0 && h < H)
+            part_lse[((int64_t)b * H + h) * num_splits + split] = empty ? -INFINITY : m_run[r] + __logf(l_run[r]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int chunk = tid + i * 256;
+        const int hr = chunk >> 7, c4 = chunk & 127;
+        if (h0 + hr < H)
+            *reinterpret_cast<f32x4*>(part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(o_lds + hr * kC + c4 * 4);
     }
 }
 
