@@ -11,7 +11,8 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchitu_hip.so")
+# CHITU_HIP_LIB: load another build of the same C-ABI instead (A/B timing of two builds on one GPU)
+LIB_PATH = os.environ.get("CHITU_HIP_LIB") or os.path.join(_HERE, "libchitu_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 _lib = None
