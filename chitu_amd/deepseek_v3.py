@@ -17,6 +17,8 @@ import math
 from dataclasses import dataclass
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -260,8 +262,10 @@ class MoEDeepSeekV3(torch.nn.Module):
         self.w2_weight = torch.nn.Parameter(torch.empty(E, args.dim, self.inter, dtype=FP8, device=device), requires_grad=False)
         self.w2_scale = torch.nn.Parameter(torch.empty(E, args.dim // BLOCK, (self.inter + BLOCK - 1) // BLOCK, dtype=torch.float32, device=device), requires_grad=False)
 
-    def forward(self, x, x_quant):
+    def forward(self, x, x_quant, defer_sum: bool = False):
         """x: ffn_norm output bf16 [bs, dim] (gate input); x_quant its fp8 (per-group) form.
+        defer_sum (one shared expert only): return the un-summed [bs, topk+1, dim] expert outputs; the
+        next RMSNorm folds the top-k sum into its residual add (ops.rms_norm(add=<3-D>)).
 
         With one shared expert (R1/V3) it is routed as slot `topk` with weight 1 and runs inside the
         same grouped GEMMs as the routed experts: its 16 tokens form one full MFMA tile and four
@@ -273,7 +277,7 @@ class MoEDeepSeekV3(torch.nn.Module):
             return fused_moe.fused_experts(
                 x, self.w1w3_weight, self.w2_weight, topk_weights=weights, topk_ids=indices, use_fp8_w8a8=True,
                 inplace=True, global_num_experts=nr + ns, w1_scale=self.w1w3_scale, w2_scale=self.w2_scale,
-                block_shape=[BLOCK, BLOCK], a1_quant=x_quant,
+                block_shape=[BLOCK, BLOCK], a1_quant=x_quant, reduce_topk=not defer_sum,
             )
         weights, indices = self.gate(x)
         y = None
@@ -313,7 +317,12 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
         a = tp.all_reduce(self.attn.decode_forward_paged((xq, xs), cos, sin))
         if self.is_moe:
             x, hn, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=True, quant="group", add=a)
-            f = self.ffn(hn, (hq, hs))
+            # without tensor parallelism nothing sits between the experts' top-k sum and the next norm's
+            # residual add: the sum moves into that norm (one launch less); with TP the all-reduce
+            # below needs the summed tensor
+            f = self.ffn(hn, (hq, hs), defer_sum=tp.get_tp_size() == 1 and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")
+            if f.dim() == 3:
+                return x, f
         else:
             x, _, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=False, quant="act", add=a)
             f = self.ffn((hq, hs))

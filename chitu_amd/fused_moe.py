@@ -162,13 +162,14 @@ def fused_experts(
     block_shape: Optional[List[int]] = None,
     soft_fp8: bool = False,
     a1_quant=None,
+    reduce_topk: bool = True,
 ) -> torch.Tensor:
-    """Same signature as chitu/fused_moe.py:1060-1127 (+ optional a1_quant, see fused_experts_impl).  (The reference's inplace=False branch
+    """Same signature as chitu/fused_moe.py:1060-1127 (+ optional a1_quant / reduce_topk, see fused_experts_impl).  (The reference's inplace=False branch
     calls an unregistered torch.ops.vllm op; here both branches work.)"""
     return fused_experts_impl(
         hidden_states, w1, w2, topk_weights, topk_ids, inplace, activation, use_fp8_w8a8,
         use_int8_w8a16, use_int4_w4a16, global_num_experts, expert_map, w1_scale, w2_scale, w1_zp,
-        w2_zp, a1_scale, a2_scale, block_shape, soft_fp8=soft_fp8, a1_quant=a1_quant,
+        w2_zp, a1_scale, a2_scale, block_shape, soft_fp8=soft_fp8, a1_quant=a1_quant, reduce_topk=reduce_topk,
     )
 
 
@@ -194,6 +195,7 @@ def fused_experts_impl(
     block_shape: Optional[List[int]] = None,
     soft_fp8: bool = False,
     a1_quant=None,
+    reduce_topk: bool = True,
 ):
     """out[t] = sum_j w[t,j] * W2[e_tj] . (silu(W1[e_tj] x_t)[:I] * (W1[e_tj] x_t)[I:])
 
@@ -202,6 +204,9 @@ def fused_experts_impl(
     weight) -> top-k sum.  Scratch lives in a persistent workspace (graph-capture safe).
     a1_quant=(q, s): the per-128-group fp8 form of hidden_states if the producer (fused RMSNorm)
     already computed it -- skips the quant launch, numerics unchanged.
+    reduce_topk=False: skip the top-k sum and return the routed-weighted expert outputs
+    [tokens, topk, hidden] (a view of the persistent workspace, valid until the next fused_experts
+    call) for a consumer that sums them itself (ops.rms_norm(add=<3-D>), same arithmetic).
     """
     assert hidden_states.shape[1] == w1.shape[2], "Hidden size mismatch"
     assert topk_weights.shape == topk_ids.shape, "topk shape mismatch"
@@ -315,6 +320,9 @@ def fused_experts_impl(
         ),
         "moe gemm2",
     )
+    if not reduce_topk:
+        c3_off = off["c3"] - base
+        return ws[c3_off : c3_off + numel * Nout * 2].view(torch.bfloat16).view(num_tokens, topk, Nout)
     check(lib.chitu_hip_moe_sum(P("c3"), ptr(out), i64(num_tokens), i32(topk), i64(Nout), st), "moe sum")
     return out
 

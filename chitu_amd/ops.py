@@ -212,7 +212,9 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
     x [..., dim] bf16 (last dim contiguous, uniform row stride); weight [dim] bf16.
     quant: None | "act" (act_quant_deepseek_v3) | "group" (per_token_group_quant_fp8, eps 1e-10).
     add: optional residual branch; the kernel first forms x_new = bf16(x + add) (the reference's
-    `x = x + attn(...)`, model_deepseek_v3.py:1107-1113) and normalises that.
+    `x = x + attn(...)`, model_deepseek_v3.py:1107-1113) and normalises that.  add may carry one extra
+    dim, [..., terms, dim] (terms <= 16): the terms are summed first with one bf16 rounding -- the fused
+    MoE's top-k sum (fused_experts(reduce_topk=False)) folded into this launch.
     Returns y, or (y, q, s) when quant is set (y is None if out_bf16=False); with `add`, x_new is
     prepended: (x_new, y) / (x_new, y, q, s).
     """
@@ -225,11 +227,18 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
         x2 = x2.contiguous()
     rows = x2.shape[0]
     a2 = sum_out = None
+    terms, term_stride = 1, 0
     if add is not None:
-        assert add.dtype == torch.bfloat16 and add.shape == x.shape
-        a2 = add.reshape(-1, dim)
-        if a2.stride(-1) != 1:
-            a2 = a2.contiguous()
+        assert add.dtype == torch.bfloat16
+        if add.dim() == x.dim() + 1:
+            assert add.shape[:-2] == x.shape[:-1] and add.shape[-1] == dim and add.is_contiguous()
+            terms, term_stride = add.shape[-2], dim
+            a2 = add.reshape(-1, terms * dim)
+        else:
+            assert add.shape == x.shape
+            a2 = add.reshape(-1, dim)
+            if a2.stride(-1) != 1:
+                a2 = a2.contiguous()
         sum_out = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device)
     y = torch.empty(rows, dim, dtype=torch.bfloat16, device=x.device) if out_bf16 else None
     q = s = None
@@ -240,7 +249,8 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
         s = torch.empty(rows, dim // 128, dtype=torch.float32, device=x.device)
     check(
         _lib.lib().chitu_hip_rmsnorm(
-            ptr(x2), i64(x2.stride(0)), ptr(a2), i64(a2.stride(0) if a2 is not None else 0), ptr(sum_out), i64(dim),
+            ptr(x2), i64(x2.stride(0)), ptr(a2), i64(a2.stride(0) if a2 is not None else 0), i32(terms), i64(term_stride),
+            ptr(sum_out), i64(dim),
             ptr(weight), ptr(y), i64(dim), i64(rows), i32(dim), f32(eps),
             ptr(q), ptr(s), i32(mode), f32(1e-10), stream_ptr(),
         ),

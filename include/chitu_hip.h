@@ -195,10 +195,14 @@ int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, int32_t num_s
  * 2 = per_token_group_quant_fp8 rule (eps = quant_eps); the codes are those of the bf16-rounded y.
  *   add_bf16 (optional): residual branch folded in first, x <- bf16(x + add) -- the reference's
  *   `x = x + attn(...)` / `x = x + ffn(...)` (model_deepseek_v3.py:1107-1113); sum_out receives it.
+ *   add_terms > 1 (<= 16): the residual of row r is first formed as bf16(sum_k float(add[r*add_row_stride +
+ *   k*add_term_stride + :])) -- chitu_hip_moe_sum's arithmetic, i.e. the fused MoE's top-k sum
+ *   (fused_moe.py:1299-1305) folded into the norm that consumes it; add_terms == 1: plain residual.
  *   x [rows, dim] bf16 (row stride given); weight [dim] bf16; y [rows, dim] bf16 or NULL;
  *   q_fp8 [rows, dim], q_scales [rows, dim/128] (dim % 128 == 0 when quantising); dim <= 8192. */
 int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
-                      int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                      int64_t add_row_stride, int32_t add_terms, int64_t add_term_stride,
+                      void* sum_out_bf16, int64_t sum_row_stride,
                       const void* weight_bf16, void* y_bf16, int64_t y_row_stride, int64_t rows,
                       int32_t dim, float eps, void* q_fp8, float* q_scales, int32_t quant_mode,
                       float quant_eps, void* stream);

@@ -19,6 +19,8 @@ from oracle import moe as omoe
 def rms_norm(x, weight, eps=1e-6, out_bf16=True, quant=None, add=None):
     res = ()
     if add is not None:
+        if add.dim() == x.dim() + 1:  # un-summed top-k terms: moe_sum's arithmetic first
+            add = add.float().sum(-2).to(x.dtype)
         x = x + add
         res = (x,)
     y = F.rms_norm(x, (x.shape[-1],), weight, eps).to(x.dtype)

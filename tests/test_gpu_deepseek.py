@@ -128,6 +128,8 @@ def test_layerwise_parity_and_graph_replay():
             layer.ffn.gate.forward = hooked
         with torch.inference_mode():
             xm, pend = layer(x.cuda(), None, cos.cuda(), sin.cuda())
+            if pend.dim() == 3:  # un-summed top-k terms (the next norm folds the sum in): moe_sum's arithmetic
+                pend = pend.float().sum(1).to(torch.bfloat16)
             y = (xm + pend).cpu()
         if layer.is_moe:
             layer.ffn.gate.forward = orig
@@ -402,3 +404,25 @@ def test_gate_route_fast_path_equals_generic_kernel(E, groups, topk, S, bias, mo
             outs.append((w.cpu(), ids.cpu()))
         assert torch.equal(outs[0][1], outs[1][1])
         assert torch.equal(outs[0][0].view(torch.int16), outs[1][0].view(torch.int16))
+
+
+@pytest.mark.parametrize("rows,terms,dim,quant", [(16, 9, 7168, "act"), (1, 9, 7168, "act"), (5, 3, 2048, "group"), (7, 16, 512, None), (3, 2, 8192, "act")])
+def test_topk_sum_folded_into_rmsnorm_is_bit_identical(rows, terms, dim, quant):
+    """rms_norm(add=[rows, terms, dim]) == chitu_hip_moe_sum followed by rms_norm(add=[rows, dim])."""
+    from chitu_amd import _lib, ops
+    from chitu_amd._lib import i32, i64, ptr, stream_ptr
+
+    g = torch.Generator().manual_seed(rows * 31 + terms)
+    x = torch.randn(rows, dim, generator=g).to(torch.bfloat16).cuda()
+    c3 = (torch.randn(rows, terms, dim, generator=g) * 0.3).to(torch.bfloat16).cuda()
+    w = (torch.rand(dim, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    summed = torch.empty(rows, dim, dtype=torch.bfloat16, device="cuda")
+    assert _lib.lib().chitu_hip_moe_sum(ptr(c3), ptr(summed), i64(rows), i32(terms), i64(dim), stream_ptr()) == 0
+    ref = ops.rms_norm(x, w, 1e-6, quant=quant, add=summed)
+    got = ops.rms_norm(x, w, 1e-6, quant=quant, add=c3)
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        if a.dtype == torch.float8_e4m3fn:
+            assert np.array_equal(bits8(a), bits8(b))
+        else:
+            assert torch.equal(a, b)
