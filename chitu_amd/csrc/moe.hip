@@ -132,6 +132,115 @@ __global__ __launch_bounds__(64 * WK * NW) void moe_gemm1_kernel(
     moe_store_tile(out + (size_t)slot * N, n0, g, N, acc, 1.0f);
 }
 
+// ---------------------------------------------------------------- GEMM1 + SiLU-and-mul
+// Same loop as moe_gemm1_kernel, but a wave owns the gate tile [n0, n0+16) AND the up tile
+// [I+n0, I+n0+16) of W1 (N = 2I): both products share the activation fragments (half the
+// activation loads per weight byte) and the wave ends up with g and u of the same 16 x 16 outputs,
+// so h = bf16(bf16(silu(bf16(g))) * bf16(u)) -- SiluAndMul with the reference's rounding points,
+// fused_moe.py:24-39 -- is formed in the epilogue and written as bf16 [numel, I].  The fp8
+// re-quantisation needs a 128-wide group maximum (8 tiles): it is done by GEMM2's prologue
+// (moe_gemm2_q_kernel).  grid (I/16, max_mblocks); block 64*WK (WK waves split K).
+struct MoeStage2 {
+    W8Frag wg, wu;
+    i32x4 x[2];
+    float xs, wsg, wsu;
+};
+
+template <int WK, int D>
+__global__ __launch_bounds__(64 * WK) void moe_gemm1_silu_kernel(
+    const fp8_t* __restrict__ Xq, const float* __restrict__ Xs, const fp8_t* __restrict__ W,
+    const float* __restrict__ Ws, const int32_t* __restrict__ sorted_ids,
+    const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
+    bf16_t* __restrict__ out, int numel, int topk, int I, int K) {
+    __shared__ float red[WK > 1 ? WK * 512 : 1];
+    const int mb = blockIdx.y;
+    if (mb * 16 >= *num_post_pad) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int N = 2 * I;
+    const int KB = K >> 7;
+    const int slot = sorted_ids[mb * 16 + j];
+    const bool valid = slot < numel;
+    const int e = expert_ids[mb];
+    f32x4 ag = f32x4{0.f, 0.f, 0.f, 0.f}, au = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e >= 0) {
+        const int kb0 = KB * wave / WK, kb1 = KB * (wave + 1) / WK;
+        const int slot0 = __builtin_amdgcn_readfirstlane(slot);
+        const int token = (valid ? slot : min(slot0, numel - 1)) / topk;
+        const fp8_t* xp = Xq + (size_t)token * K + g * 16;
+        const float* xsp = Xs + (size_t)token * KB;
+        const fp8_t* Wb = W + (size_t)e * N * K;
+        const fp8_t *gp0, *gp1, *up0, *up1;
+        w8_lane_ptrs(Wb, n0, N, K, j, g, gp0, gp1);
+        w8_lane_ptrs(Wb, I + n0, N, K, j, g, up0, up1);
+        const float* wsb = Ws + (size_t)e * ((N + 127) >> 7) * KB;
+        const float* wsgp = wsb + (size_t)(n0 >> 7) * KB;
+        const float* wsup = wsb + (size_t)((I + n0) >> 7) * KB;
+        auto load = [&](MoeStage2& st, int kb) {
+            const int off = kb << 7;
+            st.wg.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(gp0 + off));
+            st.wg.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(gp1 + off));
+            st.wu.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(up0 + off));
+            st.wu.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(up1 + off));
+            st.x[0] = *reinterpret_cast<const i32x4*>(xp + off);
+            st.x[1] = *reinterpret_cast<const i32x4*>(xp + off + 64);
+            st.xs = xsp[kb];
+            st.wsg = wsgp[kb];
+            st.wsu = wsup[kb];
+        };
+        auto compute = [&](const MoeStage2& st) {
+            const f32x4 bg = w8a8_block_dot(st.wg, st.x[0], st.x[1]);
+            const f32x4 bu = w8a8_block_dot(st.wu, st.x[0], st.x[1]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ag[r] += (bg[r] * st.xs) * st.wsg;
+                au[r] += (bu[r] * st.xs) * st.wsu;
+            }
+        };
+        MoeStage2 ring[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (kb0 + d < kb1) load(ring[d], kb0 + d);
+        for (int kb = kb0; kb < kb1; kb += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (kb + d < kb1) {
+                    compute(ring[d]);
+                    if (kb + d + D < kb1) load(ring[d], kb + d + D);
+                }
+            }
+        }
+    }
+    if (WK > 1) {
+        *reinterpret_cast<f32x4*>(&red[(wave * 128 + lane) * 4]) = ag;
+        *reinterpret_cast<f32x4*>(&red[(wave * 128 + 64 + lane) * 4]) = au;
+        __syncthreads();
+        if (wave != 0) return;
+        ag = f32x4{0.f, 0.f, 0.f, 0.f};
+        au = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WK; ++w) {
+            const f32x4 vg = *reinterpret_cast<const f32x4*>(&red[(w * 128 + lane) * 4]);
+            const f32x4 vu = *reinterpret_cast<const f32x4*>(&red[(w * 128 + 64 + lane) * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ag[r] += vg[r];
+                au[r] += vu[r];
+            }
+        }
+    }
+    if (!valid) return;
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float gv = round_bf16(ag[r]), uv = round_bf16(au[r]);  // GEMM1's bf16 output (c1)
+        const float sl = round_bf16(gv / (1.0f + expf(-gv)));
+        h[r] = round_bf16(sl * uv);
+    }
+    moe_store_tile(out + (size_t)slot * I, n0, g, I, h, 1.0f);
+}
+
 // ---------------------------------------------------------------- SiLU-and-mul + fp8 requant
 // c1 [rows, 2I] bf16 -> h = bf16(bf16(silu(gate)) * up) -> q [rows, I] e4m3, s [rows, I/128].
 // One 128-wide group per 16 lanes (same shape as act_quant_kernel MODE 1).
@@ -243,6 +352,119 @@ __global__ __launch_bounds__(256) void moe_gemm2_kernel(
             }
         }
         if (valid) moe_store_tile(out + (size_t)slot * N, n0, g, N, acc, rw);
+    }
+}
+
+// GEMM2 with the fp8 re-quantisation of its input folded into the prologue: h [numel, I] bf16 is
+// moe_gemm1_silu_kernel's output.  The 16 x I activation tile of the m-block is quantised once per
+// workgroup (per_token_group_quant_fp8 rule, fused_moe.py:701-703; same arithmetic as
+// moe_silu_quant_kernel): wave w takes the 64-column half-blocks hb = w, w+4, ..., the two halves
+// of a 128-group meet through LDS for the maximum, the bytes are parked in LDS in MFMA-fragment
+// order and every wave picks up its B operand there.  The h loads are issued BEFORE the weight
+// loads and everything up to the MFMAs is straight-line code, so the prologue's s_waitcnt counts
+// past the weight loads queued behind it (vector loads return in order).
+template <int KB, int NT>
+__global__ __launch_bounds__(256) void moe_gemm2_q_kernel(
+    const bf16_t* __restrict__ Hb, const fp8_t* __restrict__ W, const float* __restrict__ Ws,
+    const int32_t* __restrict__ sorted_ids, const int32_t* __restrict__ expert_ids,
+    const int32_t* __restrict__ num_post_pad, const void* __restrict__ topk_w, int w_dt,
+    bf16_t* __restrict__ out, int numel, int N, int mul_weight, float eps) {
+    constexpr int I = KB * 128;
+    constexpr int HPW = (2 * KB + 3) / 4;  // half-blocks per wave
+    __shared__ float amax_lds[2 * KB][16];
+    __shared__ i32x4 xq_lds[2 * KB][64];
+    const int mb = blockIdx.y;
+    if (mb * 16 >= *num_post_pad) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int slot = sorted_ids[mb * 16 + j];
+    const bool valid = slot < numel;
+    const int e = expert_ids[mb];
+    const int tile0 = (blockIdx.x * 4 + wave) * NT;
+    if (e < 0) {  // expert not on this rank (expert_map): the slot's contribution is zero
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n0 = (tile0 + t) * 16;
+            if (n0 < N && valid) moe_store_tile(out + (size_t)slot * N, n0, g, N, f32x4{0.f, 0.f, 0.f, 0.f}, 1.0f);
+        }
+        return;
+    }
+    const int row = valid ? slot : 0;
+    const bf16_t* hrow = Hb + (size_t)row * I;
+    i32x4 hraw[HPW][2];
+#pragma unroll
+    for (int q = 0; q < HPW; ++q) {
+        const int hb = min(wave + 4 * q, 2 * KB - 1);
+        hraw[q][0] = *reinterpret_cast<const i32x4*>(hrow + hb * 64 + g * 16);
+        hraw[q][1] = *reinterpret_cast<const i32x4*>(hrow + hb * 64 + g * 16 + 8);
+    }
+    const int last_tile = (N - 1) >> 4;
+    W8Frag wf[NT][KB];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n0 = min(tile0 + t, last_tile) * 16;  // tail tiles re-read the last one, never stored
+        const fp8_t *wp0, *wp1;
+        w8_lane_ptrs(W + (size_t)e * N * I, n0, N, I, j, g, wp0, wp1);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            wf[t][kb].w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + (kb << 7)));
+            wf[t][kb].w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + (kb << 7)));
+        }
+    }
+    const float rw = (mul_weight && valid) ? moe_routed_weight(topk_w, w_dt, slot) : 1.0f;
+    float h[HPW][16];
+#pragma unroll
+    for (int q = 0; q < HPW; ++q) {
+        const int hb = wave + 4 * q;
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t u = (uint32_t)hraw[q][i >> 3][(i >> 1) & 3];
+            h[q][i] = (i & 1) ? __uint_as_float(u & 0xffff0000u) : __uint_as_float(u << 16);
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(h[q][i]));
+        }
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
+        if (g == 0 && hb < 2 * KB) amax_lds[hb][j] = amax;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < HPW; ++q) {
+        const int hb = wave + 4 * q;
+        if (hb < 2 * KB) {
+            const float sc = __builtin_fmaxf(__builtin_fmaxf(amax_lds[hb & ~1][j], amax_lds[hb | 1][j]), eps) / 448.0f;
+            float lo[8], hi[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                lo[i] = h[q][i];
+                hi[i] = h[q][8 + i];
+            }
+            const i32x2 a = quant8_fp8<true>(lo, sc), b = quant8_fp8<true>(hi, sc);
+            xq_lds[hb][lane] = i32x4{a[0], a[1], b[0], b[1]};
+        }
+    }
+    __syncthreads();
+    i32x4 x[KB][2];
+    float xs[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        x[kb][0] = xq_lds[2 * kb][lane];
+        x[kb][1] = xq_lds[2 * kb + 1][lane];
+        xs[kb] = __builtin_fmaxf(__builtin_fmaxf(amax_lds[2 * kb][j], amax_lds[2 * kb + 1][j]), eps) / 448.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n0 = (tile0 + t) * 16;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wsp = Ws + ((size_t)e * ((N + 127) >> 7) + (min(n0, N - 1) >> 7)) * KB;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const f32x4 blk = w8a8_block_dot(wf[t][kb], x[kb][0], x[kb][1]);
+            const float ws = wsp[kb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * xs[kb]) * ws;
+        }
+        if (valid && n0 < N) moe_store_tile(out + (size_t)slot * N, n0, g, N, acc, rw);
     }
 }
 
@@ -446,6 +668,71 @@ extern "C" int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, 
         }
 #undef LAUNCHG
     }
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
+                                            const float* w1_scale, const int32_t* sorted_token_ids,
+                                            const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                                            void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size,
+                                            int64_t K, int64_t max_mblocks, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(a_fp8 && a_scale && w1_fp8 && w1_scale && sorted_token_ids && expert_ids);
+    CHITU_REQUIRE(num_tokens_post_pad && h_bf16);
+    CHITU_REQUIRE(numel >= 0 && topk >= 1 && inter_size >= 16 && K >= 128 && max_mblocks >= 0);
+    if (K % 128 != 0 || inter_size % 16 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (numel == 0 || max_mblocks == 0) return CHITU_OK;
+    const int n_tiles = (int)(inter_size / 16);
+    const int64_t wgs = 2 * (int64_t)n_tiles * (numel < max_mblocks ? numel : max_mblocks);
+    const int KB = (int)(K / 128);
+    int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 2048 ? 2 : 1;  // as chitu_hip_moe_gemm1_fp8 (a wave = 2 tiles)
+    if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);
+    while (WK > 1 && WK > KB) WK >>= 1;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)n_tiles, (unsigned)max_mblocks);
+#define LAUNCH1S(WKV, DV)                                                                                     \
+    hipLaunchKernelGGL((moe_gemm1_silu_kernel<WKV, DV>), grid, dim3(64 * WKV), 0, st, (const fp8_t*)a_fp8, a_scale, \
+                       (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids, num_tokens_post_pad,      \
+                       (bf16_t*)h_bf16, (int)numel, (int)topk, (int)inter_size, (int)K)
+    if (WK == 8) LAUNCH1S(8, 4);
+    else if (WK == 4) LAUNCH1S(4, 4);
+    else if (WK == 2) LAUNCH1S(2, 3);
+    else LAUNCH1S(1, 3);
+#undef LAUNCH1S
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_fp8, const float* w2_scale,
+                                             const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                                             const int32_t* num_tokens_post_pad, const void* topk_weights,
+                                             int weights_dtype, int32_t mul_routed_weight, void* out_bf16,
+                                             int64_t numel, int64_t N, int64_t inter_size, int64_t max_mblocks,
+                                             float eps, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(h_bf16 && w2_fp8 && w2_scale && sorted_token_ids && expert_ids);
+    CHITU_REQUIRE(num_tokens_post_pad && out_bf16 && (topk_weights || !mul_routed_weight));
+    CHITU_REQUIRE(numel >= 0 && N >= 1 && inter_size >= 128 && max_mblocks >= 0);
+    CHITU_REQUIRE(weights_dtype >= 0 && weights_dtype <= 2);
+    if (inter_size % 128 != 0 || inter_size > 512) return CHITU_ERR_UNSUPPORTED;
+    if (numel == 0 || max_mblocks == 0) return CHITU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_tiles = (int)((N + 15) / 16);
+    const int KB = (int)(inter_size / 128);
+    const int64_t mbs = numel < max_mblocks ? numel : max_mblocks;
+#define LAUNCH2Q(KBV, NTV)                                                                           \
+    hipLaunchKernelGGL((moe_gemm2_q_kernel<KBV, NTV>),                                               \
+                       dim3((unsigned)((n_tiles + 4 * NTV - 1) / (4 * NTV)), (unsigned)max_mblocks), \
+                       dim3(256), 0, st, (const bf16_t*)h_bf16, (const fp8_t*)w2_fp8, w2_scale,      \
+                       sorted_token_ids, expert_ids, num_tokens_post_pad, topk_weights, weights_dtype, \
+                       (bf16_t*)out_bf16, (int)numel, (int)N, (int)mul_routed_weight, eps)
+    const bool many = (int64_t)n_tiles * mbs > 8192;
+    switch (KB) {
+        case 1: if (many) LAUNCH2Q(1, 4); else LAUNCH2Q(1, 2); break;
+        case 2: if (many) LAUNCH2Q(2, 4); else LAUNCH2Q(2, 2); break;
+        case 3: LAUNCH2Q(3, 2); break;
+        default: LAUNCH2Q(4, 2); break;
+    }
+#undef LAUNCH2Q
     CHITU_RETURN_LAUNCH_STATUS();
 }
 

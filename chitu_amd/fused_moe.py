@@ -6,6 +6,7 @@ fused_experts_impl:1130-1307, SiluAndMul:24-39.  No Triton here: every step is a
 HIP kernel behind libchitu_hip.so, and there is no fallback path.
 """
 
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -200,7 +201,7 @@ def fused_experts_impl(
     """out[t] = sum_j w[t,j] * W2[e_tj] . (silu(W1[e_tj] x_t)[:I] * (W1[e_tj] x_t)[I:])
 
     FP8 W8A8 with [128,128] block scales (the DeepSeek-V3/R1 path, fused_moe.py:1130-1307).
-    Six launches: align(16) -> quant -> grouped GEMM1 -> silu*mul+requant -> grouped GEMM2 (x routed
+    Launches: align(16) -> [quant ->] grouped GEMM1 (+ silu*mul) -> grouped GEMM2 (requant +, x routed
     weight) -> top-k sum.  Scratch lives in a persistent workspace (graph-capture safe).
     a1_quant=(q, s): the per-128-group fp8 form of hidden_states if the producer (fused RMSNorm)
     already computed it -- skips the quant launch, numerics unchanged.
@@ -301,25 +302,44 @@ def fused_experts_impl(
         assert aq.is_contiguous() and as_.is_contiguous() and aq.numel() == num_tokens * K
         assert as_.dtype == torch.float32 and as_.numel() == num_tokens * KB
         a1q_p, a1s_p = ptr(aq), ptr(as_)
-    check(
-        lib.chitu_hip_moe_gemm1_fp8(
-            a1q_p, a1s_p, ptr(w1), ptr(w1_scale), P("sorted"), experts_ptr, P("npost"), P("c1"),
-            i64(numel), i32(topk), i64(N), i64(K), i64(max_mblocks), st,
-        ),
-        "moe gemm1",
-    )
-    check(
-        lib.chitu_hip_moe_silu_mul_quant_fp8(P("c1"), i64(numel), i64(I), i32(1), f32(1e-10), P("a2q"), P("a2s"), st),
-        "moe silu_mul_quant",
-    )
-    check(
-        lib.chitu_hip_moe_gemm2_fp8(
-            P("a2q"), P("a2s"), ptr(w2), ptr(w2_scale), P("sorted"), experts_ptr, P("npost"),
-            ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel), i64(Nout),
-            i64(I), i64(max_mblocks), st,
-        ),
-        "moe gemm2",
-    )
+    if I % 128 == 0 and I <= 512 and os.environ.get("CHITU_MOE_FUSE_SILU", "1") != "0":
+        # two launches: GEMM1 with SiLU-and-mul in its epilogue (gate and up tile of the same columns
+        # in one wave), GEMM2 with the fp8 re-quantisation of h in its prologue
+        check(
+            lib.chitu_hip_moe_gemm1_silu_fp8(
+                a1q_p, a1s_p, ptr(w1), ptr(w1_scale), P("sorted"), experts_ptr, P("npost"), P("c1"),
+                i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), st,
+            ),
+            "moe gemm1 (silu fused)",
+        )
+        check(
+            lib.chitu_hip_moe_gemm2_quant_fp8(
+                P("c1"), ptr(w2), ptr(w2_scale), P("sorted"), experts_ptr, P("npost"), ptr(topk_weights),
+                float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel), i64(Nout), i64(I),
+                i64(max_mblocks), f32(1e-10), st,
+            ),
+            "moe gemm2 (quant fused)",
+        )
+    else:
+        check(
+            lib.chitu_hip_moe_gemm1_fp8(
+                a1q_p, a1s_p, ptr(w1), ptr(w1_scale), P("sorted"), experts_ptr, P("npost"), P("c1"),
+                i64(numel), i32(topk), i64(N), i64(K), i64(max_mblocks), st,
+            ),
+            "moe gemm1",
+        )
+        check(
+            lib.chitu_hip_moe_silu_mul_quant_fp8(P("c1"), i64(numel), i64(I), i32(1), f32(1e-10), P("a2q"), P("a2s"), st),
+            "moe silu_mul_quant",
+        )
+        check(
+            lib.chitu_hip_moe_gemm2_fp8(
+                P("a2q"), P("a2s"), ptr(w2), ptr(w2_scale), P("sorted"), experts_ptr, P("npost"),
+                ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel), i64(Nout),
+                i64(I), i64(max_mblocks), st,
+            ),
+            "moe gemm2",
+        )
     if not reduce_topk:
         c3_off = off["c3"] - base
         return ws[c3_off : c3_off + numel * Nout * 2].view(torch.bfloat16).view(num_tokens, topk, Nout)

@@ -138,6 +138,22 @@ int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, const void*
                             const void* topk_weights, int weights_dtype,
                             int32_t mul_routed_weight, void* out_bf16, int64_t numel, int64_t N,
                             int64_t inter_size, int64_t max_mblocks, void* stream);
+/* Two-launch form of gemm1 -> silu_mul_quant -> gemm2 (same arithmetic and rounding points):
+ * gemm1_silu: a wave owns the gate tile and the up tile of the same 16 columns of W1 [E, 2I, K] and
+ *   writes h[slot, :] = bf16(bf16(silu(bf16(gate))) * bf16(up)) as bf16 [numel, I]; inter_size % 16 == 0.
+ * gemm2_quant: per_token_group_quant_fp8 (eps rule, 128-wide groups) of h in the prologue, then gemm2.
+ *   inter_size % 128 == 0 and <= 512 (CHITU_ERR_UNSUPPORTED otherwise: use the three-launch form). */
+int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
+                                 const float* w1_scale, const int32_t* sorted_token_ids,
+                                 const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                                 void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size, int64_t K,
+                                 int64_t max_mblocks, void* stream);
+int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_fp8, const float* w2_scale,
+                                  const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                                  const int32_t* num_tokens_post_pad, const void* topk_weights,
+                                  int weights_dtype, int32_t mul_routed_weight, void* out_bf16,
+                                  int64_t numel, int64_t N, int64_t inter_size, int64_t max_mblocks,
+                                  float eps, void* stream);
 int chitu_hip_moe_sum(const void* c3_bf16, void* out_bf16, int64_t tokens, int32_t topk, int64_t N,
                       void* stream);
 

@@ -102,3 +102,18 @@ def test_linearity_in_routed_weight_full_r1_shape():
     a = run_hip(x, w1, w2, w1s, w2s, ids, wts)
     b = run_hip(x, w1, w2, w1s, w2s, ids, (wts.float() * 2).to(wts.dtype))
     assert torch.equal(b.float(), a.float() * 2)
+
+
+@pytest.mark.parametrize("M,E,topk,K,I", [(1, 32, 8, 7168, 256), (16, 32, 8, 7168, 256), (33, 16, 4, 512, 128), (4, 64, 6, 2048, 384),
+                                          (3, 8, 2, 256, 512), (70, 8, 4, 1024, 256)])
+def test_two_launch_expert_path_is_bit_identical_to_three_launch(M, E, topk, K, I, monkeypatch):
+    """gemm1_silu + gemm2_quant == gemm1 + silu_mul_quant + gemm2 (all K-split variants, expert_map too)."""
+    args = make_case(M, E, topk, K, I, seed=77 + M)
+    emap = torch.arange(E, dtype=torch.int32)
+    emap[E // 2:] = -1
+    outs = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CHITU_MOE_FUSE_SILU", fuse)
+        outs[fuse] = (run_hip(*args), run_hip(*args, expert_map=emap.cuda(), global_num_experts=E))
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert torch.equal(outs["1"][1], outs["0"][1])

@@ -85,6 +85,14 @@ if want("moe"):
         fns = [(lambda l=l: lib.chitu_hip_moe_gemm2_fp8(ptr(hq), ptr(hs), ptr(w2[l]), ptr(w2s[l]), ptr(sid), ptr(eid), ptr(npost),
                                                          ptr(wts), i32(0), i32(1), ptr(c3), i64(numel), i64(K), i64(I), i64(mmb), stream_ptr())) for l in range(L)]
         timeit(f"moe_gemm2 bs={bs} distinct={distinct}", fns, distinct * K * I)
+        hb = torch.randn(numel, I, device=dev, dtype=torch.bfloat16, generator=gen)
+        fns = [(lambda l=l: lib.chitu_hip_moe_gemm1_silu_fp8(ptr(xq), ptr(xs), ptr(w1[l]), ptr(w1s[l]), ptr(sid), ptr(eid), ptr(npost),
+                                                              ptr(hb), i64(numel), i32(topk), i64(I), i64(K), i64(mmb), stream_ptr())) for l in range(L)]
+        timeit(f"moe_gemm1_silu bs={bs} distinct={distinct}", fns, distinct * 2 * I * K)
+        fns = [(lambda l=l: lib.chitu_hip_moe_gemm2_quant_fp8(ptr(hb), ptr(w2[l]), ptr(w2s[l]), ptr(sid), ptr(eid), ptr(npost), ptr(wts),
+                                                               i32(0), i32(1), ptr(c3), i64(numel), i64(K), i64(I), i64(mmb), f32(1e-10),
+                                                               stream_ptr())) for l in range(L)]
+        timeit(f"moe_gemm2_quant bs={bs} distinct={distinct}", fns, distinct * K * I)
         fns = [lambda: fused_moe.silu_and_mul_quant(c1, mode="group")]
         timeit(f"moe_silu_quant bs={bs}", fns, numel * 2 * I * 2)
         out = torch.empty(bs, K, dtype=torch.bfloat16, device=dev)
