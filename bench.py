@@ -337,6 +337,19 @@ def main():
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t_build
 
+    if use_graph and world > 1:
+        # hipGraph capture with RCCL collectives inside is the intended N > 1 path; if this ROCm/RCCL
+        # build refuses it, every rank falls back to eager launches together (and says so in the JSON)
+        ok = torch.ones(1, device="cuda")
+        try:
+            measure(model, cache, a.bs, a.ctx, 2, 1, world, True, "probe")
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: graph capture failed ({type(exc).__name__}: {exc}); eager fallback", file=sys.stderr)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            use_graph = False
+            model.graphs, model.static_tokens, model.static_out, model.graph_pool = {}, {}, {}, None
     dt = measure(model, cache, a.bs, a.ctx, a.steps, a.warmup, world, use_graph, "m")
     ms_per_step = dt / a.steps * 1e3
     node_tok_s = a.bs * a.steps / dt
