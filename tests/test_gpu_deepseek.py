@@ -23,6 +23,19 @@ def tiny_args():
     )
 
 
+def v2lite_like_args():
+    """Structure of BASELINE config 3 (DeepSeek-V2-Lite) at test size: softmax scores, one
+    expert group, no gate bias, TWO shared experts, top-6, moe_inter = 5 K-blocks (generic GEMM2 and
+    the three-launch expert path); q_lora_rank > 0 as the reference's attention requires (:477)."""
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args
+
+    return DeepSeekV3Args(
+        vocab_size=1024, dim=512, inter_dim=1024, moe_inter_dim=640, n_layers=3, n_dense_layers=1, n_heads=16,
+        n_routed_experts=16, n_shared_experts=2, n_activated_experts=6, n_expert_groups=1, n_limited_groups=1,
+        q_lora_rank=256, gate_bias=False, score_func="softmax", route_scale=1.0,
+    )
+
+
 def build(args, max_reqs=4, max_seq=512):
     from chitu_amd.attn_backend import HipAttnBackend
     from chitu_amd.cache_manager import PagedKVCacheManager
@@ -90,8 +103,9 @@ def test_absorb_projections(bs):
     assert tuple(out2.shape) == (bs, H, 128) and max_rel_to_peak(out2, ref_uv) < 5e-3
 
 
-def test_layerwise_parity_and_graph_replay():
-    args = tiny_args()
+@pytest.mark.parametrize("make_args", [tiny_args, v2lite_like_args], ids=["v3_like", "v2lite_like"])
+def test_layerwise_parity_and_graph_replay(make_args):
+    args = make_args()
     model, cache = build(args)
     cfg = cfg_of(args)
     params = {k: v.detach().cpu() for k, v in model.named_parameters()}
@@ -121,7 +135,10 @@ def test_layerwise_parity_and_graph_replay():
             def hooked(inp, _orig=orig, _store=routing, **kw):
                 w, idx = _orig(inp, **kw)
                 k = args.n_activated_experts
-                assert (idx[:, k:] == args.n_routed_experts).all() and (w[:, k:] == 1).all()  # shared-expert slot
+                if args.n_shared_experts == 1:
+                    assert (idx[:, k:] == args.n_routed_experts).all() and (w[:, k:] == 1).all()  # shared-expert slot
+                else:
+                    assert idx.shape[1] == k
                 _store["w"], _store["i"] = w[:, :k].cpu(), idx[:, :k].cpu()
                 return w, idx
 
@@ -145,7 +162,7 @@ def test_layerwise_parity_and_graph_replay():
             hn = ods.rms_norm(x + ods.attention_decode(params, f"layers.{i}.attn.", ods.rms_norm(x, params[f"layers.{i}.attn_norm.weight"], cfg["eps"]),
                                                        cos, sin, shadow[i], table, lens_excl, cfg)[0],
                               params[f"layers.{i}.ffn_norm.weight"], cfg["eps"])
-            w_ref, i_ref = ods.gate(hn, params[f"layers.{i}.ffn.gate.weight"], params[f"layers.{i}.ffn.gate.bias"],
+            w_ref, i_ref = ods.gate(hn, params[f"layers.{i}.ffn.gate.weight"], params.get(f"layers.{i}.ffn.gate.bias"),
                                     cfg["n_groups"], cfg["topk_groups"], cfg["topk"], cfg["score_func"], cfg["route_scale"])
             same = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(i_ref, rt[1])) / i_ref.numel()
             assert same >= 0.75
