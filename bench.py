@@ -176,8 +176,9 @@ def algorithmic_bytes_per_step(margs, bs, ctx, distinct):
 
 
 def roofline_dominant_kernel(model, cache, margs, bs, ctx, iters=3):
-    """Time the dominant kernel -- the routed-expert GEMM1 (chitu_hip_moe_gemm1_fp8: ~2/3 of all
-    bytes at bs=16) -- live with HIP events on the launch stream: one launch per MoE layer with that
+    """Time the dominant kernel -- the routed-expert GEMM1 with SiLU-and-mul in its epilogue
+    (chitu_hip_moe_gemm1_silu_fp8 -> moe_gemm1_silu_kernel: ~2/3 of all bytes at bs=16) -- live with
+    HIP events on the launch stream: one launch per MoE layer with that
     layer's own weights (HBM-cold) and the expert ids that layer really routed in a decode step
     (capture_step_routing), i.e. the same launches the timed step's graph replays."""
     from chitu_amd import _lib, fused_moe
@@ -196,7 +197,7 @@ def roofline_dominant_kernel(model, cache, margs, bs, ctx, iters=3):
     gen = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(bs, K, device="cuda", dtype=torch.bfloat16, generator=gen)
     xq, xs = fused_moe.per_token_group_quant_fp8(x, 128)
-    out = torch.empty(numel, N, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(numel, N // 2, dtype=torch.bfloat16, device="cuda")
     plans = []
     for ids in routing:
         sorted_ids, expert_ids, npost = fused_moe.moe_align_block_size(ids.contiguous(), 16, E)
@@ -205,9 +206,9 @@ def roofline_dominant_kernel(model, cache, margs, bs, ctx, iters=3):
 
     def launch(m, plan):
         sorted_ids, expert_ids, npost, _ = plan
-        rc = lib.chitu_hip_moe_gemm1_fp8(ptr(xq), ptr(xs), ptr(m.w1w3_weight), ptr(m.w1w3_scale), ptr(sorted_ids),
-                                         ptr(expert_ids), ptr(npost), ptr(out), i64(numel), i32(topk), i64(N), i64(K),
-                                         i64(min(expert_ids.numel(), numel)), st)
+        rc = lib.chitu_hip_moe_gemm1_silu_fp8(ptr(xq), ptr(xs), ptr(m.w1w3_weight), ptr(m.w1w3_scale), ptr(sorted_ids),
+                                              ptr(expert_ids), ptr(npost), ptr(out), i64(numel), i32(topk), i64(N // 2),
+                                              i64(K), i64(min(expert_ids.numel(), numel)), st)
         assert rc == 0
 
     for m, pl in list(zip(moe_layers, plans))[:2]:
@@ -229,22 +230,22 @@ def roofline_dominant_kernel(model, cache, margs, bs, ctx, iters=3):
     distinct = sum(pl[3] for pl in plans) / len(plans)
     w_bytes = distinct * N * K
     s_bytes = distinct * ((N + 127) // 128) * (K // 128) * 4
-    a_bytes = bs * K + bs * (K // 128) * 4 + numel * N * 2
+    a_bytes = bs * K + bs * (K // 128) * 4 + numel * (N // 2) * 2
     alg = w_bytes + s_bytes + a_bytes
     achieved = alg / (avg_ms * 1e-3) / 1e9
     # HBM traffic per launch from the committed PMC pass (profiles/r01_pmc_moe_gemm.json: FETCH_SIZE,
     # doubled per MI355X_MICROARCH.md), scaled by the distinct experts of the average launch.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_moe_gemm.json")))["moe_gemm1_kernel<1>"]
-        traffic = int(pmc["hbm_read_bytes_per_launch"] * distinct / pmc["distinct_experts"])
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_moe_gemm.json")))["moe_gemm1_silu_kernel<1,3>"]
+        traffic = int((pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) * distinct / pmc["distinct_experts"])
     except Exception:
         pass
     return {
-        "kernel": "moe_gemm1_kernel (routed experts W1, fp8 block-scaled grouped GEMM)",
+        "kernel": "moe_gemm1_silu_kernel (routed experts W1, fp8 block-scaled grouped GEMM + SiLU-and-mul epilogue)",
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "traffic_source": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction), profiles/r01_pmc_moe_gemm.json, scaled to this launch's distinct experts",
+        "traffic_source": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, profiles/r01_pmc_moe_gemm.json, scaled to this launch's distinct experts",
         "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(ms[len(ms) // 2] * 1e3, 2),
         "algorithmic_bytes_per_launch": int(alg), "distinct_experts": round(distinct, 2),
         "distinct_experts_min_max": [min(pl[3] for pl in plans), max(pl[3] for pl in plans)],
