@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void moe_gemm2_kernel(
 // order and every wave picks up its B operand there.  The h loads are issued BEFORE the weight
 // loads and everything up to the MFMAs is straight-line code, so the prologue's s_waitcnt counts
 // past the weight loads queued behind it (vector loads return in order).
-template <int KB, int NT>
+template <int KB, int NT, int ROUNDS>
 __global__ __launch_bounds__(256) void moe_gemm2_q_kernel(
     const bf16_t* __restrict__ Hb, const fp8_t* __restrict__ W, const float* __restrict__ Ws,
     const int32_t* __restrict__ sorted_ids, const int32_t* __restrict__ expert_ids,
@@ -380,13 +380,16 @@ __global__ __launch_bounds__(256) void moe_gemm2_q_kernel(
     const int slot = sorted_ids[mb * 16 + j];
     const bool valid = slot < numel;
     const int e = expert_ids[mb];
-    const int tile0 = (blockIdx.x * 4 + wave) * NT;
+    // round r of this wave covers tiles [tile_of(r), tile_of(r) + NT)
+    auto tile_of = [&](int r) { return ((blockIdx.x * ROUNDS + r) * 4 + wave) * NT; };
     if (e < 0) {  // expert not on this rank (expert_map): the slot's contribution is zero
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n0 = (tile0 + t) * 16;
-            if (n0 < N && valid) moe_store_tile(out + (size_t)slot * N, n0, g, N, f32x4{0.f, 0.f, 0.f, 0.f}, 1.0f);
-        }
+        for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n0 = (tile_of(r) + t) * 16;
+                if (n0 < N && valid) moe_store_tile(out + (size_t)slot * N, n0, g, N, f32x4{0.f, 0.f, 0.f, 0.f}, 1.0f);
+            }
         return;
     }
     const int row = valid ? slot : 0;
@@ -399,18 +402,24 @@ __global__ __launch_bounds__(256) void moe_gemm2_q_kernel(
         hraw[q][1] = *reinterpret_cast<const i32x4*>(hrow + hb * 64 + g * 16 + 8);
     }
     const int last_tile = (N - 1) >> 4;
-    W8Frag wf[NT][KB];
+    const fp8_t* We = W + (size_t)e * N * I;
+    // weights: one round (NT tiles) requested ahead of the one being multiplied, so the workgroup
+    // streams ROUNDS x NT x 4 tiles behind ONE slot/expert lookup and ONE quantisation prologue
+    W8Frag wf[ROUNDS > 1 ? 2 : 1][NT][KB];
+    auto load_round = [&](W8Frag (&dst)[NT][KB], int r) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n0 = min(tile0 + t, last_tile) * 16;  // tail tiles re-read the last one, never stored
-        const fp8_t *wp0, *wp1;
-        w8_lane_ptrs(W + (size_t)e * N * I, n0, N, I, j, g, wp0, wp1);
+        for (int t = 0; t < NT; ++t) {
+            const int n0 = min(tile_of(r) + t, last_tile) * 16;  // tail tiles re-read the last one, never stored
+            const fp8_t *wp0, *wp1;
+            w8_lane_ptrs(We, n0, N, I, j, g, wp0, wp1);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            wf[t][kb].w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + (kb << 7)));
-            wf[t][kb].w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + (kb << 7)));
+            for (int kb = 0; kb < KB; ++kb) {
+                dst[t][kb].w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + (kb << 7)));
+                dst[t][kb].w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + (kb << 7)));
+            }
         }
-    }
+    };
+    load_round(wf[0], 0);
     const float rw = (mul_weight && valid) ? moe_routed_weight(topk_w, w_dt, slot) : 1.0f;
     float h[HPW][16];
 #pragma unroll
@@ -452,19 +461,24 @@ __global__ __launch_bounds__(256) void moe_gemm2_q_kernel(
         x[kb][1] = xq_lds[2 * kb + 1][lane];
         xs[kb] = __builtin_fmaxf(__builtin_fmaxf(amax_lds[2 * kb][j], amax_lds[2 * kb + 1][j]), eps) / 448.0f;
     }
+    const float* wse = Ws + (size_t)e * ((N + 127) >> 7) * KB;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n0 = (tile0 + t) * 16;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* wsp = Ws + ((size_t)e * ((N + 127) >> 7) + (min(n0, N - 1) >> 7)) * KB;
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r + 1 < ROUNDS) load_round(wf[(r + 1) & 1], r + 1);
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const f32x4 blk = w8a8_block_dot(wf[t][kb], x[kb][0], x[kb][1]);
-            const float ws = wsp[kb];
+        for (int t = 0; t < NT; ++t) {
+            const int n0 = (tile_of(r) + t) * 16;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* wsp = wse + (size_t)(min(n0, N - 1) >> 7) * KB;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += (blk[r] * xs[kb]) * ws;
+            for (int kb = 0; kb < KB; ++kb) {
+                const f32x4 blk = w8a8_block_dot(wf[r & 1][t][kb], x[kb][0], x[kb][1]);
+                const float ws = wsp[kb];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) acc[rr] += (blk[rr] * xs[kb]) * ws;
+            }
+            if (valid && n0 < N) moe_store_tile(out + (size_t)slot * N, n0, g, N, acc, rw);
         }
-        if (valid && n0 < N) moe_store_tile(out + (size_t)slot * N, n0, g, N, acc, rw);
     }
 }
 
@@ -719,18 +733,29 @@ extern "C" int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_
     const int n_tiles = (int)((N + 15) / 16);
     const int KB = (int)(inter_size / 128);
     const int64_t mbs = numel < max_mblocks ? numel : max_mblocks;
-#define LAUNCH2Q(KBV, NTV)                                                                           \
-    hipLaunchKernelGGL((moe_gemm2_q_kernel<KBV, NTV>),                                               \
-                       dim3((unsigned)((n_tiles + 4 * NTV - 1) / (4 * NTV)), (unsigned)max_mblocks), \
+#define LAUNCH2Q(KBV, NTV, RV)                                                                       \
+    hipLaunchKernelGGL((moe_gemm2_q_kernel<KBV, NTV, RV>),                                           \
+                       dim3((unsigned)((n_tiles + 4 * NTV * RV - 1) / (4 * NTV * RV)), (unsigned)max_mblocks), \
                        dim3(256), 0, st, (const bf16_t*)h_bf16, (const fp8_t*)w2_fp8, w2_scale,      \
                        sorted_token_ids, expert_ids, num_tokens_post_pad, topk_weights, weights_dtype, \
                        (bf16_t*)out_bf16, (int)numel, (int)N, (int)mul_routed_weight, eps)
     const bool many = (int64_t)n_tiles * mbs > 8192;
+    // sweep on MI355X (bs 16, 106 experts): NT,ROUNDS = 2,4 35.6 us | 2,8 35.8 | 4,1 37.6 | 2,2 37.8 | 4,2 39.9 | 4,4 40.3
+    int cfg = many ? 24 : 21;  // NT*10 + ROUNDS
+    if (const char* ov = getenv("CHITU_MOE_GEMM2_CFG")) cfg = atoi(ov);  // tuning knob (tools/bench_kernels.py)
     switch (KB) {
-        case 1: if (many) LAUNCH2Q(1, 4); else LAUNCH2Q(1, 2); break;
-        case 2: if (many) LAUNCH2Q(2, 4); else LAUNCH2Q(2, 2); break;
-        case 3: LAUNCH2Q(3, 2); break;
-        default: LAUNCH2Q(4, 2); break;
+        case 1: if (many) LAUNCH2Q(1, 4, 1); else LAUNCH2Q(1, 2, 1); break;
+        case 2:
+            if (cfg == 42) LAUNCH2Q(2, 4, 2);
+            else if (cfg == 44) LAUNCH2Q(2, 4, 4);
+            else if (cfg == 22) LAUNCH2Q(2, 2, 2);
+            else if (cfg == 24) LAUNCH2Q(2, 2, 4);
+            else if (cfg == 28) LAUNCH2Q(2, 2, 8);
+            else if (cfg == 21) LAUNCH2Q(2, 2, 1);
+            else LAUNCH2Q(2, 4, 1);
+            break;
+        case 3: LAUNCH2Q(3, 2, 1); break;
+        default: LAUNCH2Q(4, 2, 1); break;
     }
 #undef LAUNCH2Q
     CHITU_RETURN_LAUNCH_STATUS();
