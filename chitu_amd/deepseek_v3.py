@@ -320,7 +320,9 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
             # without tensor parallelism nothing sits between the experts' top-k sum and the next norm's
             # residual add: the sum moves into that norm (one launch less); with TP the all-reduce
             # below needs the summed tensor
-            f = self.ffn(hn, (hq, hs), defer_sum=tp.get_tp_size() == 1 and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")
+            defer = (tp.get_tp_size() == 1 and self.ffn.gate.topk + 1 <= 16
+                     and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")  # chitu_hip_rmsnorm sums <= 16 terms
+            f = self.ffn(hn, (hq, hs), defer_sum=defer)
             if f.dim() == 3:
                 return x, f
         else:
