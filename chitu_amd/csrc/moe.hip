@@ -699,19 +699,25 @@ extern "C" int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_sc
     const int n_tiles = (int)(inter_size / 16);
     const int64_t wgs = 2 * (int64_t)n_tiles * (numel < max_mblocks ? numel : max_mblocks);
     const int KB = (int)(K / 128);
-    int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 2048 ? 2 : 1;  // as chitu_hip_moe_gemm1_fp8 (a wave = 2 tiles)
-    if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);
+    // Sweep on MI355X (tools/bench_kernels.py, R1 TP=8 shapes, us per launch; wgs is the worst-case grid,
+    // ~80% of it is live): bs 1/2 -> WK 8, D 2 (10.7 / 13.2); bs 4 -> WK 4, D 2 (27.5); bs 8 -> WK 2, D 3
+    // (37.5; WK 1: 50.9); bs 16+ -> WK 1, D 3 (61.9; WK 2: 69.0).  Few workgroups: split K over more waves
+    // and keep the ring shallow so every workgroup is resident at once; many: one long stream per wave.
+    int WK = wgs <= 640 ? 8 : wgs <= 1536 ? 4 : wgs <= 3200 ? 2 : 1;
+    if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);  // tuning knobs
     while (WK > 1 && WK > KB) WK >>= 1;
+    int D = WK >= 4 ? 2 : 3;
+    if (const char* ov = getenv("CHITU_MOE_GEMM1_D")) D = atoi(ov);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)n_tiles, (unsigned)max_mblocks);
 #define LAUNCH1S(WKV, DV)                                                                                     \
     hipLaunchKernelGGL((moe_gemm1_silu_kernel<WKV, DV>), grid, dim3(64 * WKV), 0, st, (const fp8_t*)a_fp8, a_scale, \
                        (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids, num_tokens_post_pad,      \
                        (bf16_t*)h_bf16, (int)numel, (int)topk, (int)inter_size, (int)K)
-    if (WK == 8) LAUNCH1S(8, 4);
-    else if (WK == 4) LAUNCH1S(4, 4);
-    else if (WK == 2) LAUNCH1S(2, 3);
-    else LAUNCH1S(1, 3);
+    if (WK == 8) { if (D == 2) LAUNCH1S(8, 2); else if (D == 3) LAUNCH1S(8, 3); else LAUNCH1S(8, 4); }
+    else if (WK == 4) { if (D == 2) LAUNCH1S(4, 2); else if (D == 3) LAUNCH1S(4, 3); else LAUNCH1S(4, 4); }
+    else if (WK == 2) { if (D == 4) LAUNCH1S(2, 4); else LAUNCH1S(2, 3); }
+    else { if (D == 4) LAUNCH1S(1, 4); else LAUNCH1S(1, 3); }
 #undef LAUNCH1S
     CHITU_RETURN_LAUNCH_STATUS();
 }
@@ -739,12 +745,14 @@ extern "C" int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_
                        dim3(256), 0, st, (const bf16_t*)h_bf16, (const fp8_t*)w2_fp8, w2_scale,      \
                        sorted_token_ids, expert_ids, num_tokens_post_pad, topk_weights, weights_dtype, \
                        (bf16_t*)out_bf16, (int)numel, (int)N, (int)mul_routed_weight, eps)
-    const bool many = (int64_t)n_tiles * mbs > 8192;
-    // sweep on MI355X (bs 16, 106 experts): NT,ROUNDS = 2,4 35.6 us | 2,8 35.8 | 4,1 37.6 | 2,2 37.8 | 4,2 39.9 | 4,4 40.3
+    // sweep on MI355X (us; NT,ROUNDS): bs 16, 106 experts: 2,4 35.6 | 2,8 35.8 | 4,1 37.6 | 2,2 37.8 | 4,2 39.9 | 4,4 40.3;
+    // bs 8: 2,1 22.2 | 2,2 22.9 | 4,1 23.4 | 2,4 25.0; bs 1: 2,1 6.7 | 2,4 10.0 -- the multi-round form pays once
+    // its 4x fewer workgroups still fill the chip several times over
+    const bool many = (int64_t)n_tiles * mbs > 50000;
     int cfg = many ? 24 : 21;  // NT*10 + ROUNDS
     if (const char* ov = getenv("CHITU_MOE_GEMM2_CFG")) cfg = atoi(ov);  // tuning knob (tools/bench_kernels.py)
     switch (KB) {
-        case 1: if (many) LAUNCH2Q(1, 4, 1); else LAUNCH2Q(1, 2, 1); break;
+        case 1: LAUNCH2Q(1, 2, 1); break;
         case 2:
             if (cfg == 42) LAUNCH2Q(2, 4, 2);
             else if (cfg == 44) LAUNCH2Q(2, 4, 4);
