@@ -3,8 +3,8 @@
 Reference (read-only): chitu/attn_backend.py -- interface AttnBackend:24-164,
 TritonAttnBackend:687-774 (the MLA decode path the reference runs on non-NVIDIA devices),
 FlashMLABackend:504-572 / FlashInferBackend:575-684 (graph-capturable third-party paths).
-`HipAttnBackend` implements `prepare_metadata_for_decode`, `mla_attn_with_kvcache` and
-`attn_with_kvcache(block_table=...)` with hand-written HIP kernels; the host side only sizes
+`HipAttnBackend` implements `prepare_metadata_for_decode`, `mla_attn_with_kvcache`,
+`attn_with_kvcache(block_table=...)` and the MLA-prefill form of `attn_varlen_func` with hand-written HIP kernels; the host side only sizes
 the KV split count from the batch (graph-static) and keeps a persistent scratch buffer.
 """
 
@@ -160,6 +160,68 @@ class HipAttnBackend(AttnBackend):
         B = q_nope.shape[0]
         o = self.mla_decode(q_nope, q_pe, kv_cache, cache_seqlens_incl_this_decode, block_table, float(softmax_scale))
         return o.view(B, 1, q_nope.shape[1], -1)
+
+    # ------------------------------------------------------------------ MLA prefill (absorb mode, MQA 576/512)
+    def attn_varlen_func(
+        self,
+        q,
+        k,
+        v,
+        cu_seqlens_q,
+        cu_seqlens_k,
+        max_seqlen_q,
+        max_seqlen_k,
+        dropout_p=0.0,
+        causal=False,
+        window_size=(-1, -1),
+        softcap=0.0,
+        softmax_scale=None,
+    ):
+        """Causal varlen self-attention in the shape AttentionDeepSeekV3.prefill_forward calls it in
+        absorb mode (model_deepseek_v3.py:589-599; interface attn_backend.py:39-90): MQA with
+        q [T, H, C+R], k [T, 1, C+R] = [kv_norm(kv_c) | rope(k_pe)], v [T, 1, C] = the latent part of k
+        (the MLA identity -- v is NOT read, k[..., :C] is used), cu_seqlens_q == cu_seqlens_k.
+
+        First cut of SURVEY 8f.1, built from the decode kernel only: the keys are staged once into
+        64-token pages and every query token runs as one decode "sequence" of length pos+1 over its own
+        sequence's pages (chitu_hip_mla_decode).  Exact causal attention with the decode path's
+        numerics; KV is re-read once per query token, which is fine for prompts of a few hundred tokens
+        and the reason a tiled prefill kernel is the next step.  No host sync; not graph-captured
+        (prefill never is, model.py:538-546)."""
+        assert causal and dropout_p == 0.0 and tuple(window_size) == (-1, -1) and softcap == 0.0
+        require_cuda(q, k, cu_seqlens_q, cu_seqlens_k)
+        T, H, Dq = q.shape
+        C, R = self.kv_lora_rank, self.qk_rope_head_dim
+        assert Dq == C + R and tuple(k.shape) == (T, 1, Dq) and v.shape[0] == T and v.shape[-1] == C, \
+            "only the MLA absorb-mode MQA shape (q/k 576, v 512) is implemented"
+        assert cu_seqlens_q.shape == cu_seqlens_k.shape and max_seqlen_q == max_seqlen_k
+        assert q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16
+        if softmax_scale is None:
+            softmax_scale = Dq ** -0.5
+        if T == 0:
+            return q.new_empty(0, H, C)
+        dev = q.device
+        page = 64
+        n_seq = cu_seqlens_k.numel() - 1
+        cu = cu_seqlens_k.to(device=dev, dtype=torch.long)
+        pos = torch.arange(T, device=dev)
+        seq = torch.searchsorted(cu[1:].contiguous(), pos, right=True).clamp_(max=n_seq - 1)
+        off = pos - cu[seq]
+        pages_per = (cu[1:] - cu[:-1] + page - 1) // page
+        base = torch.cumsum(pages_per, 0) - pages_per
+        num_pages = T // page + n_seq + 1  # upper bound known on the host
+        max_pages = max(1, (int(max_seqlen_k) + page - 1) // page)
+        staged = torch.empty(num_pages, page, Dq, dtype=torch.bfloat16, device=dev)
+        staged.view(-1, Dq).index_copy_(0, base[seq] * page + off, k.reshape(T, Dq))
+        table = (base[seq].unsqueeze(1) + torch.arange(max_pages, device=dev)).clamp_(max=num_pages - 1).to(torch.int32)
+        lens = (off + 1).to(torch.int32)
+        out = torch.empty(T, H, C, dtype=torch.bfloat16, device=dev)
+        step = 32768  # grid.y limit of one launch
+        for t0 in range(0, T, step):
+            t1 = min(T, t0 + step)
+            self.mla_decode(q[t0:t1, :, :C], q[t0:t1, :, C:], staged, lens[t0:t1].contiguous(), table[t0:t1].contiguous(),
+                            softmax_scale, out=out[t0:t1])
+        return out
 
     # ------------------------------------------------------------------ non-MLA (GQA / MHA) paged decode
     def attn_with_kvcache(

@@ -1,10 +1,12 @@
 """Oracle for paged GQA/MHA single-token decode attention (torch CPU fp32).  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED by any reference fixture: the reference's paged path is the third-party
-flash_attn.flash_attn_with_kvcache (absent here, `chitu/attn_backend.py:208-243`), and RefAttnBackend
-rejects block_table (:473).  This restates the documented contract (attn_backend.py:92-164: in-place
+The reference's PAGED path is the third-party flash_attn.flash_attn_with_kvcache (absent here,
+`chitu/attn_backend.py:208-243`) and RefAttnBackend rejects block_table (:473), so there is no reference
+run of the paged layout itself.  This restates the documented contract (attn_backend.py:92-164: in-place
 append at cache_seqlens, GQA head mapping "head i of Q attends head i // g of KV") with the math of
-RefAttnBackend._attention (:294-392) on the gathered pages.
+RefAttnBackend._attention (:294-392) on the gathered pages, and is PINNED on the arithmetic by
+tests/golden/gqa_decode.npz: RefAttnBackend.attn_with_kvcache (:457-516) run in the build container on
+contiguous caches holding the same logical content the test lays out in (shuffled) pages.
 """
 
 import torch

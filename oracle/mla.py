@@ -41,3 +41,22 @@ def mla_attn_with_kvcache(q_nope, q_pe, kv_cache, kv, seqlens_excl, seqlens_incl
 
     cache = okv.append_to_paged_kv_cache(kv_cache, block_table, kv, seqlens_excl)
     return mla_decode(q_nope, q_pe, cache, block_table, seqlens_incl, scale), cache
+
+
+def mla_prefill(q, kv, cu_seqlens, scale, kv_lora_rank=512):
+    """Causal MQA over each sequence's own keys, values = the latent part of the keys -- the call
+    AttentionDeepSeekV3.prefill_forward makes in absorb mode (model_deepseek_v3.py:589-599:
+    attn_varlen_func(q_nope|q_pe, kv|k_pe, kv, prefix_lens, ...)), with RefAttnBackend._attention's
+    math (attn_backend.py:294-392).  q [T, H, C+R], kv [T, C+R] -> [T, H, C] fp32.
+    Pinned by tests/golden/mla_prefill.npz (RefAttnBackend.attn_varlen_func run in the build container)."""
+    T, H, _ = q.shape
+    out = torch.zeros(T, H, kv_lora_rank, dtype=torch.float32)
+    cu = [int(c) for c in cu_seqlens]
+    for s0, s1 in zip(cu[:-1], cu[1:]):
+        k = kv[s0:s1].float()
+        n = s1 - s0
+        scores = torch.einsum("thd,sd->hts", q[s0:s1].float() * scale, k)
+        mask = torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1)
+        scores.masked_fill_(mask, float("-inf"))
+        out[s0:s1] = torch.einsum("hts,sc->thc", torch.softmax(scores, dim=-1), k[:, :kv_lora_rank])
+    return out

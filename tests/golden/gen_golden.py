@@ -200,6 +200,64 @@ def gen_mla_decode():
     )
 
 
+# ---------------------------------------------------------------- GQA decode + MLA prefill (RefAttnBackend, pure torch)
+def lattice(*shape, mod=97, scale=32.0, salt=0):
+    """Deterministic bf16-exact values in [-1.5, 1.5] (multiples of 1/32), recomputed by the tests:
+    v[i0, i1, ...] = ((sum_k i_k * prime_k + salt) % mod - mod//2) / scale."""
+    primes = [131, 7, 53, 3, 17]
+    acc = torch.zeros(shape, dtype=torch.int64) + salt
+    for ax, n in enumerate(shape):
+        view = [1] * len(shape)
+        view[ax] = n
+        acc = acc + torch.arange(n).view(view) * primes[ax]
+    return ((acc % mod - mod // 2).float() / scale).to(torch.bfloat16)
+
+
+def gen_gqa_decode():
+    """RefAttnBackend.attn_with_kvcache (attn_backend.py:457-516) on CONTIGUOUS caches [B, S, Hkv, D]: the
+    reference has no paged pure-torch path (block_table is rejected, :473), so the fixture pins the
+    arithmetic (in-place append at cache_seqlens, GQA head mapping, softmax) on the same logical content
+    that the tests lay out in pages."""
+    from chitu.attn_backend import RefAttnBackend
+
+    be = RefAttnBackend()
+    B, S, Hq, Hkv, D = 4, 320, 8, 2, 128
+    lens = torch.tensor([0, 255, 256, 300], dtype=torch.int64)  # empty cache, page edge (256), second page
+    k_cache = lattice(B, S, Hkv, D, salt=1)
+    v_cache = lattice(B, S, Hkv, D, salt=5)
+    q = lattice(B, 1, Hq, D, mod=89, scale=64.0, salt=11)
+    k_new = lattice(B, 1, Hkv, D, mod=83, salt=3)
+    v_new = lattice(B, 1, Hkv, D, mod=79, salt=9)
+    kc, vc = k_cache.clone(), v_cache.clone()
+    out = be.attn_with_kvcache(q, kc, vc, k_new, v_new, cache_seqlens=lens, softmax_scale=D ** -0.5)
+    for b in range(B):  # the reference appended in place
+        assert torch.equal(kc[b, lens[b]], k_new[b, 0]) and torch.equal(vc[b, lens[b]], v_new[b, 0])
+    save("gqa_decode", dims=np.array([B, S, Hq, Hkv, D], dtype=np.int64), lens=lens.numpy(), out=bits16(out))
+
+
+def gen_mla_prefill():
+    """RefAttnBackend.attn_varlen_func (attn_backend.py:394-455) called as AttentionDeepSeekV3.prefill_forward
+    does in absorb mode (model_deepseek_v3.py:589-599): MQA, q [T, H, 576], k [T, 1, 576], v = k[..., :512]."""
+    from chitu.attn_backend import RefAttnBackend
+
+    be = RefAttnBackend()
+    H, C, R = 16, 512, 64
+    seqs = [1, 64, 65, 130, 7]
+    T = sum(seqs)
+    cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32)
+    kv = lattice(T, 1, C + R, salt=2)
+    q = lattice(T, H, C + R, mod=89, scale=128.0, salt=13)
+    out = be.attn_varlen_func(q, kv, kv[..., :C].contiguous(), cu, cu, max(seqs), max(seqs), causal=True, softmax_scale=0.1352)
+    # keep the fixture small: first/last/page-edge tokens of every sequence + a stride through the rest
+    keep = set()
+    for s0, n in zip(cu[:-1].tolist(), seqs):
+        keep.update(s0 + i for i in (0, 1, 62, 63, 64, 65, 127, 128, n - 2, n - 1) if 0 <= i < n)
+    keep.update(range(0, T, 29))
+    rows = np.array(sorted(keep), dtype=np.int64)
+    save("mla_prefill", seqs=np.array(seqs, dtype=np.int64), dims=np.array([H, C, R], dtype=np.int64),
+         scale=np.array([0.1352], dtype=np.float32), rows=rows, out=bits16(out[rows]))
+
+
 GENS = {
     "moe_align": gen_moe_align,
     "fp8_linear": gen_fp8_linear,
@@ -207,6 +265,8 @@ GENS = {
     "append_rope": gen_append_rope,
     "fused_moe": gen_fused_moe,
     "mla_decode": gen_mla_decode,
+    "gqa_decode": gen_gqa_decode,
+    "mla_prefill": gen_mla_prefill,
 }
 
 if __name__ == "__main__":

@@ -162,3 +162,39 @@ def test_cache_manager_drives_the_kernel():
     n_free = len(cm.free_blocks)
     cm.finalize_cache_all_decode("a")
     assert len(cm.free_blocks) == n_free + 2 and "a" not in cm.seq_lens
+
+
+def test_prefill_varlen_matches_reference_fixture_and_oracle():
+    """attn_varlen_func (MLA absorb-mode MQA) vs RefAttnBackend.attn_varlen_func's fixture, vs the oracle on
+    random ragged data, and the last token of every sequence vs a plain decode call."""
+    from chitu_amd.attn_backend import HipAttnBackend
+    from tests.util import mla_prefill_golden_case
+
+    be = HipAttnBackend(local_n_heads=16)
+    c = mla_prefill_golden_case()
+    kv = c["kv"].cuda()
+    out = be.attn_varlen_func(c["q"].cuda(), kv, kv[..., :512].contiguous(), c["cu"].cuda(), c["cu"].cuda(), max(c["seqs"]),
+                              max(c["seqs"]), causal=True, softmax_scale=c["scale"])
+    assert tuple(out.shape) == (sum(c["seqs"]), 16, 512)
+    assert max_rel_to_peak(out.cpu()[c["rows"]], c["out"]) < REL_TOL
+
+    g = torch.Generator().manual_seed(12)
+    seqs = [3, 200, 1, 64, 129]
+    T = sum(seqs)
+    cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32)
+    q = (torch.randn(T, 16, 576, generator=g) * 0.3).to(torch.bfloat16)
+    kv = torch.randn(T, 1, 576, generator=g).to(torch.bfloat16)
+    out = be.attn_varlen_func(q.cuda(), kv.cuda(), kv[..., :512].contiguous().cuda(), cu.cuda(), cu.cuda(), max(seqs), max(seqs),
+                              causal=True, softmax_scale=0.1352).cpu()
+    ref = omla.mla_prefill(q, kv[:, 0], cu, 0.1352)
+    assert max_rel_to_peak(out, ref) < REL_TOL
+    # last token of each sequence == decode over that sequence's pages
+    for s0, s1 in zip(cu[:-1].tolist(), cu[1:].tolist()):
+        n = s1 - s0
+        pages = (n + 63) // 64
+        cache = torch.zeros(pages, 64, 576, dtype=torch.bfloat16)
+        cache.view(-1, 576)[:n] = kv[s0:s1, 0]
+        o = be.mla_decode(q[s1 - 1 : s1, :, :512].contiguous().cuda(), q[s1 - 1 : s1, :, 512:].contiguous().cuda(), cache.cuda(),
+                          torch.tensor([n], dtype=torch.int32).cuda(), torch.arange(pages, dtype=torch.int32).view(1, -1).cuda(),
+                          0.1352, num_splits=1)
+        assert max_rel_to_peak(o.cpu(), out[s1 - 1 : s1]) < 2e-3

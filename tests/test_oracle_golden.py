@@ -196,3 +196,27 @@ def test_append_and_rope():
 # NB: there is deliberately no default-cast (RNE) comparison against fused_moe_fp8.npz: ~3% of the
 # interpreter's fp8 activation codes are off by 2x (lost exponent carry), which moves that fixture
 # by ~10% of its peak.  The bit-exact test above pins the algorithm; RNE is the GPU behaviour.
+
+
+def test_gqa_oracle_matches_reference_attention_on_same_logical_cache():
+    """oracle/gqa.py on shuffled pages == RefAttnBackend.attn_with_kvcache on the contiguous cache
+    (fixture generated by the reference's own code): pins append position, GQA head mapping, softmax."""
+    from oracle import gqa as ogqa
+    from tests.util import gqa_golden_case, max_rel_to_peak
+
+    c = gqa_golden_case()
+    out, k_pages, v_pages = ogqa.attn_with_kvcache(c["q"], c["k_pages"], c["v_pages"], c["k_new"], c["v_new"], c["lens"],
+                                                   c["table"], softmax_scale=c["D"] ** -0.5)
+    assert max_rel_to_peak(out, c["out"]) < 4e-3  # the reference's output is rounded to bf16
+    for b, L in enumerate(c["lens"].tolist()):
+        assert torch.equal(k_pages[c["table"][b, L // 256], L % 256], c["k_new"][b, 0])
+        assert torch.equal(v_pages[c["table"][b, L // 256], L % 256], c["v_new"][b, 0])
+
+
+def test_mla_prefill_oracle_matches_reference_varlen_attention():
+    from oracle import mla as omla
+    from tests.util import max_rel_to_peak, mla_prefill_golden_case
+
+    c = mla_prefill_golden_case()
+    out = omla.mla_prefill(c["q"], c["kv"][:, 0], c["cu"], c["scale"], kv_lora_rank=c["C"])
+    assert max_rel_to_peak(out[c["rows"]], c["out"]) < 4e-3

@@ -46,3 +46,49 @@ def pattern_cache(pages, page, dim):
     s = torch.arange(page).view(1, -1, 1)
     d = torch.arange(dim).view(1, 1, -1)
     return (((p * 64 + s) % 251).float() * 0.25 + (d % 7).float() - 3.0).to(torch.bfloat16)
+
+
+def lattice(*shape, mod=97, scale=32.0, salt=0):
+    """Same deterministic bf16-exact values as tests/golden/gen_golden.py::lattice (fixture inputs are
+    recomputed, not stored)."""
+    primes = [131, 7, 53, 3, 17]
+    acc = torch.zeros(shape, dtype=torch.int64) + salt
+    for ax, n in enumerate(shape):
+        view = [1] * len(shape)
+        view[ax] = n
+        acc = acc + torch.arange(n).view(view) * primes[ax]
+    return ((acc % mod - mod // 2).float() / scale).to(torch.bfloat16)
+
+
+def gqa_golden_case():
+    """Inputs of tests/golden/gqa_decode.npz laid out in shuffled pages of 256 (+ the contiguous form)."""
+    g = golden("gqa_decode")
+    B, S, Hq, Hkv, D = [int(v) for v in g["dims"]]
+    lens = torch.from_numpy(g["lens"]).to(torch.int32)
+    kc, vc = lattice(B, S, Hkv, D, salt=1), lattice(B, S, Hkv, D, salt=5)
+    q = lattice(B, 1, Hq, D, mod=89, scale=64.0, salt=11)
+    k_new, v_new = lattice(B, 1, Hkv, D, mod=83, salt=3), lattice(B, 1, Hkv, D, mod=79, salt=9)
+    page = 256
+    per = (S + page - 1) // page
+    perm = torch.randperm(B * per + 3, generator=torch.Generator().manual_seed(4))
+    table = perm[: B * per].view(B, per).to(torch.int32)
+    k_pages = torch.zeros(B * per + 3, page, Hkv, D, dtype=torch.bfloat16)
+    v_pages = torch.zeros_like(k_pages)
+    for b in range(B):
+        for p in range(per):
+            n = min(page, S - p * page)
+            k_pages[table[b, p], :n] = kc[b, p * page : p * page + n]
+            v_pages[table[b, p], :n] = vc[b, p * page : p * page + n]
+    return dict(q=q, k_new=k_new, v_new=v_new, lens=lens, table=table, k_pages=k_pages, v_pages=v_pages,
+                out=bf16(g["out"]), D=D)
+
+
+def mla_prefill_golden_case():
+    g = golden("mla_prefill")
+    H, C, R = [int(v) for v in g["dims"]]
+    seqs = [int(v) for v in g["seqs"]]
+    T = sum(seqs)
+    cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32)
+    kv = lattice(T, 1, C + R, salt=2)
+    q = lattice(T, H, C + R, mod=89, scale=128.0, salt=13)
+    return dict(q=q, kv=kv, cu=cu, seqs=seqs, scale=float(g["scale"][0]), rows=torch.from_numpy(g["rows"]), out=bf16(g["out"]), C=C)
