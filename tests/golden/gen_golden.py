@@ -258,6 +258,27 @@ def gen_mla_prefill():
          scale=np.array([0.1352], dtype=np.float32), rows=rows, out=bits16(out[rows]))
 
 
+# ---------------------------------------------------------------- W8A8 int8 quantisers (pure torch in the reference)
+def gen_w8a8_quant():
+    """chitu/quantize/w8a8.py:18-35 quant_act / quant_weight, imported with the closed GEMM packages
+    (w8a8gemm / w8a8gemv, imported at module top, :4-5) stubbed -- they are not called by the quantisers."""
+    import types
+
+    for name in ("w8a8gemm", "w8a8gemv"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from chitu.quantize.w8a8 import quant_act, quant_weight
+
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(6, 512, generator=g) * 3).to(torch.float16)
+    x[2] = 0  # all-zero row: scale clamps to 1e-5 / 127
+    x[3, 7] = 60000.0  # large outlier
+    w = (torch.randn(40, 512, generator=g) * 0.2).to(torch.float16)
+    qx, sx = quant_act(x.clone())
+    qw, sw = quant_weight(w.clone())
+    save("w8a8_quant", x=x.view(torch.int16).numpy().view(np.uint16), w=w.view(torch.int16).numpy().view(np.uint16),
+         qx=qx.numpy(), sx=sx.numpy(), qw=qw.numpy(), sw=sw.numpy())
+
+
 GENS = {
     "moe_align": gen_moe_align,
     "fp8_linear": gen_fp8_linear,
@@ -267,6 +288,7 @@ GENS = {
     "mla_decode": gen_mla_decode,
     "gqa_decode": gen_gqa_decode,
     "mla_prefill": gen_mla_prefill,
+    "w8a8_quant": gen_w8a8_quant,
 }
 
 if __name__ == "__main__":

@@ -64,3 +64,17 @@ def test_module_vs_oracle(M, N, K):
     assert err < 2e-3, err  # identical integers; fp16 rounding of the scaled sum only
     full = torch.nn.functional.linear(x.view(M, K).float(), lin.weight.data.cpu(), lin.bias.data.cpu())
     assert ((y.view(M, N).cpu().float() - full).abs().max() / full.abs().max()) < 5e-2  # int8 quantisation noise
+
+
+def test_quant_act_matches_reference_fixture():
+    """chitu_hip_quant_act_int8 vs the reference's own quant_act output (tests/golden/w8a8_quant.npz):
+    incl. an all-zero row (scale clamp) and a 60000 outlier."""
+    import numpy as np
+
+    from chitu_amd.quantize import w8a8
+    from tests.util import golden
+
+    g = golden("w8a8_quant")
+    x = torch.from_numpy(g["x"].view(np.int16)).view(torch.float16)
+    q, s = w8a8.quant_act(x.cuda())
+    assert np.array_equal(q.cpu().numpy(), g["qx"]) and np.array_equal(s.cpu().numpy(), g["sx"])

@@ -220,3 +220,17 @@ def test_mla_prefill_oracle_matches_reference_varlen_attention():
     c = mla_prefill_golden_case()
     out = omla.mla_prefill(c["q"], c["kv"][:, 0], c["cu"], c["scale"], kv_lora_rank=c["C"])
     assert max_rel_to_peak(out[c["rows"]], c["out"]) < 4e-3
+
+
+def test_w8a8_quantisers_match_reference_bit_exactly():
+    """oracle/w8a8.py quant_act / quant_weight vs the reference's own functions (chitu/quantize/w8a8.py:18-35)."""
+    from oracle import w8a8 as ow
+    from tests.util import golden
+
+    g = golden("w8a8_quant")
+    x = torch.from_numpy(g["x"].view(np.int16)).view(torch.float16)
+    w = torch.from_numpy(g["w"].view(np.int16)).view(torch.float16)
+    qx, sx = ow.quant_act(x.clone())
+    qw, sw = ow.quant_weight(w.clone())
+    assert np.array_equal(qx.numpy(), g["qx"]) and np.array_equal(sx.numpy(), g["sx"])
+    assert np.array_equal(qw.numpy(), g["qw"]) and np.array_equal(sw.numpy(), g["sw"])
