@@ -70,6 +70,21 @@ class DeepSeekV3Args:
         return self.dim == 7168 if self.gate_bias is None else self.gate_bias
 
 
+class VarLens:
+    """Ragged-batch bookkeeping of a prefill call (chitu/utils.py:84-101): same fields."""
+
+    def __init__(self, tokens, device) -> None:
+        self.cpu_lens = [len(t) for t in tokens]
+        self.cpu_prefix_lens = [0]
+        for n in self.cpu_lens:
+            self.cpu_prefix_lens.append(self.cpu_prefix_lens[-1] + n)
+        self.lens = torch.tensor(self.cpu_lens, device=device, dtype=torch.int32)
+        self.prefix_lens = torch.tensor(self.cpu_prefix_lens, device=device, dtype=torch.int32)
+        self.max_len = max(self.cpu_lens)
+        self.total_len = self.cpu_prefix_lens[-1]
+        self.position_ids = torch.cat([torch.arange(n) for n in self.cpu_lens]).to(device)
+
+
 def compute_softmax_scale(args: DeepSeekV3Args) -> float:
     """chitu/models/model_deepseek_v3.py:1441-1445."""
     qk_head_dim = args.qk_nope_head_dim + args.qk_rope_head_dim
@@ -211,6 +226,32 @@ class AttentionDeepSeekV3(torch.nn.Module):
         return self.wo(None, x_quant=(oq, os_))
 
 
+    def prefill_forward(self, x_quant, cos, sin, varlens):
+        """Prefill in absorb mode (model_deepseek_v3.py:538-603): the same projections as decode on all
+        T prompt tokens, [kv_norm(kv_c) | rope(k_pe)] rows written to the pages by the cache manager
+        (cache_manager.py:93-142), causal MQA through attn_backend.attn_varlen_func.  Op-level launches
+        (prefill is outside the decode hot path; SURVEY 8f.1 first cut)."""
+        H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
+        T = x_quant[0].shape[0]
+        q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [T, q_lora + C + R]
+        ql = self.q_lora_rank
+        _, qq, qs = ops.rms_norm(q_a_kv[:, :ql], self.q_norm.weight, self.q_norm.eps, out_bf16=False, quant="act")
+        q = self.wq_b(None, x_quant=(qq, qs)).view(T, H, self.qk_head_dim)
+        q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
+        kv_c = ops.rms_norm(q_a_kv[:, ql : ql + C], self.kv_norm.weight, self.kv_norm.eps)
+        q_pe, k_pe = ops.apply_rotary_pos_emb(q_pe, q_a_kv[:, ql + C :], cos, sin, rotary_type="llama")
+        kv_pe = torch.cat([kv_c, k_pe], dim=-1)  # [T, C + R]
+        self.cache.finalize_cache_bylayer_prefill(kv_pe, None, self.cache.curr_req_ids, self.cache.curr_varlens, self.layer_id)
+        nblk = C // BLOCK
+        q_abs = ops.absorb_bmm_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0)
+        o = self.attn_backend.attn_varlen_func(
+            torch.cat([q_abs, q_pe], dim=-1), kv_pe.view(T, 1, C + R), kv_c.view(T, 1, C), varlens.prefix_lens,
+            varlens.prefix_lens, varlens.max_len, varlens.max_len, causal=True, softmax_scale=self.softmax_scale)
+        w_uv = self.wkv_b.weight.view(H, self.qk_nope_head_dim + self.v_head_dim, C)[:, self.qk_nope_head_dim :]
+        oq, os_ = ops.absorb_uv_quant_fp8(o, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1)
+        return self.wo(None, x_quant=(oq, os_))
+
+
 class MLPDeepSeekV3(torch.nn.Module):
     """Dense FFN of the first n_dense_layers (model_deepseek_v3.py:703-772), gate/up merged."""
 
@@ -305,8 +346,9 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
         self.attn_norm = RMSNormW(args.dim, args.norm_eps, device)
         self.ffn_norm = RMSNormW(args.dim, args.norm_eps, device)
 
-    def forward(self, x, pending, cos, sin):
-        """(x, pending) -> (x', pending'): the residual stream is x + pending; every residual add is
+    def forward(self, x, pending, cos, sin, varlens=None):
+        """(x, pending) -> (x', pending'); varlens given = prefill (ragged prompt tokens), else decode.
+        The residual stream is x + pending; every residual add is
         folded into the RMSNorm that consumes the sum (ops.rms_norm(add=...)), so a layer is
         norm, attention, norm, ffn with no separate add launches (reference: :1107-1113)."""
         if pending is None:
@@ -314,7 +356,10 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
         else:
             x, _, xq, xs = ops.rms_norm(x, self.attn_norm.weight, self.attn_norm.eps, out_bf16=False, quant="act",
                                         add=pending)
-        a = tp.all_reduce(self.attn.decode_forward_paged((xq, xs), cos, sin))
+        if varlens is None:
+            a = tp.all_reduce(self.attn.decode_forward_paged((xq, xs), cos, sin))
+        else:
+            a = tp.all_reduce(self.attn.prefill_forward((xq, xs), cos, sin, varlens))
         if self.is_moe:
             x, hn, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=True, quant="group", add=a)
             # without tensor parallelism nothing sits between the experts' top-k sum and the next norm's
@@ -366,6 +411,45 @@ class DeepSeekV3Decoder(torch.nn.Module):
         h = ops.rms_norm(h, self.norm.weight, self.norm.eps, add=pending)[1] if pending is not None else \
             ops.rms_norm(h, self.norm.weight, self.norm.eps)
         return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()  # bf16 logits -> fp32 (model.py:475)
+
+    @torch.inference_mode()
+    def prefill(self, tokens, req_ids):
+        """tokens: list of per-request token-id lists; req_ids: their cache keys.  Runs the prompt
+        through every layer, fills the KV pages, returns fp32 logits [n_req, vocab] of each prompt's
+        LAST token (prefill_single_device, model.py:451-465).  Eager launches."""
+        varlens = VarLens(tokens, self.device)
+        self.cache.curr_varlens, self.cache.curr_req_ids = varlens, list(req_ids)
+        flat = torch.tensor([t for seq in tokens for t in seq], dtype=torch.int64, device=self.device)
+        cos, sin = self.cos_table[varlens.position_ids], self.sin_table[varlens.position_ids]
+        h, pending = self.embed(flat), None
+        for layer in self.layers:
+            h, pending = layer(h, pending, cos, sin, varlens)
+        last = torch.tensor([p - 1 for p in varlens.cpu_prefix_lens[1:]], dtype=torch.int64, device=self.device)
+        h = h[last]
+        if pending is not None:
+            pending = pending[last]
+            h = ops.rms_norm(h, self.norm.weight, self.norm.eps, add=pending.contiguous())[1]
+        else:
+            h = ops.rms_norm(h, self.norm.weight, self.norm.eps)
+        self.cache.finalize_cache_all_prefill(req_ids, varlens)
+        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()
+
+    @torch.inference_mode()
+    def generate(self, prompts, max_new_tokens, req_ids=None, use_graph=True):
+        """Greedy generation (executor.py:103-104): prefill, then max_new_tokens-1 decode steps.
+        Returns a [n_req, max_new_tokens] int64 tensor; frees the requests' pages afterwards."""
+        req_ids = [f"gen{i}" for i in range(len(prompts))] if req_ids is None else list(req_ids)
+        tok = self.prefill(prompts, req_ids).argmax(dim=-1)
+        out = [tok]
+        for _ in range(max_new_tokens - 1):
+            self.cache.prepare_cache_decode(req_ids)
+            self.cache.prepare_block_table_for_decode(req_ids)
+            tok = self.decode(tok, use_graph=use_graph).argmax(dim=-1)
+            self.cache.finalize_cache_single_decode(req_ids)
+            out.append(tok.clone())
+        for r in req_ids:
+            self.cache.finalize_cache_all_decode(r)
+        return torch.stack(out, dim=1)
 
     def embed(self, tokens):
         """tensor_parallel.py:199-208: mask ids outside this rank's vocab slice, lookup, all-reduce."""

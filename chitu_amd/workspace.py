@@ -8,6 +8,7 @@ attn_backend.py:737-746 -- that is not capture-safe without the caching allocato
 import torch
 
 _ws = {}
+_retired = []  # outgrown buffers stay alive: hipGraphs captured earlier still launch on their addresses
 
 
 def get(nbytes: int, device, tag: str = "default") -> torch.Tensor:
@@ -19,6 +20,8 @@ def get(nbytes: int, device, tag: str = "default") -> torch.Tensor:
                 f"workspace '{tag}' must grow ({buf.numel()} -> {nbytes} B) during graph capture; "
                 "run one eager step first"
             )
+        if buf is not None:
+            _retired.append(buf)
         size = max(nbytes, 1 << 20)
         buf = torch.empty(size, dtype=torch.uint8, device=device)
         _ws[key] = buf

@@ -443,3 +443,61 @@ def test_topk_sum_folded_into_rmsnorm_is_bit_identical(rows, terms, dim, quant):
             assert np.array_equal(bits8(a), bits8(b))
         else:
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("make_args", [tiny_args, v2lite_like_args], ids=["v3_like", "v2lite_like"])
+def test_prefill_equals_token_by_token_decode(make_args):
+    """Size-independent property: running a prompt through prefill (ragged batch, causal attention over
+    the prompt, page writes by the cache manager) gives the same last-token logits and the same KV pages
+    as feeding the same tokens one at a time through the decode step -- and generation continues from
+    either state identically (within the fp8/bf16 noise of different split-K orders)."""
+    args = make_args()
+    model, cache = build(args, max_reqs=4, max_seq=512)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, args.vocab_size, (n,), generator=g).tolist() for n in (1, 70, 9)]
+
+    # (a) token by token through decode
+    reqs = ["d0", "d1", "d2"]
+    for r in reqs:
+        cache.register_sequence(r, 0)
+    last_logits = [None] * 3
+    for step in range(max(len(p) for p in prompts)):
+        live = [i for i, p in enumerate(prompts) if step < len(p)]
+        ids = [reqs[i] for i in live]
+        cache.prepare_cache_decode(ids)
+        cache.prepare_block_table_for_decode(ids)
+        toks = torch.tensor([prompts[i][step] for i in live], dtype=torch.int64, device="cuda")
+        logits = model.decode(toks, use_graph=False)
+        cache.finalize_cache_single_decode(ids)
+        for k, i in enumerate(live):
+            if step == len(prompts[i]) - 1:
+                last_logits[i] = logits[k].clone()
+    kv_decode = {}
+    for i, r in enumerate(reqs):
+        rows = torch.cat([cache.paged_kv_cache[:, b] for b in cache.block_table[r]], dim=1)[:, : len(prompts[i])]
+        kv_decode[i] = rows.clone()
+        cache.finalize_cache_all_decode(r)
+
+    # (b) one prefill call
+    preqs = ["p0", "p1", "p2"]
+    logits_p = model.prefill(prompts, preqs)
+    assert tuple(logits_p.shape) == (3, args.vocab_size) and logits_p.dtype == torch.float32
+    for i, r in enumerate(preqs):
+        assert cache.seq_lens[r] == len(prompts[i])
+        rows = torch.cat([cache.paged_kv_cache[:, b] for b in cache.block_table[r]], dim=1)[:, : len(prompts[i])]
+        assert max_rel_to_peak(rows, kv_decode[i]) < 2e-2
+        assert max_rel_to_peak(logits_p[i], last_logits[i]) < 3e-2, i
+    # generation continues from the prefilled state
+    tok = logits_p.argmax(-1)
+    cache.prepare_cache_decode(preqs)
+    cache.prepare_block_table_for_decode(preqs)
+    nxt = model.decode(tok, use_graph=True)
+    assert torch.isfinite(nxt).all()
+    cache.finalize_cache_single_decode(preqs)
+    for r in preqs:
+        cache.finalize_cache_all_decode(r)
+    # end-to-end helper: deterministic, right shape, pages returned
+    free_before = len(cache.free_blocks)
+    out1 = model.generate(prompts, 4)
+    out2 = model.generate(prompts, 4)
+    assert tuple(out1.shape) == (3, 4) and torch.equal(out1, out2) and len(cache.free_blocks) == free_before
