@@ -56,8 +56,14 @@ def setup_dist(n):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # debug only (validating the N > 1 code path on a one-GPU box): CHITU_BENCH_BACKEND=gloo puts every
+        # rank on cuda:0 and runs the collectives through gloo; such a run is flagged invalid
+        if os.environ.get("CHITU_BENCH_BACKEND") == "gloo":
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         from chitu_amd import tensor_parallel as tp
 
         tp.init_tp(world, 1)
@@ -175,7 +181,7 @@ def algorithmic_bytes_per_step(margs, bs, ctx, distinct):
     return margs.n_layers * attn + margs.n_dense_layers * dense + n_moe * moe + head + kv
 
 
-def roofline_dominant_kernel(model, cache, margs, bs, ctx, iters=3):
+def roofline_dominant_kernel(model, routing, margs, bs, iters=3):
     """Time the dominant kernel -- the routed-expert GEMM1 with SiLU-and-mul in its epilogue
     (chitu_hip_moe_gemm1_silu_fp8 -> moe_gemm1_silu_kernel: ~2/3 of all bytes at bs=16) -- live with
     HIP events on the launch stream: one launch per MoE layer with that
@@ -186,9 +192,8 @@ def roofline_dominant_kernel(model, cache, margs, bs, ctx, iters=3):
 
     lib = _lib.lib()
     moe_layers = [l.ffn for l in model.layers if l.is_moe]
-    if not moe_layers:
+    if not moe_layers or not routing:
         return None
-    routing = capture_step_routing(model, cache, bs, ctx)
     assert len(routing) == len(moe_layers)
     E, K = margs.n_routed_experts + margs.n_shared_experts, margs.dim
     N = moe_layers[0].w1w3_weight.shape[1]
@@ -346,7 +351,13 @@ def main():
             measure(model, cache, a.bs, a.ctx, 2, 1, world, True, "probe")
         except Exception as exc:  # noqa: BLE001
             print(f"[bench] rank {rank}: graph capture failed ({type(exc).__name__}: {exc}); eager fallback", file=sys.stderr)
-            ok.zero_()
+            for _ in range(3):  # drain the sticky capture-invalidated error before touching the device again
+                try:
+                    torch.cuda.synchronize()
+                    break
+                except Exception:  # noqa: BLE001
+                    pass
+            ok = torch.zeros(1, device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0:
             use_graph = False
@@ -365,8 +376,14 @@ def main():
         }
 
     roof = None
-    if rank == 0 and not a.no_roofline:
-        roof = roofline_dominant_kernel(model, cache, margs, a.bs, a.ctx)
+    if not a.no_roofline:
+        # the routing capture runs decode steps, i.e. collectives at N > 1: every rank takes part;
+        # the kernel timing itself is rank 0's
+        routing = capture_step_routing(model, cache, a.bs, a.ctx)
+        if rank == 0:
+            roof = roofline_dominant_kernel(model, routing, margs, a.bs)
+        if world > 1:
+            dist.barrier()
     distinct = (roof["distinct_experts"] - 1) if roof else min(256, a.bs * 8)  # routed only; shared counted in the formula
     step_bytes = algorithmic_bytes_per_step(margs, a.bs, a.ctx, distinct)
     cpu = None
@@ -397,7 +414,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "build_s": round(build_s, 1),
         }
         res.update(extra)
-        if a.layers != 61 or a.router_std is not None:
+        if a.layers != 61 or a.router_std is not None or os.environ.get("CHITU_BENCH_BACKEND") == "gloo":
             res["invalid"] = "debug run (reduced layer count or non-default synthetic router)"
         print(json.dumps(res))
     if world > 1:
