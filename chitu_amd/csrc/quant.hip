@@ -245,3 +245,41 @@ extern "C" int chitu_hip_selftest_arith(const float* num, const float* den, int6
                        (unsigned long long*)mismatches);
     CHITU_RETURN_LAUNCH_STATUS();
 }
+
+// ---- SiluAndMul for unquantised (bf16) MLPs: out = bf16(bf16(silu(x[:, :d])) * x[:, d:])
+// (chitu/fused_moe.py:24-39 / FeedForward.forward, models/model.py:212-214: F.silu(w1 x) * w3 x on bf16
+// tensors -- each torch op rounds once).
+namespace chitu {
+__global__ __launch_bounds__(256) void silu_and_mul_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                           int64_t rows, int d) {
+    const int chunks = d >> 3;
+    const int64_t total = rows * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i % chunks) * 8;
+        const i32x4 g = *reinterpret_cast<const i32x4*>(x + r * 2 * d + c);
+        const i32x4 u = *reinterpret_cast<const i32x4*>(x + r * 2 * d + d + c);
+        i32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t gu = (uint32_t)g[k], uu = (uint32_t)u[k];
+            const float g0 = __uint_as_float(gu << 16), g1 = __uint_as_float(gu & 0xffff0000u);
+            const float s0 = round_bf16(g0 / (1.0f + expf(-g0))), s1 = round_bf16(g1 / (1.0f + expf(-g1)));
+            o[k] = (int)f32x2_to_bf16x2(s0 * __uint_as_float(uu << 16), s1 * __uint_as_float(uu & 0xffff0000u));
+        }
+        *reinterpret_cast<i32x4*>(out + r * d + c) = o;
+    }
+}
+}  // namespace chitu
+
+extern "C" int chitu_hip_silu_and_mul(const void* x_bf16, void* out_bf16, int64_t rows, int64_t d, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && out_bf16 && rows >= 0 && d >= 8 && d < (1ll << 31));
+    if (d % 8 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (rows == 0) return CHITU_OK;
+    int64_t blocks = (rows * (d / 8) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(silu_and_mul_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x_bf16, (bf16_t*)out_bf16, rows, (int)d);
+    CHITU_RETURN_LAUNCH_STATUS();
+}

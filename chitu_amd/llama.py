@@ -1,0 +1,187 @@
+"""Llama-family (GQA / MHA, bf16) decode step on the gfx950 kernels -- BASELINE config 2
+("Llama-3-8B bf16 TP=1 on one MI355X, paged KV, hipGraph decode").
+
+Reference (read-only): chitu/models/model.py -- Attention:81-198 (decode_forward_paged:167-198),
+FeedForward:201-214, TransformerBlock, Transformer.decode:538-622; models/model_llama.py (merged
+wqkv / w13 layout of the original Meta checkpoints, rotary_type "llama" = interleaved pairs).
+
+Per layer and step, 10 launches: add+RMSNorm, wqkv GEMM, RoPE(q, k), append K, append V, paged GQA
+decode (+ merge when the KV range is split), wo GEMM, add+RMSNorm, w13 GEMM, SiluAndMul, w2 GEMM.
+All GEMMs are the weight-streaming skinny bf16 kernel (gate.hip); the whole step replays as one hipGraph.
+"""
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from . import tensor_parallel as tp
+from .attn_backend import HipAttnBackend
+from .cache_manager import PagedKVCacheManager
+
+
+@dataclass
+class LlamaArgs:
+    """Fields of chitu/config/models/Meta-Llama-3-8B-Instruct-original.yaml:6-14 (defaults = Llama-3-8B)."""
+
+    dim: int = 4096
+    n_layers: int = 32
+    n_heads: int = 32
+    n_kv_heads: int = 8
+    vocab_size: int = 128256
+    ffn_dim: int = 14336
+    norm_eps: float = 1e-5
+    rope_theta: float = 500000.0
+
+    @property
+    def head_dim(self):
+        return self.dim // self.n_heads
+
+
+def precompute_freqs_cis(head_dim: int, max_pos: int, theta: float):
+    """cos/sin [max_pos, head_dim/2] fp32 (models/model.py:381-392: precompute_freqs_cis)."""
+    freqs = 1.0 / (theta ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
+    ang = torch.outer(torch.arange(max_pos, dtype=torch.float32), freqs)
+    return torch.cos(ang), torch.sin(ang)
+
+
+def _param(*shape, device=None):
+    return torch.nn.Parameter(torch.empty(*shape, dtype=torch.bfloat16, device=device), requires_grad=False)
+
+
+class LlamaAttention(torch.nn.Module):
+    def __init__(self, args: LlamaArgs, layer_id, cache, attn_backend, device=None):
+        super().__init__()
+        t = tp.get_tp_size()
+        self.layer_id, self.cache, self.attn_backend = layer_id, cache, attn_backend
+        self.hd = args.head_dim
+        self.hq, self.hkv = args.n_heads // t, args.n_kv_heads // t
+        # merged [wq | wk | wv] rows (ColumnParallel: heads split across ranks), wo RowParallel
+        self.wqkv = _param((self.hq + 2 * self.hkv) * self.hd, args.dim, device=device)
+        self.wo = _param(args.dim, self.hq * self.hd, device=device)
+
+    def decode_forward_paged(self, x, cos, sin):
+        """x = attn_norm(h) bf16 [bs, dim] -> wo(attention) before the all-reduce (model.py:167-198)."""
+        bs = x.shape[0]
+        qkv = ops.bf16_linear(x, self.wqkv).view(bs, self.hq + 2 * self.hkv, self.hd)
+        q, k = ops.apply_rotary_pos_emb(qkv[:, : self.hq], qkv[:, self.hq : self.hq + self.hkv], cos, sin, rotary_type="llama")
+        v = qkv[:, self.hq + self.hkv :]
+        k_cache, v_cache = self.cache.get_paged_kv_cache(self.layer_id)
+        o = self.attn_backend.attn_with_kvcache(
+            q.view(bs, 1, self.hq, self.hd), k_cache, v_cache, k.view(bs, 1, self.hkv, self.hd),
+            v.reshape(bs, 1, self.hkv, self.hd), cache_seqlens=self.cache.get_gpu_seq_lens_excl_this_decode()[:bs],
+            block_table=self.cache.get_gpu_block_table()[:bs])
+        return ops.bf16_linear(o.view(bs, self.hq * self.hd), self.wo)
+
+
+class LlamaFeedForward(torch.nn.Module):
+    """w2(silu(w1 x) * w3 x) with w1 / w3 merged row-wise (model.py:201-214)."""
+
+    def __init__(self, args: LlamaArgs, device=None):
+        super().__init__()
+        t = tp.get_tp_size()
+        self.inter = args.ffn_dim // t
+        self.w13 = _param(2 * self.inter, args.dim, device=device)
+        self.w2 = _param(args.dim, self.inter, device=device)
+
+    def forward(self, x):
+        return ops.bf16_linear(ops.silu_and_mul(ops.bf16_linear(x, self.w13)), self.w2)
+
+
+class LlamaBlock(torch.nn.Module):
+    def __init__(self, layer_id, args, cache, attn_backend, device=None):
+        super().__init__()
+        self.attn = LlamaAttention(args, layer_id, cache, attn_backend, device)
+        self.ffn = LlamaFeedForward(args, device)
+        self.attn_norm = _param(args.dim, device=device)
+        self.ffn_norm = _param(args.dim, device=device)
+        self.eps = args.norm_eps
+
+    def forward(self, x, pending, cos, sin):
+        """(x, pending) -> (x', pending'): residual adds folded into the RMSNorm that consumes them."""
+        if pending is None:
+            hn = ops.rms_norm(x, self.attn_norm, self.eps)
+        else:
+            x, hn = ops.rms_norm(x, self.attn_norm, self.eps, add=pending)
+        a = tp.all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+        x, hn = ops.rms_norm(x, self.ffn_norm, self.eps, add=a)
+        return x, tp.all_reduce(self.ffn(hn))
+
+
+class LlamaDecoder(torch.nn.Module):
+    """embed -> blocks -> norm -> head -> fp32 logits; one hipGraph per batch size (model.py:538-622)."""
+
+    def __init__(self, args: LlamaArgs, cache: PagedKVCacheManager, attn_backend: HipAttnBackend,
+                 max_position_embeddings: int = 4096, device="cuda"):
+        super().__init__()
+        self.args, self.cache, self.attn_backend, self.device = args, cache, attn_backend, torch.device(device)
+        t = tp.get_tp_size()
+        assert args.vocab_size % t == 0 and args.n_kv_heads % t == 0 and args.head_dim == 128, "gqa_decode: head_dim 128"
+        self.vocab_local = args.vocab_size // t
+        self.vocab_start = tp.get_tp_rank() * self.vocab_local
+        self.embed_weight = _param(self.vocab_local, args.dim, device=device)
+        self.layers = torch.nn.ModuleList(LlamaBlock(i, args, cache, attn_backend, device) for i in range(args.n_layers))
+        self.norm = _param(args.dim, device=device)
+        self.head_weight = _param(self.vocab_local, args.dim, device=device)
+        cos, sin = precompute_freqs_cis(args.head_dim, max_position_embeddings, args.rope_theta)
+        self.cos_table, self.sin_table = cos.to(device), sin.to(device)
+        self.graphs, self.static_tokens, self.static_out = {}, {}, {}
+        self.graph_pool = None
+
+    def embed(self, tokens):
+        if self.vocab_local == self.args.vocab_size:
+            return F.embedding(tokens, self.embed_weight)
+        local = tokens - self.vocab_start
+        mask = (local < 0) | (local >= self.vocab_local)
+        y = F.embedding(torch.where(mask, torch.zeros_like(local), local), self.embed_weight)
+        return tp.all_reduce(torch.where(mask.unsqueeze(-1), torch.zeros_like(y), y))
+
+    def decode_eager(self, tokens):
+        bs = tokens.shape[0]
+        pos = self.cache.get_gpu_seq_lens_excl_this_decode()[:bs].long()
+        cos, sin = self.cos_table[pos], self.sin_table[pos]
+        h, pending = self.embed(tokens), None
+        for layer in self.layers:
+            h, pending = layer(h, pending, cos, sin)
+        h = ops.rms_norm(h, self.norm, self.args.norm_eps, add=pending)[1]
+        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()
+
+    @torch.inference_mode()
+    def decode(self, tokens, use_graph=True):
+        bs = tokens.shape[0]
+        if not use_graph:
+            return self.decode_eager(tokens)
+        if bs not in self.graphs:
+            self.static_tokens[bs] = tokens.clone()
+            sample = self.decode_eager(self.static_tokens[bs])  # also re-writes this step's KV rows
+            self.static_out[bs] = torch.zeros_like(sample)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph_pool):
+                self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs]))
+            if self.graph_pool is None:
+                self.graph_pool = g.pool()
+            self.graphs[bs] = g
+        self.static_tokens[bs].copy_(tokens)
+        self.graphs[bs].replay()
+        return self.static_out[bs]
+
+
+@torch.no_grad()
+def init_synthetic_(model: torch.nn.Module, seed: int = 0):
+    """bf16 weights randn / sqrt(fan_in) (unit-gain linears), norm weights 1, embeddings randn."""
+    dev = next(model.parameters()).device
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    for name, p in model.named_parameters():
+        if name.endswith("norm"):
+            p.data.fill_(1.0)
+            continue
+        std = 1.0 if name == "embed_weight" else p.shape[-1] ** -0.5
+        flat = p.data.view(-1)
+        for i in range(0, flat.numel(), 1 << 26):
+            n = min(1 << 26, flat.numel() - i)
+            flat[i : i + n].copy_((torch.randn(n, device=dev, generator=gen) * std).to(p.dtype))
+    return model

@@ -308,6 +308,16 @@ def bf16_linear(x: torch.Tensor, weight: torch.Tensor, out_dtype=None) -> torch.
     return out
 
 
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    """silu(x[..., :d]) * x[..., d:] on bf16 (SiluAndMul, fused_moe.py:24-39; Llama's F.silu(w1 x) * w3 x)."""
+    require_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape[-1] % 16 == 0
+    d = x.shape[-1] // 2
+    out = torch.empty(*x.shape[:-1], d, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().chitu_hip_silu_and_mul(ptr(x), ptr(out), i64(x.numel() // (2 * d)), i64(d), stream_ptr()), "silu_and_mul")
+    return out
+
+
 _GATE_SPLITS = 16
 
 

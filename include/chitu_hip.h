@@ -157,6 +157,10 @@ int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_fp8, const 
 int chitu_hip_moe_sum(const void* c3_bf16, void* out_bf16, int64_t tokens, int32_t topk, int64_t N,
                       void* stream);
 
+/* ---- SiluAndMul (unquantised MLPs: Llama FeedForward, models/model.py:212-214; fused_moe.py:24-39)
+ *   out[r, :] = bf16( bf16(silu(x[r, :d])) * x[r, d:2d] ),  x [rows, 2d] bf16, out [rows, d] bf16, d % 8 == 0. */
+int chitu_hip_silu_and_mul(const void* x_bf16, void* out_bf16, int64_t rows, int64_t d, void* stream);
+
 /* ---- arithmetic self-test ----------------------------------------------------------------------
  * The quantising kernels divide a group's values by its scale with a refined-reciprocal +
  * residual-correction sequence instead of the IEEE division expansion, and round to bf16 with

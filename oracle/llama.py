@@ -1,0 +1,35 @@
+"""Oracle for one Llama decode layer (torch CPU).  TEST INFRASTRUCTURE ONLY.
+
+Composition of pinned pieces, in the order of chitu/models/model.py (Attention.decode_forward_paged
+:167-198, FeedForward.forward :212-214, TransformerBlock.forward): RMSNorm = F.rms_norm (:29-78),
+linears = F.linear on bf16 (fp32 accumulate, one rounding), RoPE = oracle/kv.py (pinned against the
+reference kernel), attention = oracle/gqa.py (pinned against RefAttnBackend), SiluAndMul on bf16.
+"""
+
+import torch
+import torch.nn.functional as F
+
+from . import gqa as ogqa
+from . import kv as okv
+
+
+def rms_norm(x, w, eps):
+    return F.rms_norm(x, (x.shape[-1],), w, eps).to(x.dtype)
+
+
+def block(p, pre, x, cos, sin, k_cache, v_cache, block_table, lens_excl, hq, hkv, hd, eps):
+    """x [bs, dim] bf16 -> (x_out, k_cache', v_cache')."""
+    bs = x.shape[0]
+    hn = rms_norm(x, p[pre + "attn_norm"], eps)
+    qkv = F.linear(hn, p[pre + "attn.wqkv"]).view(bs, hq + 2 * hkv, hd)
+    q, k = okv.apply_rotary_pos_emb(qkv[:, :hq], qkv[:, hq : hq + hkv], cos, sin, "llama")
+    v = qkv[:, hq + hkv :]
+    o, k_cache, v_cache = ogqa.attn_with_kvcache(q.reshape(bs, 1, hq, hd), k_cache, v_cache, k.reshape(bs, 1, hkv, hd),
+                                                 v.reshape(bs, 1, hkv, hd), lens_excl, block_table)
+    a = F.linear(o.to(torch.bfloat16).view(bs, hq * hd), p[pre + "attn.wo"])
+    x = x + a
+    hn = rms_norm(x, p[pre + "ffn_norm"], eps)
+    h13 = F.linear(hn, p[pre + "ffn.w13"])
+    d = h13.shape[-1] // 2
+    f = F.linear(F.silu(h13[..., :d]) * h13[..., d:], p[pre + "ffn.w2"])
+    return x + f, k_cache, v_cache

@@ -1,0 +1,94 @@
+"""Llama-family decode step (BASELINE config 2 as a parity-test case): HIP layer vs the oracle
+composition, graph replay == eager, KV advancing over steps, silu_and_mul op."""
+
+import pytest
+import torch
+
+from oracle import llama as ollama
+from tests.util import max_rel_to_peak
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_args(n_kv_heads=2):
+    from chitu_amd.llama import LlamaArgs
+
+    return LlamaArgs(dim=1024, n_layers=3, n_heads=8, n_kv_heads=n_kv_heads, vocab_size=2048, ffn_dim=2048)
+
+
+def build(args, max_reqs=4, max_seq=1024, page=256):
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.llama import LlamaDecoder, init_synthetic_
+
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=max_reqs, block_size=page, max_seq_len=max_seq, device="cuda",
+                                n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
+    model = LlamaDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=max_seq),
+                         max_position_embeddings=max_seq, device="cuda")
+    init_synthetic_(model, seed=0)
+    return model, cache
+
+
+def test_silu_and_mul_bit_exact():
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(7, 2 * 1408, generator=g) * 3).to(torch.bfloat16)
+    ref = torch.nn.functional.silu(x[:, :1408]) * x[:, 1408:]
+    out = ops.silu_and_mul(x.cuda()).cpu()
+    d = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()
+    assert d.max() <= 1 and (d > 0).float().mean() < 0.01  # expf vs torch's exp: last-bit differences only
+
+
+@pytest.mark.parametrize("n_kv_heads", [2, 8], ids=["gqa4", "mha"])
+def test_layerwise_parity_and_graph_replay(n_kv_heads):
+    args = tiny_args(n_kv_heads)
+    model, cache = build(args)
+    params = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    bs, reqs = 3, ["r0", "r1", "r2"]
+    gen = torch.Generator().manual_seed(7)
+    for r, n in zip(reqs, (0, 255, 300)):
+        cache.register_sequence(r, n)
+        for blk in cache.block_table[r]:
+            cache.paged_k_cache[:, blk] = (torch.randn(args.n_layers, 256, n_kv_heads, 128, generator=gen) * 0.5).to(torch.bfloat16).cuda()
+            cache.paged_v_cache[:, blk] = (torch.randn(args.n_layers, 256, n_kv_heads, 128, generator=gen) * 0.5).to(torch.bfloat16).cuda()
+    shadow_k, shadow_v = cache.paged_k_cache.cpu().clone(), cache.paged_v_cache.cpu().clone()
+    cache.prepare_cache_decode(reqs)
+    cache.prepare_block_table_for_decode(reqs)
+    lens = cache.get_gpu_seq_lens_excl_this_decode()[:bs].cpu()
+    table = cache.get_gpu_block_table()[:bs].cpu()
+    cos, sin = model.cos_table.cpu()[lens.long()], model.sin_table.cpu()[lens.long()]
+    x = torch.randn(bs, args.dim, generator=gen).to(torch.bfloat16)
+    worst = 0.0
+    for i, layer in enumerate(model.layers):
+        with torch.inference_mode():
+            xm, pend = layer(x.cuda(), None, cos.cuda(), sin.cuda())
+        y = (xm + pend).cpu()
+        y_ref, k_new, v_new = ollama.block(params, f"layers.{i}.", x, cos, sin, shadow_k[i], shadow_v[i], table, lens,
+                                           args.n_heads, n_kv_heads, 128, args.norm_eps)
+        assert max_rel_to_peak(cache.paged_k_cache[i].cpu(), k_new) < 1e-2
+        assert max_rel_to_peak(cache.paged_v_cache[i].cpu(), v_new) < 1e-2
+        err = max_rel_to_peak(y, y_ref)
+        worst = max(worst, err)
+        assert err < 2e-2, (i, err)
+        x = y_ref
+    print("worst layer rel err", worst)
+
+    tokens = torch.tensor([5, 17, 900], dtype=torch.int64, device="cuda")
+    outs = []
+    for step in range(3):
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        snap_k, snap_v = cache.paged_k_cache.clone(), cache.paged_v_cache.clone()
+        eager = model.decode(tokens, use_graph=False).clone()
+        kv_eager = (cache.paged_k_cache.clone(), cache.paged_v_cache.clone())
+        cache.paged_k_cache.copy_(snap_k)
+        cache.paged_v_cache.copy_(snap_v)
+        graph = model.decode(tokens, use_graph=True).clone()
+        assert torch.equal(eager, graph)
+        assert torch.equal(kv_eager[0], cache.paged_k_cache) and torch.equal(kv_eager[1], cache.paged_v_cache)
+        assert eager.dtype == torch.float32 and tuple(eager.shape) == (bs, args.vocab_size) and torch.isfinite(eager).all()
+        outs.append(eager)
+        tokens = eager.argmax(dim=-1)
+        cache.finalize_cache_single_decode(reqs)
+    assert not torch.equal(outs[0], outs[1]) and len(model.graphs) == 1
