@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-llama", action="store_true", help="skip the extra Llama-3-8B (BASELINE config 2) measurement")
     return ap.parse_args()
 
 
@@ -334,6 +335,36 @@ def cpu_baseline(margs, bs, ctx):
     }
 
 
+def llama3_8b_extra(steps, warmup, ctx):
+    """BASELINE config 2 as an extra line: Llama-3-8B bf16, TP=1 (the whole model on this GPU), paged KV
+    (page 256), hipGraph decode, synthetic weights; bs=1 and bs=16.  Algorithmic bytes per step = every
+    weight once (16.06 GB) + the KV read."""
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.llama import LlamaArgs, LlamaDecoder, init_synthetic_
+
+    args = LlamaArgs()
+    max_seq = ctx + steps + warmup + 512
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=16, block_size=256, max_seq_len=max_seq, device="cuda",
+                                n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
+    model = LlamaDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=max_seq),
+                         max_position_embeddings=max_seq, device="cuda")
+    init_synthetic_(model, seed=3)
+    cache.paged_k_cache.normal_(0, 0.5)
+    cache.paged_v_cache.normal_(0, 0.5)
+    w_bytes = sum(p.numel() * 2 for n, p in model.named_parameters() if n != "embed_weight")
+    out = {"model": "Llama-3-8B bf16 TP=1, paged KV (page 256), hipGraph, synthetic weights", "weight_GB": round(w_bytes / 1e9, 3)}
+    for bs in (1, 16):
+        dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"l{bs}_")
+        kv = args.n_layers * bs * ctx * args.n_kv_heads * args.head_dim * 2 * 2
+        out[f"bs{bs}"] = {"ms_per_step": round(dt / steps * 1e3, 4), "tok_s": round(bs * steps / dt, 1),
+                          "hbm_GBs": round((w_bytes + kv) / (dt / steps) / 1e9, 1),
+                          "roofline_frac": round((w_bytes + kv) / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    del model, cache
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     rank, world, local = setup_dist(a.gpus)
@@ -386,9 +417,14 @@ def main():
             dist.barrier()
     distinct = (roof["distinct_experts"] - 1) if roof else min(256, a.bs * 8)  # routed only; shared counted in the formula
     step_bytes = algorithmic_bytes_per_step(margs, a.bs, a.ctx, distinct)
+    if world == 1 and not a.no_llama and a.layers == 61:
+        del model, cache
+        model = cache = None
+        torch.cuda.empty_cache()
+        extra["llama3_8b"] = llama3_8b_extra(a.steps, a.warmup, a.ctx)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        del model
+        model = cache = None
         torch.cuda.empty_cache()
         cpu = cpu_baseline(margs, a.bs, a.ctx)
 

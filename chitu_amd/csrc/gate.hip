@@ -22,7 +22,18 @@
 namespace chitu {
 
 // ---------------------------------------------------------------- skinny bf16 GEMM
-// out[m][n] = sum_k x[m][k] * w[n][k]; k-block = 64 elements (128 B of a weight row).
+// out[m][n] = sum_k x[m][k] * w[n][k]; k-block = 64 elements = one 128-B line of a weight row.
+// Full-line layout (gemm_common.h): lane (j, g) loads 16 B of weight row n0 + 8*half + j/2 at element
+// ((j%2)*4 + g)*8 of the block, so a wave-load takes whole lines from 8 rows; MFMA A-row j then holds
+// K elements [0,32) (even j) or [32,64) (odd j) of weight row j/2, the block product is taken with the
+// two activation fragments x[0..31], x[32..63] and the halves are added in-lane at the end.  bf16 has no
+// per-block scales, so the four accumulators run across the whole K range.
+template <int MT>
+struct Bf16Stage {
+    s16x8 w[2];
+    s16x8 x[MT][2];
+};
+
 template <int MT, int WK>
 __global__ __launch_bounds__(64 * WK) void bf16_gemm_kernel(const bf16_t* __restrict__ X,
                                                             const bf16_t* __restrict__ W,
@@ -37,26 +48,53 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_kernel(const bf16_t* __rest
     const int T = S * WK;
     const int t = blockIdx.y * WK + wave;
     const int kb0 = (int)((long)KB * t / T), kb1 = (int)((long)KB * (t + 1) / T);
-    const bf16_t* wp = W + (size_t)min(n0 + j, N - 1) * K + g * 8;
+    const int eoff = ((j & 1) * 4 + g) * 8;
+    const bf16_t* wp0 = W + (size_t)min(n0 + (j >> 1), N - 1) * K + eoff;
+    const bf16_t* wp1 = W + (size_t)min(n0 + 8 + (j >> 1), N - 1) * K + eoff;
     const bf16_t* xp[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xp[mt] = X + (size_t)min(m_base + mt * 16 + j, M - 1) * K + g * 8;
-    f32x4 acc[MT];
+    f32x4 e0[MT], o0[MT], e1[MT], o1[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kb = kb0; kb < kb1; ++kb) {
+    for (int mt = 0; mt < MT; ++mt) e0[mt] = o0[mt] = e1[mt] = o1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load = [&](Bf16Stage<MT>& st, int kb) {
         const int off = kb << 6;
-        const s16x8 w0 = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp + off));
-        const s16x8 w1 = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp + off + 32));
+        st.w[0] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp0 + off));
+        st.w[1] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp1 + off));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const s16x8 x0 = *reinterpret_cast<const s16x8*>(xp[mt] + off);
-            const s16x8 x1 = *reinterpret_cast<const s16x8*>(xp[mt] + off + 32);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc[mt], 0, 0, 0);
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc[mt], 0, 0, 0);
+            st.x[mt][0] = *reinterpret_cast<const s16x8*>(xp[mt] + off);
+            st.x[mt][1] = *reinterpret_cast<const s16x8*>(xp[mt] + off + 32);
+        }
+    };
+    auto compute = [&](const Bf16Stage<MT>& st) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            e0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.w[0], st.x[mt][0], e0[mt], 0, 0, 0);
+            o0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.w[0], st.x[mt][1], o0[mt], 0, 0, 0);
+            e1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.w[1], st.x[mt][0], e1[mt], 0, 0, 0);
+            o1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.w[1], st.x[mt][1], o1[mt], 0, 0, 0);
+        }
+    };
+    constexpr int D = MT >= 4 ? 2 : 4;
+    Bf16Stage<MT> ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (kb0 + d < kb1) load(ring[d], kb0 + d);
+    for (int kb = kb0; kb < kb1; kb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (kb + d < kb1) {
+                compute(ring[d]);
+                if (kb + d + D < kb1) load(ring[d], kb + d + D);
+            }
         }
     }
-    gemm_epilogue<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = f32x4{e0[mt][0] + o0[mt][1], e0[mt][2] + o0[mt][3], e1[mt][0] + o1[mt][1], e1[mt][2] + o1[mt][3]};
+    gemm_epilogue_v2<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
 }
 
 // ---------------------------------------------------------------- fused routing
