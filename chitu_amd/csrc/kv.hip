@@ -148,6 +148,51 @@ __global__ __launch_bounds__(256) void mla_kv_prep_kernel(
     }
 }
 
+// GQA / MHA decode "QKV post": RoPE on q (in place in the merged qkv row) and on k, with the rotated
+// k and the v row written straight into the token's page (Attention.decode_forward_paged,
+// models/model.py:167-198: apply_rotary_pos_emb + the in-place append that attn_with_kvcache does,
+// attn_backend.py:108-115) -- three launches of the op-level path in one, same arithmetic as
+// rope_kernel / append_paged_kv_kernel.  grid (batch); qkv row = [hq | hkv | hkv] heads of d bf16.
+__global__ __launch_bounds__(256) void gqa_qkv_post_kernel(
+    bf16_e* __restrict__ qkv, int64_t row_stride, int hq, int hkv, int d, const float* __restrict__ cos,
+    const float* __restrict__ sin, int layout, bf16_e* __restrict__ k_cache, bf16_e* __restrict__ v_cache,
+    int64_t num_pages, int page_size, const int32_t* __restrict__ table, int pages_per_seq,
+    const int32_t* __restrict__ old_lens) {
+#pragma clang fp contract(off)
+    const int b = blockIdx.x, half = d >> 1;
+    bf16_e* row = qkv + (int64_t)b * row_stride;
+    int64_t dst_row = -1;
+    {
+        const int L = old_lens[b];
+        const int pidx = L / page_size;
+        if (L >= 0 && pidx < pages_per_seq) {
+            const int64_t page = table[(int64_t)b * pages_per_seq + pidx];
+            if (page >= 0 && page < num_pages) dst_row = (page * page_size + (L % page_size)) * (int64_t)hkv * d;
+        }
+    }
+    for (int idx = threadIdx.x; idx < (hq + hkv) * half; idx += 256) {
+        const int h = idx / half, i = idx % half;
+        const int i0 = layout == 0 ? 2 * i : i, i1 = layout == 0 ? 2 * i + 1 : i + half;
+        bf16_e* src = row + h * d;
+        const float x0 = ld_f32<bf16_e>(src + i0), x1 = ld_f32<bf16_e>(src + i1);
+        const float c = cos[(int64_t)b * half + i], s = sin[(int64_t)b * half + i];
+        const float r0 = x0 * c - x1 * s, r1 = x1 * c + x0 * s;
+        if (h < hq) {
+            st_f32(src + i0, r0);
+            st_f32(src + i1, r1);
+        } else if (dst_row >= 0) {
+            bf16_e* dst = k_cache + dst_row + (h - hq) * d;
+            st_f32(dst + i0, r0);
+            st_f32(dst + i1, r1);
+        }
+    }
+    if (dst_row >= 0) {
+        const bf16_e* vsrc = row + (hq + hkv) * d;
+        for (int idx = threadIdx.x; idx < hkv * d / 8; idx += 256)
+            *reinterpret_cast<i32x4*>(v_cache + dst_row + idx * 8) = *reinterpret_cast<const i32x4*>(vsrc + idx * 8);
+    }
+}
+
 // kv_norm(kv_c) + RoPE(k_pe) of one token written straight into its page row (waves 0 and 1 of a
 // workgroup); src = [kv_c (512) | k_pe (64)].
 __device__ __forceinline__ void mla_kv_row(int b, const bf16_t* src, const bf16_t* __restrict__ kv_norm_w, float kv_eps,
@@ -298,5 +343,23 @@ extern "C" int chitu_hip_mla_qkv_post(const void* qkv_a_bf16, int64_t row_stride
                        (const bf16_t*)qkv_a_bf16, row_stride, (int)q_lora_rank, (const bf16_t*)q_norm_weight_bf16, q_eps,
                        (fp8_t*)q_fp8, q_scales, (const bf16_t*)kv_norm_weight_bf16, kv_eps, cos, sin, (bf16_t*)kv_cache,
                        num_pages, (int)page_size, page_table, (int)pages_per_seq, old_seq_lens);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_gqa_qkv_post(void* qkv_bf16, int64_t row_stride, int32_t q_heads, int32_t kv_heads,
+                                      int32_t head_dim, const float* cos, const float* sin, int32_t layout,
+                                      void* k_cache, void* v_cache, int64_t num_pages, int32_t page_size,
+                                      const int32_t* page_table, int32_t pages_per_seq,
+                                      const int32_t* old_seq_lens, int32_t batch, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(qkv_bf16 && cos && sin && k_cache && v_cache && page_table && old_seq_lens);
+    CHITU_REQUIRE(batch >= 0 && q_heads >= 1 && kv_heads >= 1 && head_dim >= 8 && num_pages >= 1 && page_size >= 1);
+    CHITU_REQUIRE(pages_per_seq >= 1 && (layout == 0 || layout == 1));
+    if (head_dim % 8 != 0 || row_stride % 8 != 0 || row_stride < (int64_t)(q_heads + 2 * kv_heads) * head_dim)
+        return CHITU_ERR_UNSUPPORTED;
+    if (batch == 0) return CHITU_OK;
+    hipLaunchKernelGGL(gqa_qkv_post_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, (bf16_e*)qkv_bf16,
+                       row_stride, (int)q_heads, (int)kv_heads, (int)head_dim, cos, sin, (int)layout, (bf16_e*)k_cache,
+                       (bf16_e*)v_cache, num_pages, (int)page_size, page_table, (int)pages_per_seq, old_seq_lens);
     CHITU_RETURN_LAUNCH_STATUS();
 }

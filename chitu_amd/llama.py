@@ -5,8 +5,8 @@ Reference (read-only): chitu/models/model.py -- Attention:81-198 (decode_forward
 FeedForward:201-214, TransformerBlock, Transformer.decode:538-622; models/model_llama.py (merged
 wqkv / w13 layout of the original Meta checkpoints, rotary_type "llama" = interleaved pairs).
 
-Per layer and step, 10 launches: add+RMSNorm, wqkv GEMM, RoPE(q, k), append K, append V, paged GQA
-decode (+ merge when the KV range is split), wo GEMM, add+RMSNorm, w13 GEMM, SiluAndMul, w2 GEMM.
+Per layer and step, 8 launches: add+RMSNorm, wqkv GEMM, [RoPE(q, k) + append K, V], paged GQA decode
+(+ merge when the KV range is split), wo GEMM, add+RMSNorm, w13 GEMM, SiluAndMul, w2 GEMM.
 All GEMMs are the weight-streaming skinny bf16 kernel (gate.hip); the whole step replays as one hipGraph.
 """
 
@@ -67,13 +67,14 @@ class LlamaAttention(torch.nn.Module):
         """x = attn_norm(h) bf16 [bs, dim] -> wo(attention) before the all-reduce (model.py:167-198)."""
         bs = x.shape[0]
         qkv = ops.bf16_linear(x, self.wqkv).view(bs, self.hq + 2 * self.hkv, self.hd)
-        q, k = ops.apply_rotary_pos_emb(qkv[:, : self.hq], qkv[:, self.hq : self.hq + self.hkv], cos, sin, rotary_type="llama")
-        v = qkv[:, self.hq + self.hkv :]
         k_cache, v_cache = self.cache.get_paged_kv_cache(self.layer_id)
+        table = self.cache.get_gpu_block_table()
+        # RoPE(q, k) + append of k and v to their pages: one launch
+        q = ops.gqa_qkv_post(qkv, self.hq, self.hkv, cos, sin, k_cache, v_cache, table,
+                             self.cache.get_gpu_seq_lens_excl_this_decode(), rotary_type="llama")
         o = self.attn_backend.attn_with_kvcache(
-            q.view(bs, 1, self.hq, self.hd), k_cache, v_cache, k.view(bs, 1, self.hkv, self.hd),
-            v.reshape(bs, 1, self.hkv, self.hd), cache_seqlens=self.cache.get_gpu_seq_lens_excl_this_decode()[:bs],
-            block_table=self.cache.get_gpu_block_table()[:bs])
+            q.unsqueeze(1), k_cache, v_cache, None, None,
+            cache_seqlens=self.cache.get_gpu_seq_lens_incl_this_decode()[:bs], block_table=table[:bs])
         return ops.bf16_linear(o.view(bs, self.hq * self.hd), self.wo)
 
 

@@ -308,6 +308,27 @@ def bf16_linear(x: torch.Tensor, weight: torch.Tensor, out_dtype=None) -> torch.
     return out
 
 
+def gqa_qkv_post(qkv, q_heads, kv_heads, cos, sin, k_cache, v_cache, page_table, old_seq_lens, rotary_type="llama"):
+    """RoPE(q in place, k) + append of the rotated k and of v to their pages in one launch (GQA / MHA
+    decode).  qkv [bs, q_heads + 2*kv_heads, head_dim] bf16 (merged projection output); returns the q view."""
+    require_cuda(qkv, cos, sin, k_cache, v_cache, page_table, old_seq_lens)
+    assert qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.is_contiguous() and qkv.shape[1] == q_heads + 2 * kv_heads
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == v_cache.shape and k_cache.dtype == torch.bfloat16
+    assert tuple(k_cache.shape[2:]) == (kv_heads, qkv.shape[2]) and page_table.dtype == torch.int32 and page_table.stride(1) == 1
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and old_seq_lens.dtype == torch.int32
+    bs, _, d = qkv.shape
+    assert cos.shape == (bs, d // 2) and page_table.shape[0] >= bs and page_table.is_contiguous()
+    check(
+        _lib.lib().chitu_hip_gqa_qkv_post(
+            ptr(qkv), i64(qkv.stride(0)), i32(q_heads), i32(kv_heads), i32(d), ptr(cos), ptr(sin),
+            i32(0 if rotary_type == "llama" else 1), ptr(k_cache), ptr(v_cache), i64(k_cache.shape[0]), i32(k_cache.shape[1]),
+            ptr(page_table), i32(page_table.shape[1]), ptr(old_seq_lens), i32(bs), stream_ptr(),
+        ),
+        "gqa_qkv_post",
+    )
+    return qkv[:, :q_heads]
+
+
 def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     """silu(x[..., :d]) * x[..., d:] on bf16 (SiluAndMul, fused_moe.py:24-39; Llama's F.silu(w1 x) * w3 x)."""
     require_cuda(x)

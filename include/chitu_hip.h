@@ -157,6 +157,18 @@ int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_fp8, const 
 int chitu_hip_moe_sum(const void* c3_bf16, void* out_bf16, int64_t tokens, int32_t topk, int64_t N,
                       void* stream);
 
+/* ---- GQA / MHA decode: RoPE(q in place, k) + paged append of k and v in one launch ----------------
+ * Replaces apply_rotary_pos_emb (ops.py:311-326) + the two in-place appends of attn_with_kvcache
+ * (attn_backend.py:108-115) in Attention.decode_forward_paged (models/model.py:167-198), same arithmetic.
+ *   qkv [batch, q_heads + 2*kv_heads, head_dim] bf16 rows (row stride in elements): q heads rotated IN
+ *   PLACE; k heads rotated into k_cache, v heads copied into v_cache [num_pages, page_size, kv_heads, head_dim]
+ *   at row (page_table[b][L/page], L%page), L = old_seq_lens[b].  layout 0 = interleaved pairs, 1 = half-split. */
+int chitu_hip_gqa_qkv_post(void* qkv_bf16, int64_t row_stride, int32_t q_heads, int32_t kv_heads,
+                           int32_t head_dim, const float* cos, const float* sin, int32_t layout,
+                           void* k_cache, void* v_cache, int64_t num_pages, int32_t page_size,
+                           const int32_t* page_table, int32_t pages_per_seq, const int32_t* old_seq_lens,
+                           int32_t batch, void* stream);
+
 /* ---- SiluAndMul (unquantised MLPs: Llama FeedForward, models/model.py:212-214; fused_moe.py:24-39)
  *   out[r, :] = bf16( bf16(silu(x[r, :d])) * x[r, d:2d] ),  x [rows, 2d] bf16, out [rows, d] bf16, d % 8 == 0. */
 int chitu_hip_silu_and_mul(const void* x_bf16, void* out_bf16, int64_t rows, int64_t d, void* stream);

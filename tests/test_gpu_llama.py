@@ -92,3 +92,25 @@ def test_layerwise_parity_and_graph_replay(n_kv_heads):
         tokens = eager.argmax(dim=-1)
         cache.finalize_cache_single_decode(reqs)
     assert not torch.equal(outs[0], outs[1]) and len(model.graphs) == 1
+
+
+@pytest.mark.parametrize("rotary", ["llama", "hf-llama"])
+def test_qkv_post_equals_rope_plus_appends(rotary):
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    bs, hq, hkv, hd, pages = 5, 8, 2, 128, 12
+    qkv = torch.randn(bs, hq + 2 * hkv, hd, generator=g).to(torch.bfloat16).cuda()
+    cos, sin = torch.randn(bs, hd // 2, generator=g).cuda(), torch.randn(bs, hd // 2, generator=g).cuda()
+    kc = torch.randn(pages, 256, hkv, hd, generator=g).to(torch.bfloat16).cuda()
+    vc = torch.randn(pages, 256, hkv, hd, generator=g).to(torch.bfloat16).cuda()
+    table = torch.stack([torch.randperm(pages, generator=g)[:2] for _ in range(bs)]).to(torch.int32).cuda()
+    lens = torch.tensor([0, 255, 256, 300, 511], dtype=torch.int32).cuda()
+    q_ref, k_ref = ops.apply_rotary_pos_emb(qkv[:, :hq], qkv[:, hq : hq + hkv], cos, sin, rotary_type=rotary)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    ops.append_to_paged_kv_cache(kc_ref, table, k_ref.view(bs, 1, hkv, hd).contiguous(), lens)
+    ops.append_to_paged_kv_cache(vc_ref, table, qkv[:, hq + hkv :].reshape(bs, 1, hkv, hd).contiguous(), lens)
+    work = qkv.clone()
+    q = ops.gqa_qkv_post(work, hq, hkv, cos, sin, kc, vc, table, lens, rotary_type=rotary)
+    assert torch.equal(q, q_ref) and torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
+    assert torch.equal(work[:, hq:], qkv[:, hq:])  # k / v parts of the row untouched
