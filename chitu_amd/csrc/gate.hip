@@ -97,6 +97,130 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_kernel(const bf16_t* __rest
     gemm_epilogue_v2<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
 }
 
+// Gate/up projection of an unquantised SwiGLU MLP with SiluAndMul in the epilogue: W = [w1 | w3] rows
+// (2*inter x K); a wave owns gate tile [n0, n0+16) and up tile [inter+n0, inter+n0+16), shares the
+// activation fragments between them and writes h = bf16(bf16(silu(bf16(g))) * bf16(u)) -- FeedForward
+// (models/model.py:212-214: F.silu(w1 x) * w3 x, every torch op rounding once) in one launch.
+template <int MT>
+struct Bf16Stage2 {
+    s16x8 wg[2], wu[2];
+    s16x8 x[MT][2];
+};
+
+template <int MT, int WK>
+__global__ __launch_bounds__(64 * WK) void bf16_gemm_silu_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                                 bf16_t* __restrict__ out, int M, int inter, int K,
+                                                                 int m_base) {
+    __shared__ float red[WK > 1 ? WK * MT * 512 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int KB = K >> 6;
+    const int kb0 = KB * wave / WK, kb1 = KB * (wave + 1) / WK;
+    const int eoff = ((j & 1) * 4 + g) * 8;
+    const int r0 = min(n0 + (j >> 1), inter - 1), r1 = min(n0 + 8 + (j >> 1), inter - 1);
+    const bf16_t* gp0 = W + (size_t)r0 * K + eoff;
+    const bf16_t* gp1 = W + (size_t)r1 * K + eoff;
+    const bf16_t* up0 = W + (size_t)(inter + r0) * K + eoff;
+    const bf16_t* up1 = W + (size_t)(inter + r1) * K + eoff;
+    const bf16_t* xp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xp[mt] = X + (size_t)min(m_base + mt * 16 + j, M - 1) * K + g * 8;
+    f32x4 ge0[MT], go0[MT], ge1[MT], go1[MT], ue0[MT], uo0[MT], ue1[MT], uo1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        ge0[mt] = go0[mt] = ge1[mt] = go1[mt] = ue0[mt] = uo0[mt] = ue1[mt] = uo1[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto load = [&](Bf16Stage2<MT>& st, int kb) {
+        const int off = kb << 6;
+        st.wg[0] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(gp0 + off));
+        st.wg[1] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(gp1 + off));
+        st.wu[0] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(up0 + off));
+        st.wu[1] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(up1 + off));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            st.x[mt][0] = *reinterpret_cast<const s16x8*>(xp[mt] + off);
+            st.x[mt][1] = *reinterpret_cast<const s16x8*>(xp[mt] + off + 32);
+        }
+    };
+    auto compute = [&](const Bf16Stage2<MT>& st) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ge0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.wg[0], st.x[mt][0], ge0[mt], 0, 0, 0);
+            go0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.wg[0], st.x[mt][1], go0[mt], 0, 0, 0);
+            ge1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.wg[1], st.x[mt][0], ge1[mt], 0, 0, 0);
+            go1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.wg[1], st.x[mt][1], go1[mt], 0, 0, 0);
+            ue0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.wu[0], st.x[mt][0], ue0[mt], 0, 0, 0);
+            uo0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.wu[0], st.x[mt][1], uo0[mt], 0, 0, 0);
+            ue1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.wu[1], st.x[mt][0], ue1[mt], 0, 0, 0);
+            uo1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.wu[1], st.x[mt][1], uo1[mt], 0, 0, 0);
+        }
+    };
+    constexpr int D = MT >= 2 ? 2 : 3;
+    Bf16Stage2<MT> ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (kb0 + d < kb1) load(ring[d], kb0 + d);
+    for (int kb = kb0; kb < kb1; kb += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (kb + d < kb1) {
+                compute(ring[d]);
+                if (kb + d + D < kb1) load(ring[d], kb + d + D);
+            }
+        }
+    }
+    f32x4 ag[MT], au[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        ag[mt] = f32x4{ge0[mt][0] + go0[mt][1], ge0[mt][2] + go0[mt][3], ge1[mt][0] + go1[mt][1], ge1[mt][2] + go1[mt][3]};
+        au[mt] = f32x4{ue0[mt][0] + uo0[mt][1], ue0[mt][2] + uo0[mt][3], ue1[mt][0] + uo1[mt][1], ue1[mt][2] + uo1[mt][3]};
+    }
+    if (WK > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            *reinterpret_cast<f32x4*>(&red[((wave * MT + mt) * 128 + lane) * 4]) = ag[mt];
+            *reinterpret_cast<f32x4*>(&red[((wave * MT + mt) * 128 + 64 + lane) * 4]) = au[mt];
+        }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ag[mt] = au[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < WK; ++w) {
+                const f32x4 vg = *reinterpret_cast<const f32x4*>(&red[((w * MT + mt) * 128 + lane) * 4]);
+                const f32x4 vu = *reinterpret_cast<const f32x4*>(&red[((w * MT + mt) * 128 + 64 + lane) * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ag[mt][r] += vg[r];
+                    au[mt][r] += vu[r];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16 + j;
+        if (m >= M) continue;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int n = n0 + h2 * 8 + 2 * g;
+            float hv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float gv = round_bf16(ag[mt][2 * h2 + q]), uv = round_bf16(au[mt][2 * h2 + q]);
+                hv[q] = round_bf16(gv / (1.0f + expf(-gv))) * uv;
+            }
+            bf16_t* dst = out + (size_t)m * inter + n;
+            if (n + 1 < inter && (inter & 1) == 0) *reinterpret_cast<uint32_t*>(dst) = f32x2_to_bf16x2(hv[0], hv[1]);
+            else {
+                if (n < inter) dst[0] = f32_to_bf16(hv[0]);
+                if (n + 1 < inter) dst[1] = f32_to_bf16(hv[1]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- fused routing
 __device__ __forceinline__ float bf16r(float v) { return round_bf16(v); }
 
@@ -449,5 +573,36 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
                            (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
                            (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
                            out_ids, (int)out_stride, (int)extra_expert_id, extra_weight);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_bf16_gemm_silu(const void* x_bf16, const void* w13_bf16, void* out_bf16, int64_t M,
+                                        int64_t inter, int64_t K, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && w13_bf16 && out_bf16 && M >= 0 && inter >= 1 && K >= 64 && inter < (1 << 29) && K < (1 << 30));
+    if (K % 64 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (M == 0) return CHITU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int KB = (int)(K / 64);
+    const int tiles = (int)((inter + 15) / 16);
+    int WK = 8;
+    while (WK > 1 && (WK > KB || (int64_t)tiles * WK > 4096)) WK >>= 1;
+    const dim3 grid((unsigned)tiles);
+#define LAUNCHS(MT, WKV)                                                                                        \
+    hipLaunchKernelGGL((bf16_gemm_silu_kernel<MT, WKV>), grid, dim3(64 * WKV), 0, st, (const bf16_t*)x_bf16,    \
+                       (const bf16_t*)w13_bf16, (bf16_t*)out_bf16, (int)M, (int)inter, (int)K, mbase)
+#define LAUNCHS_WK(MT)                   \
+    switch (WK) {                        \
+        case 8: LAUNCHS(MT, 8); break;   \
+        case 4: LAUNCHS(MT, 4); break;   \
+        case 2: LAUNCHS(MT, 2); break;   \
+        default: LAUNCHS(MT, 1); break;  \
+    }
+    for (int64_t mb = 0; mb < M; mb += 32) {
+        const int mbase = (int)mb;
+        if (M - mb <= 16) { LAUNCHS_WK(1) } else { LAUNCHS_WK(2) }
+    }
+#undef LAUNCHS_WK
+#undef LAUNCHS
     CHITU_RETURN_LAUNCH_STATUS();
 }

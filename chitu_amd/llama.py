@@ -5,8 +5,8 @@ Reference (read-only): chitu/models/model.py -- Attention:81-198 (decode_forward
 FeedForward:201-214, TransformerBlock, Transformer.decode:538-622; models/model_llama.py (merged
 wqkv / w13 layout of the original Meta checkpoints, rotary_type "llama" = interleaved pairs).
 
-Per layer and step, 8 launches: add+RMSNorm, wqkv GEMM, [RoPE(q, k) + append K, V], paged GQA decode
-(+ merge when the KV range is split), wo GEMM, add+RMSNorm, w13 GEMM, SiluAndMul, w2 GEMM.
+Per layer and step, 7 launches: add+RMSNorm, wqkv GEMM, [RoPE(q, k) + append K, V], paged GQA decode
+(+ merge when the KV range is split), wo GEMM, add+RMSNorm, [w13 GEMM + SiluAndMul], w2 GEMM.
 All GEMMs are the weight-streaming skinny bf16 kernel (gate.hip); the whole step replays as one hipGraph.
 """
 
@@ -89,7 +89,7 @@ class LlamaFeedForward(torch.nn.Module):
         self.w2 = _param(args.dim, self.inter, device=device)
 
     def forward(self, x):
-        return ops.bf16_linear(ops.silu_and_mul(ops.bf16_linear(x, self.w13)), self.w2)
+        return ops.bf16_linear(ops.bf16_linear_silu(x, self.w13), self.w2)
 
 
 class LlamaBlock(torch.nn.Module):

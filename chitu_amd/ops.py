@@ -329,6 +329,19 @@ def gqa_qkv_post(qkv, q_heads, kv_heads, cos, sin, k_cache, v_cache, page_table,
     return qkv[:, :q_heads]
 
 
+def bf16_linear_silu(x: torch.Tensor, w13: torch.Tensor) -> torch.Tensor:
+    """silu(x w1^T) * (x w3^T) for w13 = [w1; w3] (bf16), one launch: == silu_and_mul(bf16_linear(x, w13))."""
+    require_cuda(x, w13)
+    assert x.dtype == torch.bfloat16 and w13.dtype == torch.bfloat16 and x.is_contiguous() and w13.is_contiguous()
+    K = x.shape[-1]
+    inter = w13.shape[0] // 2
+    assert w13.shape[0] == 2 * inter and w13.shape[1] == K
+    out = torch.empty(*x.shape[:-1], inter, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().chitu_hip_bf16_gemm_silu(ptr(x), ptr(w13), ptr(out), i64(x.numel() // K), i64(inter), i64(K), stream_ptr()),
+          "bf16_linear_silu")
+    return out
+
+
 def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     """silu(x[..., :d]) * x[..., d:] on bf16 (SiluAndMul, fused_moe.py:24-39; Llama's F.silu(w1 x) * w3 x)."""
     require_cuda(x)

@@ -169,6 +169,12 @@ int chitu_hip_gqa_qkv_post(void* qkv_bf16, int64_t row_stride, int32_t q_heads, 
                            const int32_t* page_table, int32_t pages_per_seq, const int32_t* old_seq_lens,
                            int32_t batch, void* stream);
 
+/* Gate/up projection of an unquantised SwiGLU MLP with SiluAndMul in the epilogue (FeedForward,
+ * models/model.py:212-214): out[m, n] = bf16( bf16(silu(bf16(x[m] . w13[n]))) * bf16(x[m] . w13[inter + n]) ),
+ * x [M, K] bf16, w13 [2*inter, K] bf16 (w1 rows then w3 rows), out [M, inter] bf16; K % 64 == 0. */
+int chitu_hip_bf16_gemm_silu(const void* x_bf16, const void* w13_bf16, void* out_bf16, int64_t M, int64_t inter,
+                             int64_t K, void* stream);
+
 /* ---- SiluAndMul (unquantised MLPs: Llama FeedForward, models/model.py:212-214; fused_moe.py:24-39)
  *   out[r, :] = bf16( bf16(silu(x[r, :d])) * x[r, d:2d] ),  x [rows, 2d] bf16, out [rows, d] bf16, d % 8 == 0. */
 int chitu_hip_silu_and_mul(const void* x_bf16, void* out_bf16, int64_t rows, int64_t d, void* stream);

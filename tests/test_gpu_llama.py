@@ -114,3 +114,20 @@ def test_qkv_post_equals_rope_plus_appends(rotary):
     q = ops.gqa_qkv_post(work, hq, hkv, cos, sin, kc, vc, table, lens, rotary_type=rotary)
     assert torch.equal(q, q_ref) and torch.equal(kc, kc_ref) and torch.equal(vc, vc_ref)
     assert torch.equal(work[:, hq:], qkv[:, hq:])  # k / v parts of the row untouched
+
+
+@pytest.mark.parametrize("M,inter,K", [(1, 14336, 4096), (16, 14336, 4096), (20, 2048, 1024), (3, 1000, 512), (33, 256, 256)])
+def test_gate_up_gemm_with_silu_epilogue_equals_gemm_then_silu(M, inter, K):
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(M + inter)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w13 = (torch.randn(2 * inter, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+    ref = ops.silu_and_mul(ops.bf16_linear(x, w13))
+    out = ops.bf16_linear_silu(x, w13)
+    # same arithmetic; the K range may be split over a different number of waves (fp32 summation order),
+    # so equality is up to the last bf16 bit of a few elements
+    assert max_rel_to_peak(out, ref) < 4e-3 and (out != ref).float().mean() < 0.05
+    h13 = torch.nn.functional.linear(x.cpu().float(), w13.cpu().float()).to(torch.bfloat16)
+    cpu = torch.nn.functional.silu(h13[:, :inter]) * h13[:, inter:]
+    assert max_rel_to_peak(out, cpu) < 1e-2
