@@ -171,12 +171,19 @@ class AttentionDeepSeekV3(torch.nn.Module):
         self.qk_nope_head_dim, self.qk_rope_head_dim = args.qk_nope_head_dim, args.qk_rope_head_dim
         self.qk_head_dim = args.qk_nope_head_dim + args.qk_rope_head_dim
         self.v_head_dim = args.v_head_dim
-        assert self.q_lora_rank > 0 and self.q_lora_rank % BLOCK == 0  # model_deepseek_v3.py:423,477
+        assert self.q_lora_rank % BLOCK == 0
         assert self.qk_nope_head_dim == BLOCK and self.v_head_dim == BLOCK, "wkv_b head halves = one 128 block each"
         H = self.n_local_heads
-        self.wqkv_a = Fp8Linear(args.dim, self.q_lora_rank + self.kv_lora_rank + self.qk_rope_head_dim, device)
-        self.q_norm = RMSNormW(self.q_lora_rank, args.norm_eps, device)
-        self.wq_b = Fp8Linear(self.q_lora_rank, H * self.qk_head_dim, device)
+        if self.q_lora_rank > 0:
+            self.wqkv_a = Fp8Linear(args.dim, self.q_lora_rank + self.kv_lora_rank + self.qk_rope_head_dim, device)
+            self.q_norm = RMSNormW(self.q_lora_rank, args.norm_eps, device)
+            self.wq_b = Fp8Linear(self.q_lora_rank, H * self.qk_head_dim, device)
+        else:
+            # DeepSeek-V2-Lite (BASELINE config 3): no q low-rank path.  The reference's loader already maps
+            # q_proj -> wq (backend.py:460) but its attention asserts q_lora_rank > 0 (model_deepseek_v3.py:477,
+            # SURVEY gap G1); here wq and wkv_a are one merged GEMM [wq (H*192) | wkv_a (576)], the reference's
+            # own merge pattern for wqkv_a.
+            self.wq_kv_a = Fp8Linear(args.dim, H * self.qk_head_dim + self.kv_lora_rank + self.qk_rope_head_dim, device)
         self.kv_norm = RMSNormW(self.kv_lora_rank, args.norm_eps, device)
         self.wkv_b = Fp8Linear(self.kv_lora_rank, H * (self.qk_nope_head_dim + self.v_head_dim), device)
         self.wo = Fp8Linear(H * self.v_head_dim, args.dim, device)
@@ -201,18 +208,27 @@ class AttentionDeepSeekV3(torch.nn.Module):
         H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
         bs = x_quant[0].shape[0]
         cache = self.cache
-        q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [bs, q_lora + C + R]
         kv_cache = cache.get_paged_kv_cache(self.layer_id)
-        # q_norm + quant, and this token's [kv_norm(kv_c) | rope(k_pe)] row straight into its page
-        qq, qs = ops.mla_qkv_post(q_a_kv, self.q_lora_rank, self.q_norm.weight, self.q_norm.eps, self.kv_norm.weight,
-                                  self.kv_norm.eps, cos, sin, kv_cache, cache.get_gpu_block_table(),
-                                  cache.get_gpu_seq_lens_excl_this_decode())
-        q = self.wq_b(None, x_quant=(qq, qs)).view(bs, H, self.qk_head_dim)
-        q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
-        # q_nope' = q_nope . W_UK  (einsum "shd,hdc->shc", :529-531), wkv_b dequantised in registers;
-        # q_pe rotated in place by the same launch
         nblk = C // BLOCK
-        q_abs = ops.absorb_bmm_rope_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0, q_pe, cos, sin)
+        if self.q_lora_rank > 0:
+            q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [bs, q_lora + C + R]
+            # q_norm + quant, and this token's [kv_norm(kv_c) | rope(k_pe)] row straight into its page
+            qq, qs = ops.mla_qkv_post(q_a_kv, self.q_lora_rank, self.q_norm.weight, self.q_norm.eps, self.kv_norm.weight,
+                                      self.kv_norm.eps, cos, sin, kv_cache, cache.get_gpu_block_table(),
+                                      cache.get_gpu_seq_lens_excl_this_decode())
+            q = self.wq_b(None, x_quant=(qq, qs)).view(bs, H, self.qk_head_dim)
+            q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
+            # q_nope' = q_nope . W_UK  (einsum "shd,hdc->shc", :529-531), wkv_b dequantised in registers;
+            # q_pe rotated in place by the same launch
+            q_abs = ops.absorb_bmm_rope_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0, q_pe, cos, sin)
+        else:
+            q_kv = self.wq_kv_a(None, x_quant=x_quant)  # [bs, H*192 + C + R]
+            nq = H * self.qk_head_dim
+            q = q_kv[:, :nq].view(bs, H, self.qk_head_dim)
+            q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
+            ops.mla_kv_prep(q_kv[:, nq:], q_pe, cos, sin, self.kv_norm.weight, self.kv_norm.eps, kv_cache,
+                            cache.get_gpu_block_table(), cache.get_gpu_seq_lens_excl_this_decode())
+            q_abs = ops.absorb_bmm_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0)
         # small batches: the split-KV merge runs inside the W_UV projection kernel
         fuse_merge = bs <= 32 and C == 512
         o = self.attn_backend.mla_decode(q_abs, q_pe, kv_cache, cache.get_gpu_seq_lens_incl_this_decode(),
@@ -233,10 +249,15 @@ class AttentionDeepSeekV3(torch.nn.Module):
         (prefill is outside the decode hot path; SURVEY 8f.1 first cut)."""
         H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
         T = x_quant[0].shape[0]
-        q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [T, q_lora + C + R]
-        ql = self.q_lora_rank
-        _, qq, qs = ops.rms_norm(q_a_kv[:, :ql], self.q_norm.weight, self.q_norm.eps, out_bf16=False, quant="act")
-        q = self.wq_b(None, x_quant=(qq, qs)).view(T, H, self.qk_head_dim)
+        if self.q_lora_rank > 0:
+            q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [T, q_lora + C + R]
+            ql = self.q_lora_rank
+            _, qq, qs = ops.rms_norm(q_a_kv[:, :ql], self.q_norm.weight, self.q_norm.eps, out_bf16=False, quant="act")
+            q = self.wq_b(None, x_quant=(qq, qs)).view(T, H, self.qk_head_dim)
+        else:
+            q_a_kv = self.wq_kv_a(None, x_quant=x_quant)  # [T, H*192 + C + R]
+            ql = H * self.qk_head_dim
+            q = q_a_kv[:, :ql].view(T, H, self.qk_head_dim)
         q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
         kv_c = ops.rms_norm(q_a_kv[:, ql : ql + C], self.kv_norm.weight, self.kv_norm.eps)
         q_pe, k_pe = ops.apply_rotary_pos_emb(q_pe, q_a_kv[:, ql + C :], cos, sin, rotary_type="llama")

@@ -57,10 +57,14 @@ def attention_decode(p, pre, x, cos, sin, cache_layer, block_table, lens_excl, c
     """Returns (wo output [bs, dim], updated cache layer)."""
     H, C, R, NOPE, V, QL = cfg["H"], cfg["C"], cfg["R"], cfg["NOPE"], cfg["V"], cfg["QL"]
     bs = x.shape[0]
-    q_a_kv = fp8.linear_deepseek_v3(x, p[pre + "wqkv_a.weight"], p[pre + "wqkv_a.scale"])
-    q_a, kvr = q_a_kv[:, :QL], q_a_kv[:, QL:]
-    q = fp8.linear_deepseek_v3(rms_norm(q_a, p[pre + "q_norm.weight"], cfg["eps"]), p[pre + "wq_b.weight"], p[pre + "wq_b.scale"])
-    q = q.view(bs, H, NOPE + R)
+    if QL > 0:
+        q_a_kv = fp8.linear_deepseek_v3(x, p[pre + "wqkv_a.weight"], p[pre + "wqkv_a.scale"])
+        q_a, kvr = q_a_kv[:, :QL], q_a_kv[:, QL:]
+        q = fp8.linear_deepseek_v3(rms_norm(q_a, p[pre + "q_norm.weight"], cfg["eps"]), p[pre + "wq_b.weight"], p[pre + "wq_b.scale"])
+    else:  # q_lora_rank == 0 (DeepSeek-V2-Lite): q = wq(x) (model_deepseek_v3.py:423-432), merged with wkv_a
+        q_kv = fp8.linear_deepseek_v3(x, p[pre + "wq_kv_a.weight"], p[pre + "wq_kv_a.scale"])
+        q, kvr = q_kv[:, : H * (NOPE + R)], q_kv[:, H * (NOPE + R) :]
+    q = q.reshape(bs, H, NOPE + R)
     q_nope, q_pe = q[..., :NOPE], q[..., NOPE:]
     kv_c, k_pe = kvr[:, :C], kvr[:, C:]
     q_pe, k_pe = kv.apply_rotary_pos_emb(q_pe, k_pe, cos, sin, "llama")

@@ -26,13 +26,14 @@ def tiny_args():
 def v2lite_like_args():
     """Structure of BASELINE config 3 (DeepSeek-V2-Lite) at test size: softmax scores, one
     expert group, no gate bias, TWO shared experts, top-6, moe_inter = 5 K-blocks (generic GEMM2 and
-    the three-launch expert path); q_lora_rank > 0 as the reference's attention requires (:477)."""
+    the three-launch expert path), q_lora_rank = 0 (q = wq(x): the branch the reference's loader prepares,
+    backend.py:460, but its attention asserts away, model_deepseek_v3.py:477 -- SURVEY gap G1)."""
     from chitu_amd.deepseek_v3 import DeepSeekV3Args
 
     return DeepSeekV3Args(
         vocab_size=1024, dim=512, inter_dim=1024, moe_inter_dim=640, n_layers=3, n_dense_layers=1, n_heads=16,
         n_routed_experts=16, n_shared_experts=2, n_activated_experts=6, n_expert_groups=1, n_limited_groups=1,
-        q_lora_rank=256, gate_bias=False, score_func="softmax", route_scale=1.0,
+        q_lora_rank=0, gate_bias=False, score_func="softmax", route_scale=1.0,
     )
 
 
