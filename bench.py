@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-llama", action="store_true", help="skip the extra Llama-3-8B (BASELINE config 2) measurement")
+    ap.add_argument("--no-llama", action="store_true", help="skip the extra Llama-3-8B / DeepSeek-V2-Lite (BASELINE configs 2, 3) measurements")
     return ap.parse_args()
 
 
@@ -365,6 +365,35 @@ def llama3_8b_extra(steps, warmup, ctx):
     return out
 
 
+def v2_lite_extra(steps, warmup, ctx):
+    """BASELINE config 3 as an extra line: DeepSeek-V2-Lite shapes (dim 2048, 27 layers, 16 heads, q_lora 0,
+    64 routed + 2 shared experts, top-6, softmax router), FP8 block-scaled synthetic weights, TP=1, absorb."""
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args, DeepSeekV3Decoder, init_synthetic_
+
+    # inter_dim of the one dense layer: 10944 in the checkpoint, not a multiple of the 128 FP8 block (the
+    # reference's act_quant asserts on it, ops.py:345-348); rounded up to 11008 for this synthetic run
+    args = DeepSeekV3Args(vocab_size=102400, dim=2048, inter_dim=11008, moe_inter_dim=1408, n_layers=27, n_dense_layers=1,
+                          n_heads=16, n_routed_experts=64, n_shared_experts=2, n_activated_experts=6, n_expert_groups=1,
+                          n_limited_groups=1, route_scale=1.0, score_func="softmax", q_lora_rank=0, gate_bias=False,
+                          shard_degree=1)
+    max_seq = ctx + steps + warmup + 256
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=16, block_size=64, max_seq_len=max_seq, device="cuda",
+                                kv_shape_per_sample=(576,), dtype=torch.bfloat16)
+    model = DeepSeekV3Decoder(args, cache, HipAttnBackend(local_n_heads=16, max_seq_len=max_seq),
+                              max_position_embeddings=max(max_seq, 4097), device="cuda")
+    init_synthetic_(model, seed=5)
+    cache.paged_kv_cache.normal_(0, 0.5)
+    out = {"model": "DeepSeek-V2-Lite shapes, FP8 block-scaled weights, TP=1, MLA absorb, hipGraph, synthetic weights"}
+    for bs in (1, 16):
+        dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"v{bs}_")
+        out[f"bs{bs}"] = {"ms_per_step": round(dt / steps * 1e3, 4), "tok_s": round(bs * steps / dt, 1)}
+    del model, cache
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     rank, world, local = setup_dist(a.gpus)
@@ -422,6 +451,7 @@ def main():
         model = cache = None
         torch.cuda.empty_cache()
         extra["llama3_8b"] = llama3_8b_extra(a.steps, a.warmup, a.ctx)
+        extra["v2_lite"] = v2_lite_extra(a.steps, a.warmup, a.ctx)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         model = cache = None
