@@ -9,6 +9,7 @@ the KV split count from the batch (graph-static) and keeps a persistent scratch 
 """
 
 import ctypes
+import os
 from typing import Optional, Union
 
 import torch
@@ -182,12 +183,12 @@ class HipAttnBackend(AttnBackend):
         q [T, H, C+R], k [T, 1, C+R] = [kv_norm(kv_c) | rope(k_pe)], v [T, 1, C] = the latent part of k
         (the MLA identity -- v is NOT read, k[..., :C] is used), cu_seqlens_q == cu_seqlens_k.
 
-        First cut of SURVEY 8f.1, built from the decode kernel only: the keys are staged once into
-        64-token pages and every query token runs as one decode "sequence" of length pos+1 over its own
-        sequence's pages (chitu_hip_mla_decode).  Exact causal attention with the decode path's
-        numerics; KV is re-read once per query token, which is fine for prompts of a few hundred tokens
-        and the reason a tiled prefill kernel is the next step.  No host sync; not graph-captured
-        (prefill never is, model.py:538-546)."""
+        chitu_hip_mla_prefill: the decode kernel's tile machinery with four query tokens per workgroup
+        sharing every staged 64-key tile; per query token the arithmetic is the decode step's, so prefill
+        and token-by-token decode agree.  CHITU_MLA_PREFILL=compose selects the kernel-free composition
+        instead (keys staged into 64-token pages, every query token run as one decode "sequence" over
+        them) -- the same result bit for bit, KV re-read once per token; kept as the cross-check.
+        No host sync; not graph-captured (prefill never is, model.py:538-546)."""
         assert causal and dropout_p == 0.0 and tuple(window_size) == (-1, -1) and softcap == 0.0
         require_cuda(q, k, cu_seqlens_q, cu_seqlens_k)
         T, H, Dq = q.shape
@@ -201,6 +202,22 @@ class HipAttnBackend(AttnBackend):
         if T == 0:
             return q.new_empty(0, H, C)
         dev = q.device
+        if os.environ.get("CHITU_MLA_PREFILL", "kernel") != "compose":
+            kq = q if (q.stride(-1) == 1 and q.stride(0) % 8 == 0 and q.stride(1) % 8 == 0 and q.data_ptr() % 16 == 0) else q.contiguous()
+            kk = k.reshape(T, Dq)
+            if not (kk.stride(-1) == 1 and kk.stride(0) % 8 == 0 and kk.data_ptr() % 16 == 0):
+                kk = kk.contiguous()
+            cu32 = cu_seqlens_k.to(device=dev, dtype=torch.int32).contiguous()
+            out = torch.empty(T, H, C, dtype=torch.bfloat16, device=dev)
+            check(
+                _lib.lib().chitu_hip_mla_prefill(
+                    ptr(kq), i64(kq.stride(0)), i64(kq.stride(1)), ptr(kk), i64(kk.stride(0)), ptr(cu32),
+                    i32(cu32.numel() - 1), i32(int(max_seqlen_k)), f32(softmax_scale), ptr(out), i32(H), i32(C), i32(R),
+                    stream_ptr(),
+                ),
+                "mla_prefill",
+            )
+            return out
         page = 64
         n_seq = cu_seqlens_k.numel() - 1
         cu = cu_seqlens_k.to(device=dev, dtype=torch.long)
@@ -220,7 +237,7 @@ class HipAttnBackend(AttnBackend):
         for t0 in range(0, T, step):
             t1 = min(T, t0 + step)
             self.mla_decode(q[t0:t1, :, :C], q[t0:t1, :, C:], staged, lens[t0:t1].contiguous(), table[t0:t1].contiguous(),
-                            softmax_scale, out=out[t0:t1])
+                            softmax_scale, num_splits=1, out=out[t0:t1])
         return out
 
     # ------------------------------------------------------------------ non-MLA (GQA / MHA) paged decode

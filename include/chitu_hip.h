@@ -215,6 +215,17 @@ int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int64_t qn_str
                          int32_t kv_lora_rank, int32_t rope_dim, int32_t num_splits,
                          void* workspace, int64_t workspace_bytes, void* stream);
 
+/* MLA absorb-mode causal prefill attention (MQA, head dims 576 / 512): the attn_varlen_func call of
+ * AttentionDeepSeekV3.prefill_forward (chitu/models/model_deepseek_v3.py:589-599; chitu/attn_backend.py:39-90).
+ *   out[t,h,:] = softmax over keys s <= t of the same sequence ( scale * q[t,h,:] . kv[s,:] ) . kv[s,:512]
+ *   q [T, heads, 576] bf16 (token / head strides in elements, multiples of 8); kv [T, 576] bf16 (row stride);
+ *   cu_seqlens [n_seq + 1] i32 (device); max_seqlen bounds the grid; out [T, heads, 512] bf16 contiguous.
+ * Per query token the arithmetic and its order are chitu_hip_mla_decode's with num_splits = 1. */
+int chitu_hip_mla_prefill(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
+                          int64_t kv_stride_t, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
+                          float softmax_scale, void* out_bf16, int32_t heads, int32_t kv_lora_rank,
+                          int32_t rope_dim, void* stream);
+
 /* Split-KV merge + W_UV projection (model_deepseek_v3.py:697) + act_quant of wo's input in one
  * launch, for small batches (one workgroup per (head, token)): the same arithmetic and rounding
  * points as chitu_hip_mla_decode's merge pass followed by chitu_hip_absorb_uv_quant_fp8.

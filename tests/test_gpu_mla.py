@@ -198,3 +198,26 @@ def test_prefill_varlen_matches_reference_fixture_and_oracle():
                           torch.tensor([n], dtype=torch.int32).cuda(), torch.arange(pages, dtype=torch.int32).view(1, -1).cuda(),
                           0.1352, num_splits=1)
         assert max_rel_to_peak(o.cpu(), out[s1 - 1 : s1]) < 2e-3
+
+
+def test_prefill_kernel_equals_per_token_decode_composition(monkeypatch):
+    """chitu_hip_mla_prefill (four query tokens per workgroup share each staged tile) is bit-identical to
+    running every prompt token through the decode kernel over staged pages -- ragged batch, sequence
+    lengths around the 4-token block and the 64-key tile edges, 16 and 32 heads."""
+    from chitu_amd.attn_backend import HipAttnBackend
+
+    g = torch.Generator().manual_seed(31)
+    for H, seqs in ((16, [1, 2, 3, 4, 5, 63, 64, 65, 66, 127, 128, 129, 300]), (32, [7, 200]), (8, [70])):
+        T = sum(seqs)
+        cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32).cuda()
+        q = (torch.randn(T, H, 576, generator=g) * 0.3).to(torch.bfloat16).cuda()
+        kv = torch.randn(T, 1, 576, generator=g).to(torch.bfloat16).cuda()
+        be = HipAttnBackend(local_n_heads=H)
+        outs = {}
+        for mode in ("kernel", "compose"):
+            monkeypatch.setenv("CHITU_MLA_PREFILL", mode)
+            outs[mode] = be.attn_varlen_func(q, kv, kv[..., :512].contiguous(), cu, cu, max(seqs), max(seqs), causal=True,
+                                             softmax_scale=0.1352)
+        assert torch.equal(outs["kernel"], outs["compose"]), (H, seqs)
+        ref = omla.mla_prefill(q.cpu(), kv.cpu()[:, 0], cu.cpu(), 0.1352)
+        assert max_rel_to_peak(outs["kernel"].cpu(), ref) < REL_TOL
