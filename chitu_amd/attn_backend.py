@@ -193,6 +193,8 @@ class HipAttnBackend(AttnBackend):
         require_cuda(q, k, cu_seqlens_q, cu_seqlens_k)
         T, H, Dq = q.shape
         C, R = self.kv_lora_rank, self.qk_rope_head_dim
+        if Dq == 128 and k.dim() == 3 and k.shape[-1] == 128 and tuple(v.shape) == tuple(k.shape):
+            return self._gqa_varlen_causal(q, k, v, cu_seqlens_k, int(max_seqlen_k), softmax_scale)
         assert Dq == C + R and tuple(k.shape) == (T, 1, Dq) and v.shape[0] == T and v.shape[-1] == C, \
             "only the MLA absorb-mode MQA shape (q/k 576, v 512) is implemented"
         assert cu_seqlens_q.shape == cu_seqlens_k.shape and max_seqlen_q == max_seqlen_k
@@ -238,6 +240,42 @@ class HipAttnBackend(AttnBackend):
             t1 = min(T, t0 + step)
             self.mla_decode(q[t0:t1, :, :C], q[t0:t1, :, C:], staged, lens[t0:t1].contiguous(), table[t0:t1].contiguous(),
                             softmax_scale, num_splits=1, out=out[t0:t1])
+        return out
+
+    def _gqa_varlen_causal(self, q, k, v, cu_seqlens, max_seqlen, softmax_scale):
+        """Causal GQA / MHA prefill attention (Attention.prefill_forward, models/model.py:104-132), head_dim 128:
+        q [T, Hq, 128], k / v [T, Hkv, 128].  First cut, built from the decode kernel: keys / values are staged
+        once into 256-token pages and every query token runs as one decode "sequence" of length pos + 1 over
+        its own sequence's pages (chitu_hip_gqa_decode) -- exact causal attention with the decode numerics,
+        KV re-read once per query token (fine for prompts of a few hundred tokens; no host sync)."""
+        T, Hq, D = q.shape
+        Hkv = k.shape[1]
+        if T == 0:
+            return q.new_empty(0, Hq, D)
+        dev = q.device
+        page = 256
+        n_seq = cu_seqlens.numel() - 1
+        cu = cu_seqlens.to(device=dev, dtype=torch.long)
+        pos = torch.arange(T, device=dev)
+        seq = torch.searchsorted(cu[1:].contiguous(), pos, right=True).clamp_(max=n_seq - 1)
+        off = pos - cu[seq]
+        pages_per = (cu[1:] - cu[:-1] + page - 1) // page
+        base = torch.cumsum(pages_per, 0) - pages_per
+        num_pages = T // page + n_seq + 1
+        max_pages = max(1, (max_seqlen + page - 1) // page)
+        dst = base[seq] * page + off
+        k_pages = torch.zeros(num_pages, page, Hkv, D, dtype=torch.bfloat16, device=dev)
+        v_pages = torch.zeros(num_pages, page, Hkv, D, dtype=torch.bfloat16, device=dev)
+        k_pages.view(-1, Hkv, D).index_copy_(0, dst, k.reshape(T, Hkv, D))
+        v_pages.view(-1, Hkv, D).index_copy_(0, dst, v.reshape(T, Hkv, D))
+        table = (base[seq].unsqueeze(1) + torch.arange(max_pages, device=dev)).clamp_(max=num_pages - 1).to(torch.int32)
+        lens = (off + 1).to(torch.int32)
+        out = torch.empty(T, Hq, D, dtype=torch.bfloat16, device=dev)
+        step = 16384
+        for t0 in range(0, T, step):
+            t1 = min(T, t0 + step)
+            out[t0:t1] = self.attn_with_kvcache(q[t0:t1].unsqueeze(1), k_pages, v_pages, None, None, cache_seqlens=lens[t0:t1].contiguous(),
+                                                block_table=table[t0:t1].contiguous(), softmax_scale=softmax_scale).view(t1 - t0, Hq, D)
         return out
 
     # ------------------------------------------------------------------ non-MLA (GQA / MHA) paged decode

@@ -78,6 +78,19 @@ class LlamaAttention(torch.nn.Module):
         return ops.bf16_linear(o.view(bs, self.hq * self.hd), self.wo)
 
 
+    def prefill_forward(self, x, cos, sin, varlens):
+        """models/model.py:104-132: projections on all T prompt tokens, RoPE, page writes by the cache
+        manager (cache_manager.py:93-142), causal GQA through attn_backend.attn_varlen_func."""
+        T = x.shape[0]
+        qkv = ops.bf16_linear(x, self.wqkv).view(T, self.hq + 2 * self.hkv, self.hd)
+        q, k = ops.apply_rotary_pos_emb(qkv[:, : self.hq], qkv[:, self.hq : self.hq + self.hkv], cos, sin, rotary_type="llama")
+        v = qkv[:, self.hq + self.hkv :].contiguous()
+        self.cache.finalize_cache_bylayer_prefill(k, v, self.cache.curr_req_ids, self.cache.curr_varlens, self.layer_id)
+        o = self.attn_backend.attn_varlen_func(q, k, v, varlens.prefix_lens, varlens.prefix_lens, varlens.max_len,
+                                               varlens.max_len, causal=True)
+        return ops.bf16_linear(o.reshape(T, self.hq * self.hd), self.wo)
+
+
 class LlamaFeedForward(torch.nn.Module):
     """w2(silu(w1 x) * w3 x) with w1 / w3 merged row-wise (model.py:201-214)."""
 
@@ -101,13 +114,17 @@ class LlamaBlock(torch.nn.Module):
         self.ffn_norm = _param(args.dim, device=device)
         self.eps = args.norm_eps
 
-    def forward(self, x, pending, cos, sin):
-        """(x, pending) -> (x', pending'): residual adds folded into the RMSNorm that consumes them."""
+    def forward(self, x, pending, cos, sin, varlens=None):
+        """(x, pending) -> (x', pending'): residual adds folded into the RMSNorm that consumes them;
+        varlens given = prefill."""
         if pending is None:
             hn = ops.rms_norm(x, self.attn_norm, self.eps)
         else:
             x, hn = ops.rms_norm(x, self.attn_norm, self.eps, add=pending)
-        a = tp.all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+        if varlens is None:
+            a = tp.all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+        else:
+            a = tp.all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
         x, hn = ops.rms_norm(x, self.ffn_norm, self.eps, add=a)
         return x, tp.all_reduce(self.ffn(hn))
 
@@ -139,6 +156,40 @@ class LlamaDecoder(torch.nn.Module):
         mask = (local < 0) | (local >= self.vocab_local)
         y = F.embedding(torch.where(mask, torch.zeros_like(local), local), self.embed_weight)
         return tp.all_reduce(torch.where(mask.unsqueeze(-1), torch.zeros_like(y), y))
+
+    @torch.inference_mode()
+    def prefill(self, tokens, req_ids):
+        """Ragged prompts -> fp32 logits [n_req, vocab] of each prompt's last token; fills the KV pages
+        (prefill_single_device, model.py:451-465)."""
+        from .deepseek_v3 import VarLens
+
+        varlens = VarLens(tokens, self.device)
+        self.cache.curr_varlens, self.cache.curr_req_ids = varlens, list(req_ids)
+        flat = torch.tensor([t for seq in tokens for t in seq], dtype=torch.int64, device=self.device)
+        cos, sin = self.cos_table[varlens.position_ids], self.sin_table[varlens.position_ids]
+        h, pending = self.embed(flat), None
+        for layer in self.layers:
+            h, pending = layer(h, pending, cos, sin, varlens)
+        last = torch.tensor([p - 1 for p in varlens.cpu_prefix_lens[1:]], dtype=torch.int64, device=self.device)
+        h = ops.rms_norm(h[last], self.norm, self.args.norm_eps, add=pending[last].contiguous())[1]
+        self.cache.finalize_cache_all_prefill(req_ids, varlens)
+        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()
+
+    @torch.inference_mode()
+    def generate(self, prompts, max_new_tokens, req_ids=None, use_graph=True):
+        """Greedy generation: prefill, then max_new_tokens - 1 decode steps; returns [n_req, max_new_tokens]."""
+        req_ids = [f"gen{i}" for i in range(len(prompts))] if req_ids is None else list(req_ids)
+        tok = self.prefill(prompts, req_ids).argmax(dim=-1)
+        out = [tok]
+        for _ in range(max_new_tokens - 1):
+            self.cache.prepare_cache_decode(req_ids)
+            self.cache.prepare_block_table_for_decode(req_ids)
+            tok = self.decode(tok, use_graph=use_graph).argmax(dim=-1)
+            self.cache.finalize_cache_single_decode(req_ids)
+            out.append(tok.clone())
+        for r in req_ids:
+            self.cache.finalize_cache_all_decode(r)
+        return torch.stack(out, dim=1)
 
     def decode_eager(self, tokens):
         bs = tokens.shape[0]

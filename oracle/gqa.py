@@ -42,3 +42,22 @@ def attn_with_kvcache(q, k_cache, v_cache, k, v, cache_seqlens, block_table, sof
             p = torch.softmax(s, dim=0)
             out[b, 0, h] = p @ V[:, h // g]
     return out, k_cache, v_cache
+
+
+def attn_varlen_causal(q, k, v, cu_seqlens, softmax_scale=None):
+    """Causal GQA self-attention per sequence (Attention.prefill_forward, models/model.py:104-132, with
+    RefAttnBackend._attention's math): q [T, Hq, D], k / v [T, Hkv, D] -> [T, Hq, D] fp32.
+    Pinned by tests/golden/gqa_prefill.npz (RefAttnBackend.attn_varlen_func run in the build container)."""
+    T, Hq, D = q.shape
+    g = Hq // k.shape[1]
+    scale = softmax_scale if softmax_scale is not None else D ** -0.5
+    out = torch.zeros(T, Hq, D, dtype=torch.float32)
+    cu = [int(c) for c in cu_seqlens]
+    for s0, s1 in zip(cu[:-1], cu[1:]):
+        n = s1 - s0
+        kk = k[s0:s1].float().repeat_interleave(g, dim=1)
+        vv = v[s0:s1].float().repeat_interleave(g, dim=1)
+        sc = torch.einsum("thd,shd->hts", q[s0:s1].float() * scale, kk)
+        sc.masked_fill_(torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1), float("-inf"))
+        out[s0:s1] = torch.einsum("hts,shd->thd", torch.softmax(sc, dim=-1), vv)
+    return out

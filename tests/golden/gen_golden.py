@@ -258,6 +258,27 @@ def gen_mla_prefill():
          scale=np.array([0.1352], dtype=np.float32), rows=rows, out=bits16(out[rows]))
 
 
+def gen_gqa_prefill():
+    """RefAttnBackend.attn_varlen_func as Attention.prefill_forward calls it (models/model.py:104-132):
+    causal GQA, q [T, 8, 128], k / v [T, 2, 128]."""
+    from chitu.attn_backend import RefAttnBackend
+
+    be = RefAttnBackend()
+    seqs = [1, 255, 257, 9]
+    T = sum(seqs)
+    cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32)
+    q = lattice(T, 8, 128, mod=89, scale=64.0, salt=4)
+    k = lattice(T, 2, 128, salt=6)
+    v = lattice(T, 2, 128, mod=83, salt=8)
+    out = be.attn_varlen_func(q, k, v, cu, cu, max(seqs), max(seqs), causal=True)
+    keep = set()
+    for s0, n in zip(cu[:-1].tolist(), seqs):
+        keep.update(s0 + i for i in (0, 1, 127, 254, 255, 256, n - 1) if 0 <= i < n)
+    keep.update(range(0, T, 37))
+    rows = np.array(sorted(keep), dtype=np.int64)
+    save("gqa_prefill", seqs=np.array(seqs, dtype=np.int64), rows=rows, out=bits16(out[rows]))
+
+
 # ---------------------------------------------------------------- W8A8 int8 quantisers (pure torch in the reference)
 def gen_w8a8_quant():
     """chitu/quantize/w8a8.py:18-35 quant_act / quant_weight, imported with the closed GEMM packages
@@ -289,6 +310,7 @@ GENS = {
     "gqa_decode": gen_gqa_decode,
     "mla_prefill": gen_mla_prefill,
     "w8a8_quant": gen_w8a8_quant,
+    "gqa_prefill": gen_gqa_prefill,
 }
 
 if __name__ == "__main__":

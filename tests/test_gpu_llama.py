@@ -131,3 +131,35 @@ def test_gate_up_gemm_with_silu_epilogue_equals_gemm_then_silu(M, inter, K):
     h13 = torch.nn.functional.linear(x.cpu().float(), w13.cpu().float()).to(torch.bfloat16)
     cpu = torch.nn.functional.silu(h13[:, :inter]) * h13[:, inter:]
     assert max_rel_to_peak(out, cpu) < 1e-2
+
+
+def test_prefill_equals_token_by_token_decode_and_generate():
+    args = tiny_args(2)
+    model, cache = build(args)
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randint(0, args.vocab_size, (n,), generator=g).tolist() for n in (1, 260, 9)]
+    reqs = ["d0", "d1", "d2"]
+    for r in reqs:
+        cache.register_sequence(r, 0)
+    last_logits = [None] * 3
+    for step in range(max(len(p) for p in prompts)):
+        live = [i for i, p in enumerate(prompts) if step < len(p)]
+        ids = [reqs[i] for i in live]
+        cache.prepare_cache_decode(ids)
+        cache.prepare_block_table_for_decode(ids)
+        toks = torch.tensor([prompts[i][step] for i in live], dtype=torch.int64, device="cuda")
+        logits = model.decode(toks, use_graph=False)
+        cache.finalize_cache_single_decode(ids)
+        for kk, i in enumerate(live):
+            if step == len(prompts[i]) - 1:
+                last_logits[i] = logits[kk].clone()
+    for r in reqs:
+        cache.finalize_cache_all_decode(r)
+    logits_p = model.prefill(prompts, ["p0", "p1", "p2"])
+    for i in range(3):
+        assert max_rel_to_peak(logits_p[i], last_logits[i]) < 3e-2, i
+    for r in ("p0", "p1", "p2"):
+        cache.finalize_cache_all_decode(r)
+    free_before = len(cache.free_blocks)
+    out1, out2 = model.generate(prompts, 4), model.generate(prompts, 4)
+    assert tuple(out1.shape) == (3, 4) and torch.equal(out1, out2) and len(cache.free_blocks) == free_before

@@ -234,3 +234,12 @@ def test_w8a8_quantisers_match_reference_bit_exactly():
     qw, sw = ow.quant_weight(w.clone())
     assert np.array_equal(qx.numpy(), g["qx"]) and np.array_equal(sx.numpy(), g["sx"])
     assert np.array_equal(qw.numpy(), g["qw"]) and np.array_equal(sw.numpy(), g["sw"])
+
+
+def test_gqa_prefill_oracle_matches_reference_varlen_attention():
+    from oracle import gqa as ogqa
+    from tests.util import gqa_prefill_golden_case, max_rel_to_peak
+
+    c = gqa_prefill_golden_case()
+    out = ogqa.attn_varlen_causal(c["q"], c["k"], c["v"], c["cu"])
+    assert max_rel_to_peak(out[c["rows"]], c["out"]) < 4e-3

@@ -92,3 +92,12 @@ def mla_prefill_golden_case():
     kv = lattice(T, 1, C + R, salt=2)
     q = lattice(T, H, C + R, mod=89, scale=128.0, salt=13)
     return dict(q=q, kv=kv, cu=cu, seqs=seqs, scale=float(g["scale"][0]), rows=torch.from_numpy(g["rows"]), out=bf16(g["out"]), C=C)
+
+
+def gqa_prefill_golden_case():
+    g = golden("gqa_prefill")
+    seqs = [int(v) for v in g["seqs"]]
+    T = sum(seqs)
+    cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32)
+    return dict(q=lattice(T, 8, 128, mod=89, scale=64.0, salt=4), k=lattice(T, 2, 128, salt=6), v=lattice(T, 2, 128, mod=83, salt=8),
+                cu=cu, seqs=seqs, rows=torch.from_numpy(g["rows"]), out=bf16(g["out"]))
