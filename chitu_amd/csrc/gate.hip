@@ -231,7 +231,7 @@ template <int SIGMOID>
 __global__ __launch_bounds__(1024) void gate_route_kernel(
     const void* __restrict__ logits, int S, int M, int E, const bf16_t* __restrict__ bias, int n_groups,
     int topk_groups, int topk, float route_scale, bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids,
-    int out_stride, int extra_id, float extra_w) {
+    int out_stride, int extra_id, float extra_w, int extra_n) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sc = lds;             // [E] selection score s'
     float* red = lds + E;        // [32] wave partials
@@ -360,9 +360,9 @@ __global__ __launch_bounds__(1024) void gate_route_kernel(
         }
         out_w[(int64_t)t * out_stride + e] = f32_to_bf16(w);
     }
-    if (e == 0 && extra_id >= 0) {  // optional always-on (shared) expert appended as slot `topk`
-        out_ids[(int64_t)t * out_stride + topk] = extra_id;
-        out_w[(int64_t)t * out_stride + topk] = f32_to_bf16(extra_w);
+    if (e < extra_n && extra_id >= 0) {  // always-on (shared) experts appended as slots topk .. topk+extra_n-1
+        out_ids[(int64_t)t * out_stride + topk + e] = extra_id + e;
+        out_w[(int64_t)t * out_stride + topk + e] = f32_to_bf16(extra_w);
     }
 }
 
@@ -405,7 +405,7 @@ template <int GS>  // experts per group: 32 or 64 (or 0 = ungrouped)
 __global__ __launch_bounds__(1024) void gate_route_fast_kernel(
     const void* __restrict__ logits, int S, int M, int E, const bf16_t* __restrict__ bias, int n_groups,
     int topk_groups, int topk, float route_scale, bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids,
-    int out_stride, int extra_id, float extra_w) {
+    int out_stride, int extra_id, float extra_w, int extra_n) {
     __shared__ float orig_lds[1024];
     __shared__ float gsc[32];
     __shared__ __attribute__((aligned(16))) uint32_t cand[64];
@@ -485,9 +485,9 @@ __global__ __launch_bounds__(1024) void gate_route_fast_kernel(
         w = bf16r(w * route_scale);                // weights *= route_scale
         out_w[(int64_t)t * out_stride + lane] = f32_to_bf16(w);
     }
-    if (lane == 0 && extra_id >= 0) {  // optional always-on (shared) expert appended as slot `topk`
-        out_ids[(int64_t)t * out_stride + topk] = extra_id;
-        out_w[(int64_t)t * out_stride + topk] = f32_to_bf16(extra_w);
+    if (lane < extra_n && extra_id >= 0) {  // always-on (shared) experts appended as slots topk .. topk+extra_n-1
+        out_ids[(int64_t)t * out_stride + topk + lane] = extra_id + lane;
+        out_w[(int64_t)t * out_stride + topk + lane] = f32_to_bf16(extra_w);
     }
 }
 
@@ -535,13 +535,13 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
                                     int32_t topk_groups, int32_t topk, int32_t score_func,
                                     float route_scale, void* out_weights_bf16, int64_t* out_ids,
                                     int32_t out_stride, int32_t extra_expert_id, float extra_weight,
-                                    void* stream) {
+                                    int32_t extra_count, void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(logits && out_weights_bf16 && out_ids && tokens >= 0);
     CHITU_REQUIRE(num_experts >= 1 && num_experts <= 1024 && topk >= 1 && topk <= num_experts && topk <= 64);
     CHITU_REQUIRE(n_groups >= 1 && n_groups <= 64 && num_experts % n_groups == 0);
     CHITU_REQUIRE(topk_groups >= 1 && topk_groups <= n_groups && num_partials >= 0);
-    CHITU_REQUIRE(out_stride >= topk + (extra_expert_id >= 0 ? 1 : 0));
+    CHITU_REQUIRE(extra_count >= 0 && extra_count <= 32 && out_stride >= topk + (extra_expert_id >= 0 ? extra_count : 0));
     CHITU_REQUIRE(score_func == 0 || score_func == 1);
     if (tokens == 0) return CHITU_OK;
     const int threads = ((num_experts + 63) / 64) * 64;
@@ -556,7 +556,7 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
     hipLaunchKernelGGL(gate_route_fast_kernel<GSV>, dim3((unsigned)tokens), dim3(threads), 0, st, logits,   \
                        (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16, (int)n_groups, \
                        (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16, out_ids,         \
-                       (int)out_stride, (int)extra_expert_id, extra_weight)
+                       (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count)
         if (gs == 32) LAUNCHF(32);
         else if (gs == 64) LAUNCHF(64);
         else LAUNCHF(0);
@@ -567,12 +567,12 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
         hipLaunchKernelGGL(gate_route_kernel<1>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
                            (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
                            (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
-                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight);
+                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count);
     else
         hipLaunchKernelGGL(gate_route_kernel<0>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
                            (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
                            (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
-                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight);
+                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count);
     CHITU_RETURN_LAUNCH_STATUS();
 }
 

@@ -301,10 +301,11 @@ class GateDeepSeekV3(torch.nn.Module):
         self.bias = (torch.nn.Parameter(torch.empty(args.n_routed_experts, dtype=torch.bfloat16, device=device), requires_grad=False)
                      if args.has_gate_bias() else None)
 
-    def forward(self, x, extra_expert_id: int = -1):
-        """(weights [bs, topk(+1)] bf16, indices int64).  Two HIP launches (ops.gate_deepseek_v3)."""
+    def forward(self, x, extra_expert_id: int = -1, extra_count: int = 1):
+        """(weights [bs, topk(+extra)] bf16, indices int64).  Two HIP launches (ops.gate_deepseek_v3)."""
         return ops.gate_deepseek_v3(x, self.weight, self.bias, self.n_groups, self.topk_groups, self.topk,
-                                    self.score_func, self.route_scale, extra_expert_id=extra_expert_id)
+                                    self.score_func, self.route_scale, extra_expert_id=extra_expert_id,
+                                    extra_count=extra_count)
 
 
 class MoEDeepSeekV3(torch.nn.Module):
@@ -326,34 +327,24 @@ class MoEDeepSeekV3(torch.nn.Module):
 
     def forward(self, x, x_quant, defer_sum: bool = False):
         """x: ffn_norm output bf16 [bs, dim] (gate input); x_quant its fp8 (per-group) form.
-        defer_sum (one shared expert only): return the un-summed [bs, topk+1, dim] expert outputs; the
-        next RMSNorm folds the top-k sum into its residual add (ops.rms_norm(add=<3-D>)).
+        defer_sum: return the un-summed [bs, topk + n_shared, dim] expert outputs; the next RMSNorm folds
+        the top-k sum into its residual add (ops.rms_norm(add=<3-D>)).
 
-        With one shared expert (R1/V3) it is routed as slot `topk` with weight 1 and runs inside the
-        same grouped GEMMs as the routed experts: its 16 tokens form one full MFMA tile and four
-        launches disappear.  Only difference to the reference (:936-949, 1010): shared + routed are
-        summed in fp32 and rounded once instead of bf16 + bf16."""
+        The shared experts (1 in V3/R1, 2 in V2-Lite) are routed as slots topk .. topk+n_shared-1 with
+        weight 1 and run inside the same grouped GEMMs as the routed experts: their tokens form full MFMA
+        tiles and four launches per shared expert disappear.  Differences to the reference (:936-949,
+        1010), both inside its tolerance: shared + routed are summed in fp32 and rounded once instead of
+        bf16 + bf16, and the shared experts' input uses the group-quant rule of the routed ones."""
         nr, ns = self.n_routed, self.n_shared
-        if ns == 1:
-            weights, indices = self.gate(x, extra_expert_id=nr)
-            return fused_moe.fused_experts(
-                x, self.w1w3_weight, self.w2_weight, topk_weights=weights, topk_ids=indices, use_fp8_w8a8=True,
-                inplace=True, global_num_experts=nr + ns, w1_scale=self.w1w3_scale, w2_scale=self.w2_scale,
-                block_shape=[BLOCK, BLOCK], a1_quant=x_quant, reduce_topk=not defer_sum,
-            )
-        weights, indices = self.gate(x)
-        y = None
-        for i in range(nr, nr + ns):
-            h = linear_deepseek_v3(None, self.w1w3_weight[i], self.w1w3_scale[i], x_quant=x_quant)
-            hq, hs = fused_moe.silu_and_mul_quant(h, mode="act")
-            yi = linear_deepseek_v3(None, self.w2_weight[i], self.w2_scale[i], x_quant=(hq, hs))
-            y = yi if y is None else y + yi
-        y1 = fused_moe.fused_experts(
-            x, self.w1w3_weight[:nr], self.w2_weight[:nr], topk_weights=weights, topk_ids=indices,
-            use_fp8_w8a8=True, inplace=True, global_num_experts=nr, w1_scale=self.w1w3_scale[:nr],
-            w2_scale=self.w2_scale[:nr], block_shape=[BLOCK, BLOCK], a1_quant=x_quant,
+        if ns >= 1:
+            weights, indices = self.gate(x, extra_expert_id=nr, extra_count=ns)
+        else:
+            weights, indices = self.gate(x)
+        return fused_moe.fused_experts(
+            x, self.w1w3_weight, self.w2_weight, topk_weights=weights, topk_ids=indices, use_fp8_w8a8=True,
+            inplace=True, global_num_experts=nr + ns, w1_scale=self.w1w3_scale, w2_scale=self.w2_scale,
+            block_shape=[BLOCK, BLOCK], a1_quant=x_quant, reduce_topk=not defer_sum,
         )
-        return y1 if y is None else y + y1
 
 
 class TransformerBlockDeepSeekV3(torch.nn.Module):
@@ -386,7 +377,7 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
             # without tensor parallelism nothing sits between the experts' top-k sum and the next norm's
             # residual add: the sum moves into that norm (one launch less); with TP the all-reduce
             # below needs the summed tensor
-            defer = (tp.get_tp_size() == 1 and self.ffn.gate.topk + 1 <= 16
+            defer = (tp.get_tp_size() == 1 and self.ffn.gate.topk + self.ffn.n_shared <= 16
                      and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")  # chitu_hip_rmsnorm sums <= 16 terms
             f = self.ffn(hn, (hq, hs), defer_sum=defer)
             if f.dim() == 3:

@@ -356,17 +356,17 @@ _GATE_SPLITS = 16
 
 
 def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale,
-                     extra_expert_id: int = -1, extra_weight: float = 1.0):
+                     extra_expert_id: int = -1, extra_weight: float = 1.0, extra_count: int = 1):
     """GateDeepSeekV3.forward (chitu/models/model_deepseek_v3.py:810-842) in two launches:
     split-K skinny GEMM for the scores, then one fused routing kernel.  Returns (weights bf16
     [M, topk(+1)], indices int64 [M, topk(+1)]); the optional extra slot routes every token to
-    `extra_expert_id` with weight `extra_weight` (shared expert)."""
+    `extra_expert_id` .. `extra_expert_id + extra_count - 1` with weight `extra_weight` (shared experts)."""
     require_cuda(x, weight)
     assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous() and weight.is_contiguous()
     M, K = x.shape
     E = weight.shape[0]
     splits = _GATE_SPLITS if K % (64 * _GATE_SPLITS) == 0 else 1
-    cols = topk + (1 if extra_expert_id >= 0 else 0)
+    cols = topk + (extra_count if extra_expert_id >= 0 else 0)
     w_out = torch.empty(M, cols, dtype=torch.bfloat16, device=x.device)
     ids = torch.empty(M, cols, dtype=torch.int64, device=x.device)
     lib = _lib.lib()
@@ -381,7 +381,7 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
     check(
         lib.chitu_hip_gate_route(ptr(logits), i32(nparts), i64(M), i32(E), ptr(bias), i32(n_groups), i32(topk_groups),
                                  i32(topk), i32(1 if score_func == "sigmoid" else 0), f32(route_scale), ptr(w_out),
-                                 ptr(ids), i32(cols), i32(extra_expert_id), f32(extra_weight), stream_ptr()),
+                                 ptr(ids), i32(cols), i32(extra_expert_id), f32(extra_weight), i32(extra_count), stream_ptr()),
         "gate_route",
     )
     return w_out, ids

@@ -298,14 +298,15 @@ int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void* out, int o
  *   and rounded to bf16 like F.linear's output.  bias_bf16 [E] or NULL.  score_func 1 = sigmoid
  *   (bf16 pipeline, weights normalised), 0 = softmax (fp32 pipeline).
  *   out_weights_bf16 / out_ids (int64) [tokens, out_stride]: slots 0..topk-1 sorted by descending
- *   selection score; if extra_expert_id >= 0, slot `topk` = (extra_expert_id, extra_weight) -- used to
+ *   selection score; if extra_expert_id >= 0, slots topk .. topk+extra_count-1 = (extra_expert_id + i,
+ *   extra_weight) -- used to
  *   run the always-on shared expert (stacked last, model_deepseek_v3.py:883-919) through the same
  *   grouped GEMMs as the routed ones. */
 int chitu_hip_gate_route(const void* logits, int32_t num_partials, int64_t tokens, int32_t num_experts,
                          const void* bias_bf16, int32_t n_groups, int32_t topk_groups, int32_t topk,
                          int32_t score_func, float route_scale, void* out_weights_bf16,
                          int64_t* out_ids, int32_t out_stride, int32_t extra_expert_id,
-                         float extra_weight, void* stream);
+                         float extra_weight, int32_t extra_count, void* stream);
 
 /* ---- MLA decode KV prep (kv_norm + RoPE + append, fused) ------------------------------------
  * Replaces four launches of AttentionDeepSeekV3.decode_forward_paged: apply_rotary_pos_emb on

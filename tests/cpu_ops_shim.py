@@ -87,11 +87,11 @@ def absorb_uv_quant_fp8(x, w, scale, scale_offset, sh, sk):
 
 
 def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale, extra_expert_id=-1,
-                     extra_weight=1.0):
+                     extra_weight=1.0, extra_count=1):
     w, i = ods.gate(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale)
     if extra_expert_id >= 0:
-        w = torch.cat([w, torch.full((w.shape[0], 1), extra_weight, dtype=w.dtype)], 1)
-        i = torch.cat([i, torch.full((i.shape[0], 1), extra_expert_id, dtype=i.dtype)], 1)
+        w = torch.cat([w, torch.full((w.shape[0], extra_count), extra_weight, dtype=w.dtype)], 1)
+        i = torch.cat([i, (extra_expert_id + torch.arange(extra_count, dtype=i.dtype)).expand(i.shape[0], -1)], 1)
     return w, i
 
 

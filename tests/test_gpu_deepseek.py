@@ -136,10 +136,9 @@ def test_layerwise_parity_and_graph_replay(make_args):
             def hooked(inp, _orig=orig, _store=routing, **kw):
                 w, idx = _orig(inp, **kw)
                 k = args.n_activated_experts
-                if args.n_shared_experts == 1:
-                    assert (idx[:, k:] == args.n_routed_experts).all() and (w[:, k:] == 1).all()  # shared-expert slot
-                else:
-                    assert idx.shape[1] == k
+                ns = args.n_shared_experts  # shared-expert slots: ids n_routed .., weight 1
+                assert idx.shape[1] == k + ns and (w[:, k:] == 1).all()
+                assert torch.equal(idx[:, k:].cpu(), (args.n_routed_experts + torch.arange(ns)).expand(idx.shape[0], -1))
                 _store["w"], _store["i"] = w[:, :k].cpu(), idx[:, :k].cpu()
                 return w, idx
 
@@ -243,7 +242,7 @@ def test_gate_route_on_identical_logits(score_func, bias, groups, M):
     ld, bd = logits.cuda(), (b.cuda() if bias else None)
     rc = _lib.lib().chitu_hip_gate_route(ptr(ld), i32(0), i64(M), i32(E), ptr(bd), i32(groups[0]), i32(groups[1]),
                                          i32(topk), i32(1 if score_func == "sigmoid" else 0), f32(2.5), ptr(w_hip),
-                                         ptr(i_hip), i32(topk), i32(-1), f32(0.0), stream_ptr())
+                                         ptr(i_hip), i32(topk), i32(-1), f32(0.0), i32(0), stream_ptr())
     assert rc == 0
     w_hip, i_hip = w_hip.cpu(), i_hip.cpu()
     # expected result = the reference's intermediate tensors + the documented tie rule (lower index first)
@@ -412,11 +411,11 @@ def test_gate_route_fast_path_equals_generic_kernel(E, groups, topk, S, bias, mo
                 monkeypatch.setenv("CHITU_GATE_SLOW", "1")
             else:
                 monkeypatch.delenv("CHITU_GATE_SLOW", raising=False)
-            w = torch.zeros(M, topk + 1, dtype=torch.bfloat16, device="cuda")
-            ids = torch.zeros(M, topk + 1, dtype=torch.int64, device="cuda")
+            w = torch.zeros(M, topk + 2, dtype=torch.bfloat16, device="cuda")
+            ids = torch.zeros(M, topk + 2, dtype=torch.int64, device="cuda")
             rc = _lib.lib().chitu_hip_gate_route(ptr(logits), i32(S), i64(M), i32(E), ptr(b), i32(groups[0]), i32(groups[1]),
-                                                 i32(topk), i32(1), f32(2.5), ptr(w), ptr(ids), i32(topk + 1), i32(E),
-                                                 f32(1.0), stream_ptr())
+                                                 i32(topk), i32(1), f32(2.5), ptr(w), ptr(ids), i32(topk + 2), i32(E),
+                                                 f32(1.0), i32(2), stream_ptr())
             assert rc == 0
             torch.cuda.synchronize()
             outs.append((w.cpu(), ids.cpu()))
