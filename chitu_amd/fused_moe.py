@@ -164,6 +164,7 @@ def fused_experts(
     soft_fp8: bool = False,
     a1_quant=None,
     reduce_topk: bool = True,
+    use_int8_w8a8: bool = False,
 ) -> torch.Tensor:
     """Same signature as chitu/fused_moe.py:1060-1127 (+ optional a1_quant / reduce_topk, see fused_experts_impl).  (The reference's inplace=False branch
     calls an unregistered torch.ops.vllm op; here both branches work.)"""
@@ -171,6 +172,7 @@ def fused_experts(
         hidden_states, w1, w2, topk_weights, topk_ids, inplace, activation, use_fp8_w8a8,
         use_int8_w8a16, use_int4_w4a16, global_num_experts, expert_map, w1_scale, w2_scale, w1_zp,
         w2_zp, a1_scale, a2_scale, block_shape, soft_fp8=soft_fp8, a1_quant=a1_quant, reduce_topk=reduce_topk,
+        use_int8_w8a8=use_int8_w8a8,
     )
 
 
@@ -197,6 +199,7 @@ def fused_experts_impl(
     soft_fp8: bool = False,
     a1_quant=None,
     reduce_topk: bool = True,
+    use_int8_w8a8: bool = False,
 ):
     """out[t] = sum_j w[t,j] * W2[e_tj] . (silu(W1[e_tj] x_t)[:I] * (W1[e_tj] x_t)[I:])
 
@@ -217,10 +220,14 @@ def fused_experts_impl(
     assert hidden_states.dtype in [torch.float32, torch.float16, torch.bfloat16]
     if activation != "silu":
         raise ValueError(f"Unsupported FusedMoe activation: {activation}")
+    if use_int8_w8a8:
+        return _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts,
+                                   expert_map, w1_scale, w2_scale, reduce_topk)
     if not use_fp8_w8a8 or soft_fp8 or use_int8_w8a16 or use_int4_w4a16:
         raise NotImplementedError(
             "chitu_amd.fused_moe implements the fp8_w8a8 block-scaled path (use_fp8_w8a8=True, "
-            "block_shape=[128,128], soft_fp8=False); other modes are not built yet"
+            "block_shape=[128,128], soft_fp8=False) and the int8 W8A8 path (use_int8_w8a8=True); other modes "
+            "are not built"
         )
     assert block_shape is not None and list(block_shape) == [128, 128], "block_shape must be [128, 128]"
     assert w1_scale is not None and w2_scale is not None
@@ -340,6 +347,69 @@ def fused_experts_impl(
             ),
             "moe gemm2",
         )
+    if not reduce_topk:
+        c3_off = off["c3"] - base
+        return ws[c3_off : c3_off + numel * Nout * 2].view(torch.bfloat16).view(num_tokens, topk, Nout)
+    check(lib.chitu_hip_moe_sum(P("c3"), ptr(out), i64(num_tokens), i32(topk), i64(Nout), st), "moe sum")
+    return out
+
+
+def _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts, expert_map,
+                        w1_scale, w2_scale, reduce_topk):
+    """INT8 W8A8 experts (Mixtral + simple_w8a8, BASELINE config 4): per-token int8 activations, per-channel
+    int8 weights.  w1 [E, 2I, K] int8, w1_scale [E, 2I]; w2 [E, N, I] int8, w2_scale [E, N].
+    align(16) -> quant_act -> grouped GEMM1 (+ silu*mul) -> quant_act -> grouped GEMM2 (x routed weight) -> sum:
+    the per-expert W8A8Linear arithmetic of the reference's expert loop (model_hf_mixtral.py:76-94,
+    quantize/w8a8.py:97-132), grouped."""
+    assert hidden_states.dtype == torch.bfloat16 and w1.dtype == torch.int8 and w2.dtype == torch.int8
+    assert w1_scale is not None and w2_scale is not None and w1_scale.dtype == torch.float32 and w2_scale.dtype == torch.float32
+    require_cuda(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale)
+    num_tokens, K = hidden_states.shape
+    E, N, _ = w1.shape
+    I = N // 2
+    Nout = w2.shape[1]
+    assert w2.shape[0] == E and w2.shape[2] == I and tuple(w1_scale.shape) == (E, N) and tuple(w2_scale.shape) == (E, Nout)
+    assert w1_scale.is_contiguous() and w2_scale.is_contiguous() and K % 128 == 0 and I % 128 == 0
+    if global_num_experts == -1:
+        global_num_experts = E
+    topk = topk_ids.shape[1]
+    dev = hidden_states.device
+    out = hidden_states if inplace else torch.empty_like(hidden_states)
+    if num_tokens == 0:
+        return out
+    numel = num_tokens * topk
+    topk_ids = topk_ids.contiguous()
+    topk_weights = topk_weights.contiguous()
+    cap = numel + global_num_experts * (_MOE_BLOCK_M - 1)
+    nblk = ceil_div(cap, _MOE_BLOCK_M)
+    rnd = lambda n: (n + 255) // 256 * 256
+    sizes = [("sorted", cap * 4), ("experts", nblk * 4), ("npost", 4), ("cumsum", (global_num_experts + 1) * 4),
+             ("xq", num_tokens * K), ("xs", num_tokens * 4), ("a", numel * I * 2), ("aq", numel * I), ("as", numel * 4),
+             ("c3", numel * Nout * 2)]
+    ws = workspace.get(sum(rnd(n) for _, n in sizes), dev, "moe")
+    base, off, cur = ws.data_ptr(), {}, 0
+    for name, n in sizes:
+        off[name] = base + cur
+        cur += rnd(n)
+    import ctypes as _ct
+
+    P = lambda name: _ct.c_void_p(off[name])
+    lib, st = _lib.lib(), stream_ptr()
+    max_mblocks = min(nblk, numel)
+    check(lib.chitu_hip_moe_align_block_size(ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel), i32(global_num_experts),
+                                             i32(_MOE_BLOCK_M), P("sorted"), i64(cap), P("experts"), i64(nblk), P("npost"),
+                                             P("cumsum"), i32(1), st), "moe_align_block_size")
+    if expert_map is not None:
+        ev = _view_i32(ws, off["experts"] - base, nblk)
+        ev.copy_(expert_map.to(torch.int32)[ev.long()].contiguous())
+    check(lib.chitu_hip_quant_act_int8(ptr(hidden_states), float_dtype_code(hidden_states.dtype), i64(num_tokens), i64(K),
+                                       P("xq"), P("xs"), st), "moe int8 quant1")
+    check(lib.chitu_hip_moe_i8_gemm1_silu(P("xq"), P("xs"), ptr(w1), ptr(w1_scale), P("sorted"), P("experts"), P("npost"), P("a"),
+                                          i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), st), "moe int8 gemm1")
+    check(lib.chitu_hip_quant_act_int8(P("a"), i32(0), i64(numel), i64(I), P("aq"), P("as"), st), "moe int8 quant2")
+    check(lib.chitu_hip_moe_i8_gemm2(P("aq"), P("as"), ptr(w2), ptr(w2_scale), P("sorted"), P("experts"), P("npost"),
+                                     ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel),
+                                     i64(Nout), i64(I), i64(max_mblocks), st), "moe int8 gemm2")
     if not reduce_topk:
         c3_off = off["c3"] - base
         return ws[c3_off : c3_off + numel * Nout * 2].view(torch.bfloat16).view(num_tokens, topk, Nout)

@@ -190,6 +190,27 @@ int chitu_hip_silu_and_mul(const void* x_bf16, void* out_bf16, int64_t rows, int
 int chitu_hip_selftest_arith(const float* num, const float* den, int64_t n, uint64_t* mismatches,
                              void* stream);
 
+/* ---- fused MoE with INT8 W8A8 experts (BASELINE config 4: Mixtral-8x7B W8A8) ----------------------
+ * The reference has no int8-W8A8 fused path (Mixtral loops over experts, model_hf_mixtral.py:76-94, each
+ * linear a W8A8Linear after simple_w8a8, quantize/w8a8.py:38-164); these run the same per-expert arithmetic
+ * grouped over moe_align's sorted slots (block 16):
+ *   gemm1_silu: a[slot, :] = bf16( bf16(silu(g)) * u ), g/u = bf16( (q_x[token] . w1[e, n | I+n]) * s_x[token] * s_w1[e, n | I+n] )
+ *     a_int8 [tokens, K] + a_scale [tokens] (chitu_hip_quant_act_int8 of the hidden states); w1 [E, 2I, K] int8,
+ *     w1_scale [E, 2I] f32; h_bf16 [numel, I].
+ *   gemm2: out[slot, :] = bf16( bf16( (q_a[slot] . w2[e, n]) * s_a[slot] * s_w2[e, n] ) * topk_weights[slot] )
+ *     a_int8 [numel, I] + a_scale [numel] (chitu_hip_quant_act_int8 of a); w2 [E, N, I] int8, w2_scale [E, N].
+ *   Sum over the top-k with chitu_hip_moe_sum.  K % 128 == 0, I % 128 == 0; int32 accumulation is exact. */
+int chitu_hip_moe_i8_gemm1_silu(const void* a_int8, const float* a_scale, const void* w1_int8,
+                                const float* w1_scale, const int32_t* sorted_token_ids,
+                                const int32_t* expert_ids, const int32_t* num_tokens_post_pad, void* h_bf16,
+                                int64_t numel, int32_t topk, int64_t inter_size, int64_t K, int64_t max_mblocks,
+                                void* stream);
+int chitu_hip_moe_i8_gemm2(const void* a_int8, const float* a_scale, const void* w2_int8, const float* w2_scale,
+                           const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                           const int32_t* num_tokens_post_pad, const void* topk_weights, int weights_dtype,
+                           int32_t mul_routed_weight, void* out_bf16, int64_t numel, int64_t N,
+                           int64_t inter_size, int64_t max_mblocks, void* stream);
+
 /* ---- MLA absorb-mode paged decode attention ------------------------------------------------
  * Replaces mla_decode (chitu/triton_decode_attention.py:259-290: _mla_attn_kernel :20-130 +
  * _mla_softmax_reducev_kernel :185-232) as called from TritonAttnBackend.mla_attn_with_kvcache
