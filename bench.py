@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-llama", action="store_true", help="skip the extra Llama-3-8B / DeepSeek-V2-Lite (BASELINE configs 2, 3) measurements")
+    ap.add_argument("--no-llama", action="store_true", help="skip the extra Llama-3-8B / DeepSeek-V2-Lite / Mixtral-int8 (BASELINE configs 2, 3, 4) measurements")
     return ap.parse_args()
 
 
@@ -394,6 +394,32 @@ def v2_lite_extra(steps, warmup, ctx):
     return out
 
 
+def mixtral_extra(steps, warmup, ctx):
+    """BASELINE config 4 as an extra line: Mixtral-8x7B shapes, INT8 W8A8 experts (per-token / per-channel
+    scales) through the grouped int8 MoE kernels, bf16 attention and router; the whole model on this GPU
+    (the config's TP=4 needs 4 GPUs), paged KV (page 256), hipGraph, synthetic weights."""
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.mixtral import MixtralArgs, MixtralDecoder, init_synthetic_
+
+    args = MixtralArgs()
+    max_seq = ctx + steps + warmup + 512
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=16, block_size=256, max_seq_len=max_seq, device="cuda",
+                                n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
+    model = MixtralDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=max_seq),
+                           max_position_embeddings=max_seq, device="cuda")
+    init_synthetic_(model, seed=4)
+    cache.paged_k_cache.normal_(0, 0.5)
+    cache.paged_v_cache.normal_(0, 0.5)
+    out = {"model": "Mixtral-8x7B shapes, INT8 W8A8 experts + bf16 attention, TP=1, paged KV (page 256), hipGraph, synthetic weights"}
+    for bs in (1, 16):
+        dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"x{bs}_")
+        out[f"bs{bs}"] = {"ms_per_step": round(dt / steps * 1e3, 4), "tok_s": round(bs * steps / dt, 1)}
+    del model, cache
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     rank, world, local = setup_dist(a.gpus)
@@ -452,6 +478,7 @@ def main():
         torch.cuda.empty_cache()
         extra["llama3_8b"] = llama3_8b_extra(a.steps, a.warmup, a.ctx)
         extra["v2_lite"] = v2_lite_extra(a.steps, a.warmup, a.ctx)
+        extra["mixtral_8x7b_int8"] = mixtral_extra(a.steps, a.warmup, a.ctx)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         model = cache = None

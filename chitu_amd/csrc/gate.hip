@@ -231,7 +231,7 @@ template <int SIGMOID>
 __global__ __launch_bounds__(1024) void gate_route_kernel(
     const void* __restrict__ logits, int S, int M, int E, const bf16_t* __restrict__ bias, int n_groups,
     int topk_groups, int topk, float route_scale, bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids,
-    int out_stride, int extra_id, float extra_w, int extra_n) {
+    int out_stride, int extra_id, float extra_w, int extra_n, int renorm) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sc = lds;             // [E] selection score s'
     float* red = lds + E;        // [32] wave partials
@@ -356,6 +356,11 @@ __global__ __launch_bounds__(1024) void gate_route_kernel(
             w = bf16r(w / bf16r(sum));          // weights /= weights.sum(-1, keepdim=True)
             w = bf16r(w * route_scale);         // weights *= route_scale
         } else {
+            if (renorm) {  // Mixtral: softmax -> top-k -> weights /= weights.sum() in fp32 (model_hf_mixtral.py:58-64)
+                float sum = 0.f;
+                for (int i = 0; i < topk; ++i) sum += wsel[i];
+                w = w / sum;
+            }
             w = w * route_scale;                // fp32, then type_as(x)
         }
         out_w[(int64_t)t * out_stride + e] = f32_to_bf16(w);
@@ -542,7 +547,7 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
     CHITU_REQUIRE(n_groups >= 1 && n_groups <= 64 && num_experts % n_groups == 0);
     CHITU_REQUIRE(topk_groups >= 1 && topk_groups <= n_groups && num_partials >= 0);
     CHITU_REQUIRE(extra_count >= 0 && extra_count <= 32 && out_stride >= topk + (extra_expert_id >= 0 ? extra_count : 0));
-    CHITU_REQUIRE(score_func == 0 || score_func == 1);
+    CHITU_REQUIRE(score_func >= 0 && score_func <= 2);  // 0 softmax, 1 sigmoid (V3), 2 softmax + top-k renormalisation (Mixtral)
     if (tokens == 0) return CHITU_OK;
     const int threads = ((num_experts + 63) / 64) * 64;
     const size_t lds = sizeof(float) * (size_t)(num_experts + 32 + 64 + 64);
@@ -567,12 +572,13 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
         hipLaunchKernelGGL(gate_route_kernel<1>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
                            (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
                            (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
-                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count);
+                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count, 0);
     else
         hipLaunchKernelGGL(gate_route_kernel<0>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
                            (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
                            (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
-                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count);
+                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count,
+                           score_func == 2 ? 1 : 0);
     CHITU_RETURN_LAUNCH_STATUS();
 }
 

@@ -53,8 +53,9 @@ def _param(*shape, device=None):
 
 
 class LlamaAttention(torch.nn.Module):
-    def __init__(self, args: LlamaArgs, layer_id, cache, attn_backend, device=None):
+    def __init__(self, args, layer_id, cache, attn_backend, device=None, rotary_type="llama"):
         super().__init__()
+        self.rotary_type = rotary_type  # "llama" (Meta original, interleaved) | "hf-llama" (half split)
         t = tp.get_tp_size()
         self.layer_id, self.cache, self.attn_backend = layer_id, cache, attn_backend
         self.hd = args.head_dim
@@ -71,7 +72,7 @@ class LlamaAttention(torch.nn.Module):
         table = self.cache.get_gpu_block_table()
         # RoPE(q, k) + append of k and v to their pages: one launch
         q = ops.gqa_qkv_post(qkv, self.hq, self.hkv, cos, sin, k_cache, v_cache, table,
-                             self.cache.get_gpu_seq_lens_excl_this_decode(), rotary_type="llama")
+                             self.cache.get_gpu_seq_lens_excl_this_decode(), rotary_type=self.rotary_type)
         o = self.attn_backend.attn_with_kvcache(
             q.unsqueeze(1), k_cache, v_cache, None, None,
             cache_seqlens=self.cache.get_gpu_seq_lens_incl_this_decode()[:bs], block_table=table[:bs])
@@ -83,7 +84,7 @@ class LlamaAttention(torch.nn.Module):
         manager (cache_manager.py:93-142), causal GQA through attn_backend.attn_varlen_func."""
         T = x.shape[0]
         qkv = ops.bf16_linear(x, self.wqkv).view(T, self.hq + 2 * self.hkv, self.hd)
-        q, k = ops.apply_rotary_pos_emb(qkv[:, : self.hq], qkv[:, self.hq : self.hq + self.hkv], cos, sin, rotary_type="llama")
+        q, k = ops.apply_rotary_pos_emb(qkv[:, : self.hq], qkv[:, self.hq : self.hq + self.hkv], cos, sin, rotary_type=self.rotary_type)
         v = qkv[:, self.hq + self.hkv :].contiguous()
         self.cache.finalize_cache_bylayer_prefill(k, v, self.cache.curr_req_ids, self.cache.curr_varlens, self.layer_id)
         o = self.attn_backend.attn_varlen_func(q, k, v, varlens.prefix_lens, varlens.prefix_lens, varlens.max_len,
@@ -132,6 +133,8 @@ class LlamaBlock(torch.nn.Module):
 class LlamaDecoder(torch.nn.Module):
     """embed -> blocks -> norm -> head -> fp32 logits; one hipGraph per batch size (model.py:538-622)."""
 
+    block_type = None  # subclasses (Mixtral) swap the block
+
     def __init__(self, args: LlamaArgs, cache: PagedKVCacheManager, attn_backend: HipAttnBackend,
                  max_position_embeddings: int = 4096, device="cuda"):
         super().__init__()
@@ -141,7 +144,8 @@ class LlamaDecoder(torch.nn.Module):
         self.vocab_local = args.vocab_size // t
         self.vocab_start = tp.get_tp_rank() * self.vocab_local
         self.embed_weight = _param(self.vocab_local, args.dim, device=device)
-        self.layers = torch.nn.ModuleList(LlamaBlock(i, args, cache, attn_backend, device) for i in range(args.n_layers))
+        block = self.block_type or LlamaBlock
+        self.layers = torch.nn.ModuleList(block(i, args, cache, attn_backend, device) for i in range(args.n_layers))
         self.norm = _param(args.dim, device=device)
         self.head_weight = _param(self.vocab_local, args.dim, device=device)
         cos, sin = precompute_freqs_cis(args.head_dim, max_position_embeddings, args.rope_theta)

@@ -380,7 +380,7 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
         nparts = 0
     check(
         lib.chitu_hip_gate_route(ptr(logits), i32(nparts), i64(M), i32(E), ptr(bias), i32(n_groups), i32(topk_groups),
-                                 i32(topk), i32(1 if score_func == "sigmoid" else 0), f32(route_scale), ptr(w_out),
+                                 i32(topk), i32({"softmax": 0, "sigmoid": 1, "softmax_renorm": 2}[score_func]), f32(route_scale), ptr(w_out),
                                  ptr(ids), i32(cols), i32(extra_expert_id), f32(extra_weight), i32(extra_count), stream_ptr()),
         "gate_route",
     )

@@ -317,7 +317,8 @@ int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void* out, int o
  * top-k, weight gather / normalise / scale.  Ties go to the lower index (torch.topk: unspecified).
  *   logits: bf16 [tokens, E] when num_partials == 0, else fp32 [num_partials, tokens, E] summed here
  *   and rounded to bf16 like F.linear's output.  bias_bf16 [E] or NULL.  score_func 1 = sigmoid
- *   (bf16 pipeline, weights normalised), 0 = softmax (fp32 pipeline).
+ *   (bf16 pipeline, weights normalised), 0 = softmax (fp32 pipeline), 2 = softmax followed by renormalising the
+ *   selected weights in fp32 (Mixtral's router, chitu/models/model_hf_mixtral.py:58-64).
  *   out_weights_bf16 / out_ids (int64) [tokens, out_stride]: slots 0..topk-1 sorted by descending
  *   selection score; if extra_expert_id >= 0, slots topk .. topk+extra_count-1 = (extra_expert_id + i,
  *   extra_weight) -- used to

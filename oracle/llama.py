@@ -17,18 +17,21 @@ def rms_norm(x, w, eps):
     return F.rms_norm(x, (x.shape[-1],), w, eps).to(x.dtype)
 
 
-def block(p, pre, x, cos, sin, k_cache, v_cache, block_table, lens_excl, hq, hkv, hd, eps):
-    """x [bs, dim] bf16 -> (x_out, k_cache', v_cache')."""
+def block(p, pre, x, cos, sin, k_cache, v_cache, block_table, lens_excl, hq, hkv, hd, eps, rotary="llama", ffn=None):
+    """x [bs, dim] bf16 -> (x_out, k_cache', v_cache').  ffn: optional replacement of the dense SwiGLU MLP
+    (hn -> f), e.g. the Mixtral sparse MoE of oracle/mixtral.py."""
     bs = x.shape[0]
     hn = rms_norm(x, p[pre + "attn_norm"], eps)
     qkv = F.linear(hn, p[pre + "attn.wqkv"]).view(bs, hq + 2 * hkv, hd)
-    q, k = okv.apply_rotary_pos_emb(qkv[:, :hq], qkv[:, hq : hq + hkv], cos, sin, "llama")
+    q, k = okv.apply_rotary_pos_emb(qkv[:, :hq], qkv[:, hq : hq + hkv], cos, sin, rotary)
     v = qkv[:, hq + hkv :]
     o, k_cache, v_cache = ogqa.attn_with_kvcache(q.reshape(bs, 1, hq, hd), k_cache, v_cache, k.reshape(bs, 1, hkv, hd),
                                                  v.reshape(bs, 1, hkv, hd), lens_excl, block_table)
     a = F.linear(o.to(torch.bfloat16).view(bs, hq * hd), p[pre + "attn.wo"])
     x = x + a
     hn = rms_norm(x, p[pre + "ffn_norm"], eps)
+    if ffn is not None:
+        return x + ffn(hn), k_cache, v_cache
     h13 = F.linear(hn, p[pre + "ffn.w13"])
     d = h13.shape[-1] // 2
     f = F.linear(F.silu(h13[..., :d]) * h13[..., d:], p[pre + "ffn.w2"])

@@ -1,0 +1,83 @@
+"""Mixtral-family decode step with INT8 W8A8 experts (BASELINE config 4 as a parity-test case)."""
+
+import pytest
+import torch
+
+from oracle import llama as ollama
+from oracle import mixtral as omix
+from tests.util import max_rel_to_peak
+
+pytestmark = pytest.mark.gpu
+
+
+def build():
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.mixtral import MixtralArgs, MixtralDecoder, init_synthetic_
+
+    args = MixtralArgs(dim=1024, n_layers=2, n_heads=8, n_kv_heads=2, vocab_size=2048, ffn_dim=512, num_local_experts=8,
+                       num_experts_per_tok=2)
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=4, block_size=256, max_seq_len=1024, device="cuda",
+                                n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
+    model = MixtralDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=1024), max_position_embeddings=1024,
+                           device="cuda")
+    init_synthetic_(model, seed=0)
+    return args, model, cache
+
+
+def test_router_softmax_topk_renorm():
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(19, 1024, generator=g).to(torch.bfloat16)
+    gw = (torch.randn(8, 1024, generator=g) * 1024 ** -0.5).to(torch.bfloat16)
+    w_ref, i_ref = omix.route(x, gw, 2)
+    w, i = ops.gate_deepseek_v3(x.cuda(), gw.cuda(), None, 1, 1, 2, "softmax_renorm", 1.0)
+    assert torch.equal(i.cpu(), i_ref)
+    assert max_rel_to_peak(w.cpu(), w_ref) < 1e-2 and torch.allclose(w.float().sum(-1).cpu(), torch.ones(19), atol=1e-2)
+
+
+def test_layerwise_parity_graph_replay_and_generate():
+    args, model, cache = build()
+    params = {k: v.detach().cpu() for k, v in model.named_parameters()}
+    bs, reqs = 3, ["r0", "r1", "r2"]
+    gen = torch.Generator().manual_seed(7)
+    for r, n in zip(reqs, (0, 255, 300)):
+        cache.register_sequence(r, n)
+        for blk in cache.block_table[r]:
+            cache.paged_k_cache[:, blk] = (torch.randn(args.n_layers, 256, 2, 128, generator=gen) * 0.5).to(torch.bfloat16).cuda()
+            cache.paged_v_cache[:, blk] = (torch.randn(args.n_layers, 256, 2, 128, generator=gen) * 0.5).to(torch.bfloat16).cuda()
+    shadow_k, shadow_v = cache.paged_k_cache.cpu().clone(), cache.paged_v_cache.cpu().clone()
+    cache.prepare_cache_decode(reqs)
+    cache.prepare_block_table_for_decode(reqs)
+    lens = cache.get_gpu_seq_lens_excl_this_decode()[:bs].cpu()
+    table = cache.get_gpu_block_table()[:bs].cpu()
+    cos, sin = model.cos_table.cpu()[lens.long()], model.sin_table.cpu()[lens.long()]
+    x = torch.randn(bs, args.dim, generator=gen).to(torch.bfloat16)
+    for i, layer in enumerate(model.layers):
+        with torch.inference_mode():
+            xm, pend = layer(x.cuda(), None, cos.cuda(), sin.cuda())
+        y = (xm + pend).cpu()
+        pre = f"layers.{i}."
+        y_ref, _, _ = ollama.block(params, pre, x, cos, sin, shadow_k[i], shadow_v[i], table, lens, args.n_heads, 2, 128,
+                                   args.norm_eps, rotary="hf-llama",
+                                   ffn=lambda hn, pre=pre: omix.sparse_moe(params, pre + "ffn.", hn, 2)[0])
+        err = max_rel_to_peak(y, y_ref)
+        assert err < 2e-2, (i, err)
+        x = y_ref
+    tokens = torch.tensor([5, 17, 900], dtype=torch.int64, device="cuda")
+    for step in range(2):
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        snap_k, snap_v = cache.paged_k_cache.clone(), cache.paged_v_cache.clone()
+        eager = model.decode(tokens, use_graph=False).clone()
+        cache.paged_k_cache.copy_(snap_k)
+        cache.paged_v_cache.copy_(snap_v)
+        graph = model.decode(tokens, use_graph=True).clone()
+        assert torch.equal(eager, graph) and torch.isfinite(eager).all()
+        tokens = eager.argmax(dim=-1)
+        cache.finalize_cache_single_decode(reqs)
+    for r in reqs:
+        cache.finalize_cache_all_decode(r)
+    out1 = model.generate([[3, 4, 5], [7]], 3)
+    assert tuple(out1.shape) == (2, 3) and torch.equal(out1, model.generate([[3, 4, 5], [7]], 3))
