@@ -34,7 +34,7 @@ struct Bf16Stage {
     s16x8 x[MT][2];
 };
 
-template <int MT, int WK>
+template <int MT, int WK, bool DEEP = false>
 __global__ __launch_bounds__(64 * WK) void bf16_gemm_kernel(const bf16_t* __restrict__ X,
                                                             const bf16_t* __restrict__ W,
                                                             void* __restrict__ out, int out_dt,
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_kernel(const bf16_t* __rest
             o1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.w[1], st.x[mt][1], o1[mt], 0, 0, 0);
         }
     };
-    constexpr int D = MT >= 4 ? 2 : 4;
+    // DEEP (single token tile, <= 8 K blocks per wave): the wave's whole K range in one round trip
+    constexpr int D = DEEP ? 8 : MT >= 4 ? 2 : 4;
     Bf16Stage<MT> ring[D];
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -525,9 +526,18 @@ extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void*
         case 2: LAUNCH(MT, 2); break;      \
         default: LAUNCH(MT, 1); break;     \
     }
+    const int per_wave = KB / (WK * S);
     for (int64_t mb = 0; mb < M; mb += 32) {
         const int mbase = (int)mb;
-        if (M - mb <= 16) { LAUNCH_WK(1) } else { LAUNCH_WK(2) }
+        if (M - mb <= 16) {
+            if (WK == 8 && per_wave > 4 && per_wave <= 8)
+                hipLaunchKernelGGL((bf16_gemm_kernel<1, 8, true>), grid, dim3(512), 0, st, (const bf16_t*)x_bf16,
+                                   (const bf16_t*)w_bf16, out, out_dtype, partials, (int)M, (int)N, (int)K, S, mbase);
+            else
+                LAUNCH_WK(1)
+        } else {
+            LAUNCH_WK(2)
+        }
     }
 #undef LAUNCH_WK
 #undef LAUNCH

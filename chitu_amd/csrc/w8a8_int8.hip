@@ -46,6 +46,59 @@ __global__ __launch_bounds__(256) void quant_act_int8_kernel(const T* __restrict
     if (tid == 0) s[row] = sc;
 }
 
+// 16-bit inputs, K % 8 == 0, K <= 16384: the row is read ONCE with 16-B loads (all in flight together) and
+// quantised from registers -- same arithmetic as quant_act_int8_kernel.
+template <bool IS_BF16>
+__global__ __launch_bounds__(256) void quant_act_int8_vec_kernel(const uint16_t* __restrict__ x, int8_t* __restrict__ q,
+                                                                 float* __restrict__ s, int K) {
+    __shared__ float red[4];
+    constexpr int CH = 8;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int n_chunks = K >> 3;
+    const uint16_t* xr = x + (int64_t)row * K;
+    i32x4v raw[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) raw[c] = *reinterpret_cast<const i32x4v*>(xr + (size_t)min(tid + c * 256, n_chunks - 1) * 8);
+    float v[CH][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const bool act = tid + c * 256 < n_chunks;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t u = (uint32_t)raw[c][k];
+            v[c][2 * k] = IS_BF16 ? __uint_as_float(u << 16) : f16_to_f32((uint16_t)(u & 0xffffu));
+            v[c][2 * k + 1] = IS_BF16 ? __uint_as_float(u & 0xffff0000u) : f16_to_f32((uint16_t)(u >> 16));
+        }
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(v[c][k]));
+        }
+    }
+    amax = wave_reduce_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+    const float sc = __builtin_fmaxf(amax, 1e-5f) / 127.0f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if (tid + c * 256 >= n_chunks) continue;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float r = rintf(v[c][k] / sc);
+            r = __builtin_fminf(__builtin_fmaxf(r, -128.f), 127.f);
+            const uint32_t b = (uint32_t)(uint8_t)(int8_t)r;
+            if (k < 4) lo |= b << (8 * k); else hi |= b << (8 * (k - 4));
+        }
+        i32x2 o;
+        o[0] = (int)lo;
+        o[1] = (int)hi;
+        *reinterpret_cast<i32x2*>(q + (int64_t)row * K + (size_t)(tid + c * 256) * 8) = o;
+    }
+    if (tid == 0) s[row] = sc;
+}
+
 // grid (N/16); block 64*WK.  MT token tiles of 16.
 template <int MT, int WK>
 __global__ __launch_bounds__(64 * WK) void w8a8_int8_gemm_kernel(
@@ -130,6 +183,13 @@ extern "C" int chitu_hip_quant_act_int8(const void* x, int act_dtype, int64_t ro
     CHITU_REQUIRE(x && q_int8 && scales && rows >= 0 && cols >= 1 && cols < (1ll << 31));
     if (rows == 0) return CHITU_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (act_dtype <= 1 && cols % 8 == 0 && cols <= 16384) {
+        if (act_dtype == 0)
+            hipLaunchKernelGGL(quant_act_int8_vec_kernel<true>, dim3((unsigned)rows), dim3(256), 0, st, (const uint16_t*)x, (int8_t*)q_int8, scales, (int)cols);
+        else
+            hipLaunchKernelGGL(quant_act_int8_vec_kernel<false>, dim3((unsigned)rows), dim3(256), 0, st, (const uint16_t*)x, (int8_t*)q_int8, scales, (int)cols);
+        CHITU_RETURN_LAUNCH_STATUS();
+    }
     if (act_dtype == 0)
         hipLaunchKernelGGL(quant_act_int8_kernel<bf16_in>, dim3((unsigned)rows), dim3(256), 0, st, (const bf16_in*)x, (int8_t*)q_int8, scales, (int)cols);
     else if (act_dtype == 1)
