@@ -554,3 +554,50 @@ def test_long_decode_run_graph_equals_eager_across_page_boundaries():
     for a, b in zip(kv_g, kv_e):
         assert torch.equal(a, b)
     assert all(torch.isfinite(x).all() for x in lg) and cache.seq_lens[rb[0]] == starts[0] + 70
+
+
+def test_large_batch_matches_small_batches():
+    """Batch invariance: one decode step over 70 ragged sequences (multi-tile GEMM paths, > 32 sequences
+    => un-fused split merge, 350 routed slots) gives every sequence the logits it gets when decoded in
+    batches of 7 (different K-split heuristics => fp8-noise tolerance), graph replay == eager."""
+    args = tiny_args()
+    model, cache = build(args, max_reqs=72, max_seq=320)
+    g = torch.Generator().manual_seed(17)
+    n = 70
+    lens = torch.randint(1, 200, (n,), generator=g).tolist()
+    toks = torch.randint(0, args.vocab_size, (n,), generator=g)
+
+    def fill(tag):
+        reqs = [f"{tag}{i}" for i in range(n)]
+        gg = torch.Generator().manual_seed(5)
+        for r, L in zip(reqs, lens):
+            cache.register_sequence(r, L)
+            rows = (torch.randn(args.n_layers, 256, 576, generator=gg) * 0.5).to(torch.bfloat16).cuda()
+            for p, blk in enumerate(cache.block_table[r]):
+                cache.paged_kv_cache[:, blk] = rows[:, p * 64 : (p + 1) * 64]
+        return reqs
+
+    def step(reqs, idx, use_graph):
+        ids = [reqs[i] for i in idx]
+        cache.prepare_cache_decode(ids)
+        cache.prepare_block_table_for_decode(ids)
+        out = model.decode(toks[idx].cuda(), use_graph=use_graph).clone()
+        cache.finalize_cache_single_decode(ids)
+        return out
+
+    big = fill("b")
+    snap = cache.paged_kv_cache.clone()
+    full = step(big, list(range(n)), use_graph=False)
+    assert torch.isfinite(full).all() and tuple(full.shape) == (n, args.vocab_size)
+    # graph replay of the same step on the restored cache
+    cache.paged_kv_cache.copy_(snap)
+    for r, L in zip(big, lens):
+        cache.seq_lens[r] = L
+    assert torch.equal(step(big, list(range(n)), use_graph=True), full)
+    for r in big:
+        cache.finalize_cache_all_decode(r)
+    small = fill("s")
+    for s0 in range(0, n, 7):
+        idx = list(range(s0, s0 + 7))
+        part = step(small, idx, use_graph=False)
+        assert max_rel_to_peak(part, full[idx]) < 4e-2, s0
