@@ -111,8 +111,9 @@ def precompute_freqs_cis(args: DeepSeekV3Args, max_position_embeddings: int):
         ramp = torch.clamp((torch.arange(dim // 2, dtype=torch.float32) - low) / (high - low), 0, 1)
         smooth = 1 - ramp
         freqs = freqs / factor * (1 - smooth) + freqs * smooth
-    ang = torch.outer(torch.arange(max_position_embeddings).float(), freqs)
-    return torch.cos(ang), torch.sin(ang)
+    ang = torch.outer(torch.arange(max_position_embeddings), freqs)
+    cis = torch.polar(torch.ones_like(ang), ang)  # same host routine as the reference: bit-identical table
+    return cis.real.contiguous(), cis.imag.contiguous()
 
 
 def linear_deepseek_v3(x, weight, weight_scale=None, bias=None, x_quant=None):

@@ -42,10 +42,12 @@ class LlamaArgs:
 
 
 def precompute_freqs_cis(head_dim: int, max_pos: int, theta: float):
-    """cos/sin [max_pos, head_dim/2] fp32 (models/model.py:381-392: precompute_freqs_cis)."""
+    """cos/sin [max_pos, head_dim/2] fp32 (models/model.py:81-88: precompute_freqs_cis; torch.polar like the
+    reference so the table is bit-identical)."""
     freqs = 1.0 / (theta ** (torch.arange(0, head_dim, 2)[: head_dim // 2].float() / head_dim))
     ang = torch.outer(torch.arange(max_pos, dtype=torch.float32), freqs)
-    return torch.cos(ang), torch.sin(ang)
+    cis = torch.polar(torch.ones_like(ang), ang)
+    return cis.real.contiguous(), cis.imag.contiguous()
 
 
 def _param(*shape, device=None):

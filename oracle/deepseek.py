@@ -103,6 +103,34 @@ def moe_layer(p, pre, x, cfg, routing=None):
     return (y1 if y is None else y + y1), routing
 
 
+def moe_layer_loop(p, pre, x, cfg, routing=None):
+    """The reference's OTHER MoE branch: the per-expert loop (model_deepseek_v3.py:1012-1061) it takes where the
+    fused Triton kernel is unavailable.  Each expert's w2 output is rounded to bf16, scaled by its bf16 routing
+    weight and accumulated into a bf16 `y` in expert order, then the shared experts are added.  Used to pin this
+    file against the reference model's own CPU run (tests/golden/gen_ref_model.py), where that branch is the one
+    that runs; the product path follows the fused branch (`moe_layer`)."""
+    if routing is None:
+        routing = gate(x, p[pre + "gate.weight"], p.get(pre + "gate.bias"), cfg["n_groups"], cfg["topk_groups"],
+                       cfg["topk"], cfg["score_func"], cfg["route_scale"])
+    weights, indices = routing
+    nr = cfg["n_routed"]
+    w13, s13, w2, s2 = p[pre + "w1w3_weight"], p[pre + "w1w3_scale"], p[pre + "w2_weight"], p[pre + "w2_scale"]
+
+    def expert(e, xe):
+        h = fp8.linear_deepseek_v3(xe, w13[e], s13[e])
+        d = h.shape[-1] // 2
+        return fp8.linear_deepseek_v3(F.silu(h[..., :d]) * h[..., d:], w2[e], s2[e])
+
+    y = torch.zeros_like(x)
+    for e in range(nr):
+        idx, top = torch.where(indices == e)
+        if idx.numel():
+            y[idx] += expert(e, x[idx]) * weights[idx, top, None]
+    for e in range(nr, w13.shape[0]):
+        y += expert(e, x)
+    return y, routing
+
+
 def block(p, i, x, cos, sin, cache_layer, block_table, lens_excl, cfg, is_moe, routing=None):
     pre = f"layers.{i}."
     a, cache_layer = attention_decode(p, pre + "attn.", rms_norm(x, p[pre + "attn_norm.weight"], cfg["eps"]), cos, sin,
@@ -110,7 +138,7 @@ def block(p, i, x, cos, sin, cache_layer, block_table, lens_excl, cfg, is_moe, r
     x = x + a
     hn = rms_norm(x, p[pre + "ffn_norm.weight"], cfg["eps"])
     if is_moe:
-        f, routing = moe_layer(p, pre + "ffn.", hn, cfg, routing)
+        f, routing = (moe_layer_loop if cfg.get("moe_impl") == "loop" else moe_layer)(p, pre + "ffn.", hn, cfg, routing)
     else:
         f = mlp(p, pre + "ffn.", hn)
     return x + f, cache_layer, routing

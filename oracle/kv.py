@@ -2,6 +2,8 @@
 
 import torch
 
+from . import fp8 as _fp8  # CAST["out"]: the final bf16 rounding (swappable: the Triton interpreter truncates)
+
 
 def append_to_paged_kv_cache(kv_cache, page_table, this_kv, old_seq_lens):
     """chitu/ops.py:57-60 docstring / triton_kernels.py:18-48 (page arithmetic uses the page size;
@@ -30,13 +32,13 @@ def apply_rotary_pos_emb(q, k, cos, sin, rotary_type="llama"):
             x0, x1 = xf[..., 0::2], xf[..., 1::2]
             o0 = x0 * c + (-x1) * s
             o1 = x1 * c + x0 * s
-            return torch.stack([o0, o1], dim=-1).flatten(-2).to(x.dtype)
+            return _fp8.CAST["out"](torch.stack([o0, o1], dim=-1).flatten(-2), x.dtype)
         elif rotary_type == "hf-llama":
             h = xf.shape[-1] // 2
             x0, x1 = xf[..., :h], xf[..., h:]
             o0 = x0 * c + (-x1) * s
             o1 = x1 * c + x0 * s
-            return torch.cat([o0, o1], dim=-1).to(x.dtype)
+            return _fp8.CAST["out"](torch.cat([o0, o1], dim=-1), x.dtype)
         raise ValueError(rotary_type)
 
     return rot(q), rot(k)

@@ -101,3 +101,41 @@ def gqa_prefill_golden_case():
     cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32)
     return dict(q=lattice(T, 8, 128, mod=89, scale=64.0, salt=4), k=lattice(T, 2, 128, salt=6), v=lattice(T, 2, 128, mod=83, salt=8),
                 cu=cu, seqs=seqs, rows=torch.from_numpy(g["rows"]), out=bf16(g["out"]))
+
+
+def ref_model_case():
+    """Parameters of tests/golden/ref_model_v3.npz regenerated exactly as tests/golden/gen_ref_model.py::fill
+    does (same seed, same sorted-name order), keyed by the oracle's / chitu_amd's parameter names."""
+    g = golden("ref_model_v3")
+    # the reference model's constructor leaves torch's default dtype at bfloat16 (model_deepseek_v3.py:1131), so
+    # gen_ref_model.py::fill drew its randn / rand tensors in bf16: same here
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        return g, _ref_model_params(g)
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def _ref_model_params(g):
+    gen = torch.Generator().manual_seed(1234)
+    dts = {"torch.float8_e4m3fn": torch.float8_e4m3fn, "torch.float32": torch.float32, "torch.bfloat16": torch.bfloat16}
+    params = {}
+    for n, shp, dt in zip(g["names"].tolist(), g["shapes"].tolist(), g["dtypes"].tolist()):
+        shape, dtype = eval(shp), dts[dt]
+        if dtype == torch.float8_e4m3fn:
+            t = (torch.randn(shape, generator=gen) * 0.5).to(torch.float8_e4m3fn)
+        elif dtype == torch.float32:
+            t = torch.rand(shape, generator=gen) * 0.02 + 0.01
+        elif n.endswith("norm.weight"):
+            t = torch.ones(shape, dtype=dtype)
+        elif n.endswith("gate.weight"):
+            t = (torch.randn(shape, generator=gen) * shape[-1] ** -0.5).to(dtype)
+        else:
+            t = (torch.randn(shape, generator=gen) * 0.05).to(dtype)
+        # the reference stacks the experts as module `w1w3` / `w2` with .weight/.scale; here they are flat names
+        if t.dim() == 3:  # MoE layers only; the dense MLP keeps w1w3.weight / w2.weight
+            for m in ("w1w3", "w2"):
+                n = n.replace(f"ffn.{m}.weight", f"ffn.{m}_weight").replace(f"ffn.{m}.scale", f"ffn.{m}_scale")
+        params[n] = t.to(dtype) if t.dtype != dtype else t
+    return params
