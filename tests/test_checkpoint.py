@@ -1,0 +1,147 @@
+"""chitu_amd/checkpoint.py against the reference's own loader functions (tests/golden/gen_ckpt.py ->
+ckpt_preprocess.json: per TP rank the ordered (name, shape, dtype, sha1) list), plus load / save round trips on the
+module tree.  Host-only: runs without a GPU."""
+
+import json
+import os
+
+import pytest
+import torch
+
+from chitu_amd import checkpoint as ck
+from tests.util import CKPT_TINY, tensor_digest, tiny_hf_checkpoint
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden():
+    with open(os.path.join(HERE, "golden", "ckpt_preprocess.json")) as f:
+        return json.load(f)
+
+
+def _renamed():
+    out = {}
+    for k, v in tiny_hf_checkpoint().items():
+        n = ck.map_hf_name(k)
+        if n is not None:
+            out[n] = v
+    return out
+
+
+def _args(shard):
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args
+
+    keys = ("vocab_size", "dim", "inter_dim", "moe_inter_dim", "n_layers", "n_dense_layers", "n_heads", "n_routed_experts",
+            "n_shared_experts", "n_activated_experts", "n_expert_groups", "n_limited_groups", "route_scale", "score_func",
+            "q_lora_rank", "kv_lora_rank", "qk_nope_head_dim", "qk_rope_head_dim", "v_head_dim", "rope_theta", "rope_factor")
+    return DeepSeekV3Args(**{k: CKPT_TINY[k] for k in keys}, gate_bias=True, shard_degree=shard)
+
+
+def test_hf_names_map_like_the_reference_loader():
+    g = _golden()
+    assert sorted(_renamed().keys()) == sorted(g["names_after_rename"])  # (file key order is safetensors', not ours)
+    assert ck.map_hf_name("model.layers.61.self_attn.q_a_proj.weight") is None  # MTP layer dropped
+    assert ck.map_hf_name("model.layers.3.mlp.gate.e_score_correction_bias") == "layers.3.ffn.gate.bias"
+    assert ck.map_hf_name("model.layers.3.mlp.experts.7.down_proj.weight_scale_inv") == "layers.3.ffn.experts.7.w2.scale"
+    with pytest.raises(KeyError):
+        ck.map_hf_name("model.layers.0.self_attn.rotary_emb.inv_freq")
+
+
+@pytest.mark.parametrize("rank", [0, 1])
+def test_shard_merge_stack_bit_identical_to_the_reference(rank):
+    g = _golden()
+    mine = ck.preprocess_deepseek_v3(_renamed(), CKPT_TINY["n_routed_experts"], rank, g["tp"])
+    got = {k: tensor_digest(v) for k, v in mine.items()}
+    want = {r[0]: r[1:] for r in g["ranks"][rank]}
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k] == want[k], (k, got[k], want[k])
+
+
+def test_ranks_partition_the_checkpoint():
+    """Concatenating the two ranks' shards along the sharded dim gives back the unsharded tensors (size-independent
+    property: nothing lost, nothing duplicated)."""
+    full = ck.preprocess_deepseek_v3(_renamed(), 4, 0, 1)
+    r0 = ck.preprocess_deepseek_v3(_renamed(), 4, 0, 2)
+    r1 = ck.preprocess_deepseek_v3(_renamed(), 4, 1, 2)
+    for k, t in full.items():
+        a, b = r0[k], r1[k]
+        if a.shape == t.shape:
+            assert torch.equal(a.view(torch.uint8), t.view(torch.uint8)) and torch.equal(b.view(torch.uint8), t.view(torch.uint8))
+            continue
+        dim = [i for i in range(t.dim()) if a.shape[i] != t.shape[i]]
+        assert len(dim) == 1, k
+        d = dim[0]
+        if k.endswith(("w1w3.weight", "w1w3.scale")):  # merged [w1 shard | w3 shard]: un-merge before comparing
+            h, ht = a.shape[d] // 2, t.shape[d] // 2
+            lo = torch.cat([a.narrow(d, 0, h), b.narrow(d, 0, h)], dim=d)
+            hi = torch.cat([a.narrow(d, h, h), b.narrow(d, h, h)], dim=d)
+            assert torch.equal(lo.view(torch.uint8), t.narrow(d, 0, ht).contiguous().view(torch.uint8)), k
+            assert torch.equal(hi.view(torch.uint8), t.narrow(d, ht, ht).contiguous().view(torch.uint8)), k
+        else:
+            assert torch.equal(torch.cat([a, b], dim=d).view(torch.uint8), t.contiguous().view(torch.uint8)), k
+
+
+def test_uneven_shards_are_refused():
+    st = {"layers.0.attn.wq_b.weight": torch.zeros(6, 4)}
+    with pytest.raises(ValueError):
+        ck.chunk_for_tensor_parallel(st, 0, 4)
+
+
+@pytest.mark.parametrize("rank", [0, 1])
+def test_load_into_module_tree_and_save_round_trip(rank, tmp_path):
+    from safetensors.torch import save_file
+
+    from chitu_amd.deepseek_v3 import DeepSeekV3Decoder
+
+    save_file({k: v.contiguous() for k, v in tiny_hf_checkpoint().items()}, str(tmp_path / "model-00001-of-00001.safetensors"))
+    model = DeepSeekV3Decoder(_args(2), None, None, max_position_embeddings=64, device="cpu")
+    model.layers[1].attn._w_uk_t = "stale"
+    ck.load_checkpoint_deepseek_v3(model, str(tmp_path), rank=rank, world=2)
+    assert model.layers[1].attn._w_uk_t is None
+    want = ck.to_module_names(ck.preprocess_deepseek_v3(_renamed(), 4, rank, 2))
+    params = dict(model.named_parameters())
+    assert set(params) == set(want)
+    for k, p in params.items():
+        assert tensor_digest(p) == tensor_digest(want[k]), k
+    # spot checks of the layout the kernels assume
+    qa = tiny_hf_checkpoint()["model.layers.0.self_attn.q_a_proj.weight"]
+    assert torch.equal(params["layers.0.attn.wqkv_a.weight"][:128].view(torch.uint8), qa.view(torch.uint8))
+    sh = tiny_hf_checkpoint()["model.layers.1.mlp.shared_experts.up_proj.weight"]
+    assert torch.equal(params["layers.1.ffn.w1w3_weight"][4, 128:].view(torch.uint8),
+                       torch.chunk(sh, 2, dim=0)[rank].contiguous().view(torch.uint8))  # shared expert = last slot, up half
+    # preprocess-and-save, then the skip_preprocess load (script/preprocess_and_save.py)
+    out = tmp_path / "pre"
+    ck.save_preprocessed(model, str(out), rank)
+    model2 = DeepSeekV3Decoder(_args(2), None, None, max_position_embeddings=64, device="cpu")
+    ck.load_checkpoint_deepseek_v3(model2, str(out), rank=rank, world=2, skip_preprocess=True)
+    for (k, p), (k2, p2) in zip(model.named_parameters(), model2.named_parameters()):
+        assert k == k2 and tensor_digest(p) == tensor_digest(p2), k
+
+
+def test_load_rejects_wrong_shapes_and_fp8_casts():
+    from chitu_amd.deepseek_v3 import DeepSeekV3Decoder
+
+    model = DeepSeekV3Decoder(_args(2), None, None, max_position_embeddings=64, device="cpu")
+    good = ck.to_module_names(ck.preprocess_deepseek_v3(_renamed(), 4, 0, 2))
+    bad = dict(good)
+    bad["layers.0.attn.wo.weight"] = good["layers.0.attn.wo.weight"][:, :128]
+    with pytest.raises(ValueError):
+        ck.load_deepseek_v3(model, bad)
+    bad = dict(good)
+    bad["layers.0.attn.wo.weight"] = good["layers.0.attn.wo.weight"].to(torch.bfloat16)
+    with pytest.raises(TypeError):
+        ck.load_deepseek_v3(model, bad)
+    bad = dict(good)
+    del bad["norm.weight"]
+    with pytest.raises(KeyError):
+        ck.load_deepseek_v3(model, bad)
+
+
+def test_q_lora_rank_zero_merges_wq_with_wkv_a():
+    st = {"layers.0.attn.wq.weight": torch.arange(12.0).view(6, 2), "layers.0.attn.wkv_a.weight": torch.ones(3, 2),
+          "layers.0.attn.wq.scale": torch.zeros(2, 1), "layers.0.attn.wkv_a.scale": torch.ones(1, 1)}
+    sharded = ck.chunk_for_tensor_parallel(st, 1, 2)
+    out = ck.to_module_names(sharded, q_lora_rank=0)
+    assert set(out) == {"layers.0.attn.wq_kv_a.weight", "layers.0.attn.wq_kv_a.scale"}
+    assert torch.equal(out["layers.0.attn.wq_kv_a.weight"], torch.cat([st["layers.0.attn.wq.weight"][3:], torch.ones(3, 2)]))

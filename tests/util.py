@@ -139,3 +139,66 @@ def _ref_model_params(g):
                 n = n.replace(f"ffn.{m}.weight", f"ffn.{m}_weight").replace(f"ffn.{m}.scale", f"ffn.{m}_scale")
         params[n] = t.to(dtype) if t.dtype != dtype else t
     return params
+
+
+CKPT_TINY = dict(name="tiny-ckpt", type="deepseek-v3", vocab_size=512, dim=256, inter_dim=512, moe_inter_dim=256, n_layers=2,
+                 n_dense_layers=1, n_heads=4, n_routed_experts=4, n_shared_experts=1, n_activated_experts=2,
+                 n_expert_groups=1, n_limited_groups=1, route_scale=2.5, score_func="sigmoid", q_lora_rank=128,
+                 kv_lora_rank=128, qk_nope_head_dim=128, qk_rope_head_dim=64, v_head_dim=128, rope_theta=10000.0,
+                 rope_factor=40, main_weight_dtype="float8_e4m3fn")
+
+
+def tiny_hf_checkpoint(cfg=CKPT_TINY, seed=77):
+    """A DeepSeek-V3 checkpoint under HUGGING FACE names (FP8 weights + `weight_scale_inv` block scales, bf16 norms /
+    router / embeddings, the router's e_score_correction_bias, and one tensor of the multi-token-prediction layer
+    `model.layers.61` that the loader must drop).  Shared by tests/golden/gen_ckpt.py (fed to the reference's loader)
+    and the checkpoint tests (fed to chitu_amd.checkpoint)."""
+    g = torch.Generator().manual_seed(seed)
+    c = cfg
+    H, qk = c["n_heads"], c["qk_nope_head_dim"] + c["qk_rope_head_dim"]
+    sd = {}
+
+    def fp8w(name, n, k):
+        sd[name + ".weight"] = (torch.randn(n, k, generator=g, dtype=torch.float32) * 0.5).to(torch.float8_e4m3fn)
+        sd[name + ".weight_scale_inv"] = torch.rand((n + 127) // 128, (k + 127) // 128, generator=g, dtype=torch.float32) * 0.02 + 0.01
+
+    def bf(name, *shape):
+        sd[name] = (torch.randn(*shape, generator=g, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+
+    def mlp(prefix, inter):
+        fp8w(prefix + "gate_proj", inter, c["dim"])
+        fp8w(prefix + "up_proj", inter, c["dim"])
+        fp8w(prefix + "down_proj", c["dim"], inter)
+
+    bf("model.embed_tokens.weight", c["vocab_size"], c["dim"])
+    for i in range(c["n_layers"]):
+        p = f"model.layers.{i}."
+        bf(p + "input_layernorm.weight", c["dim"])
+        bf(p + "post_attention_layernorm.weight", c["dim"])
+        a = p + "self_attn."
+        fp8w(a + "q_a_proj", c["q_lora_rank"], c["dim"])
+        bf(a + "q_a_layernorm.weight", c["q_lora_rank"])
+        fp8w(a + "q_b_proj", H * qk, c["q_lora_rank"])
+        fp8w(a + "kv_a_proj_with_mqa", c["kv_lora_rank"] + c["qk_rope_head_dim"], c["dim"])
+        bf(a + "kv_a_layernorm.weight", c["kv_lora_rank"])
+        fp8w(a + "kv_b_proj", H * (c["qk_nope_head_dim"] + c["v_head_dim"]), c["kv_lora_rank"])
+        fp8w(a + "o_proj", c["dim"], H * c["v_head_dim"])
+        if i < c["n_dense_layers"]:
+            mlp(p + "mlp.", c["inter_dim"])
+        else:
+            bf(p + "mlp.gate.weight", c["n_routed_experts"], c["dim"])
+            bf(p + "mlp.gate.e_score_correction_bias", c["n_routed_experts"])
+            for e in range(c["n_routed_experts"]):
+                mlp(p + f"mlp.experts.{e}.", c["moe_inter_dim"])
+            mlp(p + "mlp.shared_experts.", c["moe_inter_dim"] * c["n_shared_experts"])
+    bf("model.norm.weight", c["dim"])
+    bf("lm_head.weight", c["vocab_size"], c["dim"])
+    bf("model.layers.61.embed_tokens.weight", 8, c["dim"])
+    return sd
+
+
+def tensor_digest(t):
+    import hashlib
+
+    raw = t.detach().contiguous().view(torch.uint8).numpy().tobytes()
+    return [list(t.shape), str(t.dtype), hashlib.sha1(raw).hexdigest()]
