@@ -397,6 +397,31 @@ int chitu_hip_gqa_decode(const void* q_bf16, int64_t q_stride_b, int64_t q_strid
                          int32_t head_dim, int32_t num_splits, void* workspace, int64_t workspace_bytes,
                          void* stream);
 
+/* ---- token sampling (the step after the path) -----------------------------------
+ * Replaces NormalExecutor.update_response's device work (chitu/executor.py:82-112) and
+ * top_k_top_p_min_p_sampling_from_probs_torch (chitu/utils.py:62-81: full sort + cumsum + multinomial).
+ *   frequency_penalty: logits[row, t] -= penalties[row] once per occurrence of t in
+ *     tokens[offsets[row] .. offsets[row+1]) for rows with penalties[row] > 0 (executor.py:89-102);
+ *     logits [rows, row_stride] f32 in place, tokens i32 (ids outside [0, vocab) ignored).
+ *   sample: one token per row, out_tokens [rows] i64.
+ *     top_ks == NULL: greedy for every row = first index of the row maximum (executor.py:103-104).
+ *     else per row: top_k == 1 -> arg-max; otherwise weights e = exp(x/T - max) (probs_mode 0: `logits`
+ *     are logits, temperatures [rows]) or p / max p (probs_mode 1: `logits` are probabilities,
+ *     temperatures may be NULL); the entry at position pos of the descending order (ties: lower
+ *     index first) is kept iff pos < top_k (top_k <= 0: no limit) and the exclusive cumulative
+ *     weight before it is <= top_p * sum(weights) (top_p >= 1: no limit) -- utils.py:72-76;
+ *     the token is the inverse CDF of uniforms[row] in [0, 1) over the kept weights in index
+ *     order.  Weights are accumulated as integers (scaled by 2^40), so results are deterministic.
+ *     n_kept_out [rows] i32 / kept_mass_out [rows] f32 (kept weight / total) are optional.
+ *   logits of act_dtype (0 bf16, 1 f16, 2 f32), row_stride in elements, any vocab > 0. */
+int chitu_hip_frequency_penalty(float* logits, int64_t row_stride, int64_t rows, int32_t vocab,
+                                const int32_t* tokens, const int32_t* offsets, const float* penalties,
+                                void* stream);
+int chitu_hip_sample(const void* logits, int act_dtype, int64_t row_stride, int64_t rows, int32_t vocab,
+                     const float* temperatures, const int32_t* top_ks, const float* top_ps,
+                     const float* uniforms, int32_t probs_mode, int64_t* out_tokens,
+                     int32_t* n_kept_out, float* kept_mass_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
