@@ -25,7 +25,7 @@ __global__ __launch_bounds__(kAlignThreads) void moe_align_kernel(
     const id_t* __restrict__ ids, int64_t numel, int E, int block_size,
     int32_t* __restrict__ sorted_ids, int64_t sorted_cap, int32_t* __restrict__ expert_ids,
     int64_t expert_cap, int32_t* __restrict__ num_post_pad, int32_t* __restrict__ cumsum,
-    int fill) {
+    int fill, const int32_t* __restrict__ expert_map) {
     extern __shared__ __attribute__((aligned(16))) int lds[];
     int* counts = lds;
     int* cursor = lds + E;
@@ -69,15 +69,24 @@ __global__ __launch_bounds__(kAlignThreads) void moe_align_kernel(
     incl += wave_base;
     const int start = incl - padded;
     if (tid < E) {
+        const int32_t own_id = expert_map ? expert_map[tid] : (int32_t)tid;  // local id or -1 (expert parallelism)
         cursor[tid] = start;
         cumsum[tid + 1] = incl;
         for (int i = start; i < incl; i += block_size) {
             const int b = i / block_size;
-            if (b < expert_cap) expert_ids[b] = tid;
+            if (b < expert_cap) expert_ids[b] = own_id;
         }
         if (tid == E - 1) *num_post_pad = incl;
     }
     if (tid == 0) cumsum[0] = 0;
+    if (expert_map) {
+        // expert_ids = expert_map[expert_ids] over the WHOLE array (fused_moe.py:516-517): the blocks
+        // past num_tokens_post_pad hold the allocator's 0 and therefore map to expert_map[0]
+        int total = 0;
+        for (int w = 0; w < kAlignWaves; ++w) total += wave_tot[w];
+        const int32_t tail_id = expert_map[0];
+        for (int64_t b = total / block_size + tid; b < expert_cap; b += kAlignThreads) expert_ids[b] = tail_id;
+    }
     __syncthreads();
 
     // Pass 3: stable scatter, 1024 tokens per round.
@@ -126,12 +135,13 @@ __global__ __launch_bounds__(kAlignThreads) void moe_align_kernel(
 
 // ids_dtype follows torch's integral ScalarType numbering, the set the reference
 // dispatches over (moe_align_kernel.cu:17-25): 0=u8 1=i8 2=i16 3=i32 4=i64.
-extern "C" int chitu_hip_moe_align_block_size(const void* topk_ids, int ids_dtype, int64_t numel,
-                                              int32_t num_experts, int32_t block_size,
-                                              int32_t* sorted_token_ids, int64_t sorted_cap,
-                                              int32_t* expert_ids, int64_t expert_ids_cap,
-                                              int32_t* num_tokens_post_pad, int32_t* cumsum,
-                                              int32_t fill_sentinels, void* stream) {
+extern "C" int chitu_hip_moe_align_block_size_mapped(const void* topk_ids, int ids_dtype, int64_t numel,
+                                                     int32_t num_experts, int32_t block_size,
+                                                     int32_t* sorted_token_ids, int64_t sorted_cap,
+                                                     int32_t* expert_ids, int64_t expert_ids_cap,
+                                                     int32_t* num_tokens_post_pad, int32_t* cumsum,
+                                                     int32_t fill_sentinels, const int32_t* expert_map,
+                                                     void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(sorted_token_ids && expert_ids && num_tokens_post_pad && cumsum);
     CHITU_REQUIRE(numel >= 0 && (numel == 0 || topk_ids));
@@ -148,7 +158,7 @@ extern "C" int chitu_hip_moe_align_block_size(const void* topk_ids, int ids_dtyp
     hipLaunchKernelGGL(moe_align_kernel<T>, dim3(1), dim3(kAlignThreads), lds, s,              \
                        (const T*)topk_ids, numel, (int)num_experts, (int)block_size,           \
                        sorted_token_ids, sorted_cap, expert_ids, expert_ids_cap,               \
-                       num_tokens_post_pad, cumsum, (int)fill_sentinels)
+                       num_tokens_post_pad, cumsum, (int)fill_sentinels, expert_map)
     switch (ids_dtype) {
         case 0: LAUNCH(uint8_t); break;
         case 1: LAUNCH(int8_t); break;
@@ -159,4 +169,15 @@ extern "C" int chitu_hip_moe_align_block_size(const void* topk_ids, int ids_dtyp
     }
 #undef LAUNCH
     CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_moe_align_block_size(const void* topk_ids, int ids_dtype, int64_t numel,
+                                              int32_t num_experts, int32_t block_size,
+                                              int32_t* sorted_token_ids, int64_t sorted_cap,
+                                              int32_t* expert_ids, int64_t expert_ids_cap,
+                                              int32_t* num_tokens_post_pad, int32_t* cumsum,
+                                              int32_t fill_sentinels, void* stream) {
+    return chitu_hip_moe_align_block_size_mapped(topk_ids, ids_dtype, numel, num_experts, block_size,
+                                                 sorted_token_ids, sorted_cap, expert_ids, expert_ids_cap,
+                                                 num_tokens_post_pad, cumsum, fill_sentinels, nullptr, stream);
 }

@@ -62,6 +62,13 @@ class DeepSeekV3Args:
     # (the reference's behaviour).  bench.py sets 8 to run one TP=8 rank shard per GPU even when
     # fewer than 8 ranks are live (collectives then span the live ranks only).
     shard_degree: Optional[int] = None
+    # Expert parallelism (the reference's stub: `moe_world_size = 1` hard-coded at
+    # model_deepseek_v3.py:870-871, `expert_map=None  # use when ep > 1` at :1004).  moe_world_size > 1:
+    # rank r holds routed experts [r*E/ep, (r+1)*E/ep) at FULL width and 1/ep of the shared experts' width;
+    # must equal tp_degree() (the ranks that share the replicated activations).  moe_rank None = this
+    # process's TP rank (an explicit value runs one rank's shard on a lone GPU, like shard_degree).
+    moe_world_size: int = 1
+    moe_rank: Optional[int] = None
 
     def tp_degree(self):
         return self.shard_degree if self.shard_degree is not None else tp.get_tp_size()
@@ -277,10 +284,10 @@ class AttentionDeepSeekV3(torch.nn.Module):
 class MLPDeepSeekV3(torch.nn.Module):
     """Dense FFN of the first n_dense_layers (model_deepseek_v3.py:703-772), gate/up merged."""
 
-    def __init__(self, args, device=None):
+    def __init__(self, args, device=None, inter: Optional[int] = None):
         super().__init__()
         tp_size = args.tp_degree()
-        self.inter = args.inter_dim // tp_size
+        self.inter = args.inter_dim // tp_size if inter is None else inter
         self.w1w3 = Fp8Linear(args.dim, 2 * self.inter, device)
         self.w2 = Fp8Linear(self.inter, args.dim, device)
 
@@ -318,9 +325,30 @@ class MoEDeepSeekV3(torch.nn.Module):
         super().__init__()
         tp_size = args.tp_degree()
         self.n_routed, self.n_shared = args.n_routed_experts, args.n_shared_experts
-        self.inter = args.moe_inter_dim // tp_size
-        E = self.n_routed + self.n_shared
+        self.moe_world_size = args.moe_world_size
         self.gate = GateDeepSeekV3(args, device)
+        if self.moe_world_size > 1:
+            # expert parallel: names follow model_deepseek_v3.py:870-880
+            ep = self.moe_world_size
+            assert tp_size == ep, "experts are partitioned over the ranks that share the activations (tp group)"
+            assert self.n_routed % ep == 0, f"Number of experts must be divisible by world size (world_size={ep})"
+            self.moe_rank = (tp.get_tp_rank() % ep) if args.moe_rank is None else args.moe_rank
+            self.n_local_experts = self.n_routed // ep
+            self.experts_start_idx = self.moe_rank * self.n_local_experts
+            self.experts_end_idx = self.experts_start_idx + self.n_local_experts
+            emap = torch.full((self.n_routed,), -1, dtype=torch.int32)
+            emap[self.experts_start_idx:self.experts_end_idx] = torch.arange(self.n_local_experts, dtype=torch.int32)
+            self.register_buffer("expert_map", emap.to(device) if device is not None else emap, persistent=False)
+            self.inter = args.moe_inter_dim
+            E = self.n_local_experts
+            shared_inter = self.n_shared * args.moe_inter_dim
+            assert shared_inter % (ep * BLOCK) == 0 or self.n_shared == 0, "shared width / ep must keep 128-blocks whole"
+            # n_shared experts of width I on the same input = one MLP of width n_shared * I; its width is
+            # split over the ranks like any row/column-parallel MLP and rides in the layer's all-reduce
+            self.shared = MLPDeepSeekV3(args, device, inter=shared_inter // ep) if self.n_shared else None
+        else:
+            self.inter = args.moe_inter_dim // tp_size
+            E = self.n_routed + self.n_shared
         self.w1w3_weight = torch.nn.Parameter(torch.empty(E, 2 * self.inter, args.dim, dtype=FP8, device=device), requires_grad=False)
         self.w1w3_scale = torch.nn.Parameter(torch.empty(E, (2 * self.inter + BLOCK - 1) // BLOCK, args.dim // BLOCK, dtype=torch.float32, device=device), requires_grad=False)
         self.w2_weight = torch.nn.Parameter(torch.empty(E, args.dim, self.inter, dtype=FP8, device=device), requires_grad=False)
@@ -337,6 +365,8 @@ class MoEDeepSeekV3(torch.nn.Module):
         1010), both inside its tolerance: shared + routed are summed in fp32 and rounded once instead of
         bf16 + bf16, and the shared experts' input uses the group-quant rule of the routed ones."""
         nr, ns = self.n_routed, self.n_shared
+        if self.moe_world_size > 1:
+            return self.forward_expert_parallel(x, x_quant)
         if ns >= 1:
             weights, indices = self.gate(x, extra_expert_id=nr, extra_count=ns)
         else:
@@ -346,6 +376,23 @@ class MoEDeepSeekV3(torch.nn.Module):
             inplace=True, global_num_experts=nr + ns, w1_scale=self.w1w3_scale, w2_scale=self.w2_scale,
             block_shape=[BLOCK, BLOCK], a1_quant=x_quant, reduce_topk=not defer_sum,
         )
+
+    def forward_expert_parallel(self, x, x_quant):
+        """Expert-parallel MoE.  The activations are replicated over the group (the attention
+        all-reduce leaves them so), every rank routes ALL tokens with the replicated gate, runs the slots
+        whose expert it holds (expert_map: global id -> local id, -1 = another rank's, which the grouped
+        GEMMs zero-fill like write_zeros_to_output, fused_moe.py:40-59) at full expert width, adds its slice
+        of the shared experts, and the layer's existing all-reduce is the combine -- no all-to-all is
+        needed while the tokens are replicated.  Returns this rank's partial sum [bs, dim]."""
+        weights, indices = self.gate(x)
+        y = fused_moe.fused_experts(
+            x, self.w1w3_weight, self.w2_weight, topk_weights=weights, topk_ids=indices, use_fp8_w8a8=True,
+            inplace=True, global_num_experts=self.n_routed, expert_map=self.expert_map, w1_scale=self.w1w3_scale,
+            w2_scale=self.w2_scale, block_shape=[BLOCK, BLOCK], a1_quant=x_quant,
+        )
+        if self.shared is not None:
+            y += self.shared(x_quant)
+        return y
 
 
 class TransformerBlockDeepSeekV3(torch.nn.Module):
@@ -448,18 +495,25 @@ class DeepSeekV3Decoder(torch.nn.Module):
         return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()
 
     @torch.inference_mode()
-    def generate(self, prompts, max_new_tokens, req_ids=None, use_graph=True):
-        """Greedy generation (executor.py:103-104): prefill, then max_new_tokens-1 decode steps.
-        Returns a [n_req, max_new_tokens] int64 tensor; frees the requests' pages afterwards."""
+    def generate(self, prompts, max_new_tokens, req_ids=None, use_graph=True, temperatures=None, top_ks=None,
+                 top_ps=None, frequency_penalties=None, generator=None):
+        """Prefill, then max_new_tokens - 1 decode steps; returns [n_req, max_new_tokens] int64 and frees the
+        requests' pages.  Token selection is executor.py:82-112 on the device (chitu_amd.sampling): greedy
+        unless some top_k > 1 (then per-request temperature / top-k / top-p sampling, uniforms from
+        `generator`), with an optional per-request frequency penalty; tokens never visit the host."""
+        from .sampling import DeviceSampler
+
         req_ids = [f"gen{i}" for i in range(len(prompts))] if req_ids is None else list(req_ids)
-        tok = self.prefill(prompts, req_ids).argmax(dim=-1)
+        pick = DeviceSampler(len(prompts), max_new_tokens, self.device, temperatures, top_ks, top_ps,
+                             frequency_penalties, generator)
+        tok = pick(self.prefill(prompts, req_ids))
         out = [tok]
         for _ in range(max_new_tokens - 1):
             self.cache.prepare_cache_decode(req_ids)
             self.cache.prepare_block_table_for_decode(req_ids)
-            tok = self.decode(tok, use_graph=use_graph).argmax(dim=-1)
+            tok = pick(self.decode(tok, use_graph=use_graph))
             self.cache.finalize_cache_single_decode(req_ids)
-            out.append(tok.clone())
+            out.append(tok)
         for r in req_ids:
             self.cache.finalize_cache_all_decode(r)
         return torch.stack(out, dim=1)

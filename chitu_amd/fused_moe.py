@@ -59,6 +59,17 @@ def cuda_moe_align_block_size(
     )
 
 
+def _expert_map_i32(expert_map: Optional[torch.Tensor], num_experts: int, dev) -> Optional[torch.Tensor]:
+    """expert_map [global_num_experts] -> contiguous int32 on the device (local id, or -1 for an expert that
+    lives on another rank: fused_moe.py:163-179).  Pass an int32 device tensor to make this a no-op."""
+    if expert_map is None:
+        return None
+    assert expert_map.numel() >= num_experts, "expert_map must cover every global expert id"
+    if expert_map.dtype != torch.int32 or expert_map.device != dev or not expert_map.is_contiguous():
+        expert_map = expert_map.to(device=dev, dtype=torch.int32).contiguous()
+    return expert_map
+
+
 def moe_align_block_size(
     topk_ids: torch.Tensor,
     block_size: int,
@@ -83,16 +94,15 @@ def moe_align_block_size(
     expert_ids = torch.empty((max_num_m_blocks,), dtype=torch.int32, device=dev)
     num_tokens_post_pad = torch.empty((1), dtype=torch.int32, device=dev)
     cumsum_buffer = torch.empty((num_experts + 1,), dtype=torch.int32, device=dev)
+    emap = _expert_map_i32(expert_map, num_experts, dev)
     check(
-        _lib.lib().chitu_hip_moe_align_block_size(
+        _lib.lib().chitu_hip_moe_align_block_size_mapped(
             ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel), i32(num_experts), i32(block_size),
             ptr(sorted_ids), i64(sorted_ids.numel()), ptr(expert_ids), i64(expert_ids.numel()),
-            ptr(num_tokens_post_pad), ptr(cumsum_buffer), i32(1), stream_ptr(),
+            ptr(num_tokens_post_pad), ptr(cumsum_buffer), i32(1), ptr(emap), stream_ptr(),
         ),
         "moe_align_block_size",
-    )
-    if expert_map is not None:
-        expert_ids = expert_map[expert_ids]
+    )  # expert_ids = expert_map[expert_ids] (fused_moe.py:516-517) happens inside the launch
     return sorted_ids, expert_ids, num_tokens_post_pad
 
 
@@ -282,19 +292,16 @@ def fused_experts_impl(
     st = stream_ptr()
     max_mblocks = min(nblk, numel)
 
+    emap = _expert_map_i32(expert_map, global_num_experts, dev)
     check(
-        lib.chitu_hip_moe_align_block_size(
+        lib.chitu_hip_moe_align_block_size_mapped(
             ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel), i32(global_num_experts),
             i32(_MOE_BLOCK_M), P("sorted"), i64(cap), P("experts"), i64(nblk), P("npost"), P("cumsum"),
-            i32(1), st,
+            i32(1), ptr(emap), st,
         ),
         "moe_align_block_size",
     )
     experts_ptr = P("experts")
-    if expert_map is not None:
-        ev = _view_i32(ws, off["experts"] - base, nblk)
-        mapped = expert_map.to(torch.int32)[ev.long()].contiguous()
-        ev.copy_(mapped)
     if a1_quant is None:
         check(
             lib.chitu_hip_act_quant_fp8(
@@ -396,12 +403,11 @@ def _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, 
     P = lambda name: _ct.c_void_p(off[name])
     lib, st = _lib.lib(), stream_ptr()
     max_mblocks = min(nblk, numel)
-    check(lib.chitu_hip_moe_align_block_size(ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel), i32(global_num_experts),
-                                             i32(_MOE_BLOCK_M), P("sorted"), i64(cap), P("experts"), i64(nblk), P("npost"),
-                                             P("cumsum"), i32(1), st), "moe_align_block_size")
-    if expert_map is not None:
-        ev = _view_i32(ws, off["experts"] - base, nblk)
-        ev.copy_(expert_map.to(torch.int32)[ev.long()].contiguous())
+    emap = _expert_map_i32(expert_map, global_num_experts, hidden_states.device)
+    check(lib.chitu_hip_moe_align_block_size_mapped(ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel),
+                                                    i32(global_num_experts), i32(_MOE_BLOCK_M), P("sorted"), i64(cap),
+                                                    P("experts"), i64(nblk), P("npost"), P("cumsum"), i32(1), ptr(emap), st),
+          "moe_align_block_size")
     check(lib.chitu_hip_quant_act_int8(ptr(hidden_states), float_dtype_code(hidden_states.dtype), i64(num_tokens), i64(K),
                                        P("xq"), P("xs"), st), "moe int8 quant1")
     check(lib.chitu_hip_moe_i8_gemm1_silu(P("xq"), P("xs"), ptr(w1), ptr(w1_scale), P("sorted"), P("experts"), P("npost"), P("a"),

@@ -182,17 +182,25 @@ class LlamaDecoder(torch.nn.Module):
         return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()
 
     @torch.inference_mode()
-    def generate(self, prompts, max_new_tokens, req_ids=None, use_graph=True):
-        """Greedy generation: prefill, then max_new_tokens - 1 decode steps; returns [n_req, max_new_tokens]."""
+    def generate(self, prompts, max_new_tokens, req_ids=None, use_graph=True, temperatures=None, top_ks=None,
+                 top_ps=None, frequency_penalties=None, generator=None):
+        """Prefill, then max_new_tokens - 1 decode steps; returns [n_req, max_new_tokens] int64 and frees the
+        requests' pages.  Token selection is executor.py:82-112 on the device (chitu_amd.sampling): greedy
+        unless some top_k > 1 (then per-request temperature / top-k / top-p sampling, uniforms from
+        `generator`), with an optional per-request frequency penalty; tokens never visit the host."""
+        from .sampling import DeviceSampler
+
         req_ids = [f"gen{i}" for i in range(len(prompts))] if req_ids is None else list(req_ids)
-        tok = self.prefill(prompts, req_ids).argmax(dim=-1)
+        pick = DeviceSampler(len(prompts), max_new_tokens, self.device, temperatures, top_ks, top_ps,
+                             frequency_penalties, generator)
+        tok = pick(self.prefill(prompts, req_ids))
         out = [tok]
         for _ in range(max_new_tokens - 1):
             self.cache.prepare_cache_decode(req_ids)
             self.cache.prepare_block_table_for_decode(req_ids)
-            tok = self.decode(tok, use_graph=use_graph).argmax(dim=-1)
+            tok = pick(self.decode(tok, use_graph=use_graph))
             self.cache.finalize_cache_single_decode(req_ids)
-            out.append(tok.clone())
+            out.append(tok)
         for r in req_ids:
             self.cache.finalize_cache_all_decode(r)
         return torch.stack(out, dim=1)

@@ -29,6 +29,7 @@ __all__ = [
     "top_k_top_p_sampling_from_logits",
     "top_k_top_p_min_p_sampling_from_probs_torch",
     "sample_tokens",
+    "DeviceSampler",
 ]
 
 
@@ -149,3 +150,50 @@ def sample_tokens(logits, temperatures, top_ks, top_ps, frequency_penalties=None
     if all(k <= 1 for k in ks):
         return argmax(logits2)
     return top_k_top_p_sampling_from_logits(logits2, temperatures, ks, top_ps, uniforms=uniforms, generator=generator)
+
+
+class DeviceSampler:
+    """Sampling state of one generate() call kept on the device: the per-request parameters
+    (task.py:433-457 gathers them from the requests every step), the tokens generated so far (the
+    frequency penalty's input, executor.py:89-102) and the uniform stream.  Calling it with the step's
+    fp32 logits [n_req, vocab] returns the int64 tokens [n_req] without a host round trip: at most one
+    penalty launch, one sampling launch, and the bookkeeping copies.
+
+    Greedy iff every top_k <= 1 (`is_all_greedy`, task.py:457) -- also the default when no sampling
+    parameter is given.  `generator`: a CUDA torch.Generator for the uniforms (reproducible runs)."""
+
+    def __init__(self, n_req: int, max_new_tokens: int, device, temperatures=None, top_ks=None, top_ps=None,
+                 frequency_penalties=None, generator=None):
+        self.n_req, self.device, self.generator = n_req, torch.device(device), generator
+        ks = [1] * n_req if top_ks is None else [int(k) for k in (top_ks.tolist() if isinstance(top_ks, torch.Tensor) else top_ks)]
+        assert len(ks) == n_req
+        self.greedy = all(k <= 1 for k in ks)
+        if not self.greedy:
+            self.top_ks = _per_row(ks, n_req, torch.int32, self.device)
+            self.temperatures = _per_row([1.0] * n_req if temperatures is None else temperatures, n_req, torch.float32, self.device)
+            self.top_ps = _per_row([1.0] * n_req if top_ps is None else top_ps, n_req, torch.float32, self.device)
+        pens = None if frequency_penalties is None else [float(p) for p in frequency_penalties]
+        self.penalise = pens is not None and any(p > 0 for p in pens)
+        if self.penalise:
+            assert len(pens) == n_req
+            self.penalties = torch.tensor(pens, dtype=torch.float32, device=self.device)
+            self.history = torch.zeros(n_req, max(max_new_tokens, 1), dtype=torch.int32, device=self.device)
+            self.row_ids = torch.arange(n_req + 1, dtype=torch.int32, device=self.device)
+        self.n_generated = 0
+
+    def __call__(self, logits: torch.Tensor) -> torch.Tensor:
+        lg, rows, _ = _rows(logits)
+        assert rows == self.n_req
+        t = self.n_generated
+        if self.penalise and t > 0:
+            # every request has generated exactly t tokens: row r's list is history[r, :t]
+            flat = self.history[:, :t].contiguous().view(-1)  # (a [n, 1] slice would otherwise reshape to a strided view)
+            apply_frequency_penalty_device(lg, flat, self.row_ids * t, self.penalties)
+        if self.greedy:
+            tok = argmax(lg)
+        else:
+            tok = top_k_top_p_sampling_from_logits(lg, self.temperatures, self.top_ks, self.top_ps, generator=self.generator)
+        if self.penalise and t < self.history.shape[1]:
+            self.history[:, t] = tok.to(torch.int32)
+        self.n_generated = t + 1
+        return tok

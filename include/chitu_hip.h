@@ -41,6 +41,18 @@ int chitu_hip_moe_align_block_size(const void* topk_ids, int ids_dtype, int64_t 
                                    int32_t* expert_ids, int64_t expert_ids_cap,
                                    int32_t* num_tokens_post_pad, int32_t* cumsum,
                                    int32_t fill_sentinels, void* stream);
+/* Same launch with the expert-parallel remap folded in: expert_map [num_experts] i32 on the device
+ * (local expert id, or -1 for an expert held by another rank) is applied to EVERY entry of expert_ids,
+ * exactly as `expert_ids = expert_map[expert_ids]` does after the sort (chitu/fused_moe.py:516-517):
+ * blocks of expert e carry expert_map[e], the unused tail carries expert_map[0] (the allocator's zeros
+ * mapped).  expert_map == NULL: identical to chitu_hip_moe_align_block_size. */
+int chitu_hip_moe_align_block_size_mapped(const void* topk_ids, int ids_dtype, int64_t numel,
+                                          int32_t num_experts, int32_t block_size,
+                                          int32_t* sorted_token_ids, int64_t sorted_cap,
+                                          int32_t* expert_ids, int64_t expert_ids_cap,
+                                          int32_t* num_tokens_post_pad, int32_t* cumsum,
+                                          int32_t fill_sentinels, const int32_t* expert_map,
+                                          void* stream);
 
 /* ---- FP8 activation quantisation ---------------------------------------------------
  * mode 0 replaces act_quant_deepseek_v3 (chitu/ops.py:330-353, kernel

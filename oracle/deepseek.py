@@ -103,6 +103,23 @@ def moe_layer(p, pre, x, cfg, routing=None):
     return (y1 if y is None else y + y1), routing
 
 
+def moe_layer_ep(p, pre, x, cfg, expert_map, routing=None):
+    """One rank's partial sum of the expert-parallel MoE (the reference's hooks:
+    model_deepseek_v3.py:870-880 moe_world_size / experts_start_idx, :1004 expert_map): the routed
+    experts this rank holds at full width (`w1w3_weight [n_local, 2I, dim]`) over the GLOBAL routing,
+    plus its 1/ep slice of the shared experts' width (`shared.w1w3`, `shared.w2`: a row/column-parallel
+    MLP).  Summing the ranks' results (the layer's all-reduce) gives the layer output."""
+    if routing is None:
+        routing = gate(x, p[pre + "gate.weight"], p.get(pre + "gate.bias"), cfg["n_groups"], cfg["topk_groups"],
+                       cfg["topk"], cfg["score_func"], cfg["route_scale"])
+    weights, indices = routing
+    y = moe.fused_experts_fp8(x, p[pre + "w1w3_weight"], p[pre + "w2_weight"], weights, indices,
+                              p[pre + "w1w3_scale"], p[pre + "w2_scale"], expert_map=expert_map)
+    if pre + "shared.w1w3.weight" in p:
+        y = y + mlp(p, pre + "shared.", x)
+    return y, routing
+
+
 def moe_layer_loop(p, pre, x, cfg, routing=None):
     """The reference's OTHER MoE branch: the per-expert loop (model_deepseek_v3.py:1012-1061) it takes where the
     fused Triton kernel is unavailable.  Each expert's w2 output is rounded to bf16, scaled by its bf16 routing

@@ -12,8 +12,18 @@ import torch.nn.functional as F
 from . import fp8
 
 
-def fused_experts_fp8(x, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale):
-    """x [M,K] bf16; w1 [E,2I,K] fp8; w2 [E,K,I] fp8; scales [E, rows/128, cols/128] f32."""
+def fused_experts_fp8(x, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale, expert_map=None):
+    """x [M,K] bf16; w1 [E,2I,K] fp8; w2 [E,K,I] fp8; scales [E, rows/128, cols/128] f32.
+    expert_map [global experts] (expert parallelism, fused_moe.py:449,516-517): topk_ids are GLOBAL ids,
+    expert_map[id] is the row of w1/w2 on this rank or -1; a slot whose expert is elsewhere contributes
+    zeros (write_zeros_to_output, fused_moe.py:40-59, 163-179)."""
+    if expert_map is not None:
+        local = torch.as_tensor(expert_map).long()[topk_ids.long()]
+        keep = local >= 0
+        out = fused_experts_fp8(x, w1, w2, torch.where(keep, topk_weights, torch.zeros_like(topk_weights)),
+                                torch.where(keep, local, torch.zeros_like(local)), w1_scale, w2_scale)
+        # a zero routed weight makes the slot's bf16 term exactly +-0 -- the same sum as skipping it
+        return out
     M, K = x.shape
     topk = topk_ids.shape[1]
     dt = x.dtype

@@ -100,8 +100,10 @@ def bf16_linear(x, weight, out_dtype=None):
 
 
 def fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace=False, use_fp8_w8a8=False,
-                  global_num_experts=-1, w1_scale=None, w2_scale=None, block_shape=None, a1_quant=None, **kw):
-    out = omoe.fused_experts_fp8(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale)
+                  global_num_experts=-1, w1_scale=None, w2_scale=None, block_shape=None, a1_quant=None,
+                  expert_map=None, **kw):
+    out = omoe.fused_experts_fp8(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale,
+                                 expert_map=expert_map)
     if inplace:
         hidden_states.copy_(out)
         return hidden_states

@@ -283,3 +283,64 @@ def test_full_vocab_batch_timing(capsys):
     assert np.array_equal(out.cpu().numpy(), np.argmax(x.cpu().numpy(), axis=-1))
     with capsys.disabled():
         print(f"\n[sampler] rows=16 vocab=129280: sample {res['sample']:.1f} us, argmax {res['argmax']:.1f} us per launch")
+
+
+# ---------------------------------------------------------------- DeviceSampler (generate()'s token selection)
+@pytest.mark.parametrize("greedy", [True, False])
+def test_device_sampler_bookkeeping_matches_the_reference_recipe(greedy):
+    """Five steps of random logits through DeviceSampler vs executor.py:82-112 step by step: the oracle's
+    frequency penalty over the tokens generated so far (bit-exact logits), then argmax / the sampling
+    launch on those logits with the same uniform stream."""
+    from chitu_amd import sampling
+
+    rows, vocab, steps = 6, 777, 5
+    pens = [0.5, 0.0, 2.0, 1.25, 0.0, 0.75]
+    ks = [1] * rows if greedy else [1, 5, 40, -1, 3, 50]
+    temps, ps = [0.7, 1.0, 1.3, 0.9, 1.0, 0.6], [1.0, 0.9, 0.8, 0.95, 0.5, 1.0]
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    gen_ref = torch.Generator(device="cuda").manual_seed(11)
+    pick = sampling.DeviceSampler(rows, steps, "cuda", temps, ks, ps, pens, gen)
+    assert pick.greedy == greedy
+    responses = [[] for _ in range(rows)]
+    g = torch.Generator().manual_seed(3)
+    for step in range(steps):
+        base = torch.round(torch.randn(rows, vocab, generator=g) * 4) / 4  # coarse values: repeated tokens happen
+        dev = base.clone().cuda()
+        tok = pick(dev)
+        want_logits = osmp.frequency_penalty(base.clone(), responses, pens, is_decode=step > 0)
+        assert np.array_equal(dev.cpu().numpy().view(np.uint32), want_logits.numpy().view(np.uint32)), step
+        if greedy:
+            want = sampling.argmax(want_logits.cuda())
+            assert np.array_equal(want.cpu().numpy(), np.argmax(want_logits.numpy(), axis=-1))
+        else:
+            u = torch.rand(rows, dtype=torch.float32, device="cuda", generator=gen_ref)
+            want = sampling.top_k_top_p_sampling_from_logits(want_logits.cuda(), temps, ks, ps, uniforms=u)
+        assert torch.equal(tok, want), step
+        for r in range(rows):
+            responses[r].append(int(tok[r]))
+    assert pick.n_generated == steps
+
+
+def test_generate_with_sampling_parameters():
+    """generate(): all top_k == 1 is the greedy run; a sampling run is reproducible from the generator's
+    seed, respects top_k = 1 rows, and the frequency penalty changes a greedy run that repeats itself."""
+    from tests.test_gpu_deepseek import build, tiny_args
+
+    model, _ = build(tiny_args())
+    prompts = [[5, 6, 7, 8], [100], [9, 10]]
+    greedy = model.generate(prompts, 6)
+    assert torch.equal(greedy, model.generate(prompts, 6, top_ks=[1, 1, 1], temperatures=[0.5, 1.0, 2.0], top_ps=[0.9] * 3))
+
+    def run(seed):
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        return model.generate(prompts, 6, temperatures=[1.0, 1.5, 1.0], top_ks=[50, -1, 1], top_ps=[0.95, 0.9, 1.0],
+                              generator=gen)
+
+    a, b, c = run(1), run(1), run(2)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.equal(a[2], greedy[2])  # the top_k == 1 request stays greedy inside a sampling batch
+    assert int(a.min()) >= 0 and int(a.max()) < model.args.vocab_size
+    pen = model.generate(prompts, 6, frequency_penalties=[100.0, 100.0, 0.0])
+    assert torch.equal(pen[2], greedy[2]) and torch.equal(pen[:, 0], greedy[:, 0])
+    for r in (0, 1):  # a huge penalty forbids repeating any generated token
+        assert len(set(pen[r].tolist())) == 6

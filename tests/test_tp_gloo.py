@@ -172,7 +172,38 @@ def _shard(sd, args, rank, world):
     return out
 
 
-def _decode_tp(rank, world):
+def _shard_ep(sd, args, rank, world):
+    """Expert-parallel layout of the MoE layers (chitu_amd.deepseek_v3.MoEDeepSeekV3, moe_world_size = world):
+    routed experts [rank*E/ep, (rank+1)*E/ep) whole, the shared experts as ONE MLP of width n_shared*I chunked
+    like a column/row-parallel MLP; everything else as _shard."""
+    nr, ns = args.n_routed_experts, args.n_shared_experts
+    n_local = nr // world
+    lo, hi = rank * n_local, (rank + 1) * n_local
+    out = {k: v for k, v in _shard(sd, args, rank, world).items() if ".ffn.w1w3_" not in k and ".ffn.w2_" not in k}
+
+    def chunk(t, dim):
+        c = t.shape[dim] // world
+        return t.narrow(dim, rank * c, c)
+
+    for k, v in sd.items():
+        pre = k[: k.rfind(".") + 1]
+        if k.endswith(".ffn.w1w3_weight") or k.endswith(".ffn.w1w3_scale"):
+            out[k] = v[lo:hi].contiguous()
+            name = "shared.w1w3.weight" if k.endswith("weight") else "shared.w1w3.scale"
+            sh = v[nr:]  # [ns, 2I(/128), K(/128)] = per expert [gate | up]
+            i = sh.shape[1] // 2
+            gate = sh[:, :i].reshape(ns * i, -1)
+            up = sh[:, i:].reshape(ns * i, -1)
+            out[pre + name] = torch.cat([chunk(gate, 0), chunk(up, 0)], 0).contiguous()
+        elif k.endswith(".ffn.w2_weight") or k.endswith(".ffn.w2_scale"):
+            out[k] = v[lo:hi].contiguous()
+            name = "shared.w2.weight" if k.endswith("weight") else "shared.w2.scale"
+            sh = torch.cat(list(v[nr:]), dim=-1)  # [K(/128), ns*I(/128)]
+            out[pre + name] = chunk(sh, 1).contiguous()
+    return out
+
+
+def _decode_tp(rank, world, expert_parallel=False):
     import copy
 
     from tests import cpu_ops_shim
@@ -182,8 +213,11 @@ def _decode_tp(rank, world):
     full = _full_state(args)
     a = copy.copy(args)
     a.shard_degree = None  # live TP group size
+    if expert_parallel:
+        a.moe_world_size = world
     model, cache = _build_cpu_model(a)
-    sharded = _shard(full, args, rank, world)
+    sharded = (_shard_ep if expert_parallel else _shard)(full, args, rank, world)
+    assert set(sharded) == {k for k, _ in model.named_parameters()}
     for k, p in model.named_parameters():
         assert p.shape == sharded[k].shape, (k, p.shape, sharded[k].shape)
         p.data.copy_(sharded[k])
@@ -210,7 +244,7 @@ def _decode_tp(rank, world):
         dist.broadcast(ref, 0)
         assert torch.equal(ref, t)
     if rank == 0:
-        torch.save({"logits": outs}, os.environ["TP_OUT"] + f".w{world}")
+        torch.save({"logits": outs}, os.environ["TP_OUT"] + (f".ep{world}" if expert_parallel else f".w{world}"))
 
 
 def test_decode_step_tp2_matches_tp1(tmp_path):
@@ -223,3 +257,17 @@ def test_decode_step_tp2_matches_tp1(tmp_path):
     for a, b in zip(l1, l2):
         err = ((a - b).abs().max() / a.abs().max()).item()
         assert err < 5e-2, err  # bf16 partial sums are rounded per rank before the all-reduce
+
+
+def test_decode_step_ep2_matches_tp1(tmp_path):
+    """Expert parallelism: 2 ranks, each holding half of the routed experts at full width and
+    half of the shared expert's width; attention stays tensor parallel; the layer's all-reduce is the combine."""
+    base = str(tmp_path / "ep")
+    os.environ["TP_OUT"] = base
+    _run(_decode_tp, 1)
+    _run(_decode_tp, 2, True)
+    l1 = torch.load(base + ".w1")["logits"]
+    l2 = torch.load(base + ".ep2")["logits"]
+    for a, b in zip(l1, l2):
+        err = ((a - b).abs().max() / a.abs().max()).item()
+        assert err < 5e-2, err
