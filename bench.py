@@ -394,6 +394,33 @@ def v2_lite_extra(steps, warmup, ctx):
     return out
 
 
+def ep8_rank_extra(steps, warmup, ctx, moe_rank=0):
+    """Not part of the default run (tools/run_extra.py ep8): ONE rank of an expert-parallel R1 deployment
+     -- attention at 1/8 of the heads as in the TP=8 shard, routed experts
+    [32*moe_rank, 32*moe_rank + 32) at full width, 1/8 of the shared expert's width; same weight bytes
+    per rank as the TP shard.  The combine all-reduce is not paid on a lone GPU (as in the TP shard run)."""
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args, DeepSeekV3Decoder, init_synthetic_
+
+    margs = DeepSeekV3Args(shard_degree=SHARD, moe_world_size=SHARD, moe_rank=moe_rank)
+    max_seq = ctx + steps + warmup + 256
+    cache = PagedKVCacheManager(0, margs.n_layers, num_hot_req=16, block_size=64, max_seq_len=max_seq, device="cuda",
+                                kv_shape_per_sample=(576,), dtype=torch.bfloat16)
+    model = DeepSeekV3Decoder(margs, cache, HipAttnBackend(local_n_heads=margs.n_heads // SHARD, max_seq_len=max_seq),
+                              max_position_embeddings=max(max_seq, 4097), device="cuda")
+    init_synthetic_(model, seed=1000)
+    cache.paged_kv_cache.normal_(0, 0.5)
+    out = {"model": f"DeepSeek-R1 FP8, one expert-parallel rank (ep=8, rank {moe_rank}: 32 routed experts at full "
+                    "width + 1/8 shared width, attention 1/8 heads), hipGraph, synthetic weights"}
+    for bs in (1, 16):
+        dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"e{bs}_")
+        out[f"bs{bs}"] = {"ms_per_step": round(dt / steps * 1e3, 4), "node_tok_s": round(bs * steps / dt, 1)}
+    del model, cache
+    torch.cuda.empty_cache()
+    return out
+
+
 def mixtral_extra(steps, warmup, ctx):
     """BASELINE config 4 as an extra line: Mixtral-8x7B shapes, INT8 W8A8 experts (per-token / per-channel
     scales) through the grouped int8 MoE kernels, bf16 attention and router; the whole model on this GPU

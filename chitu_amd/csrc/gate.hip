@@ -18,6 +18,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "gemm_common.h"
+#include "moe_align_device.h"
 
 namespace chitu {
 
@@ -222,6 +223,48 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_silu_kernel(const bf16_t* _
     }
 }
 
+// ---------------------------------------------------------------- route + align in one launch
+// moe_align_block_size needs every token's ids, and the routing launch has one workgroup per token:
+// each workgroup publishes its ids (fence), takes a ticket, and the LAST one to arrive runs the sort
+// for the whole batch (moe_align_workgroup) before the launch ends -- the pattern of a single-pass
+// reduction, one launch less per MoE layer.  `ticket` is a zero-initialised device word that the
+// last workgroup resets, so hipGraph replays and later launches need no memset; launches that share
+// a ticket must not overlap (one stream per device drives the step).
+struct RouteAlign {
+    int num_experts;          // experts the sort ranges over (routed + always-on slots); 0 = no align tail
+    int block_size;
+    int32_t* sorted_ids;
+    int64_t sorted_cap;
+    int32_t* expert_ids;
+    int64_t expert_cap;
+    int32_t* num_post_pad;
+    int32_t* cumsum;
+    const int32_t* expert_map;
+    unsigned int* ticket;
+};
+
+// Called by EVERY thread of every routing workgroup after its ids are written.
+__device__ __forceinline__ void route_align_tail(const RouteAlign& a, const int64_t* ids, int64_t numel, int* lds) {
+    __shared__ int last_flag;
+    __threadfence();  // this thread's id / weight stores are visible device-wide before the ticket
+    __syncthreads();
+    if (gridDim.x == 1) {  // a single token (bs 1): this workgroup is the last one by construction
+        moe_align_workgroup<int64_t>(ids, numel, a.num_experts, a.block_size, a.sorted_ids, a.sorted_cap, a.expert_ids,
+                                     a.expert_cap, a.num_post_pad, a.cumsum, 1, a.expert_map, lds, (int)blockDim.x);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (t == gridDim.x - 1) ? 1 : 0;
+        if (last_flag) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();  // acquire: the other workgroups' ids
+    moe_align_workgroup<int64_t>(ids, numel, a.num_experts, a.block_size, a.sorted_ids, a.sorted_cap, a.expert_ids,
+                                 a.expert_cap, a.num_post_pad, a.cumsum, 1, a.expert_map, lds, (int)blockDim.x);
+}
+
 // ---------------------------------------------------------------- fused routing
 __device__ __forceinline__ float bf16r(float v) { return round_bf16(v); }
 
@@ -232,7 +275,7 @@ template <int SIGMOID>
 __global__ __launch_bounds__(1024) void gate_route_kernel(
     const void* __restrict__ logits, int S, int M, int E, const bf16_t* __restrict__ bias, int n_groups,
     int topk_groups, int topk, float route_scale, bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids,
-    int out_stride, int extra_id, float extra_w, int extra_n, int renorm) {
+    int out_stride, int extra_id, float extra_w, int extra_n, int renorm, RouteAlign al) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sc = lds;             // [E] selection score s'
     float* red = lds + E;        // [32] wave partials
@@ -370,6 +413,8 @@ __global__ __launch_bounds__(1024) void gate_route_kernel(
         out_ids[(int64_t)t * out_stride + topk + e] = extra_id + e;
         out_w[(int64_t)t * out_stride + topk + e] = f32_to_bf16(extra_w);
     }
+    if (al.num_experts > 0)  // uniform over the launch
+        route_align_tail(al, out_ids, (int64_t)M * out_stride, reinterpret_cast<int*>(lds));
 }
 
 // ---------------------------------------------------------------- fused routing, fast path
@@ -411,7 +456,8 @@ template <int GS>  // experts per group: 32 or 64 (or 0 = ungrouped)
 __global__ __launch_bounds__(1024) void gate_route_fast_kernel(
     const void* __restrict__ logits, int S, int M, int E, const bf16_t* __restrict__ bias, int n_groups,
     int topk_groups, int topk, float route_scale, bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids,
-    int out_stride, int extra_id, float extra_w, int extra_n) {
+    int out_stride, int extra_id, float extra_w, int extra_n, RouteAlign al) {
+    extern __shared__ __attribute__((aligned(16))) int align_lds[];  // only the align tail uses dynamic LDS
     __shared__ float orig_lds[1024];
     __shared__ float gsc[32];
     __shared__ __attribute__((aligned(16))) uint32_t cand[64];
@@ -468,33 +514,36 @@ __global__ __launch_bounds__(1024) void gate_route_fast_kernel(
     }
     if (lane < topk) cand[wave * topk + lane] = mine_k;
     __syncthreads();
-    if (wave != 0) return;
-    // ---- rank the nw * topk (<= 64) wave winners; keys are unique, 0 = empty slot
-    const int nc = nw * topk;
-    const uint32_t ck = lane < nc ? cand[lane] : 0u;
-    int rank = 0;
-    for (int i = 0; i < nc; i += 4) {
-        const i32x4 o = *reinterpret_cast<const i32x4*>(&cand[i]);
-        rank += ((uint32_t)o[0] > ck) + ((uint32_t)o[1] > ck) + ((uint32_t)o[2] > ck) + ((uint32_t)o[3] > ck);
+    if (wave == 0) {
+        // ---- rank the nw * topk (<= 64) wave winners; keys are unique, 0 = empty slot
+        const int nc = nw * topk;
+        const uint32_t ck = lane < nc ? cand[lane] : 0u;
+        int rank = 0;
+        for (int i = 0; i < nc; i += 4) {
+            const i32x4 o = *reinterpret_cast<const i32x4*>(&cand[i]);
+            rank += ((uint32_t)o[0] > ck) + ((uint32_t)o[1] > ck) + ((uint32_t)o[2] > ck) + ((uint32_t)o[3] > ck);
+        }
+        if (lane < nc && ck != 0u && rank < topk) {
+            const int we = 0xffff - (int)(ck & 0xffffu);
+            out_ids[(int64_t)t * out_stride + rank] = we;
+            wsel[rank] = orig_lds[we];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-local LDS hand-off (wsel)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < topk) {
+            float sum = 0.f;
+            for (int i = 0; i < topk; ++i) sum += wsel[i];
+            float w = bf16r(wsel[lane] / bf16r(sum));  // weights /= weights.sum(-1, keepdim=True)
+            w = bf16r(w * route_scale);                // weights *= route_scale
+            out_w[(int64_t)t * out_stride + lane] = f32_to_bf16(w);
+        }
+        if (lane < extra_n && extra_id >= 0) {  // always-on (shared) experts appended as slots topk .. topk+extra_n-1
+            out_ids[(int64_t)t * out_stride + topk + lane] = extra_id + lane;
+            out_w[(int64_t)t * out_stride + topk + lane] = f32_to_bf16(extra_w);
+        }
     }
-    if (lane < nc && ck != 0u && rank < topk) {
-        const int we = 0xffff - (int)(ck & 0xffffu);
-        out_ids[(int64_t)t * out_stride + rank] = we;
-        wsel[rank] = orig_lds[we];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-local LDS hand-off (wsel)
-    __builtin_amdgcn_wave_barrier();
-    if (lane < topk) {
-        float sum = 0.f;
-        for (int i = 0; i < topk; ++i) sum += wsel[i];
-        float w = bf16r(wsel[lane] / bf16r(sum));  // weights /= weights.sum(-1, keepdim=True)
-        w = bf16r(w * route_scale);                // weights *= route_scale
-        out_w[(int64_t)t * out_stride + lane] = f32_to_bf16(w);
-    }
-    if (lane < extra_n && extra_id >= 0) {  // always-on (shared) experts appended as slots topk .. topk+extra_n-1
-        out_ids[(int64_t)t * out_stride + topk + lane] = extra_id + lane;
-        out_w[(int64_t)t * out_stride + topk + lane] = f32_to_bf16(extra_w);
-    }
+    if (al.num_experts > 0)  // uniform over the launch
+        route_align_tail(al, out_ids, (int64_t)M * out_stride, align_lds);
 }
 
 }  // namespace chitu
@@ -545,12 +594,11 @@ extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void*
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, int64_t tokens,
-                                    int32_t num_experts, const void* bias_bf16, int32_t n_groups,
-                                    int32_t topk_groups, int32_t topk, int32_t score_func,
-                                    float route_scale, void* out_weights_bf16, int64_t* out_ids,
-                                    int32_t out_stride, int32_t extra_expert_id, float extra_weight,
-                                    int32_t extra_count, void* stream) {
+static int gate_route_launch(const void* logits, int32_t num_partials, int64_t tokens, int32_t num_experts,
+                             const void* bias_bf16, int32_t n_groups, int32_t topk_groups, int32_t topk,
+                             int32_t score_func, float route_scale, void* out_weights_bf16, int64_t* out_ids,
+                             int32_t out_stride, int32_t extra_expert_id, float extra_weight,
+                             int32_t extra_count, const chitu::RouteAlign& al, void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(logits && out_weights_bf16 && out_ids && tokens >= 0);
     CHITU_REQUIRE(num_experts >= 1 && num_experts <= 1024 && topk >= 1 && topk <= num_experts && topk <= 64);
@@ -559,8 +607,12 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
     CHITU_REQUIRE(extra_count >= 0 && extra_count <= 32 && out_stride >= topk + (extra_expert_id >= 0 ? extra_count : 0));
     CHITU_REQUIRE(score_func >= 0 && score_func <= 2);  // 0 softmax, 1 sigmoid (V3), 2 softmax + top-k renormalisation (Mixtral)
     if (tokens == 0) return CHITU_OK;
-    const int threads = ((num_experts + 63) / 64) * 64;
-    const size_t lds = sizeof(float) * (size_t)(num_experts + 32 + 64 + 64);
+    // the align tail needs one thread per sorted-over expert (routed + always-on slots)
+    const int threads = ((max(num_experts, al.num_experts) + 63) / 64) * 64;
+    CHITU_REQUIRE(threads <= 1024);
+    const size_t align_lds = al.num_experts > 0 ? sizeof(int) * moe_align_lds_ints(al.num_experts, threads) : 0;
+    const size_t lds = max(sizeof(float) * (size_t)(num_experts + 32 + 64 + 64), align_lds);
+    CHITU_REQUIRE(lds <= 60 * 1024);
     hipStream_t st = (hipStream_t)stream;
     const int gs = n_groups > 1 ? num_experts / n_groups : 0;
     const bool fast = score_func == 1 && (gs == 0 || gs == 32 || gs == 64) && num_partials <= 16 &&
@@ -568,28 +620,65 @@ extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, in
                       !getenv("CHITU_GATE_SLOW");
     if (fast) {
 #define LAUNCHF(GSV)                                                                                         \
-    hipLaunchKernelGGL(gate_route_fast_kernel<GSV>, dim3((unsigned)tokens), dim3(threads), 0, st, logits,   \
+    hipLaunchKernelGGL(gate_route_fast_kernel<GSV>, dim3((unsigned)tokens), dim3(threads), align_lds, st, logits, \
                        (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16, (int)n_groups, \
                        (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16, out_ids,         \
-                       (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count)
+                       (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count, al)
         if (gs == 32) LAUNCHF(32);
         else if (gs == 64) LAUNCHF(64);
         else LAUNCHF(0);
 #undef LAUNCHF
         CHITU_RETURN_LAUNCH_STATUS();
     }
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)gate_route_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gate_route_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (score_func == 1)
         hipLaunchKernelGGL(gate_route_kernel<1>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
                            (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
                            (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
-                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count, 0);
+                           out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count, 0, al);
     else
         hipLaunchKernelGGL(gate_route_kernel<0>, dim3((unsigned)tokens), dim3(threads), lds, st, logits,
                            (int)num_partials, (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16,
                            (int)n_groups, (int)topk_groups, (int)topk, route_scale, (bf16_t*)out_weights_bf16,
                            out_ids, (int)out_stride, (int)extra_expert_id, extra_weight, (int)extra_count,
-                           score_func == 2 ? 1 : 0);
+                           score_func == 2 ? 1 : 0, al);
     CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_gate_route(const void* logits, int32_t num_partials, int64_t tokens,
+                                    int32_t num_experts, const void* bias_bf16, int32_t n_groups,
+                                    int32_t topk_groups, int32_t topk, int32_t score_func,
+                                    float route_scale, void* out_weights_bf16, int64_t* out_ids,
+                                    int32_t out_stride, int32_t extra_expert_id, float extra_weight,
+                                    int32_t extra_count, void* stream) {
+    chitu::RouteAlign none{};
+    return gate_route_launch(logits, num_partials, tokens, num_experts, bias_bf16, n_groups, topk_groups, topk,
+                             score_func, route_scale, out_weights_bf16, out_ids, out_stride, extra_expert_id,
+                             extra_weight, extra_count, none, stream);
+}
+
+extern "C" int chitu_hip_gate_route_align(const void* logits, int32_t num_partials, int64_t tokens,
+                                          int32_t num_experts, const void* bias_bf16, int32_t n_groups,
+                                          int32_t topk_groups, int32_t topk, int32_t score_func,
+                                          float route_scale, void* out_weights_bf16, int64_t* out_ids,
+                                          int32_t out_stride, int32_t extra_expert_id, float extra_weight,
+                                          int32_t extra_count, int32_t align_num_experts, int32_t align_block_size,
+                                          int32_t* sorted_token_ids, int64_t sorted_cap, int32_t* expert_ids,
+                                          int64_t expert_ids_cap, int32_t* num_tokens_post_pad, int32_t* cumsum,
+                                          const int32_t* expert_map, uint32_t* ticket, void* stream) {
+    CHITU_REQUIRE(sorted_token_ids && expert_ids && num_tokens_post_pad && cumsum && ticket);
+    CHITU_REQUIRE(align_num_experts >= 1 && align_num_experts <= 1024 && align_block_size >= 1);
+    CHITU_REQUIRE(sorted_cap >= 0 && expert_ids_cap >= 0 && tokens * (int64_t)out_stride < (1ll << 31));
+    // the sort runs over out_ids as a dense [tokens * out_stride] array: every column must be written
+    CHITU_REQUIRE(out_stride == topk + (extra_expert_id >= 0 ? extra_count : 0));
+    chitu::RouteAlign al{align_num_experts, align_block_size, sorted_token_ids, sorted_cap, expert_ids, expert_ids_cap,
+                         num_tokens_post_pad, cumsum, expert_map, ticket};
+    return gate_route_launch(logits, num_partials, tokens, num_experts, bias_bf16, n_groups, topk_groups, topk,
+                             score_func, route_scale, out_weights_bf16, out_ids, out_stride, extra_expert_id,
+                             extra_weight, extra_count, al, stream);
 }
 
 extern "C" int chitu_hip_bf16_gemm_silu(const void* x_bf16, const void* w13_bf16, void* out_bf16, int64_t M,

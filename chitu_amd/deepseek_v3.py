@@ -297,6 +297,15 @@ class MLPDeepSeekV3(torch.nn.Module):
         return self.w2(None, x_quant=(hq, hs))
 
 
+_ROUTE_ALIGN_MAX_TOKENS = 64
+
+
+def _route_align_enabled(tokens: int) -> bool:
+    """Routing + moe_align in one launch for decode-sized batches (the sort is done by the last routing
+    workgroup: fine for a few hundred ids, slower than the 1024-thread align kernel for prefill-sized ones)."""
+    return tokens <= _ROUTE_ALIGN_MAX_TOKENS and os.environ.get("CHITU_ROUTE_ALIGN", "1") != "0"
+
+
 class GateDeepSeekV3(torch.nn.Module):
     """Router (model_deepseek_v3.py:774-842): bf16 scores, sigmoid/softmax, bias, group-limited
     top-k, normalise, route_scale."""
@@ -309,11 +318,12 @@ class GateDeepSeekV3(torch.nn.Module):
         self.bias = (torch.nn.Parameter(torch.empty(args.n_routed_experts, dtype=torch.bfloat16, device=device), requires_grad=False)
                      if args.has_gate_bias() else None)
 
-    def forward(self, x, extra_expert_id: int = -1, extra_count: int = 1):
-        """(weights [bs, topk(+extra)] bf16, indices int64).  Two HIP launches (ops.gate_deepseek_v3)."""
+    def forward(self, x, extra_expert_id: int = -1, extra_count: int = 1, align=None):
+        """(weights [bs, topk(+extra)] bf16, indices int64).  Two HIP launches (ops.gate_deepseek_v3).
+        align=(num_experts, block, expert_map): also the moe_align triple, sorted inside the routing launch."""
         return ops.gate_deepseek_v3(x, self.weight, self.bias, self.n_groups, self.topk_groups, self.topk,
                                     self.score_func, self.route_scale, extra_expert_id=extra_expert_id,
-                                    extra_count=extra_count)
+                                    extra_count=extra_count, align=align)
 
 
 class MoEDeepSeekV3(torch.nn.Module):
@@ -367,14 +377,15 @@ class MoEDeepSeekV3(torch.nn.Module):
         nr, ns = self.n_routed, self.n_shared
         if self.moe_world_size > 1:
             return self.forward_expert_parallel(x, x_quant)
-        if ns >= 1:
-            weights, indices = self.gate(x, extra_expert_id=nr, extra_count=ns)
-        else:
-            weights, indices = self.gate(x)
+        # decode-sized batches: moe_align runs inside the routing launch (last workgroup sorts)
+        align = (nr + ns, fused_moe._MOE_BLOCK_M, None) if _route_align_enabled(x.shape[0]) else None
+        routed = self.gate(x, extra_expert_id=nr, extra_count=ns, align=align) if ns >= 1 else self.gate(x, align=align)
+        weights, indices = routed[0], routed[1]
+        aligned = routed[2] if len(routed) > 2 else None
         return fused_moe.fused_experts(
             x, self.w1w3_weight, self.w2_weight, topk_weights=weights, topk_ids=indices, use_fp8_w8a8=True,
             inplace=True, global_num_experts=nr + ns, w1_scale=self.w1w3_scale, w2_scale=self.w2_scale,
-            block_shape=[BLOCK, BLOCK], a1_quant=x_quant, reduce_topk=not defer_sum,
+            block_shape=[BLOCK, BLOCK], a1_quant=x_quant, reduce_topk=not defer_sum, aligned=aligned,
         )
 
     def forward_expert_parallel(self, x, x_quant):
@@ -384,11 +395,14 @@ class MoEDeepSeekV3(torch.nn.Module):
         GEMMs zero-fill like write_zeros_to_output, fused_moe.py:40-59) at full expert width, adds its slice
         of the shared experts, and the layer's existing all-reduce is the combine -- no all-to-all is
         needed while the tokens are replicated.  Returns this rank's partial sum [bs, dim]."""
-        weights, indices = self.gate(x)
+        align = (self.n_routed, fused_moe._MOE_BLOCK_M, self.expert_map) if _route_align_enabled(x.shape[0]) else None
+        routed = self.gate(x, align=align)
+        weights, indices = routed[0], routed[1]
         y = fused_moe.fused_experts(
             x, self.w1w3_weight, self.w2_weight, topk_weights=weights, topk_ids=indices, use_fp8_w8a8=True,
             inplace=True, global_num_experts=self.n_routed, expert_map=self.expert_map, w1_scale=self.w1w3_scale,
             w2_scale=self.w2_scale, block_shape=[BLOCK, BLOCK], a1_quant=x_quant,
+            aligned=routed[2] if len(routed) > 2 else None,
         )
         if self.shared is not None:
             y += self.shared(x_quant)

@@ -175,6 +175,7 @@ def fused_experts(
     a1_quant=None,
     reduce_topk: bool = True,
     use_int8_w8a8: bool = False,
+    aligned=None,
 ) -> torch.Tensor:
     """Same signature as chitu/fused_moe.py:1060-1127 (+ optional a1_quant / reduce_topk, see fused_experts_impl).  (The reference's inplace=False branch
     calls an unregistered torch.ops.vllm op; here both branches work.)"""
@@ -182,7 +183,7 @@ def fused_experts(
         hidden_states, w1, w2, topk_weights, topk_ids, inplace, activation, use_fp8_w8a8,
         use_int8_w8a16, use_int4_w4a16, global_num_experts, expert_map, w1_scale, w2_scale, w1_zp,
         w2_zp, a1_scale, a2_scale, block_shape, soft_fp8=soft_fp8, a1_quant=a1_quant, reduce_topk=reduce_topk,
-        use_int8_w8a8=use_int8_w8a8,
+        use_int8_w8a8=use_int8_w8a8, aligned=aligned,
     )
 
 
@@ -210,6 +211,7 @@ def fused_experts_impl(
     a1_quant=None,
     reduce_topk: bool = True,
     use_int8_w8a8: bool = False,
+    aligned=None,
 ):
     """out[t] = sum_j w[t,j] * W2[e_tj] . (silu(W1[e_tj] x_t)[:I] * (W1[e_tj] x_t)[I:])
 
@@ -221,6 +223,9 @@ def fused_experts_impl(
     reduce_topk=False: skip the top-k sum and return the routed-weighted expert outputs
     [tokens, topk, hidden] (a view of the persistent workspace, valid until the next fused_experts
     call) for a consumer that sums them itself (ops.rms_norm(add=<3-D>), same arithmetic).
+    aligned=(sorted_token_ids, expert_ids, num_tokens_post_pad): moe_align_block_size(topk_ids, 16,
+    global_num_experts, expert_map) already computed by the producer of topk_ids
+    (ops.gate_deepseek_v3(align=...): routing and sort in one launch) -- skips the align launch.
     """
     assert hidden_states.shape[1] == w1.shape[2], "Hidden size mismatch"
     assert topk_weights.shape == topk_ids.shape, "topk shape mismatch"
@@ -231,6 +236,7 @@ def fused_experts_impl(
     if activation != "silu":
         raise ValueError(f"Unsupported FusedMoe activation: {activation}")
     if use_int8_w8a8:
+        assert aligned is None, "aligned= is wired for the fp8 path only"
         return _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts,
                                    expert_map, w1_scale, w2_scale, reduce_topk)
     if not use_fp8_w8a8 or soft_fp8 or use_int8_w8a16 or use_int4_w4a16:
@@ -292,16 +298,23 @@ def fused_experts_impl(
     st = stream_ptr()
     max_mblocks = min(nblk, numel)
 
-    emap = _expert_map_i32(expert_map, global_num_experts, dev)
-    check(
-        lib.chitu_hip_moe_align_block_size_mapped(
-            ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel), i32(global_num_experts),
-            i32(_MOE_BLOCK_M), P("sorted"), i64(cap), P("experts"), i64(nblk), P("npost"), P("cumsum"),
-            i32(1), ptr(emap), st,
-        ),
-        "moe_align_block_size",
-    )
-    experts_ptr = P("experts")
+    if aligned is None:
+        emap = _expert_map_i32(expert_map, global_num_experts, dev)
+        check(
+            lib.chitu_hip_moe_align_block_size_mapped(
+                ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel), i32(global_num_experts),
+                i32(_MOE_BLOCK_M), P("sorted"), i64(cap), P("experts"), i64(nblk), P("npost"), P("cumsum"),
+                i32(1), ptr(emap), st,
+            ),
+            "moe_align_block_size",
+        )
+        sorted_p, experts_ptr, npost_p = P("sorted"), P("experts"), P("npost")
+    else:
+        a_sorted, a_experts, a_npost = aligned
+        require_cuda(a_sorted, a_experts, a_npost)
+        assert a_sorted.dtype == torch.int32 and a_experts.dtype == torch.int32 and a_npost.dtype == torch.int32
+        assert a_sorted.numel() == cap and a_experts.numel() == nblk, "aligned buffers must come from block 16 over global_num_experts"
+        sorted_p, experts_ptr, npost_p = ptr(a_sorted), ptr(a_experts), ptr(a_npost)
     if a1_quant is None:
         check(
             lib.chitu_hip_act_quant_fp8(
@@ -321,14 +334,14 @@ def fused_experts_impl(
         # in one wave), GEMM2 with the fp8 re-quantisation of h in its prologue
         check(
             lib.chitu_hip_moe_gemm1_silu_fp8(
-                a1q_p, a1s_p, ptr(w1), ptr(w1_scale), P("sorted"), experts_ptr, P("npost"), P("c1"),
+                a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("c1"),
                 i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), st,
             ),
             "moe gemm1 (silu fused)",
         )
         check(
             lib.chitu_hip_moe_gemm2_quant_fp8(
-                P("c1"), ptr(w2), ptr(w2_scale), P("sorted"), experts_ptr, P("npost"), ptr(topk_weights),
+                P("c1"), ptr(w2), ptr(w2_scale), sorted_p, experts_ptr, npost_p, ptr(topk_weights),
                 float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel), i64(Nout), i64(I),
                 i64(max_mblocks), f32(1e-10), st,
             ),
@@ -337,7 +350,7 @@ def fused_experts_impl(
     else:
         check(
             lib.chitu_hip_moe_gemm1_fp8(
-                a1q_p, a1s_p, ptr(w1), ptr(w1_scale), P("sorted"), experts_ptr, P("npost"), P("c1"),
+                a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("c1"),
                 i64(numel), i32(topk), i64(N), i64(K), i64(max_mblocks), st,
             ),
             "moe gemm1",
@@ -348,7 +361,7 @@ def fused_experts_impl(
         )
         check(
             lib.chitu_hip_moe_gemm2_fp8(
-                P("a2q"), P("a2s"), ptr(w2), ptr(w2_scale), P("sorted"), experts_ptr, P("npost"),
+                P("a2q"), P("a2s"), ptr(w2), ptr(w2_scale), sorted_p, experts_ptr, npost_p,
                 ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel), i64(Nout),
                 i64(I), i64(max_mblocks), st,
             ),

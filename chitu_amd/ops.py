@@ -355,12 +355,33 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
 _GATE_SPLITS = 16
 
 
+_route_tickets = {}
+
+
+def _route_ticket(device) -> torch.Tensor:
+    """The zero-initialised word chitu_hip_gate_route_align's workgroups count themselves on (reset by
+    the kernel).  Created on the first eager call per device -- before any graph capture (decode() warms up
+    eagerly) -- and kept for the life of the process, so captured launches keep a valid address."""
+    key = torch.device(device).index or 0
+    t = _route_tickets.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("gate_deepseek_v3(align=...) must run once eagerly before graph capture")
+        t = _route_tickets[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
 def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale,
-                     extra_expert_id: int = -1, extra_weight: float = 1.0, extra_count: int = 1):
+                     extra_expert_id: int = -1, extra_weight: float = 1.0, extra_count: int = 1, align=None):
     """GateDeepSeekV3.forward (chitu/models/model_deepseek_v3.py:810-842) in two launches:
     split-K skinny GEMM for the scores, then one fused routing kernel.  Returns (weights bf16
     [M, topk(+1)], indices int64 [M, topk(+1)]); the optional extra slot routes every token to
-    `extra_expert_id` .. `extra_expert_id + extra_count - 1` with weight `extra_weight` (shared experts)."""
+    `extra_expert_id` .. `extra_expert_id + extra_count - 1` with weight `extra_weight` (shared experts).
+
+    align=(num_experts, block_size, expert_map or None): additionally run moe_align_block_size over the
+    returned ids inside the routing launch (chitu_hip_gate_route_align) and return a third value
+    (sorted_token_ids, expert_ids, num_tokens_post_pad) -- what fused_moe.moe_align_block_size(ids.flatten(),
+    block_size, num_experts, expert_map) returns, for fused_experts(aligned=...)."""
     require_cuda(x, weight)
     assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous() and weight.is_contiguous()
     M, K = x.shape
@@ -378,12 +399,33 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
     else:
         logits = bf16_linear(x, weight)
         nparts = 0
+    sf = {"softmax": 0, "sigmoid": 1, "softmax_renorm": 2}[score_func]
+    if align is None:
+        check(
+            lib.chitu_hip_gate_route(ptr(logits), i32(nparts), i64(M), i32(E), ptr(bias), i32(n_groups), i32(topk_groups),
+                                     i32(topk), i32(sf), f32(route_scale), ptr(w_out), ptr(ids), i32(cols),
+                                     i32(extra_expert_id), f32(extra_weight), i32(extra_count), stream_ptr()),
+            "gate_route",
+        )
+        return w_out, ids
+    a_experts, a_block, a_map = align
+    cap = M * cols + a_experts * (a_block - 1)
+    nblk = (cap + a_block - 1) // a_block
+    sorted_ids = torch.empty(cap, dtype=torch.int32, device=x.device)
+    expert_ids = torch.empty(nblk, dtype=torch.int32, device=x.device)
+    npost = torch.empty(1, dtype=torch.int32, device=x.device)
+    cumsum = torch.empty(a_experts + 1, dtype=torch.int32, device=x.device)
+    if a_map is not None:
+        assert a_map.dtype == torch.int32 and a_map.is_cuda and a_map.is_contiguous() and a_map.numel() >= a_experts
     check(
-        lib.chitu_hip_gate_route(ptr(logits), i32(nparts), i64(M), i32(E), ptr(bias), i32(n_groups), i32(topk_groups),
-                                 i32(topk), i32({"softmax": 0, "sigmoid": 1, "softmax_renorm": 2}[score_func]), f32(route_scale), ptr(w_out),
-                                 ptr(ids), i32(cols), i32(extra_expert_id), f32(extra_weight), i32(extra_count), stream_ptr()),
-        "gate_route",
+        lib.chitu_hip_gate_route_align(ptr(logits), i32(nparts), i64(M), i32(E), ptr(bias), i32(n_groups), i32(topk_groups),
+                                       i32(topk), i32(sf), f32(route_scale), ptr(w_out), ptr(ids), i32(cols),
+                                       i32(extra_expert_id), f32(extra_weight), i32(extra_count), i32(a_experts),
+                                       i32(a_block), ptr(sorted_ids), i64(cap), ptr(expert_ids), i64(nblk), ptr(npost),
+                                       ptr(cumsum), ptr(a_map), ptr(_route_ticket(x.device)), stream_ptr()),
+        "gate_route_align",
     )
+    return w_out, ids, (sorted_ids, expert_ids, npost)
     return w_out, ids
 
 

@@ -341,6 +341,20 @@ int chitu_hip_gate_route(const void* logits, int32_t num_partials, int64_t token
                          int32_t score_func, float route_scale, void* out_weights_bf16,
                          int64_t* out_ids, int32_t out_stride, int32_t extra_expert_id,
                          float extra_weight, int32_t extra_count, void* stream);
+/* chitu_hip_gate_route and chitu_hip_moe_align_block_size_mapped in ONE launch (decode batches): the routing
+ * workgroups (one per token) publish their ids and take a ticket; the last to arrive sorts the whole
+ * [tokens * out_stride] id array (sentinels written by the kernel, fill_sentinels = 1 semantics).  Outputs
+ * are those of the two separate launches, bit for bit.  align_num_experts covers every id that can appear
+ * (routed + always-on slots), <= 1024; out_stride must equal topk + extra slots.  `ticket`: one
+ * zero-initialised uint32 in device memory, reset by the kernel; launches sharing it must not overlap. */
+int chitu_hip_gate_route_align(const void* logits, int32_t num_partials, int64_t tokens, int32_t num_experts,
+                               const void* bias_bf16, int32_t n_groups, int32_t topk_groups, int32_t topk,
+                               int32_t score_func, float route_scale, void* out_weights_bf16,
+                               int64_t* out_ids, int32_t out_stride, int32_t extra_expert_id,
+                               float extra_weight, int32_t extra_count, int32_t align_num_experts,
+                               int32_t align_block_size, int32_t* sorted_token_ids, int64_t sorted_cap,
+                               int32_t* expert_ids, int64_t expert_ids_cap, int32_t* num_tokens_post_pad,
+                               int32_t* cumsum, const int32_t* expert_map, uint32_t* ticket, void* stream);
 
 /* ---- MLA decode KV prep (kv_norm + RoPE + append, fused) ------------------------------------
  * Replaces four launches of AttentionDeepSeekV3.decode_forward_paged: apply_rotary_pos_emb on

@@ -87,7 +87,8 @@ def absorb_uv_quant_fp8(x, w, scale, scale_offset, sh, sk):
 
 
 def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale, extra_expert_id=-1,
-                     extra_weight=1.0, extra_count=1):
+                     extra_weight=1.0, extra_count=1, align=None):
+    # align (the fused route + sort launch) is a launch-count optimisation: the 2-tuple makes the caller sort itself
     w, i = ods.gate(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale)
     if extra_expert_id >= 0:
         w = torch.cat([w, torch.full((w.shape[0], extra_count), extra_weight, dtype=w.dtype)], 1)

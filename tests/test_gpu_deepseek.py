@@ -134,13 +134,14 @@ def test_layerwise_parity_and_graph_replay(make_args):
             orig = layer.ffn.gate.forward
 
             def hooked(inp, _orig=orig, _store=routing, **kw):
-                w, idx = _orig(inp, **kw)
+                res = _orig(inp, **kw)  # (weights, ids[, moe_align triple of the fused route + sort launch])
+                w, idx = res[0], res[1]
                 k = args.n_activated_experts
                 ns = args.n_shared_experts  # shared-expert slots: ids n_routed .., weight 1
                 assert idx.shape[1] == k + ns and (w[:, k:] == 1).all()
                 assert torch.equal(idx[:, k:].cpu(), (args.n_routed_experts + torch.arange(ns)).expand(idx.shape[0], -1))
                 _store["w"], _store["i"] = w[:, :k].cpu(), idx[:, :k].cpu()
-                return w, idx
+                return res
 
             layer.ffn.gate.forward = hooked
         with torch.inference_mode():

@@ -94,3 +94,56 @@ def test_expert_map_and_determinism():
     for _ in range(20):  # stable => run-to-run identical (the CUDA kernel is not)
         s1, e1, n1 = fused_moe.moe_align_block_size(ids, 16, 32)
         assert torch.equal(s1, s0) and torch.equal(e1, e0) and torch.equal(n1, n0)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(E=256, groups=(8, 4), topk=8, extra=1, score="sigmoid", bias=True),     # R1: fast routing kernel
+    dict(E=64, groups=(1, 1), topk=6, extra=2, score="softmax", bias=False),     # V2-Lite: generic kernel
+    dict(E=16, groups=(4, 2), topk=4, extra=1, score="sigmoid", bias=True),      # test-size V3
+    dict(E=8, groups=(1, 1), topk=2, extra=0, score="softmax_renorm", bias=False),  # Mixtral-style, no extra slot
+    dict(E=256, groups=(8, 4), topk=8, extra=0, score="sigmoid", bias=True, ep=(2, 8)),  # expert-parallel rank 2 of 8
+], ids=["r1", "v2lite", "tiny_v3", "mixtral", "r1_ep"])
+@pytest.mark.parametrize("M", [1, 2, 16, 19, 64])
+def test_route_and_align_in_one_launch_equals_the_two_launches(cfg, M):
+    """chitu_hip_gate_route_align (last routing workgroup sorts) == gate_route + moe_align_block_size, bit for
+    bit, across repeated launches (the ticket resets itself) and under hipGraph replay with new inputs."""
+    from chitu_amd import fused_moe, ops
+
+    E, K = cfg["E"], 1024  # 16 K-splits: the routing kernel sums fp32 partials
+    g = torch.Generator().manual_seed(E + M)
+    w = (torch.randn(E, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+    bias = (torch.randn(E, generator=g) * 0.01).to(torch.bfloat16).cuda() if cfg["bias"] else None
+    n_align = E + cfg["extra"]
+    emap = None
+    if "ep" in cfg:
+        r, ep = cfg["ep"]
+        emap = torch.full((E,), -1, dtype=torch.int32)
+        emap[r * (E // ep):(r + 1) * (E // ep)] = torch.arange(E // ep, dtype=torch.int32)
+        emap = emap.cuda()
+    kw = dict(extra_expert_id=E if cfg["extra"] else -1, extra_count=max(cfg["extra"], 1))
+
+    def run(x, fused):
+        if fused:
+            return ops.gate_deepseek_v3(x, w, bias, *cfg["groups"], cfg["topk"], cfg["score"], 2.5,
+                                        align=(n_align, 16, emap), **kw)
+        wt, ids = ops.gate_deepseek_v3(x, w, bias, *cfg["groups"], cfg["topk"], cfg["score"], 2.5, **kw)
+        return wt, ids, fused_moe.moe_align_block_size(ids, 16, n_align, emap)
+
+    def same(a, b):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for p, q in zip(a[2], b[2]):
+            assert p.shape == q.shape and torch.equal(p, q)
+
+    xs = [torch.randn(M, K, generator=g).to(torch.bfloat16).cuda() for _ in range(6)]
+    for x in xs:
+        same(run(x, True), run(x, False))
+    x_static = xs[0].clone()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = run(x_static, True)
+    for x in xs[1:4]:
+        x_static.copy_(x)
+        graph.replay()
+        torch.cuda.synchronize()
+        same(out, run(x, False))

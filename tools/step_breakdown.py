@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Per-decode-step kernel breakdown from a rocprofv3 rocpd .db of `bench.py --steps K`.
-Usage: python tools/step_breakdown.py <db> <timed_steps> [moe_layers_per_step=58] [tail_aligns=3*moe_layers]
-tail_aligns = moe_align launches bench.py issues AFTER the timed steps (roofline leg: two eager
-routing-capture steps + one align per layer for the launch plans); run bench.py with --no-bs1."""
+Usage: python tools/step_breakdown.py <db> <timed_steps> [moe_layers_per_step=58] [tail_markers=2*moe_layers]
+The step boundaries are found from the routing launches (one `gate_route*` kernel per MoE layer per step);
+tail_markers = routing launches bench.py issues AFTER the timed steps (roofline leg: two eager
+routing-capture steps); run bench.py with --no-bs1 --no-llama."""
 import sqlite3, sys
 db, steps = sys.argv[1], int(sys.argv[2])
 nmoe = int(sys.argv[3]) if len(sys.argv) > 3 else 58
 con = sqlite3.connect(db)
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
-al = [i for i, r in enumerate(rows) if "moe_align_kernel" in r[0]]
-tail = int(sys.argv[4]) if len(sys.argv) > 4 else 3 * nmoe
+al = [i for i, r in enumerate(rows) if "gate_route" in r[0]]
+tail = int(sys.argv[4]) if len(sys.argv) > 4 else 2 * nmoe
 first, last = al[-tail - nmoe * steps], al[-tail]
 t0, t1 = rows[first][1], rows[last][1]
 sel = [r for r in rows if t0 <= r[1] < t1]
