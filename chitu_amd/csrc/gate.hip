@@ -546,6 +546,122 @@ __global__ __launch_bounds__(1024) void gate_route_fast_kernel(
         route_align_tail(al, out_ids, (int64_t)M * out_stride, align_lds);
 }
 
+// ---------------------------------------------------------------- routing + align, one workgroup
+// Decode batches of <= 16 tokens on the DeepSeek-V3/R1 router shape (256 experts, sigmoid scores, groups
+// of 32 or none): ONE workgroup, one wave per token, four experts per lane (expert e = 4*lane + i, so a
+// group of 32 is 8 neighbouring lanes).  Everything a token needs stays inside its wave -- no
+// workgroup barrier until the ids of all tokens sit in LDS -- and the same workgroup then sorts them
+// (moe_align_workgroup reading the ids from LDS): no ticket, no global round trip between routing and
+// sort.  Arithmetic, rounding points and tie rule are gate_route_fast_kernel's, so ids, weights and the
+// align outputs are bit-identical to the separate launches.
+template <int GS>  // experts per group: 32, or 0 = ungrouped
+__global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
+    const void* __restrict__ logits, int S, int M, const bf16_t* __restrict__ bias, int n_groups, int topk_groups,
+    int topk, float route_scale, bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids, int out_stride,
+    int extra_id, float extra_w, int extra_n, RouteAlign al) {
+    constexpr int E = 256;
+    extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
+    const int nwaves = blockDim.x >> 6;
+    float* orig_lds = reinterpret_cast<float*>(dyn_lds);                      // [nwaves][E]
+    int64_t* ids_lds = reinterpret_cast<int64_t*>(dyn_lds + nwaves * E);     // [M * out_stride]
+    int* align_lds = dyn_lds + nwaves * E + 2 * ((M * out_stride + 1) & ~1);
+    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+    if (t < M) {  // wave-uniform
+        // ---- logits of experts 4*lane .. 4*lane+3: all loads up front
+        float lg[4];
+        if (S == 0) {
+            const i32x2 raw = *reinterpret_cast<const i32x2*>((const bf16_t*)logits + (int64_t)t * E + lane * 4);
+            lg[0] = bf16_to_f32((bf16_t)((uint32_t)raw[0] & 0xffffu));
+            lg[1] = bf16_to_f32((bf16_t)((uint32_t)raw[0] >> 16));
+            lg[2] = bf16_to_f32((bf16_t)((uint32_t)raw[1] & 0xffffu));
+            lg[3] = bf16_to_f32((bf16_t)((uint32_t)raw[1] >> 16));
+        } else {
+            f32x4 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                v[i] = *reinterpret_cast<const f32x4*>((const float*)logits + ((int64_t)min(i, S - 1) * M + t) * E + lane * 4);
+            f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] += i < S ? v[i][c] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lg[c] = bf16r(a[c]);  // F.linear output in bf16 (model_deepseek_v3.py:820)
+        }
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const i32x2 raw = *reinterpret_cast<const i32x2*>(bias + lane * 4);
+            bv[0] = bf16_to_f32((bf16_t)((uint32_t)raw[0] & 0xffffu));
+            bv[1] = bf16_to_f32((bf16_t)((uint32_t)raw[0] >> 16));
+            bv[2] = bf16_to_f32((bf16_t)((uint32_t)raw[1] & 0xffffu));
+            bv[3] = bf16_to_f32((bf16_t)((uint32_t)raw[1] >> 16));
+        }
+        float orig[4], sel[4];
+        uint32_t key[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            orig[c] = bf16r(1.0f / (1.0f + expf(-lg[c])));  // original_scores
+            sel[c] = bias ? bf16r(orig[c] + bv[c]) : orig[c];
+            key[c] = score_key(sel[c], lane * 4 + c);
+        }
+        *reinterpret_cast<f32x4*>(&orig_lds[t * E + lane * 4]) = f32x4{orig[0], orig[1], orig[2], orig[3]};
+        if (GS == 32) {
+            // group score = sum of the group's top-2 (bias) or its max (no bias), :827-831; group = 8 lanes
+            uint32_t k1 = max(max(key[0], key[1]), max(key[2], key[3]));
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) k1 = max(k1, (uint32_t)__shfl_xor((int)k1, off, 64));
+            uint32_t k2 = 0u;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) k2 = max(k2, key[c] == k1 ? 0u : key[c]);
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) k2 = max(k2, (uint32_t)__shfl_xor((int)k2, off, 64));
+            const float m1 = key_score(k1), m2 = key_score(k2);
+            const float mine = bias ? bf16r(m1 + m2) : m1;
+            const int grp = lane >> 3;
+            int rank = 0;
+            for (int g2 = 0; g2 < n_groups; ++g2) {
+                const float o = __shfl(mine, g2 * 8, 64);
+                rank += (o > mine) || (o == mine && g2 < grp);
+            }
+            if (rank >= topk_groups) {  // scores * mask
+#pragma unroll
+                for (int c = 0; c < 4; ++c) key[c] = score_key(0.f, lane * 4 + c);
+            }
+        }
+        // ---- top-k: topk rounds of a wave-wide maximum; round r's winner is slot r (descending score)
+        uint32_t mine_k = 0u;
+        for (int r = 0; r < topk; ++r) {
+            const uint32_t m = wave_max_u32_uniform(max(max(key[0], key[1]), max(key[2], key[3])));
+            if (lane == r) mine_k = m;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (key[c] == m) key[c] = 0u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-local LDS hand-off (orig_lds)
+        __builtin_amdgcn_wave_barrier();
+        const int we = 0xffff - (int)(mine_k & 0xffffu);
+        const float ws = lane < topk ? orig_lds[t * E + (we & (E - 1))] : 0.f;
+        float sum = 0.f;
+        for (int i = 0; i < topk; ++i) sum += __shfl(ws, i, 64);
+        if (lane < topk) {
+            float w = bf16r(ws / bf16r(sum));  // weights /= weights.sum(-1, keepdim=True)
+            w = bf16r(w * route_scale);       // weights *= route_scale
+            out_w[(int64_t)t * out_stride + lane] = f32_to_bf16(w);
+            out_ids[(int64_t)t * out_stride + lane] = we;
+            ids_lds[t * out_stride + lane] = we;
+        }
+        if (lane < extra_n && extra_id >= 0) {  // always-on (shared) experts appended as slots topk .. topk+extra_n-1
+            out_ids[(int64_t)t * out_stride + topk + lane] = extra_id + lane;
+            out_w[(int64_t)t * out_stride + topk + lane] = f32_to_bf16(extra_w);
+            ids_lds[t * out_stride + topk + lane] = extra_id + lane;
+        }
+    }
+    __syncthreads();
+    moe_align_workgroup<int64_t>(ids_lds, (int64_t)M * out_stride, al.num_experts, al.block_size, al.sorted_ids,
+                                 al.sorted_cap, al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, 1,
+                                 al.expert_map, align_lds, (int)blockDim.x);
+}
+
 }  // namespace chitu
 
 extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void* out, int out_dtype,
@@ -618,6 +734,24 @@ static int gate_route_launch(const void* logits, int32_t num_partials, int64_t t
     const bool fast = score_func == 1 && (gs == 0 || gs == 32 || gs == 64) && num_partials <= 16 &&
                       (threads / 64) * topk <= 64 && ((threads / 64) * topk) % 4 == 0 && n_groups <= 32 &&
                       !getenv("CHITU_GATE_SLOW");
+    if (fast && al.num_experts > 0 && num_experts == 256 && (gs == 0 || gs == 32) && tokens <= 16 &&
+        extra_count <= 32 && !getenv("CHITU_GATE_TICKET")) {
+        // one workgroup: a wave per token, then the sort (needs a thread per sorted-over expert)
+        const int wg_threads = 64 * max((int)tokens, (max(num_experts, al.num_experts) + 63) / 64);
+        const size_t ids_ints = 2 * (((size_t)tokens * out_stride + 1) & ~(size_t)1);
+        const size_t wg_lds = sizeof(int) * ((size_t)(wg_threads / 64) * 256 + ids_ints +
+                                             moe_align_lds_ints(al.num_experts, wg_threads));
+        CHITU_REQUIRE(wg_threads <= 1024 && wg_lds <= 64 * 1024);
+#define LAUNCHW(GSV)                                                                                          \
+    hipLaunchKernelGGL(gate_route_align_wg_kernel<GSV>, dim3(1), dim3(wg_threads), wg_lds, st, logits,         \
+                       (int)num_partials, (int)tokens, (const bf16_t*)bias_bf16, (int)n_groups, (int)topk_groups, \
+                       (int)topk, route_scale, (bf16_t*)out_weights_bf16, out_ids, (int)out_stride,           \
+                       (int)extra_expert_id, extra_weight, (int)extra_count, al)
+        if (gs == 32) LAUNCHW(32);
+        else LAUNCHW(0);
+#undef LAUNCHW
+        CHITU_RETURN_LAUNCH_STATUS();
+    }
     if (fast) {
 #define LAUNCHF(GSV)                                                                                         \
     hipLaunchKernelGGL(gate_route_fast_kernel<GSV>, dim3((unsigned)tokens), dim3(threads), align_lds, st, logits, \
