@@ -456,24 +456,28 @@ def main():
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t_build
 
-    if use_graph and world > 1:
-        # hipGraph capture with RCCL collectives inside is the intended N > 1 path; if this ROCm/RCCL
-        # build refuses it, every rank falls back to eager launches together (and says so in the JSON)
+    # N > 1: the step replays as hipGraph PIECES cut at every collective, the collectives are issued between
+    # them (DeepSeekV3Decoder.decode, "piecewise") -- nothing depends on RCCL being capturable.
+    # CHITU_TP_GRAPH=full asks for ONE graph with the RCCL collectives captured inside it; that attempt is
+    # probed first and every rank falls back to eager launches together if the capture is refused.
+    graph_mode = "off" if not use_graph else "on" if world == 1 else os.environ.get("CHITU_TP_GRAPH", "piecewise")
+    if use_graph and world > 1 and graph_mode == "full":
         ok = torch.ones(1, device="cuda")
         try:
             measure(model, cache, a.bs, a.ctx, 2, 1, world, True, "probe")
         except Exception as exc:  # noqa: BLE001
             print(f"[bench] rank {rank}: graph capture failed ({type(exc).__name__}: {exc}); eager fallback", file=sys.stderr)
-            for _ in range(3):  # drain the sticky capture-invalidated error before touching the device again
+            torch.cuda.set_stream(torch.cuda.default_stream())  # the failed capture leaves its side stream current
+            for _ in range(16):  # drain the sticky capture-invalidated errors before touching the device again
                 try:
                     torch.cuda.synchronize()
+                    ok = torch.zeros(1, device="cuda")
                     break
                 except Exception:  # noqa: BLE001
                     pass
-            ok = torch.zeros(1, device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() == 0:
-            use_graph = False
+            use_graph, graph_mode = False, "off (full capture refused)"
             model.graphs, model.static_tokens, model.static_out, model.graph_pool = {}, {}, {}, None
     dt = measure(model, cache, a.bs, a.ctx, a.steps, a.warmup, world, use_graph, "m")
     ms_per_step = dt / a.steps * 1e3
@@ -524,7 +528,7 @@ def main():
             "config": {
                 "workload": f"DeepSeek-R1-671B FP8 decode, one TP=8 rank shard per GPU "
                             f"({margs.n_layers} layers, 16 heads, 257 experts x 1/8 width), {world} of 8 shards live, "
-                            f"bs={a.bs}, ctx={a.ctx}, greedy, hipGraph={'on' if use_graph else 'off'}",
+                            f"bs={a.bs}, ctx={a.ctx}, greedy, hipGraph={graph_mode}",
                 "batch": a.bs, "context": a.ctx, "parallelism": f"tp8-shard x{world}", "layers": margs.n_layers,
             },
             "node_tok_s": round(node_tok_s, 2),

@@ -243,10 +243,15 @@ struct RouteAlign {
     unsigned int* ticket;
 };
 
-// Called by EVERY thread of every routing workgroup after its ids are written.
+// Called by EVERY thread of every routing workgroup after its ids are written.  The hand-off is the
+// agent-scope release / ticket / acquire sequence of the CDNA4 guide (Guideline 16, counter form):
+// every wave drains its stores, ONE lane releases at agent scope (the XCD's L2 write-back) and THEN
+// takes the ticket; the last arriver's one lane acquires (drops its CU's stale L1 lines) before the
+// workgroup reads the other workgroups' ids with plain loads.  Correct for any placement of the
+// workgroups over CUs / XCDs.
 __device__ __forceinline__ void route_align_tail(const RouteAlign& a, const int64_t* ids, int64_t numel, int* lds) {
     __shared__ int last_flag;
-    __threadfence();  // this thread's id / weight stores are visible device-wide before the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's id / weight stores have left the CU
     __syncthreads();
     if (gridDim.x == 1) {  // a single token (bs 1): this workgroup is the last one by construction
         moe_align_workgroup<int64_t>(ids, numel, a.num_experts, a.block_size, a.sorted_ids, a.sorted_cap, a.expert_ids,
@@ -254,13 +259,18 @@ __device__ __forceinline__ void route_align_tail(const RouteAlign& a, const int6
         return;
     }
     if (threadIdx.x == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = (t == gridDim.x - 1) ? 1 : 0;
-        if (last_flag) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back is complete before the ticket
+        const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == gridDim.x - 1) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch starts from 0
+        }
+        last_flag = last;
     }
     __syncthreads();
     if (!last_flag) return;
-    __threadfence();  // acquire: the other workgroups' ids
     moe_align_workgroup<int64_t>(ids, numel, a.num_experts, a.block_size, a.sorted_ids, a.sorted_cap, a.expert_ids,
                                  a.expert_cap, a.num_post_pad, a.cumsum, 1, a.expert_map, lds, (int)blockDim.x);
 }
@@ -751,6 +761,11 @@ static int gate_route_launch(const void* logits, int32_t num_partials, int64_t t
         else LAUNCHW(0);
 #undef LAUNCHW
         CHITU_RETURN_LAUNCH_STATUS();
+    }
+    if (al.num_experts > 0 && tokens > 1)  // the ticket starts from 0 on EVERY launch (a memset node under capture)
+    {
+        const hipError_t me = hipMemsetAsync(al.ticket, 0, sizeof(unsigned int), st);
+        if (me != hipSuccess) return (int)me;
     }
     if (fast) {
 #define LAUNCHF(GSV)                                                                                         \

@@ -22,7 +22,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from . import fused_moe, ops
+from . import fused_moe, graphs, ops
 from . import tensor_parallel as tp
 from .attn_backend import HipAttnBackend
 from .cache_manager import PagedKVCacheManager
@@ -551,25 +551,40 @@ class DeepSeekV3Decoder(torch.nn.Module):
 
     @torch.inference_mode()
     def decode(self, tokens, use_graph=True):
+        """One decode step -> fp32 logits [bs, vocab].  use_graph: False = eager launches; True = replay of
+        the step captured per batch size -- as ONE hipGraph when this rank has no collectives (or when
+        CHITU_TP_GRAPH=full asks for the collectives to be captured too), else PIECEWISE: the step is cut at
+        every all-reduce / all-gather, the pieces are hipGraphs and the collectives are issued between them
+        (RCCL never has to be capturable; 2 x layers + 2 host calls per step, far below the pieces' GPU
+        time); "piecewise" / "full" force a mode."""
         self.prepare_decoding_attn()
         bs = tokens.shape[0]
         if not use_graph:
             return self.decode_eager(tokens)
-        if bs not in self.graphs:
-            self.static_tokens[bs] = tokens.clone()
-            # Warm-up replicates the graph's side effect (append at position L), which the captured
-            # run then overwrites with the same values.
-            sample = self.decode_eager(self.static_tokens[bs])
-            self.static_out[bs] = torch.zeros_like(sample)
+        mode = graphs.graph_mode(use_graph)
+        key = (bs, mode)
+        if key not in self.graphs:
+            if bs not in self.static_tokens:
+                self.static_tokens[bs] = tokens.clone()
+                # Warm-up replicates the graph's side effect (append at position L), which the captured
+                # run then overwrites with the same values.
+                sample = self.decode_eager(self.static_tokens[bs])
+                self.static_out[bs] = torch.zeros_like(sample)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graph_pool):
-                self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs]))
-            if self.graph_pool is None:
-                self.graph_pool = g.pool()
-            self.graphs[bs] = g
+            if mode == "full":
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graph_pool):
+                    self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs]))
+                if self.graph_pool is None:
+                    self.graph_pool = g.pool()
+            else:
+                if self.graph_pool is None:
+                    self.graph_pool = torch.cuda.graph_pool_handle()
+                g = graphs.capture_piecewise(
+                    lambda: self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs])), self.graph_pool)
+            self.graphs[key] = g
         self.static_tokens[bs].copy_(tokens)
-        self.graphs[bs].replay()
+        self.graphs[key].replay()
         return self.static_out[bs]
 
 

@@ -1,0 +1,70 @@
+"""Piecewise hipGraph capture of a decode step that contains collectives.
+
+Reference: chitu/models/model.py:538-622 captures the whole step, NCCL all-reduces included, in one CUDA
+graph.  Here a rank with collectives replays the step as hipGraph PIECES cut at every collective
+(`tensor_parallel._graph_break`), and issues the collectives eagerly between the pieces: the N > 1 step
+then never depends on RCCL calls being capturable, costs 2 x layers + 2 extra host calls per step (each far
+shorter than the GPU time of the piece it follows, so the device stays fed), and is bit-identical to eager.
+"""
+
+import torch
+
+from . import tensor_parallel as tp
+
+
+class PiecewiseGraph:
+    """The pieces of one step with the collectives that sit between them (closures over the pieces' static
+    tensors, issued on the current stream after the piece that produces their input)."""
+
+    def __init__(self):
+        self.pieces = []
+
+    def add(self, graph, run_after):
+        self.pieces.append((graph, run_after))
+
+    def replay(self):
+        for graph, run_after in self.pieces:
+            graph.replay()
+            if run_after is not None:
+                run_after()
+
+
+def capture_piecewise(step, pool) -> PiecewiseGraph:
+    """Capture `step()` (one eager step on static inputs that writes static outputs; it must have run once
+    eagerly already) into pieces that share the memory pool `pool` (torch.cuda.graph_pool_handle())."""
+    pieces = PiecewiseGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    cur = [None]
+
+    def begin():
+        cur[0] = torch.cuda.CUDAGraph()
+        cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")
+
+    def cut(run):  # tensor_parallel._graph_break: a collective sits here
+        cur[0].capture_end()
+        pieces.add(cur[0], run)
+        begin()
+
+    with torch.cuda.stream(side):
+        begin()
+        tp._graph_break = cut
+        try:
+            step()
+        finally:
+            tp._graph_break = None
+        cur[0].capture_end()
+        pieces.add(cur[0], None)
+    torch.cuda.current_stream().wait_stream(side)
+    return pieces
+
+
+def graph_mode(use_graph) -> str:
+    """decode(use_graph=...) -> "full" | "piecewise": a string forces the mode; True picks piecewise on a
+    rank with collectives unless CHITU_TP_GRAPH=full asks for them to be captured into the one graph."""
+    import os
+
+    if isinstance(use_graph, str):
+        assert use_graph in ("full", "piecewise")
+        return use_graph
+    return "piecewise" if tp.get_tp_size() > 1 and os.environ.get("CHITU_TP_GRAPH", "piecewise") != "full" else "full"

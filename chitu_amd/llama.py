@@ -17,7 +17,7 @@ from typing import List, Optional
 import torch
 import torch.nn.functional as F
 
-from . import ops
+from . import graphs, ops
 from . import tensor_parallel as tp
 from .attn_backend import HipAttnBackend
 from .cache_manager import PagedKVCacheManager
@@ -217,22 +217,33 @@ class LlamaDecoder(torch.nn.Module):
 
     @torch.inference_mode()
     def decode(self, tokens, use_graph=True):
+        """Eager, or the step captured per batch size: one hipGraph, or -- on a rank with collectives --
+        hipGraph pieces with the collectives between them (chitu_amd/graphs.py)."""
         bs = tokens.shape[0]
         if not use_graph:
             return self.decode_eager(tokens)
-        if bs not in self.graphs:
-            self.static_tokens[bs] = tokens.clone()
-            sample = self.decode_eager(self.static_tokens[bs])  # also re-writes this step's KV rows
-            self.static_out[bs] = torch.zeros_like(sample)
+        mode = graphs.graph_mode(use_graph)
+        key = (bs, mode)
+        if key not in self.graphs:
+            if bs not in self.static_tokens:
+                self.static_tokens[bs] = tokens.clone()
+                sample = self.decode_eager(self.static_tokens[bs])  # also re-writes this step's KV rows
+                self.static_out[bs] = torch.zeros_like(sample)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graph_pool):
-                self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs]))
-            if self.graph_pool is None:
-                self.graph_pool = g.pool()
-            self.graphs[bs] = g
+            step = lambda: self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs]))
+            if mode == "full":
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graph_pool):
+                    step()
+                if self.graph_pool is None:
+                    self.graph_pool = g.pool()
+            else:
+                if self.graph_pool is None:
+                    self.graph_pool = torch.cuda.graph_pool_handle()
+                g = graphs.capture_piecewise(step, self.graph_pool)
+            self.graphs[key] = g
         self.static_tokens[bs].copy_(tokens)
-        self.graphs[bs].replay()
+        self.graphs[key].replay()
         return self.static_out[bs]
 
 

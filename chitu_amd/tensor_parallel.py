@@ -57,10 +57,21 @@ def get_tp_rank():
     return dist.get_rank(group=get_tp_group()) if tp_comm_group is not None else 0
 
 
+# Piecewise hipGraph capture (deepseek_v3.DeepSeekV3Decoder.decode, mode "piecewise"): while a step is
+# being captured this is a callable `cut(run)`; every collective below then ENDS the graph piece being
+# recorded, hands its own launch (`run`, or None when the group has one rank) to the capture to be issued
+# eagerly between the pieces at replay time, and a new piece begins.  No collective is ever recorded into
+# a graph that way, so the N > 1 step does not depend on RCCL being capturable.
+_graph_break = None
+
+
 def all_reduce(t: torch.Tensor) -> torch.Tensor:
     """Sum over the TP group, in place (tensor_parallel.py:166, model_deepseek_v3.py:1011)."""
-    if get_tp_size() > 1:
-        dist.all_reduce(t, group=get_tp_group())
+    run = (lambda: dist.all_reduce(t, group=get_tp_group())) if get_tp_size() > 1 else None
+    if _graph_break is not None:
+        _graph_break(run)
+    elif run is not None:
+        run()
     return t
 
 
@@ -74,7 +85,11 @@ def all_gather_last_dim(y: torch.Tensor) -> torch.Tensor:
     shape = list(y_t.shape)
     shape[0] *= tp
     gathered = y.new_empty(shape)
-    dist.all_gather_into_tensor(gathered, y_t, group=get_tp_group())
+    run = lambda: dist.all_gather_into_tensor(gathered, y_t, group=get_tp_group())
+    if _graph_break is not None:
+        _graph_break(run)
+    else:
+        run()
     return gathered.permute(*range(1, y.dim()), 0)
 
 

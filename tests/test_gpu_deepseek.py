@@ -191,6 +191,21 @@ def test_layerwise_parity_and_graph_replay(make_args):
     assert not torch.equal(outs[0], outs[1])
     assert len(model.graphs) == 1
 
+    # ---- piecewise replay (the N > 1 form: the step cut at every collective, collectives between the pieces;
+    # with one rank every cut carries no collective) == eager, KV advancing
+    for step in range(2):
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        snap = cache.paged_kv_cache.clone()
+        eager = model.decode(tokens, use_graph=False).clone()
+        kv_eager = cache.paged_kv_cache.clone()
+        cache.paged_kv_cache.copy_(snap)
+        pieces = model.decode(tokens, use_graph="piecewise").clone()
+        assert torch.equal(eager, pieces) and torch.equal(kv_eager, cache.paged_kv_cache)
+        tokens = eager.argmax(dim=-1)
+        cache.finalize_cache_single_decode(reqs)
+    assert len(model.graphs[(bs, "piecewise")].pieces) > args.n_layers
+
 
 def test_rmsnorm_with_residual_add():
     from chitu_amd import ops

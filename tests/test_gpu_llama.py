@@ -87,11 +87,16 @@ def test_layerwise_parity_and_graph_replay(n_kv_heads):
         graph = model.decode(tokens, use_graph=True).clone()
         assert torch.equal(eager, graph)
         assert torch.equal(kv_eager[0], cache.paged_k_cache) and torch.equal(kv_eager[1], cache.paged_v_cache)
+        if step == 2:  # the N > 1 replay form (graph pieces cut at the collectives) on one rank
+            cache.paged_k_cache.copy_(snap_k)
+            cache.paged_v_cache.copy_(snap_v)
+            assert torch.equal(eager, model.decode(tokens, use_graph="piecewise"))
+            assert torch.equal(kv_eager[0], cache.paged_k_cache) and torch.equal(kv_eager[1], cache.paged_v_cache)
         assert eager.dtype == torch.float32 and tuple(eager.shape) == (bs, args.vocab_size) and torch.isfinite(eager).all()
         outs.append(eager)
         tokens = eager.argmax(dim=-1)
         cache.finalize_cache_single_decode(reqs)
-    assert not torch.equal(outs[0], outs[1]) and len(model.graphs) == 1
+    assert not torch.equal(outs[0], outs[1]) and len(model.graphs) == 2
 
 
 @pytest.mark.parametrize("rotary", ["llama", "hf-llama"])
