@@ -21,6 +21,7 @@
 //
 // One workgroup (1024 threads) per row; rows are independent.
 #include "common.h"
+#include <stdlib.h>
 
 namespace chitu {
 
@@ -102,10 +103,37 @@ __device__ __forceinline__ int load4(const void* row, int i0, int vocab, bool ve
     return n;
 }
 
+// One pass over a row: every wave visits its 256-element chunks (wave w: [256 w + 4096 j, + 256)), a lane
+// four consecutive elements per chunk.  The loads of U chunks are issued before the first is consumed:
+// a pass is otherwise one dependent HBM / L2 round trip per chunk (measured: 25 us per pass over
+// 129280 floats with one load in flight per lane).  body(i0, v[4], n) is called by the WHOLE wave for
+// every chunk (n = 0 for lanes past the end of the row), so it may use wave-wide operations.
+constexpr int kSampleUnroll = 8;
+template <int DT, int U, typename F>
+__device__ __forceinline__ void for_each_quad(const void* row, int vocab, bool vec, F&& body) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = wave * 256; base < vocab; base += kSampleThreads * 4 * U) {  // wave-uniform trip count
+        float v[U][4];
+        int n[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int i0 = base + q * kSampleThreads * 4 + lane * 4;
+            n[q] = i0 < vocab ? load4<DT>(row, i0, vocab, vec, v[q]) : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            if (base + q * kSampleThreads * 4 < vocab)  // wave-uniform
+                body(base + q * kSampleThreads * 4 + lane * 4, v[q], n[q]);
+        }
+    }
+}
+
 // x = logits / temperature (executor.py:106, an IEEE f32 division) in logits mode; the probability
 // itself in probs mode (utils.py:62 takes probabilities).
 __device__ __forceinline__ float sample_x(float v, float temperature, int probs_mode) {
-    return probs_mode ? v : v / temperature;
+    // v / 1.0f == v bit for bit: greedy batches and unit temperatures skip the ~10-instruction IEEE
+    // division (the passes over a row are VALU-bound: one workgroup per row)
+    return (probs_mode || temperature == 1.0f) ? v : v / temperature;
 }
 // weight in [0, 1] relative to the row maximum m: exp(x - m) (softmax numerator) or p / max p.  The
 // same expression is evaluated in every pass, so every pass sees the same bits.
@@ -137,16 +165,13 @@ template <int DT>
 __device__ __forceinline__ void sample_hist_level(SampleShared& sh, const void* row, int vocab, bool vec,
                                                   float temperature, float m, int probs_mode, int shift,
                                                   bool use_prefix, uint32_t prefix) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     for (int b = tid; b < kSampleBins; b += kSampleThreads) {
         sh.cnt[b] = 0;
         sh.sum[b] = 0;
     }
     __syncthreads();
-    for (int base = wave * 256; base < vocab; base += kSampleThreads * 4) {  // wave-uniform trip count
-        const int i0 = base + lane * 4;
-        float v[4];
-        const int n = i0 < vocab ? load4<DT>(row, i0, vocab, vec, v) : 0;
+    for_each_quad<DT, kSampleUnroll>(row, vocab, vec, [&](int i0, const float (&v)[4], int n) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float e = sample_e(sample_x(v[k], temperature, probs_mode), m, probs_mode);
@@ -175,7 +200,7 @@ __device__ __forceinline__ void sample_hist_level(SampleShared& sh, const void* 
                 atomicAdd(reinterpret_cast<unsigned long long*>(&sh.sum[b]), (unsigned long long)w);
             }
         }
-    }
+    });
     __syncthreads();
 }
 
@@ -239,12 +264,196 @@ __device__ __forceinline__ void sample_find_boundary(SampleShared& sh, uint32_t 
     __syncthreads();
 }
 
+// ---------------------------------------------------------------- candidate fast path
+// Peaked rows (what a language model emits) keep a few dozen tokens out of 129280, so the prefix can be
+// cut from a short candidate list instead of three histogram passes over the row:
+//   pass 1  Z = sum of the fixed-point weights, and how many weights reach each of five thresholds
+//           2^-4 .. 2^-20 of the maximum (register counters, no atomics);
+//   pass 2  the elements above the lowest threshold that admits <= kCandCap of them are appended
+//           (key, index) to LDS (one LDS atomic per wave-load);
+//   then    a bitonic sort in the specification's order (key descending, index ascending), a scan of
+//           the exact integer weights for the top-k / top-p cut, a second sort of the kept entries by
+//           index and a scan for the inverse CDF.
+// The list provably holds the whole kept prefix iff the cut falls inside it, or it is as long as
+// top_k, or its mass already exceeds top_p * Z, or it is the whole row; otherwise (flat rows, huge
+// top_k, no limits at all) the radix descent below runs.  Both paths evaluate the same integer
+// specification (oracle/sampling.py::sample_fixed_point), so which one ran cannot be told from the
+// result.
+constexpr int kCandCap = 1024;
+constexpr int kCandLevels = 5;
+__device__ __forceinline__ uint32_t cand_threshold_key(int j) { return (uint32_t)(127 - 4 * (j + 1)) << 23; }  // bits of 2^-(4j+4)
+
+__device__ __forceinline__ uint64_t block_sum_u64(SampleShared& sh, uint64_t v) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum_u64(v);
+    __syncthreads();  // earlier readers of wave_u64 are done
+    if (lane == 0) sh.wave_u64[wave] = v;
+    __syncthreads();
+    uint64_t s = 0;
+#pragma unroll
+    for (int w = 0; w < kSampleWaves; ++w) s += sh.wave_u64[w];
+    return s;
+}
+
+// exclusive prefix sum over the workgroup's threads (thread order); `total` = sum over all threads
+__device__ __forceinline__ uint64_t block_excl_scan_u64(SampleShared& sh, uint64_t v, uint64_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t o = shfl_up_u64(incl, off);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63) sh.wave_u64[wave] = incl;
+    __syncthreads();
+    uint64_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSampleWaves; ++w) {
+        if (w < wave) before += sh.wave_u64[w];
+        tot += sh.wave_u64[w];
+    }
+    total = tot;
+    return before + incl - v;
+}
+
+// in-place bitonic sort of a[0 .. n) in LDS, n a power of two <= kSampleThreads, one element per thread
+template <bool DESCENDING>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* a, int n) {
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int p = tid ^ j;
+            if (tid < n && p > tid) {
+                const uint64_t x = a[tid], y = a[p];
+                const bool first_half = (tid & k) == 0;
+                const bool swap = (DESCENDING == first_half) ? x < y : x > y;
+                if (swap) {
+                    a[tid] = y;
+                    a[p] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Returns true when the token (and the optional statistics) have been written; false = not applicable,
+// nothing written, the caller runs the radix descent.  Must be called by the whole workgroup.
+template <int DT>
+__device__ __forceinline__ bool sample_candidates(SampleShared& sh, const void* row, int vocab, bool vec, float temperature,
+                                                  float m, int probs_mode, int top_k, float top_p, float u, int row_id,
+                                                  int64_t arg_max, int64_t* out_tokens, int32_t* n_kept_out,
+                                                  float* kept_mass_out) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint64_t* arr = sh.sum;  // the histogram's sum array doubles as the sort buffer (kCandCap == kSampleBins)
+    // ---- pass 1: Z and the five threshold counts (21 bits each: vocab < 2^21 per the entry point)
+    uint64_t z = 0, ca = 0, cb = 0;
+    for_each_quad<DT, kSampleUnroll>(row, vocab, vec, [&](int i0, const float (&v)[4], int n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < n) {
+                const float e = sample_e(sample_x(v[k], temperature, probs_mode), m, probs_mode);
+                const uint32_t key = __float_as_uint(e);
+                z += sample_fix(e);
+                ca += (uint64_t)(key >= cand_threshold_key(0)) | ((uint64_t)(key >= cand_threshold_key(1)) << 21) |
+                      ((uint64_t)(key >= cand_threshold_key(2)) << 42);
+                cb += (uint64_t)(key >= cand_threshold_key(3)) | ((uint64_t)(key >= cand_threshold_key(4)) << 21);
+            }
+        }
+    });
+    z = block_sum_u64(sh, z);
+    ca = block_sum_u64(sh, ca);
+    cb = block_sum_u64(sh, cb);
+    const uint32_t counts[kCandLevels] = {(uint32_t)(ca & 0x1fffffu), (uint32_t)((ca >> 21) & 0x1fffffu),
+                                          (uint32_t)((ca >> 42) & 0x1fffffu), (uint32_t)(cb & 0x1fffffu),
+                                          (uint32_t)((cb >> 21) & 0x1fffffu)};
+    if (z == 0 || counts[0] > (uint32_t)kCandCap) return false;
+    int level = 0;
+#pragma unroll
+    for (int j = 1; j < kCandLevels; ++j)
+        if (counts[j] <= (uint32_t)kCandCap) level = j;
+    const uint32_t tkey = cand_threshold_key(level);
+    const int n_cand = (int)counts[level];
+    uint64_t p_rem;
+    {
+        const double pz = (double)__builtin_fmaxf(top_p, 0.f) * (double)z;  // as sample_find_boundary
+        p_rem = (top_p >= 1.0f || pz >= 18446744073709549568.0) ? ~0ull : (uint64_t)pz;
+    }
+    const uint32_t k_eff = top_k <= 0 ? 0xffffffffu : (uint32_t)top_k;
+    // ---- pass 2: append (key, index) of every weight >= the threshold; one LDS atomic per wave-load
+    if (tid == 0) sh.b_cnt = 0;
+    __syncthreads();
+    for_each_quad<DT, kSampleUnroll>(row, vocab, vec, [&](int i0, const float (&v)[4], int n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t key = 0;
+            if (k < n) key = __float_as_uint(sample_e(sample_x(v[k], temperature, probs_mode), m, probs_mode));
+            const bool take = k < n && key >= tkey;
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(take);
+            if (mask) {  // wave-uniform
+                uint32_t start = 0;
+                if (lane == 0) start = atomicAdd(&sh.b_cnt, (uint32_t)__builtin_popcountll(mask));
+                start = (uint32_t)__builtin_amdgcn_readfirstlane((int)start);
+                const uint64_t below = lane == 0 ? 0ull : (mask & (~0ull >> (64 - lane)));
+                if (take)
+                    arr[start + (uint32_t)__builtin_popcountll(below)] =
+                        ((uint64_t)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)(i0 + k));
+            }
+        }
+    });
+    int npow = 64;
+    while (npow < n_cand) npow <<= 1;
+    __syncthreads();
+    if (tid >= n_cand && tid < npow) arr[tid] = 0ull;  // below every real entry (a real key is >= the threshold > 0)
+    __syncthreads();
+    bitonic_sort_lds<true>(arr, npow);  // key descending, ties: lower index first
+    // ---- the cut: position < top_k and exclusive cumulative weight <= top_p * Z (utils.py:72-76)
+    const uint64_t mine = tid < n_cand ? arr[tid] : 0ull;
+    const uint32_t my_key = (uint32_t)(mine >> 32);
+    const uint32_t my_idx = 0xffffffffu - (uint32_t)mine;
+    const uint64_t w = tid < n_cand ? sample_fix(__uint_as_float(my_key)) : 0ull;
+    uint64_t s_cand;
+    const uint64_t excl = block_excl_scan_u64(sh, w, s_cand);
+    const bool kept = tid < n_cand && (uint32_t)tid < k_eff && excl <= p_rem;
+    const uint64_t packed = block_sum_u64(sh, kept ? ((w << 11) | 1ull) : 0ull);  // w <= 2^40, <= 1024 kept: 51 + 11 bits
+    const int n_kept = (int)(packed & 0x7ffu);
+    const uint64_t s_kept = packed >> 11;
+    const bool sufficient = n_kept < n_cand || (uint32_t)n_cand >= k_eff || s_cand > p_rem || n_cand == vocab;
+    if (!sufficient) return false;
+    if (tid == 0) {
+        if (n_kept_out) n_kept_out[row_id] = n_kept;
+        if (kept_mass_out) kept_mass_out[row_id] = (float)((double)s_kept / (double)z);
+    }
+    if (s_kept == 0) {
+        if (tid == 0) out_tokens[row_id] = arg_max;
+        return true;
+    }
+    uint64_t target;
+    {
+        const double t = (double)__builtin_fminf(__builtin_fmaxf(u, 0.f), 1.f) * (double)s_kept;
+        target = t >= (double)s_kept ? s_kept - 1 : (uint64_t)t;
+        if (target >= s_kept) target = s_kept - 1;
+    }
+    // ---- inverse CDF over the kept entries in INDEX order: sort them by index, scan, pick
+    __syncthreads();
+    if (tid < npow) arr[tid] = kept ? (((uint64_t)my_idx << 32) | my_key) : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds<false>(arr, npow);
+    const uint64_t ent = tid < n_kept ? arr[tid] : 0ull;
+    const uint64_t w2 = tid < n_kept ? sample_fix(__uint_as_float((uint32_t)ent)) : 0ull;
+    uint64_t unused_total;
+    const uint64_t excl2 = block_excl_scan_u64(sh, w2, unused_total);
+    if (tid < n_kept && excl2 <= target && target < excl2 + w2) out_tokens[row_id] = (int64_t)(ent >> 32);
+    return true;
+}
+
 template <int DT>
 __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     const void* __restrict__ logits, int64_t row_stride, int vocab, const float* __restrict__ temperatures,
     const int32_t* __restrict__ top_ks, const float* __restrict__ top_ps, const float* __restrict__ uniforms,
     int probs_mode, int64_t* __restrict__ out_tokens, int32_t* __restrict__ n_kept_out,
-    float* __restrict__ kept_mass_out) {
+    float* __restrict__ kept_mass_out, int use_candidates) {
     __shared__ SampleShared sh;
     const int row_id = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -257,9 +466,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
 
     // ---- pass 0: row maximum and its (lowest) index
     uint64_t best = 0;
-    for (int i0 = tid * 4; i0 < vocab; i0 += kSampleThreads * 4) {
-        float v[4];
-        const int n = load4<DT>(row, i0, vocab, vec, v);
+    for_each_quad<DT, kSampleUnroll>(row, vocab, vec, [&](int i0, const float (&v)[4], int n) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < n) {
@@ -268,7 +475,7 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
                 best = key > best ? key : best;
             }
         }
-    }
+    });
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const uint64_t o = shfl_xor_u64(best, off);
@@ -292,6 +499,13 @@ __global__ __launch_bounds__(kSampleThreads) void sample_kernel(
     }
     const float top_p = top_ps[row_id];
     const float u = uniforms[row_id];
+
+    // ---- short candidate list first (peaked rows); the radix descent below is the general path
+    if (use_candidates && vocab < (1 << 21) &&
+        sample_candidates<DT>(sh, row, vocab, vec, temperature, m, probs_mode, top_k, top_p, u, row_id, arg_max,
+                              out_tokens, n_kept_out, kept_mass_out))
+        return;
+    __syncthreads();  // the candidate path's LDS (sh.sum, counters) is about to be reused
 
     // ---- radix descent for (tau, c_keep)
     uint32_t k_rem = top_k <= 0 ? 0xffffffffu : (uint32_t)top_k;  // <= 0: no top-k limit
@@ -509,10 +723,11 @@ extern "C" int chitu_hip_sample(const void* logits, int act_dtype, int64_t row_s
     // greedy for every row: top_ks == NULL; otherwise all four per-row arrays are required
     if (top_ks != nullptr) CHITU_REQUIRE(top_ps && uniforms && (probs_mode || temperatures));
     if (rows == 0) return CHITU_OK;
+    const int use_candidates = getenv("CHITU_SAMPLE_RADIX") ? 0 : 1;  // A/B and test knob: radix descent only
 #define LAUNCH(DT)                                                                                          \
     hipLaunchKernelGGL(chitu::sample_kernel<DT>, dim3((unsigned)rows), dim3(chitu::kSampleThreads), 0,      \
                        (hipStream_t)stream, logits, row_stride, (int)vocab, temperatures, top_ks, top_ps,   \
-                       uniforms, (int)probs_mode, out_tokens, n_kept_out, kept_mass_out)
+                       uniforms, (int)probs_mode, out_tokens, n_kept_out, kept_mass_out, use_candidates)
     if (act_dtype == 0) LAUNCH(0);
     else if (act_dtype == 1) LAUNCH(1);
     else LAUNCH(2);

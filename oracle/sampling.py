@@ -228,3 +228,52 @@ def sample_radix_model(row, temperature, top_k, top_p, u, probs_mode=False, wave
         if run > target:
             return i, n_kept
     raise AssertionError("unreachable")
+
+
+def sample_candidate_model(row, temperature, top_k, top_p, u, probs_mode=False, cap=1024):
+    """The candidate fast path of csrc/sample.hip (sample_candidates) restated: threshold counts at
+    2^-4 .. 2^-20 of the maximum, the lowest threshold admitting <= cap candidates, the cut on the sorted
+    candidates, the sufficiency rule, the inverse CDF over the kept entries in index order.  Returns
+    (token, n_kept), or None where the kernel falls back to the radix descent -- so the rule that decides
+    when the short list provably holds the whole kept prefix is checked on the CPU against
+    `sample_fixed_point` (tests/test_sampler_oracle.py) with caps small enough to hit every branch."""
+    x, e, fix = _weights_fixed(row, temperature, probs_mode)
+    vocab = e.size
+    if top_k == 1:
+        return _argmax(x), 1
+    keys = e.view(np.uint32).astype(np.int64)
+    fixl = [int(f) for f in fix]
+    z = sum(fixl)
+    tkeys = [(127 - 4 * (j + 1)) << 23 for j in range(5)]
+    counts = [int((keys >= t).sum()) for t in tkeys]
+    if z == 0 or counts[0] > cap:
+        return None
+    level = max(j for j in range(5) if counts[j] <= cap)
+    cand = [i for i in range(vocab) if int(keys[i]) >= tkeys[level]]
+    cand.sort(key=lambda i: (-int(keys[i]), i))
+    if top_p >= 1.0:
+        p_rem = (1 << 64) - 1
+    else:
+        p_rem = int(np.floor(np.float64(max(np.float32(top_p), np.float32(0))) * np.float64(z)))
+    k_eff = (1 << 32) - 1 if top_k <= 0 else int(top_k)
+    kept, run = [], 0
+    for pos, i in enumerate(cand):
+        if pos < k_eff and run <= p_rem:
+            kept.append(i)
+        run += fixl[i]
+    s_cand = run
+    n_cand, n_kept = len(cand), len(kept)
+    if not (n_kept < n_cand or n_cand >= k_eff or s_cand > p_rem or n_cand == vocab):
+        return None
+    s_kept = sum(fixl[i] for i in kept)
+    if s_kept == 0:
+        return _argmax(x), n_kept
+    uu = np.float32(min(max(np.float32(u), np.float32(0)), np.float32(1)))
+    t = np.float64(uu) * np.float64(s_kept)
+    target = s_kept - 1 if t >= np.float64(s_kept) else min(int(t), s_kept - 1)
+    run = 0
+    for i in sorted(kept):
+        run += fixl[i]
+        if run > target:
+            return i, n_kept
+    raise AssertionError("unreachable")

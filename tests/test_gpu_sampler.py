@@ -12,6 +12,18 @@ from tests.util import golden
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["candidates", "radix"], autouse=True)
+def sampler_path(request, monkeypatch):
+    """Every test runs twice: with the short candidate-list path enabled (the default; it declines where it
+    cannot prove the list complete and the radix descent runs) and with the radix descent alone
+    (CHITU_SAMPLE_RADIX, read by chitu_hip_sample at every call).  Both implement one integer specification."""
+    if request.param == "radix":
+        monkeypatch.setenv("CHITU_SAMPLE_RADIX", "1")
+    else:
+        monkeypatch.delenv("CHITU_SAMPLE_RADIX", raising=False)
+    return request.param
+
+
 def _responses(g):
     off = g["resp_off"].tolist()
     flat = g["resp_flat"].tolist()
@@ -256,7 +268,7 @@ def test_deterministic_and_graph_replay():
     assert torch.equal(out, want)
 
 
-def test_full_vocab_batch_timing(capsys):
+def test_full_vocab_batch_timing(capsys, sampler_path):
     """[16, 129280] fp32 logits (one R1 decode step's sampler input): sanity + microseconds per launch."""
     from chitu_amd import sampling
 
@@ -272,17 +284,22 @@ def test_full_vocab_batch_timing(capsys):
                      ("argmax", lambda: sampling.argmax(x, out=out))):
         for _ in range(3):
             fn()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()  # 20 launches in one graph: device time, not the Python call overhead
+        with torch.cuda.graph(graph):
+            for _ in range(20):
+                fn()
+        graph.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
-            fn()
+        graph.replay()
         e1.record()
         torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 20 * 1e3
     assert int(out.min()) >= 0 and int(out.max()) < vocab
     assert np.array_equal(out.cpu().numpy(), np.argmax(x.cpu().numpy(), axis=-1))
     with capsys.disabled():
-        print(f"\n[sampler] rows=16 vocab=129280: sample {res['sample']:.1f} us, argmax {res['argmax']:.1f} us per launch")
+        print(f"\n[sampler/{sampler_path}] rows=16 vocab=129280: sample {res['sample']:.1f} us, argmax {res['argmax']:.1f} us per launch")
 
 
 # ---------------------------------------------------------------- DeviceSampler (generate()'s token selection)

@@ -89,6 +89,35 @@ def test_radix_descent_model_equals_specification(seed):
         assert (tok, n) == (tok2, n2), (trial, vocab, kind, t, top_k, top_p, u, probs_mode)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_candidate_path_model_equals_specification_or_declines(seed):
+    """The kernel's short-list path (thresholds, sufficiency rule, two sorts) restated on the CPU: wherever
+    it answers, the answer is the specification's; caps of 4 .. 1024 make it decline, cut inside the list,
+    stop at top_k, stop at top_p and take the whole row."""
+    rng = np.random.default_rng(100 + seed)
+    answered = declined = 0
+    for trial in range(160):
+        vocab = int(rng.choice([5, 64, 257, 1000, 4099]))
+        kind = trial % 6
+        logits = [rng.normal(0, 3, vocab), rng.normal(0, 0.01, vocab), np.round(rng.normal(0, 2, vocab)),
+                  np.zeros(vocab), rng.normal(0, 30, vocab), rng.normal(0, 1, vocab)][kind].astype(np.float32)
+        t = float(rng.choice([0.3, 0.8, 1.0, 1.7]))
+        top_k = int(rng.choice([-1, 0, 2, 5, 50, vocab, vocab + 10]))
+        top_p = float(rng.choice([0.0, 0.1, 0.5, 0.9, 0.999, 1.0]))
+        u = [0.0, 0.99999994, float(rng.random())][min(trial % 5, 2)]
+        probs_mode = trial % 4 == 0
+        cap = int(rng.choice([4, 16, 64, 1024]))
+        row = torch.softmax(torch.from_numpy(logits) / t, -1).numpy() if probs_mode else logits
+        got = osmp.sample_candidate_model(row, t, top_k, top_p, u, probs_mode, cap=cap)
+        if got is None:
+            declined += 1
+            continue
+        answered += 1
+        tok, n, _ = osmp.sample_fixed_point(row, t, top_k, top_p, u, probs_mode)
+        assert got == (tok, n), (trial, vocab, kind, t, top_k, top_p, u, probs_mode, cap)
+    assert answered > 40 and declined > 20
+
+
 def test_draws_follow_the_kept_distribution():
     """Inverse CDF over the kept weights: a fine grid of u reproduces the kept distribution."""
     rng = np.random.default_rng(0)
