@@ -82,6 +82,113 @@ __global__ __launch_bounds__(64) void k(const uint8_t* __restrict__ Xq, const fl
     o[8] = (uint16_t)(__float_as_uint(acc[2]) >> 16); o[9] = (uint16_t)(__float_as_uint(acc[3]) >> 16);
 }
 
+// V8: the m-block's VALID activation rows (<= NVMAX; more -> the global path of V0) and their scales are staged
+// in LDS once per workgroup; the k loop then reads x from LDS (ds_read_b128) and only weights from HBM.
+template <int D, int NVMAX>
+__global__ __launch_bounds__(64) void k8(const uint8_t* __restrict__ Xq, const float* __restrict__ Xs, const uint8_t* __restrict__ W,
+                                         const float* __restrict__ Ws, const int* __restrict__ slot_tok, const int* __restrict__ eids,
+                                         uint16_t* __restrict__ out, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    const int mb = blockIdx.y, n0 = blockIdx.x * 16;
+    const int KB = K >> 7;
+    const int e = __builtin_amdgcn_readfirstlane(eids[mb]);
+    const int tok_raw = slot_tok[mb * 16 + j];
+    const bool valid = tok_raw >= 0;
+    const int nv = __builtin_popcountll(__builtin_amdgcn_ballot_w64(valid && g == 0));  // valid slots are the first nv
+    const int off = ((j & 1) * 4 + g) * 16;
+    const uint8_t* wp0 = W + ((size_t)e * N + n0 + (j >> 1)) * K + off;
+    const uint8_t* wp1 = W + ((size_t)e * N + n0 + 8 + (j >> 1)) * K + off;
+    const float* wsp = Ws + ((size_t)e * (N >> 7) + (n0 >> 7)) * KB;
+    const int RS = K + 64;                       // row stride: rows land 16 banks apart
+    float* xs_lds = (float*)(lds + NVMAX * RS);  // [NVMAX][KB]
+    const bool staged = nv <= NVMAX;
+    const int token = valid ? tok_raw : 0;
+    const uint8_t* xp = Xq + (size_t)token * K + g * 16;
+    const float* xsp = Xs + (size_t)token * KB;
+    struct St { i32x4 w0, w1, x0, x1; float xs, ws; };
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    St ring[D];
+    auto loadw = [&](St& s, int kb) {
+        const int o = kb << 7;
+        s.w0 = __builtin_nontemporal_load((const i32x4*)(wp0 + o));
+        s.w1 = __builtin_nontemporal_load((const i32x4*)(wp1 + o));
+        s.ws = wsp[kb];
+    };
+    if (staged) {
+        // weights of the first D blocks are requested before the staging round trip
+#pragma unroll
+        for (int d = 0; d < D; ++d) loadw(ring[d], d);
+        for (int r = 0; r < nv; ++r) {
+            const int tr = __builtin_amdgcn_readlane(tok_raw, r);
+            const uint8_t* src = Xq + (size_t)tr * K;
+            for (int b = lane * 16; b < K; b += 1024) *(i32x4*)(lds + r * RS + b) = *(const i32x4*)(src + b);
+            if (lane < KB) xs_lds[r * KB + lane] = Xs[(size_t)tr * KB + lane];
+        }
+        __syncthreads();
+        const int row = valid ? j : 0;
+        const uint8_t* xl = lds + row * RS + g * 16;
+        const float* xsl = xs_lds + row * KB;
+        for (int kb = 0; kb < KB; kb += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (kb + d < KB) {
+                    const int kk = kb + d;
+                    const i32x4 x0 = *(const i32x4*)(xl + (kk << 7)), x1 = *(const i32x4*)(xl + (kk << 7) + 64);
+                    const float xs = xsl[kk];
+                    const f32x4 b = dot(ring[d].w0, ring[d].w1, x0, x1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += (b[r] * xs) * ring[d].ws;
+                    if (kk + D < KB) loadw(ring[d], kk + D);
+                }
+            }
+        }
+    } else {
+        auto load = [&](St& s, int kb) {
+            loadw(s, kb);
+            const int o = kb << 7;
+            s.x0 = *(const i32x4*)(xp + o); s.x1 = *(const i32x4*)(xp + o + 64);
+            s.xs = xsp[kb];
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) load(ring[d], d);
+        for (int kb = 0; kb < KB; kb += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (kb + d < KB) {
+                    const int kk = kb + d;
+                    const f32x4 b = dot(ring[d].w0, ring[d].w1, ring[d].x0, ring[d].x1);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[r] += (b[r] * ring[d].xs) * ring[d].ws;
+                    if (kk + D < KB) load(ring[d], kk + D);
+                }
+            }
+        }
+    }
+    uint16_t* o = out + ((size_t)mb * 16 + j) * N + n0 + 2 * g;
+    o[0] = (uint16_t)(__float_as_uint(acc[0]) >> 16); o[1] = (uint16_t)(__float_as_uint(acc[1]) >> 16);
+    o[8] = (uint16_t)(__float_as_uint(acc[2]) >> 16); o[9] = (uint16_t)(__float_as_uint(acc[3]) >> 16);
+}
+
+template <int D, int NVMAX>
+int run8(const char* name, uint8_t* Xq, float* Xs, uint8_t** W, float* Ws, int* st, int* eids, uint16_t* out, int MB) {
+    const int N = 512, K = 7168;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const size_t lds = (size_t)NVMAX * (K + 64) + (size_t)NVMAX * (K / 128) * 4;
+    CK(hipFuncSetAttribute((const void*)k8<D, NVMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    float best = 1e9, sum = 0;
+    for (int it = 0; it < 6; ++it) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k8<D, NVMAX>), dim3(N / 16, MB), dim3(64), lds, 0, Xq, Xs, W[it & 1], Ws, st, eids, out, N, K);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0) { sum += ms; if (ms < best) best = ms; }
+    }
+    const double bytes = (double)MB * N * K;
+    printf("%-44s D=%d NV=%d avg %.2f us  min %.2f us  %.0f GB/s (min)\n", name, D, NVMAX, sum / 5 * 1e3, best * 1e3, bytes / best / 1e6);
+    return 0;
+}
+
 template <int V, int D>
 int run(const char* name, uint8_t* Xq, float* Xs, uint8_t** W, float* Ws, int* st, int* eids, uint16_t* out, int MB) {
     const int N = 512, K = 7168;
@@ -120,6 +227,10 @@ int main() {
     run<2, 3>("V2 scalar ws + x scales per 4 blocks", Xq, Xs, W, Ws, st, eids, out, MB);
     run<2, 4>("V2", Xq, Xs, W, Ws, st, eids, out, MB);
     run<2, 6>("V2", Xq, Xs, W, Ws, st, eids, out, MB);
+    run8<3, 3>("V8 valid rows staged in LDS", Xq, Xs, W, Ws, st, eids, out, MB);
+    run8<4, 3>("V8", Xq, Xs, W, Ws, st, eids, out, MB);
+    run8<3, 2>("V8", Xq, Xs, W, Ws, st, eids, out, MB);
+    run8<6, 2>("V8", Xq, Xs, W, Ws, st, eids, out, MB);
     run<3, 3>("V3 no activation loads", Xq, Xs, W, Ws, st, eids, out, MB);
     run<4, 3>("V4 no activation loads, no scales", Xq, Xs, W, Ws, st, eids, out, MB);
     run<4, 6>("V4", Xq, Xs, W, Ws, st, eids, out, MB);
