@@ -228,8 +228,10 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_silu_kernel(const bf16_t* _
 // each workgroup publishes its ids (fence), takes a ticket, and the LAST one to arrive runs the sort
 // for the whole batch (moe_align_workgroup) before the launch ends -- the pattern of a single-pass
 // reduction, one launch less per MoE layer.  `ticket` is a zero-initialised device word that the
-// last workgroup resets, so hipGraph replays and later launches need no memset; launches that share
-// a ticket must not overlap (one stream per device drives the step).
+// last workgroup resets, so hipGraph replays and later launches need no memset (a memset NODE ahead of
+// the launch was tried and faulted on replay after other graphs of the process had been destroyed --
+// ROCm 7.2; the self-resetting word has no such dependency); launches that share a ticket must not
+// overlap (one stream per device drives the step).
 struct RouteAlign {
     int num_experts;          // experts the sort ranges over (routed + always-on slots); 0 = no align tail
     int block_size;
@@ -761,11 +763,6 @@ static int gate_route_launch(const void* logits, int32_t num_partials, int64_t t
         else LAUNCHW(0);
 #undef LAUNCHW
         CHITU_RETURN_LAUNCH_STATUS();
-    }
-    if (al.num_experts > 0 && tokens > 1)  // the ticket starts from 0 on EVERY launch (a memset node under capture)
-    {
-        const hipError_t me = hipMemsetAsync(al.ticket, 0, sizeof(unsigned int), st);
-        if (me != hipSuccess) return (int)me;
     }
     if (fast) {
 #define LAUNCHF(GSV)                                                                                         \
