@@ -107,7 +107,8 @@ def _chunk(t: torch.Tensor, world: int, rank: int, dim: int, name: str) -> torch
 
 
 def chunk_for_tensor_parallel(state: Mapping[str, torch.Tensor], rank: int, world: int,
-                              column: Iterable[str] = COLUMN_PARALLEL, row: Iterable[str] = ROW_PARALLEL) -> Dict[str, torch.Tensor]:
+                              column: Iterable[str] = COLUMN_PARALLEL, row: Iterable[str] = ROW_PARALLEL,
+                              keep_whole: str = "") -> Dict[str, torch.Tensor]:
     """models/model.py:332-370 for type deepseek-v3: weights AND block scales of column-parallel layers are chunked
     along dim 0, of row-parallel layers along dim 1; column biases along the last dim; row biases stay on rank 0;
     everything else (norms, wq_a / wkv_a, router) is replicated."""
@@ -116,7 +117,9 @@ def chunk_for_tensor_parallel(state: Mapping[str, torch.Tensor], rank: int, worl
     out = {}
     for name, t in state.items():
         kind = name.rsplit(".", 1)[-1]
-        if any(_is_layer(s, name) for s in column):
+        if keep_whole and keep_whole in name:  # expert parallelism: the routed experts are partitioned by id instead
+            out[name] = t
+        elif any(_is_layer(s, name) for s in column):
             if kind in ("weight", "scale"):
                 out[name] = _chunk(t, world, rank, 0, name)
             elif kind == "bias":
@@ -187,10 +190,63 @@ def merge_experts(state: Mapping[str, torch.Tensor], n_routed: int) -> Dict[str,
     return out
 
 
+def select_local_experts(state: Mapping[str, torch.Tensor], n_routed: int, moe_rank: int, moe_world_size: int) -> Dict[str, torch.Tensor]:
+    """Expert parallelism (the reference's hooks: model_deepseek_v3.py:870-880): keep routed experts
+    [moe_rank * n_local, (moe_rank + 1) * n_local) and renumber them from 0 -- the order `expert_map` assigns local
+    ids in; everything else is passed through."""
+    if n_routed % moe_world_size:
+        raise ValueError(f"Number of experts must be divisible by world size (world_size={moe_world_size})")
+    n_local = n_routed // moe_world_size
+    lo = moe_rank * n_local
+    pat = re.compile(r"^(.*\.experts\.)(\d+)(\..*)$")
+    out = {}
+    for k, t in state.items():
+        m = pat.match(k)
+        if not m:
+            out[k] = t
+            continue
+        i = int(m.group(2))
+        if lo <= i < lo + n_local:
+            out[f"{m.group(1)}{i - lo}{m.group(3)}"] = t
+    return out
+
+
+def merge_experts_expert_parallel(state: Mapping[str, torch.Tensor], n_local: int) -> Dict[str, torch.Tensor]:
+    """The expert-parallel counterpart of `merge_experts`: local routed experts stacked `[n_local, ...]` under
+    `<p>.<w>.<part>`; the (already width-chunked) shared experts stay a plain MLP under `<p>.shared.<w>.<part>`
+    (chitu_amd.deepseek_v3.MoEDeepSeekV3 with moe_world_size > 1)."""
+    out = {}
+    pat = re.compile(r"^(.*\.)experts\.0\.(w1w3|w1|w2|w3)\.(weight|scale|bias)$")
+    for k, t in state.items():
+        m = pat.match(k)
+        if m:
+            prefix, w, part = m.groups()
+            out[f"{prefix}{w}.{part}"] = torch.stack([state[f"{prefix}experts.{i}.{w}.{part}"] for i in range(n_local)], dim=0)
+        elif ".experts." in k:
+            continue
+        elif ".shared_experts." in k:
+            out[k.replace(".shared_experts.", ".shared.")] = t
+        else:
+            out[k] = t
+    return out
+
+
 def preprocess_deepseek_v3(state: Mapping[str, torch.Tensor], n_routed: int, rank: int = 0, world: int = 1,
-                           merge_qkv_gate_up: bool = True) -> Dict[str, torch.Tensor]:
+                           merge_qkv_gate_up: bool = True, moe_world_size: int = 1) -> Dict[str, torch.Tensor]:
     """chitu-named full checkpoint -> this rank's tensors under the reference's final names
-    (load_state_dict_parallel, models/model.py:372-390 + TransformerDeepSeekV3.load_state_dict :1273-1288)."""
+    (load_state_dict_parallel, models/model.py:372-390 + TransformerDeepSeekV3.load_state_dict :1273-1288).
+
+    moe_world_size > 1 (== world): the expert-parallel layout -- attention, dense MLPs, embeddings and the SHARED
+    experts are tensor-parallel chunks as before, the routed experts are partitioned by id and kept at full width."""
+    if moe_world_size > 1:
+        if moe_world_size != world:
+            raise ValueError("experts are partitioned over the tensor-parallel ranks: moe_world_size must equal world")
+        if not merge_qkv_gate_up:
+            raise ValueError("the expert-parallel module tree uses the merged w1w3 layout")
+        state = select_local_experts(state, n_routed, rank, moe_world_size)
+        state = chunk_for_tensor_parallel(state, rank, world, keep_whole=".experts.")
+        state = merge_gate_up(merge_qkv(state))
+        return merge_experts_expert_parallel(state, n_routed // moe_world_size)
     state = chunk_for_tensor_parallel(state, rank, world)
     if merge_qkv_gate_up:
         state = merge_gate_up(merge_qkv(state))
@@ -250,7 +306,8 @@ def load_checkpoint_deepseek_v3(model, path: str, rank: int = 0, world: int = 1,
     args = model.args
     state = read_safetensors_dir(path, skip_preprocess=skip_preprocess, rank=rank, n_layers=args.n_layers)
     if not skip_preprocess:
-        state = to_module_names(preprocess_deepseek_v3(state, args.n_routed_experts, rank, world), args.q_lora_rank)
+        state = to_module_names(preprocess_deepseek_v3(state, args.n_routed_experts, rank, world,
+                                                       moe_world_size=args.moe_world_size), args.q_lora_rank)
     load_deepseek_v3(model, state)
 
 

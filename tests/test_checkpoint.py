@@ -145,3 +145,49 @@ def test_q_lora_rank_zero_merges_wq_with_wkv_a():
     out = ck.to_module_names(sharded, q_lora_rank=0)
     assert set(out) == {"layers.0.attn.wq_kv_a.weight", "layers.0.attn.wq_kv_a.scale"}
     assert torch.equal(out["layers.0.attn.wq_kv_a.weight"], torch.cat([st["layers.0.attn.wq.weight"][3:], torch.ones(3, 2)]))
+
+
+def test_expert_parallel_layout_partitions_the_checkpoint_and_loads():
+    """moe_world_size = 2: the routed experts are split by id at full width, the shared expert by
+    width; the two ranks together hold every byte of the unsharded layer exactly once, and each rank's dict loads
+    strictly into the expert-parallel module tree."""
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.deepseek_v3 import DeepSeekV3Decoder
+    from tests import cpu_ops_shim
+
+    nr = CKPT_TINY["n_routed_experts"]
+    full = ck.to_module_names(ck.preprocess_deepseek_v3(_renamed(), nr, 0, 1))
+    ranks = [ck.to_module_names(ck.preprocess_deepseek_v3(_renamed(), nr, r, 2, moe_world_size=2)) for r in range(2)]
+    pre = "layers.1.ffn."
+    for part in ("weight", "scale"):
+        w13 = full[pre + "w1w3_" + part]  # [nr + 1, 2I(/128), K(/128)], shared last
+        w2 = full[pre + "w2_" + part]
+        assert torch.equal(torch.cat([r[pre + "w1w3_" + part] for r in ranks]).view(torch.uint8), w13[:nr].view(torch.uint8))
+        assert torch.equal(torch.cat([r[pre + "w2_" + part] for r in ranks]).view(torch.uint8), w2[:nr].view(torch.uint8))
+        i = w13.shape[1] // 2
+        halves = [r[pre + "shared.w1w3." + part] for r in ranks]  # each [gate chunk | up chunk]
+        c = halves[0].shape[0] // 2
+        gate = torch.cat([h[:c] for h in halves])
+        up = torch.cat([h[c:] for h in halves])
+        assert torch.equal(gate.view(torch.uint8), w13[nr, :i].view(torch.uint8))
+        assert torch.equal(up.view(torch.uint8), w13[nr, i:].view(torch.uint8))
+        assert torch.equal(torch.cat([r[pre + "shared.w2." + part] for r in ranks], dim=1).view(torch.uint8), w2[nr].view(torch.uint8))
+    # everything that is not an expert is the plain tensor-parallel shard
+    tp_rank = [ck.to_module_names(ck.preprocess_deepseek_v3(_renamed(), nr, r, 2)) for r in range(2)]
+    for r in range(2):
+        for k, t in tp_rank[r].items():
+            if ".ffn.w1w3_" in k or ".ffn.w2_" in k:
+                continue
+            assert torch.equal(ranks[r][k].view(torch.uint8), t.view(torch.uint8)), k
+    for r in range(2):
+        args = _args(2)
+        args.moe_world_size, args.moe_rank = 2, r
+        cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=1, block_size=64, max_seq_len=64, device="cpu",
+                                    kv_shape_per_sample=(args.kv_lora_rank + args.qk_rope_head_dim,), dtype=torch.bfloat16)
+        model = DeepSeekV3Decoder(args, cache, cpu_ops_shim.CpuAttnBackend(args.n_heads // 2), max_position_embeddings=64,
+                                  device="cpu")
+        ck.load_deepseek_v3(model, ranks[r])  # strict: names, shapes and dtypes all match
+        moe = model.layers[1].ffn
+        assert moe.expert_map.tolist() == [0, 1, -1, -1] if r == 0 else moe.expert_map.tolist() == [-1, -1, 0, 1]
+    with pytest.raises(ValueError):
+        ck.preprocess_deepseek_v3(_renamed(), nr, 0, 2, moe_world_size=4)

@@ -271,3 +271,35 @@ def test_decode_step_ep2_matches_tp1(tmp_path):
     for a, b in zip(l1, l2):
         err = ((a - b).abs().max() / a.abs().max()).item()
         assert err < 5e-2, err
+
+
+def _graph_break_protocol(rank, world):
+    """tensor_parallel's cut points (chitu_amd/graphs.py): while a piecewise capture is active every collective
+    hands its launch to the capture instead of running it; issued later, in order, the closures do the step's
+    communication.  (The hipGraph side of the protocol is tested on the GPU.)"""
+    from chitu_amd import tensor_parallel as tp
+
+    deferred = []
+    tp._graph_break = deferred.append
+    try:
+        a = torch.full((4,), float(rank + 1))
+        out = tp.all_reduce(a)
+        assert out is a and torch.equal(a, torch.full((4,), float(rank + 1)))  # nothing has run yet
+        y = torch.arange(6, dtype=torch.float32).view(2, 3) + 10 * rank
+        g = tp.all_gather_last_dim(y)
+    finally:
+        tp._graph_break = None
+    assert len(deferred) == 2 and all(callable(r) for r in deferred)
+    for run in deferred:
+        run()
+    assert torch.equal(a, torch.full((4,), float(sum(range(1, world + 1)))))
+    want = torch.cat([torch.arange(6, dtype=torch.float32).view(2, 3) + 10 * r for r in range(world)], dim=-1)
+    assert torch.equal(g, want)
+    # outside a capture the collectives run immediately
+    b = torch.ones(2)
+    tp.all_reduce(b)
+    assert torch.equal(b, torch.full((2,), float(world)))
+
+
+def test_graph_break_protocol_world2():
+    _run(_graph_break_protocol, 2)
