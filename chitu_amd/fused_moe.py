@@ -436,10 +436,6 @@ def _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, 
     return out
 
 
-def _view_i32(ws: torch.Tensor, byte_off: int, n: int) -> torch.Tensor:
-    return ws[byte_off : byte_off + 4 * n].view(torch.int32)
-
-
 def silu_and_mul_quant(x: torch.Tensor, mode: str = "act"):
     """h = silu(x[..., :d]) * x[..., d:] (SiluAndMul, fused_moe.py:24-39) followed by the 128-group
     fp8 quantisation the next fp8 GEMM needs.  mode "act": act_quant_deepseek_v3 rule (dense and
