@@ -67,4 +67,6 @@ def graph_mode(use_graph) -> str:
     if isinstance(use_graph, str):
         assert use_graph in ("full", "piecewise")
         return use_graph
+    if os.environ.get("CHITU_GRAPH_MODE") in ("full", "piecewise"):  # measurement knob: force a mode on any rank count
+        return os.environ["CHITU_GRAPH_MODE"]
     return "piecewise" if tp.get_tp_size() > 1 and os.environ.get("CHITU_TP_GRAPH", "piecewise") != "full" else "full"
