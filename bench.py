@@ -7,7 +7,9 @@ cache -- i.e. exactly the bytes and kernels one GPU of the 8-GPU node executes p
 (35.7 GB/step at bs=16, 5.7 GB at bs=1).  Random synthetic weights and KV
 (no network for checkpoints), batch `--bs` sequences at context `--ctx`, greedy sampling, the
 whole step replayed as one hipGraph.  With N ranks live, the TP all-reduces / all-gather run over
-RCCL across those N ranks; at N=8 this IS the metric's configuration.
+RCCL across those N ranks (the step then replays as hipGraph pieces with the collectives issued
+between them, chitu_amd/graphs.py; CHITU_TP_GRAPH=full captures them into one graph instead); at N=8
+this IS the metric's configuration.
 
 A "step" = one decode token for the whole batch.  value = (N/8) * bs * K / T: N GPUs complete N/8
 of the model's work for every token they emit, so this is the full-model-equivalent rate the job
