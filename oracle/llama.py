@@ -36,3 +36,28 @@ def block(p, pre, x, cos, sin, k_cache, v_cache, block_table, lens_excl, hq, hkv
     d = h13.shape[-1] // 2
     f = F.linear(F.silu(h13[..., :d]) * h13[..., d:], p[pre + "ffn.w2"])
     return x + f, k_cache, v_cache
+
+
+def decode_sequence(p, tokens, n_layers, hq, hkv, hd, eps, theta, page=256, rotary="llama"):
+    """A whole (tiny) Llama on ONE sequence, token by token through `block` over a paged cache: embedding, layers,
+    final norm, head -> fp32 logits [len(tokens), vocab] (models/model.py:468-475 decode_single_device per step).
+    Pinned against the reference's own TransformerLlama run (BASELINE config 1: tests/golden/ref_llama.npz); the
+    reference prefills the prompt in one varlen pass, which differs from this token-by-token form only in fp32
+    summation order."""
+    n = len(tokens)
+    nblk = (n + page - 1) // page
+    k_cache = [torch.zeros(nblk, page, hkv, hd, dtype=torch.bfloat16) for _ in range(n_layers)]
+    v_cache = [torch.zeros(nblk, page, hkv, hd, dtype=torch.bfloat16) for _ in range(n_layers)]
+    table = torch.arange(nblk, dtype=torch.int32).view(1, nblk)
+    freqs = 1.0 / (theta ** (torch.arange(0, hd, 2)[: hd // 2].float() / hd))  # models/model.py:81-88
+    cis = torch.polar(torch.ones(n, hd // 2), torch.outer(torch.arange(n, dtype=torch.float32), freqs))
+    out = []
+    for pos, tok in enumerate(tokens):
+        x = p["embed_weight"][int(tok)].view(1, -1)
+        cos, sin = cis.real[pos : pos + 1].contiguous(), cis.imag[pos : pos + 1].contiguous()
+        lens = torch.tensor([pos], dtype=torch.int32)
+        for i in range(n_layers):
+            x, k_cache[i], v_cache[i] = block(p, f"layers.{i}.", x, cos, sin, k_cache[i], v_cache[i], table, lens,
+                                              hq, hkv, hd, eps, rotary)
+        out.append(F.linear(rms_norm(x, p["norm"], eps), p["head_weight"]).float())
+    return torch.cat(out)

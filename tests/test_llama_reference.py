@@ -1,0 +1,71 @@
+"""BASELINE config 1 -- "Llama-2-7B bf16 TP=1 decode on the reference CPU path, bs=1, 64 new tokens (plumbing, no
+GPU)" -- as a parity case at test size: the reference's own TransformerLlama run on CPU (tests/golden/gen_ref_llama.py
+-> ref_llama.npz) against the oracle's Llama composition here, and against the HIP LlamaDecoder on the GPU."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llama as ollama
+from tests.util import ref_llama_fixture
+
+
+def _check(logits, g, n_prompt, what):
+    """logits [n_prompt + 64, vocab] of a teacher-forced run vs the fixture's 65 rows (prefill's last + 64 steps)."""
+    ref = torch.from_numpy(g["logits"])
+    mine = logits[n_prompt - 1:]
+    assert mine.shape == ref.shape
+    err = ((mine - ref).abs().amax(-1) / ref.abs().amax(-1)).max().item()
+    assert err < 2e-2, (what, err)
+    top2 = ref.topk(2, -1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.05 * ref.abs().amax(-1)  # rows whose greedy choice is not a near-tie
+    agree = mine.argmax(-1) == torch.from_numpy(g["tokens"])
+    assert clear.sum() >= 30 and bool(agree[clear].all()), (what, int(clear.sum()), int(agree.sum()))
+    return err, int(agree.sum())
+
+
+def test_oracle_llama_reproduces_the_reference_cpu_run():
+    g, cfg, p = ref_llama_fixture()
+    prompt, toks = g["prompt"].tolist(), g["tokens"].tolist()
+    fed = prompt + toks[:-1]  # teacher forcing: the reference's own greedy tokens
+    hd = cfg["dim"] // cfg["n_heads"]
+    logits = ollama.decode_sequence(p, fed, cfg["n_layers"], cfg["n_heads"], cfg["n_kv_heads"], hd, cfg["norm_eps"],
+                                    cfg["rope_theta"], page=64)
+    err, agree = _check(logits, g, len(prompt), "oracle")
+    assert agree >= 63  # 65 greedy tokens; a bf16 near-tie may flip
+    print("oracle vs reference Llama: rel err", err, "greedy agreement", agree, "/ 65")
+
+
+@pytest.mark.gpu
+def test_hip_llama_reproduces_the_reference_cpu_run():
+    """Prefill of the prompt, then 64 hipGraph decode steps fed the reference's tokens: logits within 2e-2 of the
+    reference's CPU run, identical greedy tokens wherever the reference's choice is not a near-tie."""
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.llama import LlamaArgs, LlamaDecoder
+
+    g, cfg, p = ref_llama_fixture()
+    prompt, toks = g["prompt"].tolist(), g["tokens"].tolist()
+    ffn = p["layers.0.ffn.w2"].shape[1]
+    args = LlamaArgs(dim=cfg["dim"], n_layers=cfg["n_layers"], n_heads=cfg["n_heads"], n_kv_heads=cfg["n_kv_heads"],
+                     vocab_size=cfg["vocab_size"], ffn_dim=ffn, norm_eps=cfg["norm_eps"], rope_theta=cfg["rope_theta"])
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=1, block_size=256, max_seq_len=512, device="cuda",
+                                n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
+    model = LlamaDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=512),
+                         max_position_embeddings=512, device="cuda")
+    params = dict(model.named_parameters())
+    assert set(params) == set(p)
+    for k, t in p.items():
+        assert params[k].shape == t.shape, k
+        params[k].data.copy_(t)
+    rows = [model.prefill([prompt], ["r"]).float().cpu()]
+    tok = torch.tensor([toks[0]], dtype=torch.int64, device="cuda")
+    for step in range(64):
+        cache.prepare_cache_decode(["r"])
+        cache.prepare_block_table_for_decode(["r"])
+        rows.append(model.decode(tok, use_graph=True).float().cpu())
+        cache.finalize_cache_single_decode(["r"])
+        tok = torch.tensor([toks[step + 1]], dtype=torch.int64, device="cuda")
+    logits = torch.cat([torch.zeros(len(prompt) - 1, rows[0].shape[-1])] + rows)
+    err, agree = _check(logits, g, len(prompt), "hip")
+    print("HIP vs reference Llama: rel err", err, "greedy agreement", agree, "/ 65")

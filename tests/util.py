@@ -202,3 +202,35 @@ def tensor_digest(t):
 
     raw = t.detach().contiguous().view(torch.uint8).numpy().tobytes()
     return [list(t.shape), str(t.dtype), hashlib.sha1(raw).hexdigest()]
+
+
+# ---------------------------------------------------------------- BASELINE config 1: the reference's Llama on CPU
+def ref_llama_fixture():
+    """tests/golden/ref_llama.npz (tests/golden/gen_ref_llama.py: the reference's TransformerLlama, bs 1, prefill +
+    64 greedy decode steps on CPU) plus the parameters, regenerated from the generator's seed in its sorted-name
+    order and mapped onto chitu_amd.llama / oracle.llama names (wq|wk|wv -> wqkv, w1|w3 -> w13)."""
+    import ast
+
+    g = golden("ref_llama")
+    cfg = ast.literal_eval(str(g["cfg"][0]))
+    gen = torch.Generator().manual_seed(4321)  # gen_ref_llama.py::SEED / fill
+    ref = {}
+    for name, shape in zip(g["names"].tolist(), g["shapes"].tolist()):
+        shape = ast.literal_eval(shape)
+        if name.endswith("norm.weight"):
+            t = (1.0 + 0.1 * torch.randn(shape, generator=gen, dtype=torch.float32)).to(torch.bfloat16)
+        elif name.startswith("tok_embeddings"):
+            t = torch.randn(shape, generator=gen, dtype=torch.float32).to(torch.bfloat16)
+        else:
+            t = (torch.randn(shape, generator=gen, dtype=torch.float32) * shape[-1] ** -0.5).to(torch.bfloat16)
+        ref[name] = t
+    p = {"embed_weight": ref["tok_embeddings.weight"], "norm": ref["norm.weight"], "head_weight": ref["output.weight"]}
+    for i in range(cfg["n_layers"]):
+        a, f = f"layers.{i}.attention.", f"layers.{i}.feed_forward."
+        p[f"layers.{i}.attn.wqkv"] = torch.cat([ref[a + "wq.weight"], ref[a + "wk.weight"], ref[a + "wv.weight"]], 0)
+        p[f"layers.{i}.attn.wo"] = ref[a + "wo.weight"]
+        p[f"layers.{i}.ffn.w13"] = torch.cat([ref[f + "w1.weight"], ref[f + "w3.weight"]], 0)
+        p[f"layers.{i}.ffn.w2"] = ref[f + "w2.weight"]
+        p[f"layers.{i}.attn_norm"] = ref[f"layers.{i}.attention_norm.weight"]
+        p[f"layers.{i}.ffn_norm"] = ref[f"layers.{i}.ffn_norm.weight"]
+    return g, cfg, p
