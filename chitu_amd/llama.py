@@ -10,9 +10,7 @@ Per layer and step, 7 launches: add+RMSNorm, wqkv GEMM, [RoPE(q, k) + append K, 
 All GEMMs are the weight-streaming skinny bf16 kernel (gate.hip); the whole step replays as one hipGraph.
 """
 
-import math
 from dataclasses import dataclass
-from typing import List, Optional
 
 import torch
 import torch.nn.functional as F
