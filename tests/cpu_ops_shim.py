@@ -128,6 +128,57 @@ class CpuAttnBackend:
         return omla.mla_decode(q_nope, q_pe, kv_cache, block_table, lens_incl, softmax_scale).to(torch.bfloat16)
 
 
+# ---------------------------------------------------------------- Llama-family ops (chitu_amd/llama.py wiring on CPU)
+def gqa_qkv_post(qkv, q_heads, kv_heads, cos, sin, k_cache, v_cache, page_table, old_seq_lens, rotary_type="llama"):
+    from oracle import kv as okv_
+
+    q, k = okv_.apply_rotary_pos_emb(qkv[:, :q_heads], qkv[:, q_heads : q_heads + kv_heads], cos, sin, rotary_type)
+    v = qkv[:, q_heads + kv_heads :]
+    page = k_cache.shape[1]
+    for b in range(qkv.shape[0]):
+        L = int(old_seq_lens[b])
+        blk = int(page_table[b][L // page])
+        k_cache[blk][L % page] = k[b]
+        v_cache[blk][L % page] = v[b]
+    return q.contiguous()
+
+
+def bf16_linear_silu(x, w13):
+    h = F.linear(x, w13)
+    d = h.shape[-1] // 2
+    return F.silu(h[..., :d]) * h[..., d:]
+
+
+def apply_rotary_pos_emb(q, k, cos, sin, rotary_type="hf-llama"):
+    return okv.apply_rotary_pos_emb(q, k, cos, sin, rotary_type)
+
+
+class CpuGqaBackend:
+    """attn_with_kvcache / attn_varlen_func of HipAttnBackend on the oracle (oracle/gqa.py)."""
+
+    def attn_with_kvcache(self, q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, block_table=None, **kw):
+        from oracle import gqa as ogqa
+
+        out, kc, vc = ogqa.attn_with_kvcache(q, k_cache, v_cache, k, v, cache_seqlens, block_table)
+        if k is not None:
+            k_cache.copy_(kc)
+            v_cache.copy_(vc)
+        return out.to(torch.bfloat16)
+
+    def attn_varlen_func(self, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal=False, **kw):
+        from oracle import gqa as ogqa
+
+        assert causal
+        return ogqa.attn_varlen_causal(q, k, v, cu_seqlens_q).to(torch.bfloat16)
+
+
+def install_llama(monkeypatch_setattr):
+    from chitu_amd import ops
+
+    for name in ("rms_norm", "bf16_linear", "gqa_qkv_post", "bf16_linear_silu", "apply_rotary_pos_emb"):
+        monkeypatch_setattr(ops, name, globals()[name])
+
+
 def install(monkeypatch_setattr):
     """monkeypatch_setattr(obj, name, value) -- e.g. pytest's monkeypatch.setattr or plain setattr."""
     from chitu_amd import fused_moe, ops

@@ -303,3 +303,65 @@ def _graph_break_protocol(rank, world):
 
 def test_graph_break_protocol_world2():
     _run(_graph_break_protocol, 2)
+
+
+def _llama_tp(rank, world):
+    """chitu_amd/llama.py's wiring under tensor parallelism (heads, SwiGLU width and vocabulary split, two
+    all-reduces per layer, logits all-gather) on the REFERENCE'S Llama CPU run (BASELINE config 1,
+    tests/golden/ref_llama.npz): prefill of the prompt + 64 decode steps fed the reference's greedy tokens."""
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.llama import LlamaArgs, LlamaDecoder
+    from tests import cpu_ops_shim
+    from tests.util import ref_llama_fixture
+
+    cpu_ops_shim.install_llama(setattr)
+    g, cfg, full = ref_llama_fixture()
+    hq, hkv, hd = cfg["n_heads"], cfg["n_kv_heads"], cfg["dim"] // cfg["n_heads"]
+    ffn = full["layers.0.ffn.w2"].shape[1]
+    args = LlamaArgs(dim=cfg["dim"], n_layers=cfg["n_layers"], n_heads=hq, n_kv_heads=hkv, vocab_size=cfg["vocab_size"],
+                     ffn_dim=ffn, norm_eps=cfg["norm_eps"], rope_theta=cfg["rope_theta"])
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=1, block_size=64, max_seq_len=128, device="cpu",
+                                n_local_kv_heads=hkv // world, head_dim=hd, dtype=torch.bfloat16)
+    model = LlamaDecoder(args, cache, cpu_ops_shim.CpuGqaBackend(), max_position_embeddings=128, device="cpu")
+
+    def chunk(t, dim):
+        c = t.shape[dim] // world
+        return t.narrow(dim, rank * c, c)
+
+    for k, p in model.named_parameters():
+        t = full[k]
+        if k.endswith("attn.wqkv"):  # [wq | wk | wv] rows: every part is split by heads (models/model.py:332-370)
+            q, kk, v = t[: hq * hd], t[hq * hd : (hq + hkv) * hd], t[(hq + hkv) * hd :]
+            t = torch.cat([chunk(q, 0), chunk(kk, 0), chunk(v, 0)], 0)
+        elif k.endswith("ffn.w13"):
+            i = t.shape[0] // 2
+            t = torch.cat([chunk(t[:i], 0), chunk(t[i:], 0)], 0)
+        elif k.endswith("attn.wo") or k.endswith("ffn.w2"):
+            t = chunk(t, 1)
+        elif k in ("embed_weight", "head_weight"):
+            t = chunk(t, 0)
+        assert p.shape == t.shape, (k, p.shape, t.shape)
+        p.data.copy_(t)
+    prompt, toks = g["prompt"].tolist(), g["tokens"].tolist()
+    rows = [model.prefill([prompt], ["r"]).float()]
+    for step in range(64):
+        cache.prepare_cache_decode(["r"])
+        cache.prepare_block_table_for_decode(["r"])
+        rows.append(model.decode(torch.tensor([toks[step]]), use_graph=False).float())
+        cache.finalize_cache_single_decode(["r"])
+    logits = torch.cat(rows)
+    ref = torch.from_numpy(g["logits"])
+    assert logits.shape == ref.shape
+    err = ((logits - ref).abs().amax(-1) / ref.abs().amax(-1)).max().item()
+    assert err < 3e-2, err  # bf16 partial sums are rounded per rank before each all-reduce
+    top2 = ref.topk(2, -1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 0.08 * ref.abs().amax(-1)
+    assert clear.sum() >= 20 and bool((logits.argmax(-1) == torch.from_numpy(g["tokens"]))[clear].all())
+    same = logits.clone()
+    dist.broadcast(same, 0)
+    assert torch.equal(same, logits)  # every rank holds the gathered logits
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_llama_wiring_reproduces_the_reference_cpu_run(world):
+    _run(_llama_tp, world)
