@@ -1,30 +1,41 @@
-"""Vendor seam.  Mirrors chitu/device_type.py:13-20 and adds `is_amd()`.
+"""Vendor seam of the operator surface: which device family are we on?
 
-The reference dispatches on substrings of the device name (fused_moe.py:605,
-model_deepseek_v3.py:85,935,968).  On MI355X both is_nvidia() and is_muxi() are False.
+The reference dispatches on substrings of the CUDA device name (chitu/device_type.py:13-20, consulted at
+fused_moe.py:605 and model_deepseek_v3.py:85,935,968).  The same three predicates exist here under the same
+names, plus `is_amd()`; on an MI355X `is_nvidia()` and `is_muxi()` are both False, so reference call sites that
+import this module fall through to the HIP path.  One table, one cached lookup.
 """
+
+import functools
 
 import torch
 
-_device_name = None
+# family -> substrings of torch.cuda.get_device_name() that identify it
+_FAMILIES = {
+    "nvidia": ("NVIDIA",),
+    "muxi": ("4000", "4001"),
+    "amd": ("AMD", "MI3", "Instinct"),
+}
 
 
-def get_device_name():
-    global _device_name
-    if _device_name is None:
-        _device_name = torch.cuda.get_device_name() if torch.cuda.is_available() else "cpu"
-    return _device_name
+@functools.lru_cache(maxsize=None)
+def get_device_name() -> str:
+    """Name of the current accelerator ("cpu" where there is none: host-side tests import this module)."""
+    return torch.cuda.get_device_name() if torch.cuda.is_available() else "cpu"
 
 
-def is_nvidia():
-    return "NVIDIA" in get_device_name()
-
-
-def is_muxi():
+def _is(family: str) -> bool:
     name = get_device_name()
-    return any(p in name for p in ("4000", "4001"))
+    return any(tag in name for tag in _FAMILIES[family])
 
 
-def is_amd():
-    name = get_device_name()
-    return ("AMD" in name) or ("MI3" in name) or ("Instinct" in name)
+def is_nvidia() -> bool:
+    return _is("nvidia")
+
+
+def is_muxi() -> bool:
+    return _is("muxi")
+
+
+def is_amd() -> bool:
+    return _is("amd")

@@ -93,94 +93,70 @@ def all_gather_last_dim(y: torch.Tensor) -> torch.Tensor:
     return gathered.permute(*range(1, y.dim()), 0)
 
 
-class ColumnParallelLinear(torch.nn.Module):
-    """Output-dimension-parallel linear (tensor_parallel.py:42-103)."""
+class _ShardedLinear(torch.nn.Module):
+    """Shared part of the two Megatron linears: group bookkeeping and the `[out, in]` weight (and bias) of THIS
+    rank, `split` naming the dimension the full matrix is cut along ("out": rows / column-parallel, "in":
+    columns / row-parallel).  Parameters are uninitialised, like the reference's (the loader fills them)."""
 
-    def __init__(self, in_features, out_features, has_bias=True, gather_output=True, dtype=None,
-                 bias_dtype=None, linear_op=torch.nn.functional.linear):
+    def __init__(self, in_features, out_features, split, has_bias, dtype, bias_dtype, linear_op):
         super().__init__()
-        self.tp_group = get_tp_group()
-        self.tp_size = get_tp_size()
-        self.in_features = in_features
-        self.out_features = out_features
-        assert out_features % self.tp_size == 0, "out_features must be divisible by tp_size"
+        self.tp_group, self.tp_size, self.rank = get_tp_group(), get_tp_size(), get_tp_rank()
+        self.in_features, self.out_features, self.linear_op = in_features, out_features, linear_op
+        cut = out_features if split == "out" else in_features
+        assert cut % self.tp_size == 0, f"{split}_features must be divisible by tp_size"
+        rows = out_features // self.tp_size if split == "out" else out_features
+        cols = in_features if split == "out" else in_features // self.tp_size
+        self.weight = torch.nn.Parameter(torch.empty(rows, cols, dtype=dtype), requires_grad=False)
+        self.bias = torch.nn.Parameter(torch.empty(rows, dtype=bias_dtype or dtype), requires_grad=False) if has_bias else None
+
+
+class ColumnParallelLinear(_ShardedLinear):
+    """y = x W_r^T (+ b_r) with the OUTPUT features split over the ranks; gather_output concatenates the ranks'
+    slices along the last dimension (tensor_parallel.py:42-103)."""
+
+    def __init__(self, in_features, out_features, has_bias=True, gather_output=True, dtype=None, bias_dtype=None,
+                 linear_op=torch.nn.functional.linear):
+        super().__init__(in_features, out_features, "out", has_bias, dtype, bias_dtype, linear_op)
         self.gather_output = gather_output
-        self.linear_op = linear_op
-        self.weight = torch.nn.Parameter(
-            torch.empty(out_features // self.tp_size, in_features, dtype=dtype), requires_grad=False
-        )
-        if has_bias:
-            self.bias = torch.nn.Parameter(
-                torch.empty(out_features // self.tp_size, dtype=bias_dtype or dtype), requires_grad=False
-            )
-        else:
-            self.bias = None
 
     def forward(self, x):
         y = self.linear_op(x, self.weight, self.bias)
-        if self.gather_output and self.tp_size > 1:
-            y = all_gather_last_dim(y)
-        return y
+        return all_gather_last_dim(y) if self.gather_output and self.tp_size > 1 else y
 
 
-class RowParallelLinear(torch.nn.Module):
-    """Input-dimension-parallel linear followed by an all-reduce (tensor_parallel.py:106-169)."""
+class RowParallelLinear(_ShardedLinear):
+    """y = sum over ranks of x_r W_r^T with the INPUT features split; the bias is added once (by rank 0, before the
+    all-reduce); an input that is not already this rank's slice is sliced here (tensor_parallel.py:106-169)."""
 
-    def __init__(self, in_features, out_features, has_bias=True, input_is_parallel=False, dtype=None,
-                 bias_dtype=None, linear_op=torch.nn.functional.linear):
-        super().__init__()
-        self.tp_group = get_tp_group()
-        self.tp_size = get_tp_size()
-        self.rank = get_tp_rank()
-        self.in_features = in_features
-        self.out_features = out_features
-        assert in_features % self.tp_size == 0, "in_features must be divisible by tp_size"
+    def __init__(self, in_features, out_features, has_bias=True, input_is_parallel=False, dtype=None, bias_dtype=None,
+                 linear_op=torch.nn.functional.linear):
+        super().__init__(in_features, out_features, "in", has_bias, dtype, bias_dtype, linear_op)
         self.input_is_parallel = input_is_parallel
-        self.linear_op = linear_op
-        self.weight = torch.nn.Parameter(
-            torch.empty(out_features, in_features // self.tp_size, dtype=dtype), requires_grad=False
-        )
-        if has_bias:
-            self.bias = torch.nn.Parameter(torch.empty(out_features, dtype=bias_dtype or dtype), requires_grad=False)
-        else:
-            self.bias = None
 
     def forward(self, x):
-        if not self.input_is_parallel and self.tp_size > 1:
-            shape = list(x.shape)
-            this_rank_dim = shape[-1] // self.tp_size
-            shape[-1] = self.tp_size
-            shape.append(this_rank_dim)
-            x = x.view(shape).select(-2, self.rank)
-        if self.tp_size > 1:
-            y = self.linear_op(x, self.weight, self.bias if self.rank == 0 else None)
-            all_reduce(y)
-        else:
-            y = self.linear_op(x, self.weight, self.bias)
-        return y
+        if self.tp_size == 1:
+            return self.linear_op(x, self.weight, self.bias)
+        if not self.input_is_parallel:
+            x = x.unflatten(-1, (self.tp_size, -1)).select(-2, self.rank)
+        return all_reduce(self.linear_op(x, self.weight, self.bias if self.rank == 0 else None))
 
 
 class VocabParallelEmbedding(torch.nn.Module):
-    """Vocabulary-sharded embedding: mask, local lookup, all-reduce (tensor_parallel.py:172-208)."""
+    """Embedding table split by vocabulary rows: ids outside this rank's range look up row 0 and are zeroed, the
+    all-reduce assembles the batch (tensor_parallel.py:172-208).  The caller's id tensor is not modified."""
 
     def __init__(self, num_embeddings, embedding_dim, dtype=None):
         super().__init__()
-        self.tp_group = get_tp_group()
-        self.tp_size = get_tp_size()
-        self.rank = get_tp_rank()
+        self.tp_group, self.tp_size, self.rank = get_tp_group(), get_tp_size(), get_tp_rank()
         assert num_embeddings % self.tp_size == 0, "num_embeddings must be divisible by tp_size"
-        self.vocab_start_idx = self.rank * (num_embeddings // self.tp_size)
-        self.vocab_end_idx = self.vocab_start_idx + (num_embeddings // self.tp_size)
-        self.weight = torch.nn.Parameter(
-            torch.empty(num_embeddings // self.tp_size, embedding_dim, dtype=dtype), requires_grad=False
-        )
+        per_rank = num_embeddings // self.tp_size
+        self.vocab_start_idx, self.vocab_end_idx = self.rank * per_rank, (self.rank + 1) * per_rank
+        self.weight = torch.nn.Parameter(torch.empty(per_rank, embedding_dim, dtype=dtype), requires_grad=False)
 
     def forward(self, x):
-        if self.tp_size > 1:
-            mask = (x < self.vocab_start_idx) | (x >= self.vocab_end_idx)
-            x = torch.where(mask, torch.zeros_like(x), x - self.vocab_start_idx)  # no in-place on the caller's ids
-        y = torch.nn.functional.embedding(x, self.weight)
-        if self.tp_size > 1:
-            y = torch.where(mask.unsqueeze(-1), torch.zeros_like(y), y)
-            all_reduce(y)
-        return y
+        if self.tp_size == 1:
+            return torch.nn.functional.embedding(x, self.weight)
+        local = x - self.vocab_start_idx
+        foreign = (local < 0) | (local >= self.weight.shape[0])
+        y = torch.nn.functional.embedding(local.masked_fill(foreign, 0), self.weight)
+        return all_reduce(y.masked_fill(foreign.unsqueeze(-1), 0))
