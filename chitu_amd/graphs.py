@@ -51,6 +51,13 @@ def capture_piecewise(step, pool) -> PiecewiseGraph:
         tp._graph_break = cut
         try:
             step()
+        except BaseException:
+            # leave no capture open behind a failing step (the stream would stay in capture mode for good)
+            try:
+                cur[0].capture_end()
+            except Exception:  # noqa: BLE001 -- the original error is the one to report
+                pass
+            raise
         finally:
             tp._graph_break = None
         cur[0].capture_end()
