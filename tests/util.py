@@ -234,3 +234,80 @@ def ref_llama_fixture():
         p[f"layers.{i}.attn_norm"] = ref[f"layers.{i}.attention_norm.weight"]
         p[f"layers.{i}.ffn_norm"] = ref[f"layers.{i}.ffn_norm.weight"]
     return g, cfg, p
+
+
+# ---------------------------------------------------------------- cache manager scenario
+def cache_manager_scenario(make_manager, make_varlens):
+    """One scripted life of a paged cache manager (prefill of ragged prompts, decode steps across page boundaries with
+    the kernels' in-place append simulated through the manager's own block table, a finished request, its pages reused
+    by a new one), observed only through quantities that do not depend on WHICH physical pages were handed out:
+    sequence lengths, the device length buffers, pages per request, free-page count, distinctness of live pages, the
+    device block table == the host one, and a digest of every request's logical cache content per layer.
+    Run on the reference's PagedKVCacheManager by tests/golden/gen_cache_manager.py and on chitu_amd's by the test."""
+    import hashlib
+
+    layers, page, width = 2, 4, 8
+    mgr = make_manager(layers=layers, page=page, width=width, max_reqs=3, max_seq_len=16)
+    obs = []
+    counter = [0]
+
+    def rows(n):  # deterministic, distinct payload rows
+        base = counter[0]
+        counter[0] += n
+        return (torch.arange(base * width, (base + n) * width, dtype=torch.float32).view(n, width) % 251).to(torch.bfloat16)
+
+    def gathered(req, layer):
+        ids, n = mgr.block_table[req], mgr.seq_lens[req]
+        cache = mgr.get_paged_kv_cache(layer)
+        parts = [cache[b][: min(page, n - i * page)] for i, b in enumerate(ids) if n - i * page > 0]
+        flat = torch.cat(parts).contiguous() if parts else torch.zeros(0, width, dtype=torch.bfloat16)
+        return hashlib.sha1(flat.view(torch.int16).numpy().tobytes()).hexdigest()
+
+    def observe(tag, live):
+        live_pages = [b for r in live for b in mgr.block_table[r]]
+        obs.append({
+            "tag": tag,
+            "seq_lens": sorted((r, int(mgr.seq_lens[r])) for r in live),
+            "pages": sorted((r, len(mgr.block_table[r])) for r in live),
+            "free": len(mgr.free_blocks),
+            "pages_distinct": len(set(live_pages)) == len(live_pages),
+            "content": sorted((r, l, gathered(r, l)) for r in live for l in range(layers)),
+        })
+
+    def prefill(reqs, lens):
+        vl = make_varlens([[0] * n for n in lens])
+        mgr.curr_varlens, mgr.curr_req_ids = vl, reqs
+        for layer in range(layers):
+            data = rows(sum(lens))
+            mgr.finalize_cache_bylayer_prefill(data, None, reqs, vl, layer)
+        mgr.finalize_cache_all_prefill(reqs, vl)
+
+    def decode(reqs, tag):
+        mgr.prepare_cache_decode(reqs)
+        mgr.prepare_block_table_for_decode(reqs)
+        n = len(reqs)
+        excl = mgr.get_gpu_seq_lens_excl_this_decode().tolist()
+        incl = mgr.get_gpu_seq_lens_incl_this_decode().tolist()
+        table = mgr.get_gpu_block_table()
+        same_table = all(table[i, : len(mgr.block_table[r])].tolist() == list(mgr.block_table[r]) for i, r in enumerate(reqs))
+        for layer in range(layers):  # what append_to_paged_kv_cache / the attention kernels do in place
+            new = rows(n)
+            cache = mgr.get_paged_kv_cache(layer)
+            for i, r in enumerate(reqs):
+                L = excl[i]
+                cache[int(table[i, L // page])][L % page] = new[i]
+        mgr.finalize_cache_single_decode(reqs)
+        observe(tag, reqs)
+        obs[-1].update(excl=excl, incl=incl, table_rows=int(table.shape[0]), device_table_matches=same_table)
+
+    prefill(["a", "b"], [5, 2])
+    observe("prefill ab", ["a", "b"])
+    for step in range(4):  # a: 5 -> 9 (new page at 8), b: 2 -> 6 (new page at 4)
+        decode(["a", "b"], f"decode ab {step}")
+    mgr.finalize_cache_all_decode("b")
+    observe("b finished", ["a"])
+    prefill(["c"], [3])
+    observe("prefill c", ["a", "c"])
+    for step in range(2):
+        decode(["c", "a"], f"decode ca {step}")
+    return obs
