@@ -37,6 +37,26 @@ def test_router_softmax_topk_renorm():
     assert max_rel_to_peak(w.cpu(), w_ref) < 1e-2 and torch.allclose(w.float().sum(-1).cpu(), torch.ones(19), atol=1e-2)
 
 
+def test_router_against_the_reference_block_fixture():
+    """The HIP router (softmax -> top-2 -> renormalise) on the inputs of tests/golden/gen_mixtral_router.py vs what the
+    reference's SparseMoeBlockHFMixtral.forward produced for them: same experts wherever the reference's second and
+    third probabilities are not a near-tie, weights within 1e-2."""
+    from chitu_amd import ops
+    from tests.util import golden
+
+    g = golden("mixtral_router")
+    x = torch.from_numpy(g["x"].copy()).view(torch.bfloat16)
+    gate_w = torch.from_numpy(g["gate_w"].copy()).view(torch.bfloat16)
+    want = torch.from_numpy(g["weights"].copy()).view(torch.bfloat16).float()
+    w, ids = ops.gate_deepseek_v3(x.cuda(), gate_w.cuda(), None, 1, 1, int(g["topk"][0]), "softmax_renorm", 1.0)
+    got = torch.zeros_like(want).scatter_(1, ids.cpu(), w.float().cpu())
+    probs = torch.softmax(torch.nn.functional.linear(x.float(), gate_w.float()), -1).sort(-1, descending=True).values
+    clear = (probs[:, 1] - probs[:, 2]) > 2e-3
+    assert clear.sum() >= 60
+    assert torch.equal(got[clear] != 0, want[clear] != 0)
+    assert (got[clear] - want[clear]).abs().max() < 1e-2
+
+
 def test_layerwise_parity_graph_replay_and_generate():
     args, model, cache = build()
     params = {k: v.detach().cpu() for k, v in model.named_parameters()}

@@ -374,3 +374,17 @@ def test_decode_model_free_running_vs_the_reference_models_own_run(interpreter_c
         top2 = ref.topk(2, dim=-1).values
         safe = (top2[:, 0] - top2[:, 1]) > 0.1 * ref.abs().max()
         assert torch.equal(out[k].argmax(-1)[safe], ref.argmax(-1)[safe])
+
+
+def test_mixtral_router_matches_the_reference_block():
+    """oracle/mixtral.py::route vs the reference's SparseMoeBlockHFMixtral.forward observed through one-hot probe
+    experts (tests/golden/gen_mixtral_router.py): per token, the same two experts and bit-identical bf16 weights."""
+    from oracle import mixtral as omix
+
+    g = golden("mixtral_router")
+    x = torch.from_numpy(g["x"].copy()).view(torch.bfloat16)
+    gate_w = torch.from_numpy(g["gate_w"].copy()).view(torch.bfloat16)
+    want = torch.from_numpy(g["weights"].copy()).view(torch.bfloat16)
+    w, ids = omix.route(x, gate_w, int(g["topk"][0]))
+    got = torch.zeros_like(want).scatter_(1, ids, w)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
