@@ -6,15 +6,22 @@ Workload (named in `config.workload`): DeepSeek-R1-671B FP8, one TP=8 rank shard
 cache -- i.e. exactly the bytes and kernels one GPU of the 8-GPU node executes per decode step
 (35.7 GB/step at bs=16, 5.7 GB at bs=1).  Random synthetic weights and KV
 (no network for checkpoints), batch `--bs` sequences at context `--ctx`, greedy sampling, the
-whole step replayed as one hipGraph.  With N ranks live, the TP all-reduces / all-gather run over
-RCCL across those N ranks (the step then replays as hipGraph pieces with the collectives issued
-between them, chitu_amd/graphs.py; CHITU_TP_GRAPH=full captures them into one graph instead); at N=8
-this IS the metric's configuration.
+whole step replayed as one hipGraph.  With N ranks live the step's 124 collectives (2 all-reduces
+per layer, the embedding's, the logits all-gather) run across those N ranks: by default as the in-graph
+xGMI kernels of chitu_amd/csrc/comm.hip (the step stays ONE hipGraph and every per-layer all-reduce is
+fused into the norm launch that consumes it; `collective_transport` in the output says which path ran),
+or -- CHITU_ALLREDUCE=rccl, or when the xGMI self-test fails -- through RCCL with the step replayed as
+hipGraph pieces between the library calls (chitu_amd/graphs.py).  At N=8 this IS the metric's configuration.
 
-A "step" = one decode token for the whole batch.  value = (N/8) * bs * K / T: N GPUs complete N/8
-of the model's work for every token they emit, so this is the full-model-equivalent rate the job
-sustains (weak scaling: per-GPU work fixed).  `node_tok_s` = bs*K/T is what an 8-GPU node would
-emit at this per-rank step time.
+`python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself under
+`torch.distributed.run` (one rank per GPU; when the box has fewer than N GPUs every rank shares cuda:0,
+the process group is gloo, the layer count is cut to what fits, and the line is flagged invalid: a
+functional check of the N > 1 code path, not a measurement).
+
+A "step" = one decode token for the whole batch.  value = (N/8) * bs * K / T: N GPUs carry N/8 of the
+model's weights, so N/8 of an 8-GPU node's tokens are attributed to them (weak scaling: per-GPU work fixed).
+`node_tok_s` = bs*K/T is what an 8-GPU node emits at this per-rank step time; at N < 8 the collectives it
+would pay span only the live ranks (`collectives_in_step` is 0 at N=1), so only N=8 is the metric itself.
 
 Prints ONE JSON line on rank 0.
 """
@@ -45,35 +52,108 @@ def parse():
     ap.add_argument("--layers", type=int, default=61, help="debug only: fewer layers => result flagged invalid")
     ap.add_argument("--router-std", type=float, default=None, help="debug only: synthetic router weight std (result flagged invalid)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 measurement")
+    ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 and bs=32 measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-llama", action="store_true", help="skip the extra Llama-3-8B / DeepSeek-V2-Lite / Mixtral-int8 (BASELINE configs 2, 3, 4) measurements")
     return ap.parse_args()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks."""
+    import socket
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if torch.cuda.device_count() < n:
+        env["CHITU_BENCH_BACKEND"] = "gloo"  # every rank on cuda:0: functional check only
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(sys.executable, cmd, env)
+
+
 def setup_dist(n):
+    if n > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(n)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    info = {"backend": None, "ranks_seen": 1, "shared_device": False}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # debug only (validating the N > 1 code path on a one-GPU box): CHITU_BENCH_BACKEND=gloo puts every
-        # rank on cuda:0 and runs the collectives through gloo; such a run is flagged invalid
+        # functional check on a box with fewer GPUs than ranks (CHITU_BENCH_BACKEND=gloo, set by self_launch):
+        # every rank on cuda:0, library collectives through gloo; such a run is flagged invalid
         if os.environ.get("CHITU_BENCH_BACKEND") == "gloo":
             torch.cuda.set_device(0)
             dist.init_process_group("gloo")
+            info["shared_device"] = True
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         from chitu_amd import tensor_parallel as tp
 
         tp.init_tp(world, 1)
+        info["backend"] = dist.get_backend()
+        # the ranks the library itself sees: a sum of ones through the backend's own all-reduce
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        info["ranks_seen"] = int(ones.item())
     else:
         torch.cuda.set_device(0)
     assert world == n, f"--gpus {n} but WORLD_SIZE={world}"
-    return rank, world, local
+    return rank, world, local, info
+
+
+def enable_collectives(world, max_bs, vocab_local):
+    """N > 1: the in-graph xGMI collectives unless CHITU_ALLREDUCE=rccl (or their self-test fails on any rank)."""
+    if world == 1:
+        return "none (one rank)"
+    from chitu_amd import tensor_parallel as tp
+
+    if os.environ.get("CHITU_ALLREDUCE", "xgmi") != "rccl" and tp.enable_xgmi(
+            max_rows=max(max_bs, 32), max_dim=8192, gather_bytes=max(max_bs, 32) * vocab_local * 2):
+        return "xgmi (hand-written push all-reduce / all-gather kernels inside the step's hipGraph)"
+    return f"{dist.get_backend()} (library calls between hipGraph pieces)"
+
+
+def time_collectives(bs, dim, vocab_local, iters=200):
+    """GPU time of one fused all-reduce launch and one logits all-gather at this batch size: `iters` launches
+    of each captured in a hipGraph, timed with events on the replay stream (every rank runs them)."""
+    from chitu_amd import tensor_parallel as tp
+
+    comm = tp.xgmi_comm()
+    if comm is None:
+        return None
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    part = torch.randn(bs, dim, device="cuda", generator=gen).to(torch.bfloat16)
+    x = torch.randn(bs, dim, device="cuda", generator=gen).to(torch.bfloat16)
+    w = torch.ones(dim, device="cuda", dtype=torch.bfloat16)
+    y = torch.randn(bs, vocab_local, device="cuda", generator=gen).to(torch.bfloat16)
+    out = {}
+    for name, fn in (("allreduce_add_norm_quant_us", lambda: comm.allreduce_rmsnorm(part, x, w, 1e-6, out_bf16=False, quant="act")),
+                     ("logits_all_gather_us", lambda: comm.all_gather_last_dim(y, torch.float32))):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(e0.elapsed_time(e1) * 1e3 / iters, 2)
+        del g
+    return out
 
 
 def barrier_sync(world):
@@ -90,7 +170,7 @@ def build_model(args_ns, rank):
 
     margs = DeepSeekV3Args(shard_degree=SHARD, n_layers=args_ns.layers)
     max_seq = args_ns.ctx + args_ns.steps + args_ns.warmup + 256
-    max_reqs = max(args_ns.bs, 1)
+    max_reqs = max(args_ns.bs, 1 if args_ns.no_bs1 else 32)
     cache = PagedKVCacheManager(0, margs.n_layers, num_hot_req=max_reqs, block_size=64, max_seq_len=max_seq,
                                 device="cuda", kv_shape_per_sample=(margs.kv_lora_rank + margs.qk_rope_head_dim,),
                                 dtype=torch.bfloat16)
@@ -108,6 +188,8 @@ def build_model(args_ns, rank):
 
 def run_decode(model, cache, reqs, tokens, steps, world, use_graph, timed):
     """Exactly `steps` decode steps; returns (seconds (max over ranks) or None, final tokens)."""
+    from chitu_amd import sampling
+
     if timed:
         barrier_sync(world)
         t0 = time.perf_counter()
@@ -115,7 +197,7 @@ def run_decode(model, cache, reqs, tokens, steps, world, use_graph, timed):
         cache.prepare_cache_decode(reqs)
         cache.prepare_block_table_for_decode(reqs)
         logits = model.decode(tokens, use_graph=use_graph)
-        tokens = logits.argmax(dim=-1)  # greedy (executor.py:103-104), stays on device
+        tokens = sampling.argmax(logits)  # greedy (executor.py:103-104): chitu_hip_sample, stays on device
         cache.finalize_cache_single_decode(reqs)
     if not timed:
         torch.cuda.synchronize()
@@ -451,19 +533,27 @@ def mixtral_extra(steps, warmup, ctx):
 
 def main():
     a = parse()
-    rank, world, local = setup_dist(a.gpus)
+    rank, world, local, dinfo = setup_dist(a.gpus)
     use_graph = not a.no_graph
+    if dinfo["shared_device"]:
+        # all ranks on one GPU: keep the layers that fit (1.45 GB per layer and rank); flagged invalid below
+        fit = int(torch.cuda.mem_get_info()[0] * 0.7 / world / 1.45e9)
+        a.layers = max(4, min(a.layers, fit))
     t_build = time.perf_counter()
     margs, model, cache = build_model(a, rank)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t_build
+    batches = [a.bs] + [b for b in ((1, 32) if not a.no_bs1 else ()) if b != a.bs]
+    transport = enable_collectives(world, max(batches), model.vocab_local)
 
-    # N > 1: the step replays as hipGraph PIECES cut at every collective, the collectives are issued between
-    # them (DeepSeekV3Decoder.decode, "piecewise") -- nothing depends on RCCL being capturable.
-    # CHITU_TP_GRAPH=full asks for ONE graph with the RCCL collectives captured inside it; that attempt is
-    # probed first and every rank falls back to eager launches together if the capture is refused.
-    graph_mode = "off" if not use_graph else "on" if world == 1 else os.environ.get("CHITU_TP_GRAPH", "piecewise")
-    if use_graph and world > 1 and graph_mode == "full":
+    # One rank, or N ranks on the xGMI collectives: the step is ONE hipGraph.  N ranks on the library: hipGraph
+    # PIECES cut at every collective (DeepSeekV3Decoder.decode, "piecewise"); CHITU_TP_GRAPH=full asks for the
+    # RCCL calls to be captured too -- that attempt is probed first and every rank falls back to eager launches
+    # together if the capture is refused.
+    from chitu_amd import graphs
+
+    graph_mode = "off" if not use_graph else {"full": "on", "piecewise": "piecewise"}[graphs.graph_mode(True)]
+    if use_graph and world > 1 and transport.startswith("nccl") and graph_mode == "on":
         ok = torch.ones(1, device="cuda")
         try:
             measure(model, cache, a.bs, a.ctx, 2, 1, world, True, "probe")
@@ -487,12 +577,31 @@ def main():
     value = node_tok_s * world / SHARD
 
     extra = {}
-    if not a.no_bs1 and a.bs != 1:
-        dt1 = measure(model, cache, 1, a.ctx, a.steps, a.warmup, world, use_graph, "s")
-        extra["bs1"] = {
-            "ms_per_step": round(dt1 / a.steps * 1e3, 4), "node_tok_s": round(a.steps / dt1, 2),
-            "value": round(a.steps / dt1 * world / SHARD, 3),
+    for b in batches[1:]:  # BASELINE config 5: bs in {1, 16, 32}
+        dtb = measure(model, cache, b, a.ctx, a.steps, a.warmup, world, use_graph, f"s{b}_")
+        extra[f"bs{b}"] = {
+            "ms_per_step": round(dtb / a.steps * 1e3, 4), "node_tok_s": round(b * a.steps / dtb, 2),
+            "value": round(b * a.steps / dtb * world / SHARD, 3),
         }
+    coll = None
+    if world > 1:
+        n_coll = 2 * margs.n_layers + 2
+        coll = {"collectives_in_step": n_coll, "transport": transport, "library_backend": dinfo["backend"],
+                "ranks_seen_by_library": dinfo["ranks_seen"],
+                "fused": "every per-layer all-reduce runs inside the launch that also does the top-k sum, the residual "
+                         "add, the RMSNorm and the fp8 quant" if transport.startswith("xgmi") else "no"}
+        timing = time_collectives(a.bs, margs.dim, model.vocab_local)
+        if timing:
+            coll.update(timing)
+            coll["collective_ms_per_step_est"] = round(
+                ((n_coll - 1) * timing["allreduce_add_norm_quant_us"] + timing["logits_all_gather_us"]) * 1e-3, 3)
+        from chitu_amd import tensor_parallel as tp
+
+        if tp.xgmi_comm() is not None:
+            coll["xgmi_error_word"] = tp.xgmi_comm().status()
+    else:
+        coll = {"collectives_in_step": 0, "transport": transport,
+                "note": "one rank of eight: the 124 collectives of the TP=8 step are not paid here"}
 
     roof = None
     if not a.no_roofline:
@@ -534,16 +643,24 @@ def main():
                 "batch": a.bs, "context": a.ctx, "parallelism": f"tp8-shard x{world}", "layers": margs.n_layers,
             },
             "node_tok_s": round(node_tok_s, 2),
+            "collectives": coll,
             "step_algorithmic_GB": round(step_bytes / 1e9, 3),
             "step_hbm_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "step_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof, "cpu_baseline": cpu, "build_s": round(build_s, 1),
         }
         res.update(extra)
-        if a.layers != 61 or a.router_std is not None or os.environ.get("CHITU_BENCH_BACKEND") == "gloo":
-            res["invalid"] = "debug run (reduced layer count or non-default synthetic router)"
+        if a.layers != 61 or a.router_std is not None or dinfo["shared_device"]:
+            res["invalid"] = ("debug run: " + ", ".join(
+                w for w, c in (("reduced layer count", a.layers != 61), ("non-default synthetic router", a.router_std is not None),
+                               ("all ranks share one GPU (functional check of the N > 1 path)", dinfo["shared_device"])) if c))
         print(json.dumps(res))
     if world > 1:
+        from chitu_amd import tensor_parallel as tp
+
+        torch.cuda.synchronize()
+        dist.barrier()
+        tp.disable_xgmi()
         dist.destroy_process_group()
 
 

@@ -62,9 +62,9 @@ class PagedKVCacheManager:
         self.gpu_block_table_buffer = torch.zeros(
             (num_hot_req, self.max_blocks_per_req), dtype=torch.int32, device=self.device
         )
-        # Pageable host staging: copy_() from pageable memory returns only after the runtime has
-        # staged the bytes, so these buffers can be rewritten for the next step while the GPU is
-        # still several (graph-replayed) steps behind the host.
+        # Pageable host staging: copy_() from pageable memory returns only after the runtime has staged
+        # the bytes, so these buffers can be rewritten for the next step right away.  (That copy waits for
+        # the stream, as the reference's per-request copies do: the host is never ahead of the GPU here.)
         self._host_lens = torch.zeros(2, num_hot_req, dtype=torch.int32)
         self._host_table = torch.zeros((num_hot_req, self.max_blocks_per_req), dtype=torch.int32)
         self.free_blocks = deque(range(self.num_blocks))

@@ -171,9 +171,30 @@ def merge_gate_up(state):
     return _merge_pairs(state, "w1", "w3", "w1w3")
 
 
-def merge_experts(state: Mapping[str, torch.Tensor], n_routed: int) -> Dict[str, torch.Tensor]:
+def _split_shared(t: torch.Tensor, w: str, part: str, n_shared: int):
+    """The HF shared MLP is ONE MLP of width n_shared * I (DeepSeek-V2-Lite: 2 x 1408); the fused path runs it
+    as n_shared expert slots of width I.  Slice j of the width: rows of w1 / w3 (each half of a merged w1w3),
+    columns of w2; block scales likewise (I % 128 == 0 keeps 128-blocks whole)."""
+    if n_shared == 1:
+        return [t]
+    if part == "bias":
+        raise ValueError("a shared-expert bias cannot be split over expert slots")
+    if w == "w2":
+        if t.shape[1] % n_shared:
+            raise ValueError(f"shared_experts.w2.{part}: width {t.shape[1]} not divisible by n_shared_experts={n_shared}")
+        return list(t.chunk(n_shared, dim=1))
+    halves = t.chunk(2, dim=0) if w == "w1w3" else (t,)
+    if any(h.shape[0] % n_shared for h in halves):
+        raise ValueError(f"shared_experts.{w}.{part}: width {halves[0].shape[0]} not divisible by n_shared_experts={n_shared}")
+    pieces = [h.chunk(n_shared, dim=0) for h in halves]
+    return [torch.cat([pc[j] for pc in pieces], dim=0) for j in range(n_shared)]
+
+
+def merge_experts(state: Mapping[str, torch.Tensor], n_routed: int, n_shared: int = 1) -> Dict[str, torch.Tensor]:
     """`<p>.experts.{i}.<w>.<part>` (i < n_routed) + `<p>.shared_experts.<w>.<part>` -> `<p>.<w>.<part>` stacked
-    [n_routed + 1, ...], shared expert last (:1167-1195)."""
+    [n_routed + n_shared, ...], shared experts last (:1167-1195; the reference appends the shared MLP as ONE slot,
+    i.e. n_shared == 1 -- V3 / R1).  n_shared > 1 (DeepSeek-V2-Lite): the shared MLP's width is cut into n_shared
+    slots of the routed experts' width, the layout MoEDeepSeekV3 runs."""
     out = {}
     pat = re.compile(r"^(.*\.)experts\.0\.(w1w3|w1|w2|w3)\.(weight|scale|bias)$")
     for k, t in state.items():
@@ -181,8 +202,11 @@ def merge_experts(state: Mapping[str, torch.Tensor], n_routed: int) -> Dict[str,
         if m:
             prefix, w, part = m.groups()
             parts = [state[f"{prefix}experts.{i}.{w}.{part}"] for i in range(n_routed)]
-            parts.append(state[f"{prefix}shared_experts.{w}.{part}"])
-            out[f"{prefix}{w}.{part}"] = torch.stack(parts, dim=0)
+            shared = _split_shared(state[f"{prefix}shared_experts.{w}.{part}"], w, part, n_shared)
+            if any(sh.shape != parts[0].shape for sh in shared):
+                raise ValueError(f"{prefix}shared_experts.{w}.{part}: slot shape {tuple(shared[0].shape)} != routed expert "
+                                 f"{tuple(parts[0].shape)} (n_shared_experts={n_shared})")
+            out[f"{prefix}{w}.{part}"] = torch.stack(parts + shared, dim=0)
         elif ".experts." in k or ".shared_experts." in k:
             continue
         else:
@@ -232,7 +256,7 @@ def merge_experts_expert_parallel(state: Mapping[str, torch.Tensor], n_local: in
 
 
 def preprocess_deepseek_v3(state: Mapping[str, torch.Tensor], n_routed: int, rank: int = 0, world: int = 1,
-                           merge_qkv_gate_up: bool = True, moe_world_size: int = 1) -> Dict[str, torch.Tensor]:
+                           merge_qkv_gate_up: bool = True, moe_world_size: int = 1, n_shared: int = 1) -> Dict[str, torch.Tensor]:
     """chitu-named full checkpoint -> this rank's tensors under the reference's final names
     (load_state_dict_parallel, models/model.py:372-390 + TransformerDeepSeekV3.load_state_dict :1273-1288).
 
@@ -250,7 +274,7 @@ def preprocess_deepseek_v3(state: Mapping[str, torch.Tensor], n_routed: int, ran
     state = chunk_for_tensor_parallel(state, rank, world)
     if merge_qkv_gate_up:
         state = merge_gate_up(merge_qkv(state))
-    return merge_experts(state, n_routed)
+    return merge_experts(state, n_routed, n_shared)
 
 
 def to_module_names(state: Mapping[str, torch.Tensor], q_lora_rank: int = 1) -> Dict[str, torch.Tensor]:
@@ -277,7 +301,7 @@ def to_module_names(state: Mapping[str, torch.Tensor], q_lora_rank: int = 1) -> 
 def load_deepseek_v3(model: torch.nn.Module, state: Mapping[str, torch.Tensor], strict: bool = True) -> None:
     """Copy module-named tensors into `model`'s parameters in place (addresses captured by hipGraphs stay valid),
     with shape / dtype checks instead of nn.Module.load_state_dict's silent fp8 casts.  Derived layouts cached by
-    the modules (the transposed W_UK of the absorbed MLA) are dropped so they are rebuilt from the new weights."""
+    the modules (the transposed W_UK of the absorbed MLA) are marked stale so they are rebuilt from the new weights."""
     params = dict(model.named_parameters())
     missing = sorted(set(params) - set(state))
     unexpected = sorted(set(state) - set(params))
@@ -297,8 +321,8 @@ def load_deepseek_v3(model: torch.nn.Module, state: Mapping[str, torch.Tensor], 
                 t = t.to(p.dtype)
             p.copy_(t)
     for mod in model.modules():
-        if hasattr(mod, "_w_uk_t"):
-            mod._w_uk_t = None
+        if hasattr(mod, "_w_uk_key"):
+            mod._w_uk_key = None  # rebuilt in place on next use: buffers captured by hipGraphs stay valid
 
 
 def load_checkpoint_deepseek_v3(model, path: str, rank: int = 0, world: int = 1, skip_preprocess: bool = False) -> None:

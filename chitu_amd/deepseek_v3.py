@@ -196,15 +196,26 @@ class AttentionDeepSeekV3(torch.nn.Module):
         self.wkv_b = Fp8Linear(self.kv_lora_rank, H * (self.qk_nope_head_dim + self.v_head_dim), device)
         self.wo = Fp8Linear(H * self.v_head_dim, args.dim, device)
         self.softmax_scale = compute_softmax_scale(args)
-        self._w_uk_t = None
+        self._w_uk_t, self._w_uk_key = None, None
 
     def w_uk_transposed(self):
         """fp8 copy of W_UK laid out [H, kv_lora, nope] so the absorbed contraction index is
-        contiguous.  Layout-only preprocessing of wkv_b; values and scales untouched."""
-        if self._w_uk_t is None:
+        contiguous.  Layout-only preprocessing of wkv_b; values and scales untouched.
+        The copy is keyed on wkv_b's storage and version counter and rebuilt IN PLACE when they change
+        (load_state_dict, copy_, .to()), so a captured hipGraph keeps reading the right bytes; writers that
+        bypass the counter (`.data` fills: init_synthetic_, checkpoint.load_deepseek_v3) call
+        `refresh_derived_layouts`."""
+        wt = self.wkv_b.weight
+        key = (wt.data_ptr(), wt._version)
+        if self._w_uk_t is None or self._w_uk_key != key:
             H = self.n_local_heads
-            w = self.wkv_b.weight.view(torch.uint8).view(H, self.qk_nope_head_dim + self.v_head_dim, self.kv_lora_rank)
-            self._w_uk_t = w[:, : self.qk_nope_head_dim].transpose(1, 2).contiguous().view(FP8)
+            w = wt.view(torch.uint8).view(H, self.qk_nope_head_dim + self.v_head_dim, self.kv_lora_rank)
+            t = w[:, : self.qk_nope_head_dim].transpose(1, 2)
+            if self._w_uk_t is not None and self._w_uk_t.device == wt.device:
+                self._w_uk_t.view(torch.uint8).copy_(t)
+            else:
+                self._w_uk_t = t.contiguous().view(FP8)
+            self._w_uk_key = key
         return self._w_uk_t
 
     def decode_forward_paged(self, x_quant, cos, sin):
@@ -422,32 +433,44 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
 
     def forward(self, x, pending, cos, sin, varlens=None):
         """(x, pending) -> (x', pending'); varlens given = prefill (ragged prompt tokens), else decode.
-        The residual stream is x + pending; every residual add is
-        folded into the RMSNorm that consumes the sum (ops.rms_norm(add=...)), so a layer is
-        norm, attention, norm, ffn with no separate add launches (reference: :1107-1113)."""
-        if pending is None:
-            _, xq, xs = ops.rms_norm(x, self.attn_norm.weight, self.attn_norm.eps, out_bf16=False, quant="act")
-        else:
-            x, _, xq, xs = ops.rms_norm(x, self.attn_norm.weight, self.attn_norm.eps, out_bf16=False, quant="act",
-                                        add=pending)
+        The residual stream is x + pending; every residual add is folded into the RMSNorm that consumes the sum
+        (`add_norm`), so a layer is norm, attention, norm, ffn with no separate add launches (reference:
+        :1107-1113).  With tensor parallelism the sublayer outputs are partials: `tp.defer_all_reduce` hands
+        their all-reduce to that same norm launch when the in-graph xGMI collectives are on (then a layer has
+        no stand-alone collective at all), and performs it through the library otherwise."""
+        x, _, xq, xs = add_norm(x, pending, self.attn_norm, out_bf16=False, quant="act")
         if varlens is None:
-            a = tp.all_reduce(self.attn.decode_forward_paged((xq, xs), cos, sin))
+            a = tp.defer_all_reduce(self.attn.decode_forward_paged((xq, xs), cos, sin))
         else:
-            a = tp.all_reduce(self.attn.prefill_forward((xq, xs), cos, sin, varlens))
+            a = tp.defer_all_reduce(self.attn.prefill_forward((xq, xs), cos, sin, varlens))
         if self.is_moe:
-            x, hn, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=True, quant="group", add=a)
-            # without tensor parallelism nothing sits between the experts' top-k sum and the next norm's
-            # residual add: the sum moves into that norm (one launch less); with TP the all-reduce
-            # below needs the summed tensor
-            defer = (tp.get_tp_size() == 1 and self.ffn.gate.topk + self.ffn.n_shared <= 16
-                     and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")  # chitu_hip_rmsnorm sums <= 16 terms
+            x, hn, hq, hs = add_norm(x, a, self.ffn_norm, out_bf16=True, quant="group")
+            # the experts' top-k sum moves into the next norm launch whenever nothing else needs the summed
+            # tensor: always on one rank, and under TP when the all-reduce is that launch too
+            defer = (tp.defers_topk_sum(hn.shape[0], hn.shape[1], self.ffn.gate.topk + self.ffn.n_shared)
+                     and self.ffn.moe_world_size == 1 and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")
             f = self.ffn(hn, (hq, hs), defer_sum=defer)
-            if f.dim() == 3:
-                return x, f
         else:
-            x, _, hq, hs = ops.rms_norm(x, self.ffn_norm.weight, self.ffn_norm.eps, out_bf16=False, quant="act", add=a)
+            x, _, hq, hs = add_norm(x, a, self.ffn_norm, out_bf16=False, quant="act")
             f = self.ffn((hq, hs))
-        return x, tp.all_reduce(f)
+        return x, tp.defer_all_reduce(f)
+
+
+def add_norm(x, pending, norm, out_bf16=True, quant=None):
+    """(x_new, y, q, s) with x_new = x + pending and y / (q, s) = RMSNorm(x_new) [quantised]; entries not asked
+    for are None.  pending: None | a tensor ([rows, dim], or [rows, terms, dim]: terms summed first) | a
+    tp.PendingAllReduce (partial of this rank: all-reduced over xGMI inside the same launch)."""
+    if isinstance(pending, tp.PendingAllReduce):
+        res = tp.xgmi_comm().allreduce_rmsnorm(pending.part, x, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant)
+    elif pending is None:
+        res = (x,) + _as_tuple(ops.rms_norm(x, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant))
+    else:
+        res = ops.rms_norm(x, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant, add=pending)
+    return tuple(res) + (None,) * (4 - len(res))
+
+
+def _as_tuple(r):
+    return r if isinstance(r, tuple) else (r,)
 
 
 class DeepSeekV3Decoder(torch.nn.Module):
@@ -482,9 +505,9 @@ class DeepSeekV3Decoder(torch.nn.Module):
         h, pending = self.embed(tokens), None
         for layer in self.layers:
             h, pending = layer(h, pending, cos, sin)
-        h = ops.rms_norm(h, self.norm.weight, self.norm.eps, add=pending)[1] if pending is not None else \
-            ops.rms_norm(h, self.norm.weight, self.norm.eps)
-        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()  # bf16 logits -> fp32 (model.py:475)
+        h = add_norm(h, pending, self.norm)[1]
+        # bf16 logits -> fp32 (model.py:475), the cast riding in the gather
+        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight), out_dtype=torch.float32)
 
     @torch.inference_mode()
     def prefill(self, tokens, req_ids):
@@ -500,13 +523,12 @@ class DeepSeekV3Decoder(torch.nn.Module):
             h, pending = layer(h, pending, cos, sin, varlens)
         last = torch.tensor([p - 1 for p in varlens.cpu_prefix_lens[1:]], dtype=torch.int64, device=self.device)
         h = h[last]
+        pending = tp.resolve(pending)
         if pending is not None:
-            pending = pending[last]
-            h = ops.rms_norm(h, self.norm.weight, self.norm.eps, add=pending.contiguous())[1]
-        else:
-            h = ops.rms_norm(h, self.norm.weight, self.norm.eps)
+            pending = pending[last].contiguous()
+        h = add_norm(h, pending, self.norm)[1]
         self.cache.finalize_cache_all_prefill(req_ids, varlens)
-        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()
+        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight), out_dtype=torch.float32)
 
     @torch.inference_mode()
     def generate(self, prompts, max_new_tokens, req_ids=None, use_graph=True, temperatures=None, top_ks=None,
@@ -588,6 +610,15 @@ class DeepSeekV3Decoder(torch.nn.Module):
         return self.static_out[bs]
 
 
+def refresh_derived_layouts(model: torch.nn.Module):
+    """Rebuild every layout derived from the weights (the transposed W_UK copies) after the weights were written
+    through a path the version counters do not see."""
+    for mod in model.modules():
+        if isinstance(mod, AttentionDeepSeekV3) and mod._w_uk_t is not None:
+            mod._w_uk_key = None
+            mod.w_uk_transposed()
+
+
 # ---------------------------------------------------------------- synthetic weights (SURVEY 8d)
 def _fill_fp8(t: torch.Tensor, gen: torch.Generator, std=0.5, chunk=1 << 26):
     flat = t.view(-1)
@@ -623,4 +654,5 @@ def init_synthetic_(model: torch.nn.Module, seed: int = 0, router_std: float = N
             for i in range(0, flat.numel(), 1 << 26):
                 n = min(1 << 26, flat.numel() - i)
                 flat[i : i + n].copy_((torch.randn(n, device=dev, generator=gen) * 0.05).to(p.dtype))
+    refresh_derived_layouts(model)
     return model

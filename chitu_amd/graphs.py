@@ -1,10 +1,12 @@
 """Piecewise hipGraph capture of a decode step that contains collectives.
 
 Reference: chitu/models/model.py:538-622 captures the whole step, NCCL all-reduces included, in one CUDA
-graph.  Here a rank with collectives replays the step as hipGraph PIECES cut at every collective
-(`tensor_parallel._graph_break`), and issues the collectives eagerly between the pieces: the N > 1 step
-then never depends on RCCL calls being capturable, costs 2 x layers + 2 extra host calls per step (each far
-shorter than the GPU time of the piece it follows, so the device stays fed), and is bit-identical to eager.
+graph.  The default here at N > 1 is the same one-graph form on the in-graph xGMI collectives
+(tensor_parallel.enable_xgmi).  This module is the FALLBACK for a rank whose collectives go through the
+library (RCCL / gloo): the step is replayed as hipGraph PIECES cut at every library collective
+(`tensor_parallel._graph_break`) with the collectives issued eagerly between the pieces, so that path never
+depends on RCCL calls being capturable; it costs 2 x layers + 2 extra host calls per step and is
+bit-identical to eager.
 """
 
 import torch
@@ -67,13 +69,17 @@ def capture_piecewise(step, pool) -> PiecewiseGraph:
 
 
 def graph_mode(use_graph) -> str:
-    """decode(use_graph=...) -> "full" | "piecewise": a string forces the mode; True picks piecewise on a
-    rank with collectives unless CHITU_TP_GRAPH=full asks for them to be captured into the one graph."""
+    """decode(use_graph=...) -> "full" | "piecewise".  A string forces the mode.  True: ONE graph when the rank has
+    no library collective in its step -- a single rank, or tensor parallelism on the in-graph xGMI collectives
+    (tensor_parallel.enable_xgmi) -- else piecewise, unless CHITU_TP_GRAPH=full asks for the library's calls to
+    be captured too.  CHITU_GRAPH_MODE=full|piecewise is a measurement knob that forces a mode on any rank count."""
     import os
 
     if isinstance(use_graph, str):
         assert use_graph in ("full", "piecewise")
         return use_graph
-    if os.environ.get("CHITU_GRAPH_MODE") in ("full", "piecewise"):  # measurement knob: force a mode on any rank count
+    if os.environ.get("CHITU_GRAPH_MODE") in ("full", "piecewise"):
         return os.environ["CHITU_GRAPH_MODE"]
-    return "piecewise" if tp.get_tp_size() > 1 and os.environ.get("CHITU_TP_GRAPH", "piecewise") != "full" else "full"
+    if tp.get_tp_size() == 1 or tp.xgmi_comm() is not None:
+        return "full"
+    return "full" if os.environ.get("CHITU_TP_GRAPH", "piecewise") == "full" else "piecewise"

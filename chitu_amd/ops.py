@@ -426,7 +426,6 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
         "gate_route_align",
     )
     return w_out, ids, (sorted_ids, expert_ids, npost)
-    return w_out, ids
 
 
 def mla_kv_prep(kv_in, q_pe, cos, sin, kv_norm_weight, eps, kv_cache, page_table, old_seq_lens):

@@ -185,6 +185,8 @@ class DeviceSampler:
         lg, rows, _ = _rows(logits)
         assert rows == self.n_req
         t = self.n_generated
+        if self.penalise:
+            assert t <= self.history.shape[1], "DeviceSampler: more calls than max_new_tokens (the penalty history is full)"
         if self.penalise and t > 0:
             # every request has generated exactly t tokens: row r's list is history[r, :t]
             flat = self.history[:, :t].contiguous().view(-1)  # (a [n, 1] slice would otherwise reshape to a strided view)

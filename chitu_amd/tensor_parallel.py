@@ -5,8 +5,12 @@ backend string "nccl" IS RCCL on ROCm (collectives run over xGMI and are hipGrap
 "gloo" is used by the CPU tests.  `linear_op` stays the GEMM plug point (tensor_parallel.py:50,
 :125): the DeepSeek modules pass the HIP fp8 linear through it.
 
-All collectives go through `all_reduce` / `all_gather_last_dim` below so the decode step has ONE
-place where communication is issued (and where a custom xGMI all-reduce can later replace RCCL).
+All collectives go through `all_reduce` / `defer_all_reduce` / `all_gather_last_dim` below, so the
+decode step has ONE place where communication is issued.  Two transports sit behind that seam: the
+library (`torch.distributed`: RCCL, or gloo in the CPU tests) and, after `enable_xgmi()`, the in-graph
+xGMI kernels of csrc/comm.hip (chitu_amd/xgmi.py) for decode-sized bf16 tensors -- with those the whole
+step is one hipGraph, as in the reference (chitu/models/model.py:554-617), and an all-reduce is fused
+with the top-k sum in front of it and the residual add + RMSNorm + fp8 quant behind it.
 """
 
 __all__ = [
@@ -17,6 +21,9 @@ __all__ = [
     "ColumnParallelLinear",
     "RowParallelLinear",
     "VocabParallelEmbedding",
+    "enable_xgmi",
+    "all_reduce",
+    "all_gather_last_dim",
 ]
 
 import torch
@@ -58,15 +65,104 @@ def get_tp_rank():
 
 
 # Piecewise hipGraph capture (deepseek_v3.DeepSeekV3Decoder.decode, mode "piecewise"): while a step is
-# being captured this is a callable `cut(run)`; every collective below then ENDS the graph piece being
+# being captured this is a callable `cut(run)`; every LIBRARY collective below then ENDS the graph piece being
 # recorded, hands its own launch (`run`, or None when the group has one rank) to the capture to be issued
-# eagerly between the pieces at replay time, and a new piece begins.  No collective is ever recorded into
-# a graph that way, so the N > 1 step does not depend on RCCL being capturable.
+# eagerly between the pieces at replay time, and a new piece begins.  No library collective is ever recorded
+# into a graph that way, so that path does not depend on RCCL being capturable.  With the in-graph xGMI
+# collectives (`enable_xgmi`) there is nothing to cut: they are ordinary kernel launches.
 _graph_break = None
+
+# XgmiComm of this rank when the hand-written collectives (csrc/comm.hip) carry the decode step, else None.
+_xgmi = None
+
+
+def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, timeout_ms: int = 20000,
+                selftest: bool = True) -> bool:
+    """Switch the TP group's decode-sized collectives to the in-graph xGMI kernels: every rank creates its
+    buffer, the IPC handles travel over the process group, and (selftest) one all-reduce and one all-gather are
+    checked against the library's on every rank.  All ranks agree on the outcome (an all-reduce of the verdicts);
+    on any failure the library path stays in place and False is returned.  Collective over the TP group."""
+    global _xgmi
+    if get_tp_size() <= 1 or not torch.cuda.is_available():
+        return False
+    from .xgmi import XgmiComm
+
+    group, rank, world = get_tp_group(), get_tp_rank(), get_tp_size()
+    ok, comm, why = 1, None, ""
+    try:
+        comm = XgmiComm.from_group(group, max_rows=max_rows, max_dim=max_dim, gather_bytes=gather_bytes,
+                                   timeout_ms=timeout_ms)
+        if selftest:
+            # the library's answer is computed where its backend works (gloo: host tensors)
+            lib_dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+            dim = min(max_dim, 1024)
+            for rows in (1, min(max_rows, 5)):
+                part = torch.randn(rows, dim, device="cuda", generator=gen).to(torch.bfloat16)
+                want = part.float().to(lib_dev)
+                dist.all_reduce(want, group=group)  # fp32 sum: order-free up to rounding
+                got = comm.allreduce_rmsnorm(part).float().to(lib_dev)
+                if comm.status() != 0 or not torch.allclose(got, want, rtol=2e-2, atol=2e-2):
+                    ok, why = 0, "all-reduce self-test mismatch / timeout"
+            if ok and gather_bytes >= 2 * 32 * 2:
+                y = torch.randn(2, 32, device="cuda", generator=gen).to(torch.bfloat16)
+                ref = [torch.empty(2, 32, dtype=torch.float32, device=lib_dev) for _ in range(world)]
+                dist.all_gather(ref, y.float().to(lib_dev), group=group)
+                got = comm.all_gather_last_dim(y).float().to(lib_dev)
+                if comm.status() != 0 or not torch.equal(got, torch.cat(ref, dim=-1)):
+                    ok, why = 0, "all-gather self-test mismatch / timeout"
+    except Exception as e:  # noqa: BLE001 -- any setup failure means: keep the library path
+        ok, why = 0, repr(e)
+    verdict = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+    if int(verdict.item()) != 1:
+        if why:
+            print(f"[chitu_amd] rank {rank}: xGMI collectives not enabled ({why}); using the library path", flush=True)
+        if comm is not None:
+            comm.close()
+        return False
+    _xgmi = comm
+    return True
+
+
+def disable_xgmi():
+    global _xgmi
+    if _xgmi is not None:
+        _xgmi.close()
+    _xgmi = None
+
+
+def xgmi_comm():
+    return _xgmi
+
+
+class PendingAllReduce:
+    """A rank's partial ([rows, dim] or the fused MoE's un-summed [rows, terms, dim]) whose all-reduce has been
+    handed to the kernel that consumes it: [top-k sum ->] all-reduce -> residual add -> RMSNorm -> quant is one
+    launch (XgmiComm.allreduce_rmsnorm).  `resolve()` performs the plain all-reduce instead."""
+
+    __slots__ = ("part",)
+
+    def __init__(self, part):
+        self.part = part
+
+    def resolve(self) -> torch.Tensor:
+        return _xgmi.allreduce_rmsnorm(self.part)
+
+
+def resolve(t):
+    return t.resolve() if isinstance(t, PendingAllReduce) else t
+
+
+def _xgmi_fits(t: torch.Tensor) -> bool:
+    return (_xgmi is not None and t.is_cuda and t.dtype == torch.bfloat16 and t.dim() >= 2 and t.is_contiguous()
+            and _xgmi.fits(t.numel() // t.shape[-1], t.shape[-1]))
 
 
 def all_reduce(t: torch.Tensor) -> torch.Tensor:
     """Sum over the TP group, in place (tensor_parallel.py:166, model_deepseek_v3.py:1011)."""
+    if get_tp_size() > 1 and _xgmi_fits(t):
+        return _xgmi.all_reduce_(t)
     run = (lambda: dist.all_reduce(t, group=get_tp_group())) if get_tp_size() > 1 else None
     if _graph_break is not None:
         _graph_break(run)
@@ -75,12 +171,42 @@ def all_reduce(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def all_gather_last_dim(y: torch.Tensor) -> torch.Tensor:
+def defer_all_reduce(t: torch.Tensor):
+    """The all-reduce of a decode-step partial that the next residual-add + RMSNorm consumes.  t: [rows, dim], or
+    the fused MoE's un-summed [rows, terms, dim] when `defers_topk_sum()`.  One rank: t itself (the norm sums
+    the terms); xGMI collectives: a PendingAllReduce (the norm launch does the reduction); library path: the
+    all-reduced tensor."""
+    if get_tp_size() == 1:
+        return t
+    if _xgmi is not None and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and (
+            (t.dim() == 2 and _xgmi.fits(t.shape[0], t.shape[1])) or
+            (t.dim() == 3 and _xgmi.fits(t.shape[0], t.shape[2], t.shape[1]))):
+        return PendingAllReduce(t)
+    assert t.dim() == 2, "the library all-reduce needs the summed tensor"
+    return all_reduce(t)
+
+
+def defers_topk_sum(rows: int, dim: int, terms: int) -> bool:
+    """May the fused MoE leave its top-k sum to the consumer of defer_all_reduce()?  Yes when nothing sits
+    between the experts and the next norm (one rank) or when the in-graph all-reduce takes the terms."""
+    if terms > 16:  # chitu_hip_rmsnorm / comm_allreduce_rmsnorm sum <= 16 terms
+        return False
+    return get_tp_size() == 1 or (_xgmi is not None and _xgmi.fits(rows, dim, terms))
+
+
+def all_gather_last_dim(y: torch.Tensor, out_dtype=None) -> torch.Tensor:
     """Concatenate the last dimension over TP ranks (tensor_parallel.py:94-102: the reference
-    gathers on a permuted [N/tp, ...] layout so the result is rank-major along the last dim)."""
+    gathers on a permuted [N/tp, ...] layout so the result is rank-major along the last dim).  out_dtype:
+    cast of the result folded into the gather (the logits' `.float()`)."""
     tp = get_tp_size()
     if tp == 1:
-        return y
+        return y if out_dtype is None else y.to(out_dtype)
+    if (_xgmi is not None and y.is_cuda and y.dtype == torch.bfloat16 and y.stride(-1) == 1
+            and out_dtype in (None, torch.bfloat16, torch.float32)):
+        y2 = y.reshape(-1, y.shape[-1])
+        if _xgmi.gather_fits(y2.shape[0], y2.shape[1]):
+            out = _xgmi.all_gather_last_dim(y2, out_dtype or torch.bfloat16)
+            return out.view(*y.shape[:-1], out.shape[-1])
     y_t = y.permute(-1, *range(y.dim() - 1)).contiguous()
     shape = list(y_t.shape)
     shape[0] *= tp
@@ -90,7 +216,8 @@ def all_gather_last_dim(y: torch.Tensor) -> torch.Tensor:
         _graph_break(run)
     else:
         run()
-    return gathered.permute(*range(1, y.dim()), 0)
+    out = gathered.permute(*range(1, y.dim()), 0)
+    return out if out_dtype is None else out.to(out_dtype)
 
 
 class _ShardedLinear(torch.nn.Module):

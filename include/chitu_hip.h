@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define CHITU_HIP_ABI_VERSION 1
+#define CHITU_HIP_ABI_VERSION 2
 
 /* ---- fused MoE: token alignment -------------------------------------------------
  * Replaces chitu_backend.cuda_moe_align_block_size (reference csrc/binding.cpp:11,
@@ -447,6 +447,50 @@ int chitu_hip_sample(const void* logits, int act_dtype, int64_t row_stride, int6
                      const float* temperatures, const int32_t* top_ks, const float* top_ps,
                      const float* uniforms, int32_t probs_mode, int64_t* out_tokens,
                      int32_t* n_kept_out, float* kept_mass_out, void* stream);
+
+/* ---- in-graph tensor-parallel collectives over xGMI (csrc/comm.hip) --------------------------------
+ * Replace the NCCL calls of the reference's decode step -- dist.all_reduce after every RowParallelLinear
+ * (chitu/tensor_parallel.py:157-169) and after the MoE (chitu/models/model_deepseek_v3.py:1010-1011), the
+ * all_gather_into_tensor of a gather_output ColumnParallelLinear (tensor_parallel.py:94-102) -- with plain
+ * kernel launches that a hipGraph captures like any other (the reference captures its NCCL calls into the
+ * step's CUDA graph, chitu/models/model.py:554-617).
+ * SETUP entries (these DO allocate / synchronise; call them once, outside any capture):
+ *   comm_create: one uncached device buffer on the current device for rank `rank` of `world` (<= 8) ranks:
+ *     all-reduce of up to max_rows x max_dim bf16 (max_dim <= 8192), all-gather of up to gather_bytes per rank;
+ *     every wait inside the kernels gives up after timeout_ms and sets a sticky error word (comm_status).
+ *   comm_ipc_handle / comm_open_peer: the 64-byte hipIpcMemHandle_t of this rank's buffer / map a peer's
+ *     (ranks in different processes; exchange the handles over any host channel, e.g. the process group's
+ *     store).  comm_local_ptr / comm_set_peer: the same for ranks that share one process (raw pointers).
+ *     Every rank must have created (and thereby zeroed) its buffer before any peer launches a collective.
+ *   comm_status: blocking read of the error word (0 = fine, bit 0 = a wait timed out).
+ * COLLECTIVES (enqueue only; every rank of the group must issue the same sequence of calls):
+ *   comm_allreduce_rmsnorm -- one launch for [top-k sum ->] all-reduce -> residual add -> RMSNorm -> fp8 quant:
+ *     part_r = terms > 1 ? bf16(sum_k float(part[row*part_row_stride + k*term_stride + :])) : part[row]
+ *              (terms <= 16: chitu_hip_moe_sum's arithmetic, fused_moe.py:1299-1305)
+ *     a      = bf16(sum over ranks r = 0..world-1, in that order, of float(part_r))   -- identical on every rank
+ *     v      = x ? bf16(x + a) : a            -> sum_out [rows, dim]   (optional when a weight is given)
+ *     weight: y = rmsnorm(v) * weight -> y_bf16 and / or (q_fp8, q_scales), exactly chitu_hip_rmsnorm's
+ *     arithmetic and quant modes; weight == NULL: plain all-reduce (y, q must be NULL, sum_out required).
+ *     rows <= max_rows, dim <= max_dim, dim % 8 == 0 (CHITU_ERR_UNSUPPORTED otherwise: use the library path).
+ *   comm_all_gather: out[row, r*cols + j] = in_r[row, j] (rank-major concat of the last dimension);
+ *     in bf16 [rows, cols] (row stride given, cols % 8 == 0, rows*cols*2 <= gather_bytes); out_dtype 0 = bf16,
+ *     2 = f32 (the logits' `.float()`, models/model.py:475, rides along); out [rows, world*cols] dense. */
+int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_rows, int32_t max_dim,
+                          int64_t gather_bytes, int32_t timeout_ms, void** comm_out);
+int chitu_hip_comm_ipc_handle(void* comm, void* handle_out_64);
+int chitu_hip_comm_open_peer(void* comm, int32_t peer, const void* handle_64);
+int chitu_hip_comm_local_ptr(void* comm, void** ptr_out);
+int chitu_hip_comm_set_peer(void* comm, int32_t peer, void* ptr);
+int chitu_hip_comm_status(void* comm, uint32_t* err_out);
+int chitu_hip_comm_destroy(void* comm);
+int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf16, int64_t part_row_stride,
+                                     int32_t terms, int64_t term_stride, const void* x_bf16,
+                                     int64_t x_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                     const void* weight_bf16, void* y_bf16, int64_t y_row_stride,
+                                     int64_t rows, int32_t dim, float eps, void* q_fp8, float* q_scales,
+                                     int32_t quant_mode, float quant_eps, void* stream);
+int chitu_hip_comm_all_gather(void* comm, const void* in_bf16, int64_t in_row_stride, int64_t rows,
+                              int64_t cols, void* out, int32_t out_dtype, void* stream);
 
 #ifdef __cplusplus
 }

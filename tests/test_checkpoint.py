@@ -96,9 +96,9 @@ def test_load_into_module_tree_and_save_round_trip(rank, tmp_path):
 
     save_file({k: v.contiguous() for k, v in tiny_hf_checkpoint().items()}, str(tmp_path / "model-00001-of-00001.safetensors"))
     model = DeepSeekV3Decoder(_args(2), None, None, max_position_embeddings=64, device="cpu")
-    model.layers[1].attn._w_uk_t = "stale"
+    model.layers[1].attn._w_uk_key = "stale"
     ck.load_checkpoint_deepseek_v3(model, str(tmp_path), rank=rank, world=2)
-    assert model.layers[1].attn._w_uk_t is None
+    assert model.layers[1].attn._w_uk_key is None
     want = ck.to_module_names(ck.preprocess_deepseek_v3(_renamed(), 4, rank, 2))
     params = dict(model.named_parameters())
     assert set(params) == set(want)
@@ -191,3 +191,39 @@ def test_expert_parallel_layout_partitions_the_checkpoint_and_loads():
         assert moe.expert_map.tolist() == [0, 1, -1, -1] if r == 0 else moe.expert_map.tolist() == [-1, -1, 0, 1]
     with pytest.raises(ValueError):
         ck.preprocess_deepseek_v3(_renamed(), nr, 0, 2, moe_world_size=4)
+
+
+def test_two_shared_experts_become_two_slots_of_the_routed_width():
+    """DeepSeek-V2-Lite layout (n_shared_experts = 2): the HF shared MLP of width 2*I is cut into two expert slots
+    of width I -- rows of w1 / w3 inside the merged w1w3, columns of w2, block scales alike -- so that running the
+    slots as experts with weight 1 and summing equals the one wide MLP.  n_shared = 1 stays the reference's append."""
+    g = torch.Generator().manual_seed(3)
+    I, K, nr = 256, 384, 3
+    st = {}
+    for i in range(nr):
+        st[f"layers.1.ffn.experts.{i}.w1.weight"] = torch.randn(I, K, generator=g)
+        st[f"layers.1.ffn.experts.{i}.w3.weight"] = torch.randn(I, K, generator=g)
+        st[f"layers.1.ffn.experts.{i}.w2.weight"] = torch.randn(K, I, generator=g)
+        st[f"layers.1.ffn.experts.{i}.w1.scale"] = torch.rand(I // 128, K // 128, generator=g)
+        st[f"layers.1.ffn.experts.{i}.w3.scale"] = torch.rand(I // 128, K // 128, generator=g)
+        st[f"layers.1.ffn.experts.{i}.w2.scale"] = torch.rand(K // 128, I // 128, generator=g)
+    sw1, sw3, sw2 = torch.randn(2 * I, K, generator=g), torch.randn(2 * I, K, generator=g), torch.randn(K, 2 * I, generator=g)
+    st["layers.1.ffn.shared_experts.w1.weight"], st["layers.1.ffn.shared_experts.w3.weight"] = sw1, sw3
+    st["layers.1.ffn.shared_experts.w2.weight"] = sw2
+    st["layers.1.ffn.shared_experts.w1.scale"] = torch.rand(2 * I // 128, K // 128, generator=g)
+    st["layers.1.ffn.shared_experts.w3.scale"] = torch.rand(2 * I // 128, K // 128, generator=g)
+    st["layers.1.ffn.shared_experts.w2.scale"] = torch.rand(K // 128, 2 * I // 128, generator=g)
+    out = ck.preprocess_deepseek_v3(st, nr, n_shared=2)
+    w13, w2 = out["layers.1.ffn.w1w3.weight"], out["layers.1.ffn.w2.weight"]
+    assert w13.shape == (nr + 2, 2 * I, K) and w2.shape == (nr + 2, K, I)
+    assert out["layers.1.ffn.w1w3.scale"].shape == (nr + 2, 2 * I // 128, K // 128)
+    assert out["layers.1.ffn.w2.scale"].shape == (nr + 2, K // 128, I // 128)
+    x = torch.randn(5, K, generator=g)
+    wide = (torch.nn.functional.silu(x @ sw1.T) * (x @ sw3.T)) @ sw2.T
+    slots = sum((torch.nn.functional.silu(x @ w13[nr + j, :I].T) * (x @ w13[nr + j, I:].T)) @ w2[nr + j].T for j in range(2))
+    assert torch.allclose(wide, slots, rtol=1e-4, atol=1e-3)
+    for j in range(2):
+        assert torch.equal(out["layers.1.ffn.w1w3.scale"][nr + j, : I // 128], st["layers.1.ffn.shared_experts.w1.scale"][j * (I // 128):(j + 1) * (I // 128)])
+        assert torch.equal(out["layers.1.ffn.w2.scale"][nr + j], st["layers.1.ffn.shared_experts.w2.scale"][:, j * (I // 128):(j + 1) * (I // 128)])
+    with pytest.raises(ValueError):  # the wide MLP handed over as ONE slot does not have the routed experts' shape
+        ck.preprocess_deepseek_v3(st, nr, n_shared=1)

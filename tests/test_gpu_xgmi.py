@@ -1,0 +1,374 @@
+"""In-graph xGMI collectives (csrc/comm.hip, chitu_amd/xgmi.py) vs the oracle (oracle/comm.py).
+
+A 1-GPU box has no second device, so the ranks share `cuda:0`:
+  * two ranks inside ONE process, each on its own stream, wired with raw pointers -- the kernels' protocol
+    (push, flag, wait, rank-order reduction, epochs under hipGraph replay);
+  * 2 / 4 / 8 ranks as separate PROCESSES exchanging hipIpcMemHandles over a gloo group -- the real wiring
+    (`tensor_parallel.enable_xgmi`), the same code path an 8-GPU node runs; then a TP=2 DeepSeek decode
+    step captured as ONE hipGraph on the xGMI collectives against eager launches on the library's.
+Bar: bit-exact (the kernels' arithmetic is fully specified: fp32 sum in rank order, one rounding, then
+chitu_hip_rmsnorm's arithmetic).  Every in-kernel wait is bounded, so a broken hand-off fails, it does not hang.
+"""
+
+import os
+import socket
+
+import pytest
+import torch
+
+from oracle import comm as ocomm
+from tests.util import bits16, bits8
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # rows, dim, terms, residual, norm, quant
+    (1, 7168, 1, False, False, None),
+    (16, 7168, 1, True, True, "act"),
+    (16, 7168, 9, True, True, "group"),
+    (1, 7168, 9, True, True, "group"),
+    (32, 7168, 1, True, True, "act"),
+    (5, 512, 3, True, True, None),
+    (3, 8192, 1, False, True, "act"),
+    (7, 2048, 16, True, False, None),
+    (16, 7168, 1, True, True, "act"),
+]
+
+
+def _inputs(case, rank, salt=0):
+    rows, dim, terms, has_x, has_w, _ = case
+    g = torch.Generator().manual_seed(1000 * salt + 17 * rank + rows + dim + terms)
+    shape = (rows, terms, dim) if terms > 1 else (rows, dim)
+    part = (torch.randn(shape, generator=g) * 0.7).to(torch.bfloat16)
+    g2 = torch.Generator().manual_seed(77 + salt + rows + dim)  # replicated tensors: same on every rank
+    x = (torch.randn(rows, dim, generator=g2)).to(torch.bfloat16) if has_x else None
+    w = (1 + 0.1 * torch.randn(dim, generator=g2)).to(torch.bfloat16) if has_w else None
+    return part, x, w
+
+
+def _expected(case, world, salt=0):
+    parts = [_inputs(case, r, salt)[0] for r in range(world)]
+    _, x, w = _inputs(case, 0, salt)
+    return ocomm.allreduce_rmsnorm(parts, x, w, 1e-6, case[5])
+
+
+def _run_case(comm, case, rank, salt=0):
+    part, x, w = _inputs(case, rank, salt)
+    part, x, w = part.cuda(), (x.cuda() if x is not None else None), (w.cuda() if w is not None else None)
+    res = comm.allreduce_rmsnorm(part, x, w, 1e-6, out_bf16=True, quant=case[5])
+    return res if isinstance(res, tuple) else (res,)
+
+
+def _check(res, exp, what):
+    v, y, q, s = exp
+    assert (bits16(res[0]) == bits16(v)).all(), (what, "all-reduced / residual stream")
+    if y is not None:
+        assert (bits16(res[1]) == bits16(y)).all(), (what, "norm output")
+    if q is not None:
+        assert (bits8(res[2]) == bits8(q)).all(), (what, "fp8 codes")
+        assert torch.equal(res[3].cpu(), s), (what, "scales")
+
+
+# ------------------------------------------------------------------ two ranks, one process
+def _local_pair(**kw):
+    from chitu_amd.xgmi import XgmiComm
+
+    comms = [XgmiComm(r, 2, timeout_ms=3000, **kw) for r in range(2)]
+    XgmiComm.connect_local(comms)
+    return comms, [torch.cuda.Stream() for _ in range(2)]
+
+
+def test_two_ranks_one_process_every_fusion_is_bit_exact():
+    comms, streams = _local_pair(max_rows=32, max_dim=8192)
+    torch.cuda.synchronize()
+    for salt in range(3):  # the same slots again: epochs / parity advance
+        for case in CASES:
+            out = []
+            for r in range(2):
+                with torch.cuda.stream(streams[r]):
+                    out.append(_run_case(comms[r], case, r, salt))
+            torch.cuda.synchronize()
+            assert [c.status() for c in comms] == [0, 0], case
+            exp = _expected(case, 2, salt)
+            for r in range(2):
+                _check(out[r], exp, (case, salt, r))
+    for c in comms:
+        c.close()
+
+
+def test_two_ranks_one_process_graph_replay_and_in_place():
+    """A chain of collectives captured once per rank and replayed with new inputs: the flags' epochs live in
+    device memory, so a replay is a new call; the in-place plain all-reduce (`out` aliasing `part`)."""
+    comms, streams = _local_pair(max_rows=16, max_dim=7168)
+    case = (16, 7168, 1, True, True, "act")
+    statics, graphs, outs = [], [], []
+    for r in range(2):
+        part, x, w = _inputs(case, r)
+        statics.append((part.cuda(), x.cuda(), w.cuda()))
+    torch.cuda.synchronize()
+
+    def chain(r):
+        part, x, w = statics[r]
+        xn, y, q, s = comms[r].allreduce_rmsnorm(part, x, w, 1e-6, quant="act")
+        t = y.clone()
+        comms[r].all_reduce_(t)  # in place, chained on the first one's output
+        xn2, y2 = comms[r].allreduce_rmsnorm(t, xn, w, 1e-6)
+        return xn, y, q, s, t, xn2, y2
+
+    for r in range(2):  # eager warm-up of both ranks (a capture executes nothing)
+        with torch.cuda.stream(streams[r]):
+            chain(r)
+    torch.cuda.synchronize()
+    for r in range(2):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(streams[r]):
+            with torch.cuda.graph(g, stream=streams[r]):
+                outs.append(chain(r))
+        graphs.append(g)
+    for salt in range(1, 5):
+        for r in range(2):
+            part, x, w = _inputs(case, r, salt)
+            statics[r][0].copy_(part)
+            statics[r][1].copy_(x)
+            statics[r][2].copy_(w)
+        torch.cuda.synchronize()
+        for r in range(2):
+            with torch.cuda.stream(streams[r]):
+                graphs[r].replay()
+        torch.cuda.synchronize()
+        assert [c.status() for c in comms] == [0, 0]
+        parts = [_inputs(case, r, salt)[0] for r in range(2)]
+        _, x, w = _inputs(case, 0, salt)
+        xn, y, q, s = ocomm.allreduce_rmsnorm(parts, x, w, 1e-6, "act")
+        t = ocomm.all_reduce([y, y])
+        xn2, y2, _, _ = ocomm.allreduce_rmsnorm([t, t], xn, w, 1e-6)
+        for r in range(2):
+            _check(outs[r][:4], (xn, y, q, s), (salt, r, "first"))
+            assert (bits16(outs[r][4]) == bits16(t)).all()
+            _check(outs[r][5:], (xn2, y2, None, None), (salt, r, "third"))
+    for c in comms:
+        c.close()
+
+
+def test_missing_peer_times_out_instead_of_hanging():
+    """Rank 1 never launches: rank 0's wait gives up after the timeout, the error word is sticky and later
+    launches return at once."""
+    import time
+
+    from chitu_amd.xgmi import XgmiComm
+
+    comms = [XgmiComm(r, 2, max_rows=4, max_dim=512, timeout_ms=300) for r in range(2)]
+    XgmiComm.connect_local(comms)
+    part = torch.ones(4, 512, dtype=torch.bfloat16, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    comms[0].allreduce_rmsnorm(part)
+    torch.cuda.synchronize()
+    first = time.time() - t0
+    assert comms[0].status() == 1 and 0.2 < first < 5.0
+    t0 = time.time()
+    for _ in range(20):
+        comms[0].allreduce_rmsnorm(part)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 0.3 and comms[1].status() == 0
+    for c in comms:
+        c.close()
+
+
+def test_unsupported_shapes_are_refused_not_truncated():
+    from chitu_amd._lib import HipCallError
+    from chitu_amd.xgmi import XgmiComm
+
+    comms = [XgmiComm(r, 2, max_rows=4, max_dim=512, gather_bytes=1024, timeout_ms=300) for r in range(2)]
+    with pytest.raises(HipCallError):  # peers not wired yet
+        comms[0].allreduce_rmsnorm(torch.ones(1, 512, dtype=torch.bfloat16, device="cuda"))
+    XgmiComm.connect_local(comms)
+    for bad in (torch.ones(5, 512), torch.ones(1, 1024), torch.ones(1, 17, 512)):
+        with pytest.raises(HipCallError):
+            comms[0].allreduce_rmsnorm(bad.to(torch.bfloat16).cuda())
+    with pytest.raises(HipCallError):
+        comms[0].all_gather_last_dim(torch.ones(2, 512, dtype=torch.bfloat16, device="cuda"))  # 2 KB > 1 KB
+    for c in comms:
+        c.close()
+
+
+# ------------------------------------------------------------------ one process per rank, IPC handles
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(fn, world, *args, timeout=420):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = [q.get(timeout=timeout) for _ in range(world)]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()  # our own children, by handle
+    for r in results:
+        assert r[1] == "ok", r
+    return results
+
+
+def _entry(fn, rank, world, port, q, *args):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from chitu_amd import tensor_parallel as tp
+
+        tp.init_tp(world, 1)
+        fn(rank, world, *args)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tp.disable_xgmi()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except BaseException as e:  # noqa: BLE001 -- reported to the parent
+        import traceback
+
+        q.put((rank, "fail: " + repr(e) + traceback.format_exc()))
+
+
+def _collectives_worker(rank, world):
+    import torch.distributed as dist
+
+    from chitu_amd import tensor_parallel as tp
+
+    assert tp.enable_xgmi(max_rows=32, max_dim=8192, gather_bytes=16 * 16160 * 2, timeout_ms=8000), "xGMI setup / self-test failed"
+    comm = tp.xgmi_comm()
+    for salt in range(2):
+        for case in CASES:
+            res = _run_case(comm, case, rank, salt)
+            torch.cuda.synchronize()
+            assert comm.status() == 0, case
+            _check(res, _expected(case, world, salt), (case, salt, rank))
+    # tensor_parallel's seam: all_reduce in place, all_gather with the fp32 cast folded in
+    for rows, cols in ((16, 16160), (1, 16160), (3, 64)):
+        ys = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(5 + r + rows)) * 3).to(torch.bfloat16) for r in range(world)]
+        got = tp.all_gather_last_dim(ys[rank].cuda(), out_dtype=torch.float32)
+        assert got.dtype == torch.float32 and torch.equal(got.cpu(), ocomm.all_gather_last_dim(ys, torch.float32))
+        got = tp.all_gather_last_dim(ys[rank].cuda())
+        assert (bits16(got) == bits16(ocomm.all_gather_last_dim(ys))).all()
+    t = _inputs(CASES[1], rank)[0].cuda()
+    want = ocomm.all_reduce([_inputs(CASES[1], r)[0] for r in range(world)])
+    assert tp.all_reduce(t) is t and (bits16(t) == bits16(want)).all()
+    if world == 2:  # order-free: must equal what ANY all-reduce gives, e.g. the library's on the same inputs
+        lib = _inputs(CASES[1], rank)[0].float()
+        dist.all_reduce(lib)
+        assert torch.equal(lib.to(torch.bfloat16), want)
+    # hipGraph: a chain captured once, replayed with new inputs on every rank
+    case = (16, 7168, 9, True, True, "group")
+    part, x, w = [v.cuda() for v in _inputs(case, rank)]
+    comm.allreduce_rmsnorm(part, x, w, 1e-6, quant="group")
+    torch.cuda.synchronize()
+    dist.barrier()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = comm.allreduce_rmsnorm(part, x, w, 1e-6, quant="group")
+        gathered = comm.all_gather_last_dim(out[1][:, :4096])
+    for salt in range(1, 6):
+        p2, x2, w2 = _inputs(case, rank, salt)
+        part.copy_(p2), x.copy_(x2), w.copy_(w2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert comm.status() == 0
+        exp = _expected(case, world, salt)
+        _check(out, exp, ("graph", salt, rank))
+        assert (bits16(gathered) == bits16(torch.cat([exp[1][:, :4096]] * world, dim=-1))).all()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_ranks_as_processes_over_ipc_handles(world):
+    _spawn(_collectives_worker, world)
+
+
+def _decode_worker(rank, world):
+    """TP = world decode of a tiny DeepSeek-V3: eager launches + library all-reduce (gloo) vs ONE hipGraph on
+    the xGMI collectives, same rank-local weights and cache contents, teacher-forced tokens."""
+    import torch.distributed as dist
+
+    from chitu_amd import graphs
+    from chitu_amd import tensor_parallel as tp
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args, DeepSeekV3Decoder, init_synthetic_
+
+    # heads and FFN / expert widths scale with the world, so a rank's shard has the tiny model's tested shapes
+    args = DeepSeekV3Args(
+        vocab_size=1024, dim=512, inter_dim=1024 * world, moe_inter_dim=256 * world, n_layers=3, n_dense_layers=1,
+        n_heads=16 * world, n_routed_experts=16, n_shared_experts=1, n_activated_experts=4, n_expert_groups=4,
+        n_limited_groups=2, q_lora_rank=256, gate_bias=True)
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=4, block_size=64, max_seq_len=256, device="cuda",
+                                kv_shape_per_sample=(576,), dtype=torch.bfloat16)
+    model = DeepSeekV3Decoder(args, cache, HipAttnBackend(local_n_heads=16, max_seq_len=256),
+                              max_position_embeddings=256, device="cuda")
+    # rank-local synthetic weights; the replicated ones (router, wqkv_a, norms, embedding rows) differ per rank,
+    # which a transport comparison does not mind: both runs see the same rank-local model
+    init_synthetic_(model, seed=100 + rank)
+    starts = (60, 63, 127)
+
+    def fresh(tag):
+        reqs = [f"{tag}{i}" for i in range(3)]
+        g = torch.Generator().manual_seed(99)
+        for r, n in zip(reqs, starts):
+            cache.register_sequence(r, n)
+            rows = (torch.randn(args.n_layers, 256, 576, generator=g) * 0.5).to(torch.bfloat16).cuda()
+            for p, blk in enumerate(cache.block_table[r]):
+                cache.paged_kv_cache[:, blk] = rows[:, p * 64 : (p + 1) * 64]
+        return reqs
+
+    def run(reqs, use_graph, forced=None, steps=6):
+        toks = torch.tensor([5, 17, 900], dtype=torch.int64, device="cuda")
+        logits_all, toks_all = [], []
+        for step in range(steps):
+            cache.prepare_cache_decode(reqs)
+            cache.prepare_block_table_for_decode(reqs)
+            logits = model.decode(toks, use_graph=use_graph).clone()
+            cache.finalize_cache_single_decode(reqs)
+            logits_all.append(logits)
+            toks = logits.argmax(-1) if forced is None else forced[step]
+            toks_all.append(toks.clone())
+        return logits_all, toks_all
+
+    ra = fresh("lib")
+    l_lib, t_lib = run(ra, False)  # library collectives (gloo moves the device tensors through the host)
+    for r in ra:
+        cache.finalize_cache_all_decode(r)
+    assert tp.enable_xgmi(max_rows=16, max_dim=1024, gather_bytes=16 * args.vocab_size * 2, timeout_ms=8000)
+    assert graphs.graph_mode(True) == "full"
+    rb = fresh("xg")
+    l_x, _ = run(rb, True, forced=t_lib)
+    assert tp.xgmi_comm().status() == 0
+    assert isinstance(model.graphs[(3, "full")], torch.cuda.CUDAGraph)
+    for step, (a, b) in enumerate(zip(l_lib, l_x)):
+        assert torch.isfinite(a).all()
+        if world == 2:
+            assert torch.equal(a, b), step  # two ranks: the sum has one possible value
+        else:
+            assert (a - b).abs().max() <= 2e-2 * a.abs().max(), step
+    # every rank holds the same logits (replicated sampling relies on it)
+    mine = l_x[-1].cpu()
+    ref = mine.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(mine, ref)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tp_decode_step_one_graph_on_xgmi_equals_eager_on_library(world):
+    _spawn(_decode_worker, world)
