@@ -120,6 +120,7 @@ def enable_collectives(world, max_bs, vocab_local):
     return f"{dist.get_backend()} (library calls between hipGraph pieces)"
 
 
+@torch.inference_mode()  # like the decode step: the capture touches state created under inference mode
 def time_collectives(bs, dim, vocab_local, iters=200):
     """GPU time of one fused all-reduce launch and one logits all-gather at this batch size: `iters` launches
     of each captured in a hipGraph, timed with events on the replay stream (every rank runs them)."""

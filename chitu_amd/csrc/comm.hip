@@ -35,13 +35,14 @@
 // Failure.  Every spin is bounded (wall clock, `timeout_ms` at creation); a timeout sets a sticky error
 // word that later waits test first, so a missing peer costs one timeout per process, not one per launch.
 #include "common.h"
+#include "norm_common.h"
 #include <string.h>
 
 namespace chitu {
 
 constexpr int kCommMaxRanks = 8;
-constexpr int kCommThreads = 1024;
-constexpr int kCommMaxTerms = 16;
+constexpr int kCommThreads = kNormWideThreads;  // one 8-element chunk per thread, the wide row form of norm_common.h
+constexpr int kCommMaxTerms = kNormMaxTerms;
 constexpr int kCommAux = 17;  // sc0 | sc1: system scope, write-through / L2 bypass
 
 struct CommPeers {
@@ -135,25 +136,7 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
     if (x) xraw = *reinterpret_cast<const i32x4*>(x + (int64_t)row * x_stride + c * 8);
     if (w) wraw = *reinterpret_cast<const i32x4*>(w + c * 8);
 
-    i32x4 mine;
-    if (terms == 1) {
-        mine = traw[0];
-    } else {
-        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < kCommMaxTerms; ++k) {
-            if (k < terms) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t u = (uint32_t)traw[k][i];
-                    a[2 * i] += __uint_as_float(u << 16);
-                    a[2 * i + 1] += __uint_as_float(u & 0xffff0000u);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mine[i] = (int)f32x2_to_bf16x2(a[2 * i], a[2 * i + 1]);
-    }
+    const i32x4 mine = terms == 1 ? traw[0] : sum_terms_bf16x8<kCommMaxTerms>(traw, terms);
 
     // push this rank's row into its slot of every peer
     const uint32_t slot_off = (uint32_t)(((((int64_t)parity * kCommMaxRanks + g.rank) * g.max_rows + row) * g.max_dim + c * 8) * 2);
@@ -190,60 +173,16 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
             }
         }
     }
-    float v[8], ss = 0.f;
-    i32x4 sraw;
+    i32x4 sraw;  // the all-reduce's rounding
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint32_t s2 = f32x2_to_bf16x2(a[2 * i], a[2 * i + 1]);  // the all-reduce's rounding
-        if (x) {
-            const uint32_t u = (uint32_t)xraw[i];
-            s2 = f32x2_to_bf16x2(__uint_as_float(u << 16) + __uint_as_float(s2 << 16),
-                                 __uint_as_float(u & 0xffff0000u) + __uint_as_float(s2 & 0xffff0000u));
-        }
-        v[2 * i] = __uint_as_float(s2 << 16);
-        v[2 * i + 1] = __uint_as_float(s2 & 0xffff0000u);
-        sraw[i] = (int)s2;
-    }
+    for (int i = 0; i < 4; ++i) sraw[i] = (int)f32x2_to_bf16x2(a[2 * i], a[2 * i + 1]);
+    float v[8];
+    if (x) add_bf16x8(xraw, sraw, v, sraw);
+    else unpack_bf16x8(sraw, v);
     if (act && sum_out) *reinterpret_cast<i32x4*>(sum_out + (int64_t)row * sum_stride + tid * 8) = sraw;
     if (tid == 0) epoch_ar[row] = epoch;
     if (!w) return;  // uniform
-
-    if (act) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
-    }
-    ss = wave_reduce_sum(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
-    __syncthreads();
-    ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < kCommThreads / 64; ++i) ss += red[i];
-    const float rr = rsqrtf(ss / (float)dim + eps);
-    float o[8];
-    i32x4 out;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t u = (uint32_t)wraw[i];
-        const uint32_t h2 = f32x2_to_bf16x2((v[2 * i] * rr) * __uint_as_float(u << 16),
-                                            (v[2 * i + 1] * rr) * __uint_as_float(u & 0xffff0000u));
-        out[i] = (int)h2;
-        o[2 * i] = act ? __uint_as_float(h2 << 16) : 0.f;
-        o[2 * i + 1] = act ? __uint_as_float(h2 & 0xffff0000u) : 0.f;
-    }
-    if (y && act) *reinterpret_cast<i32x4*>(y + (int64_t)row * y_stride + tid * 8) = out;
-    if (QMODE != 0) {
-        float amax = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) amax = __builtin_fmaxf(amax, __builtin_fabsf(o[i]));
-        amax = row16_reduce_max(amax);
-        if (QMODE == 2) amax = __builtin_fmaxf(amax, qeps);
-        const float sc = amax / 448.0f;
-        const i32x2 packed = quant8_fp8<QMODE == 2>(o, act ? sc : 1.0f);
-        if (act) {
-            *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + tid * 8) = packed;
-            if ((tid & 15) == 0) qs[(int64_t)row * (dim >> 7) + (tid >> 4)] = sc;
-        }
-    }
+    rmsnorm_wide_finish<QMODE>(v, act, row, wraw, y, y_stride, q, qs, dim, eps, qeps, red);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -107,4 +107,100 @@ __device__ __forceinline__ void rmsnorm_row(
     }
 }
 
+
+// ---- the WIDE row form: 1024 threads per row, ONE 8-element chunk per thread (dim <= 8192) -------------
+// Used wherever a full hidden-state row is normalised behind a residual add: chitu_hip_rmsnorm with `add`
+// (norm.hip) and the fused all-reduce launch (comm.hip).  Both call the two functions below, so the library
+// transport and the in-graph xGMI transport give bit-identical steps.
+constexpr int kNormWideThreads = 1024;
+constexpr int kNormMaxTerms = 16;
+
+// 4 packed bf16 pairs + 4 packed bf16 pairs -> v[8] = bf16(a + b) as floats, sraw = the packed sums.
+__device__ __forceinline__ void add_bf16x8(const i32x4& a, const i32x4& b, float (&v)[8], i32x4& sraw) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ua = (uint32_t)a[i], ub = (uint32_t)b[i];
+        const uint32_t s2 = f32x2_to_bf16x2(__uint_as_float(ua << 16) + __uint_as_float(ub << 16),
+                                            __uint_as_float(ua & 0xffff0000u) + __uint_as_float(ub & 0xffff0000u));
+        v[2 * i] = __uint_as_float(s2 << 16);
+        v[2 * i + 1] = __uint_as_float(s2 & 0xffff0000u);
+        sraw[i] = (int)s2;
+    }
+}
+__device__ __forceinline__ void unpack_bf16x8(const i32x4& a, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(((uint32_t)a[i]) << 16);
+        v[2 * i + 1] = __uint_as_float(((uint32_t)a[i]) & 0xffff0000u);
+    }
+}
+// fp32 sum of `terms` packed rows (k < terms of MAXT loaded registers), ONE rounding: chitu_hip_moe_sum's arithmetic.
+template <int MAXT>
+__device__ __forceinline__ i32x4 sum_terms_bf16x8(const i32x4 (&t)[MAXT], int terms) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < MAXT; ++k) {
+        if (k < terms) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t u = (uint32_t)t[k][i];
+                a[2 * i] += __uint_as_float(u << 16);
+                a[2 * i + 1] += __uint_as_float(u & 0xffff0000u);
+            }
+        }
+    }
+    i32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (int)f32x2_to_bf16x2(a[2 * i], a[2 * i + 1]);
+    return r;
+}
+
+// v[8]: this thread's chunk `tid` of the (already residual-added, bf16-valued) row; act: chunk inside the row.
+// Mean square over the row (per-thread sequential, wave butterfly, the 16 wave sums in order), y = (v * rr) * w
+// with one rounding, optional fp8 quantisation of the rounded y (16 lanes = one 128-wide group).
+template <int QMODE>
+__device__ __forceinline__ void rmsnorm_wide_finish(const float (&v)[8], bool act, int row, const i32x4& wraw, bf16_t* y,
+                                                    int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs,
+                                                    int dim, float eps, float qeps, float* red) {
+    const int tid = threadIdx.x;
+    float ss = 0.f;
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
+    }
+    ss = wave_reduce_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kNormWideThreads / 64; ++i) ss += red[i];
+    const float rr = rsqrtf(ss / (float)dim + eps);
+    float o[8];
+    i32x4 out;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t u = (uint32_t)wraw[i];
+        const uint32_t h2 = f32x2_to_bf16x2((v[2 * i] * rr) * __uint_as_float(u << 16),
+                                            (v[2 * i + 1] * rr) * __uint_as_float(u & 0xffff0000u));
+        out[i] = (int)h2;
+        o[2 * i] = act ? __uint_as_float(h2 << 16) : 0.f;
+        o[2 * i + 1] = act ? __uint_as_float(h2 & 0xffff0000u) : 0.f;
+    }
+    if (y && act) *reinterpret_cast<i32x4*>(y + (int64_t)row * y_stride + tid * 8) = out;
+    if (QMODE != 0) {
+        // dim % 128 == 0 => a 16-lane group is either fully active or fully idle
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) amax = __builtin_fmaxf(amax, __builtin_fabsf(o[i]));
+        amax = row16_reduce_max(amax);
+        if (QMODE == 2) amax = __builtin_fmaxf(amax, qeps);
+        const float sc = amax / 448.0f;
+        const i32x2 packed = quant8_fp8<QMODE == 2>(o, act ? sc : 1.0f);
+        if (act) {
+            *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + tid * 8) = packed;
+            if ((tid & 15) == 0) qs[(int64_t)row * (dim >> 7) + (tid >> 4)] = sc;
+        }
+    }
+}
+
 }  // namespace chitu

@@ -177,6 +177,8 @@ def defer_all_reduce(t: torch.Tensor):
     the terms); xGMI collectives: a PendingAllReduce (the norm launch does the reduction); library path: the
     all-reduced tensor."""
     if get_tp_size() == 1:
+        if _graph_break is not None:
+            _graph_break(None)  # piecewise replay on one rank: the cut stays where a library collective would sit
         return t
     if _xgmi is not None and t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous() and (
             (t.dim() == 2 and _xgmi.fits(t.shape[0], t.shape[1])) or
