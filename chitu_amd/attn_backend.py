@@ -27,10 +27,12 @@ class AttnBackend:
     def prepare_metadata_for_decode(self, *args, **kwargs):
         pass
 
-    def attn_varlen_func(self, *args, **kwargs):
+    def attn_varlen_func(self, q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, dropout_p=0.0,
+                         causal=False, window_size=(-1, -1), softcap=0.0, softmax_scale=None):
         raise NotImplementedError()
 
-    def attn_with_kvcache(self, *args, **kwargs):
+    def attn_with_kvcache(self, q, k_cache, v_cache, k=None, v=None, cache_seqlens=None, cache_leftpad=None,
+                          block_table=None, causal=False, window_size=(-1, -1), softcap=0.0, softmax_scale=None):
         raise NotImplementedError()
 
     def mla_attn_with_kvcache(self, *args, **kwargs):

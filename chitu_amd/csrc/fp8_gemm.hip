@@ -277,6 +277,41 @@ extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_s
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
+// Split-K form for the few dense GEMMs whose N alone cannot fill the chip (wqkv_a: 132 tiles on 256 CUs): the K
+// range is cut over `num_splits` workgroups per tile and the fp32 partial planes [num_splits, M, N] are the
+// OUTPUT -- no reduce launch; the consumer (chitu_hip_mla_qkv_post with num_partials) sums the planes in order
+// as it loads them.
+extern "C" int chitu_hip_fp8_gemm_blockscale_partials(const void* a_fp8, const float* a_scale, const void* b_fp8,
+                                                      const float* b_scale, float* partials, int64_t M, int64_t N,
+                                                      int64_t K, int32_t num_splits, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(a_fp8 && a_scale && b_fp8 && b_scale && partials);
+    CHITU_REQUIRE(M >= 0 && N >= 1 && K >= 128 && N < (1 << 30) && K < (1 << 30));
+    if (K % 128 != 0) return CHITU_ERR_UNSUPPORTED;
+    const int KB = (int)(K / 128);
+    CHITU_REQUIRE(num_splits >= 2 && num_splits <= 16 && num_splits <= KB);
+    if (M == 0) return CHITU_OK;
+    hipStream_t st = (hipStream_t)stream;
+    SplitPlan plan{1, (int)num_splits};
+    while (plan.WK < 8 && plan.WK * 2 * plan.S <= KB) plan.WK *= 2;
+    const dim3 grid((unsigned)((N + 15) / 16), (unsigned)plan.S);
+    for (int64_t mb = 0; mb < M; mb += 64) {
+        const int rem = (int)(M - mb);
+        const int mbase = (int)mb;
+        if (rem <= 16) {
+            DISPATCH_WK(fp8_gemm_kernel, 1, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, nullptr, 2,
+                        partials, (int)M, (int)N, (int)K, plan.S, mbase)
+        } else if (rem <= 32) {
+            DISPATCH_WK(fp8_gemm_kernel, 2, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, nullptr, 2,
+                        partials, (int)M, (int)N, (int)K, plan.S, mbase)
+        } else {
+            DISPATCH_WK(fp8_gemm_kernel, 4, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, nullptr, 2,
+                        partials, (int)M, (int)N, (int)K, plan.S, mbase)
+        }
+    }
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int chitu_hip_soft_fp8_gemm(const void* a_bf16, const void* b_fp8, const float* b_scale,
                                        void* out, int out_dtype, int64_t M, int64_t N, int64_t K,
                                        void* workspace, int64_t workspace_bytes, void* stream) {

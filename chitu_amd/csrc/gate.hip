@@ -578,6 +578,14 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     int64_t* ids_lds = reinterpret_cast<int64_t*>(dyn_lds + nwaves * E);     // [M * out_stride]
     int* align_lds = dyn_lds + nwaves * E + 2 * ((M * out_stride + 1) & ~1);
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+    // the sort's sentinels (fused_moe.py:493-502; expert_ids' unused tail = expert_map[0] under expert parallelism,
+    // :516-517) go out first: fire-and-forget stores that overlap the logits round trip
+    {
+        const int32_t tail_id = al.expert_map ? al.expert_map[0] : 0;
+        const int32_t numel = M * out_stride;
+        for (int64_t i = threadIdx.x; i < al.sorted_cap; i += blockDim.x) al.sorted_ids[i] = numel;
+        for (int64_t i = threadIdx.x; i < al.expert_cap; i += blockDim.x) al.expert_ids[i] = tail_id;
+    }
     if (t < M) {  // wave-uniform
         // ---- logits of experts 4*lane .. 4*lane+3: all loads up front
         float lg[4];
@@ -668,10 +676,17 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
             ids_lds[t * out_stride + topk + lane] = extra_id + lane;
         }
     }
-    __syncthreads();
+    __syncthreads();  // ids of every token in LDS; every wave's sentinel stores drained (vmcnt(0) precedes the barrier)
+    // the sort of <= a few hundred ids is one wave's work: wave-local steps only, the other waves are done
+#ifdef CHITU_AB_WORKGROUP_ALIGN  // A/B build only (tools/ab_bench.sh): the sort on the whole workgroup
     moe_align_workgroup<int64_t>(ids_lds, (int64_t)M * out_stride, al.num_experts, al.block_size, al.sorted_ids,
                                  al.sorted_cap, al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, 1,
                                  al.expert_map, align_lds, (int)blockDim.x);
+#else
+    if (t == 0)
+        moe_align_wave<int64_t>(ids_lds, M * out_stride, al.num_experts, al.block_size, al.sorted_ids, al.sorted_cap,
+                                al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, al.expert_map, align_lds);
+#endif
 }
 
 }  // namespace chitu

@@ -246,18 +246,46 @@ __device__ __forceinline__ void mla_kv_row(int b, const bf16_t* src, const bf16_
 //   blockIdx.y == 1: kv_norm(kv_c) and RoPE(k_pe) written straight into the token's page row
 // (the two parts of mla_kv_prep_kernel that do not need wq_b's output; q_pe is rotated by the
 // W_UK absorb launch, absorb.hip).  Same arithmetic as chitu_hip_rmsnorm + chitu_hip_mla_kv_prep.
+// num_partials > 0: `qkv` is not the bf16 GEMM output but the fp32 split-K planes [num_partials, batch,
+// row_stride] of chitu_hip_fp8_gemm_blockscale_partials: the role's slice of row b is summed over the planes in
+// order, rounded to bf16 once (= the GEMM's own output rounding) into LDS, and processed from there.
+constexpr int kQkvPostMaxStage = 2048;  // q_lora_rank <= 2048 on the partial path
 __global__ __launch_bounds__(256) void mla_qkv_post_kernel(
-    const bf16_t* qkv, int64_t row_stride, int q_lora, const bf16_t* __restrict__ q_norm_w, float q_eps,
-    fp8_t* __restrict__ q_fp8, float* __restrict__ q_scales, const bf16_t* __restrict__ kv_norm_w, float kv_eps,
+    const void* qkv_any, int num_partials, int batch, int64_t row_stride, int q_lora, const bf16_t* __restrict__ q_norm_w,
+    float q_eps, fp8_t* __restrict__ q_fp8, float* __restrict__ q_scales, const bf16_t* __restrict__ kv_norm_w, float kv_eps,
     const float* __restrict__ cos, const float* __restrict__ sin, bf16_t* __restrict__ cache, int64_t num_pages,
     int page_size, const int32_t* __restrict__ table, int pages_per_seq, const int32_t* __restrict__ old_lens) {
+    __shared__ __attribute__((aligned(16))) bf16_t stage[kQkvPostMaxStage];
     const int b = blockIdx.x;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(qkv_any);
+    const bf16_t* src = qkv + (int64_t)b * row_stride + (blockIdx.y == 0 ? 0 : q_lora);
+    int64_t src_stride = row_stride;
+    if (num_partials > 0) {
+        const float* planes = reinterpret_cast<const float*>(qkv_any);
+        const int col0 = blockIdx.y == 0 ? 0 : q_lora, n = blockIdx.y == 0 ? q_lora : 576;
+        const int64_t plane = (int64_t)batch * row_stride;
+        for (int c = threadIdx.x; c < (n >> 3); c += 256) {
+            const float* p = planes + (int64_t)b * row_stride + col0 + c * 8;
+            f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+            for (int s = 1; s < num_partials; ++s) {
+                const f32x4 l2 = *reinterpret_cast<const f32x4*>(p + s * plane), h2 = *reinterpret_cast<const f32x4*>(p + s * plane + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lo[r] += l2[r], hi[r] += h2[r];
+            }
+            i32x4 o;
+            o[0] = (int)f32x2_to_bf16x2(lo[0], lo[1]), o[1] = (int)f32x2_to_bf16x2(lo[2], lo[3]);
+            o[2] = (int)f32x2_to_bf16x2(hi[0], hi[1]), o[3] = (int)f32x2_to_bf16x2(hi[2], hi[3]);
+            *reinterpret_cast<i32x4*>(stage + c * 8) = o;
+        }
+        __syncthreads();
+        src = stage;
+        src_stride = 0;
+    }
     if (blockIdx.y == 0)
-        rmsnorm_row<1, false>(b, qkv, row_stride, nullptr, 0, nullptr, 0, q_norm_w, nullptr, 0, q_fp8, q_scales, q_lora,
-                              q_eps, 0.f);
+        rmsnorm_row<1, false>(b, src - (int64_t)b * src_stride, src_stride, nullptr, 0, nullptr, 0, q_norm_w, nullptr, 0, q_fp8,
+                              q_scales, q_lora, q_eps, 0.f);
     else
-        mla_kv_row(b, qkv + (int64_t)b * row_stride + q_lora, kv_norm_w, kv_eps, cos, sin, cache, num_pages, page_size,
-                   table, pages_per_seq, old_lens);
+        mla_kv_row(b, src, kv_norm_w, kv_eps, cos, sin, cache, num_pages, page_size, table, pages_per_seq, old_lens);
 }
 
 }  // namespace chitu
@@ -324,7 +352,7 @@ extern "C" int chitu_hip_rope(const void* q, const void* k, void* out_q, void* o
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int chitu_hip_mla_qkv_post(const void* qkv_a_bf16, int64_t row_stride, int32_t q_lora_rank,
+extern "C" int chitu_hip_mla_qkv_post(const void* qkv_a, int32_t num_partials, int64_t row_stride, int32_t q_lora_rank,
                                       const void* q_norm_weight_bf16, float q_eps, void* q_fp8, float* q_scales,
                                       const void* kv_norm_weight_bf16, float kv_eps, const float* cos,
                                       const float* sin, void* kv_cache, int64_t num_pages, int32_t page_size,
@@ -332,15 +360,17 @@ extern "C" int chitu_hip_mla_qkv_post(const void* qkv_a_bf16, int64_t row_stride
                                       const int32_t* old_seq_lens, int32_t batch, int32_t kv_lora_rank,
                                       int32_t rope_dim, void* stream) {
     using namespace chitu;
-    CHITU_REQUIRE(qkv_a_bf16 && q_norm_weight_bf16 && q_fp8 && q_scales && kv_norm_weight_bf16 && cos && sin);
+    CHITU_REQUIRE(qkv_a && q_norm_weight_bf16 && q_fp8 && q_scales && kv_norm_weight_bf16 && cos && sin);
     CHITU_REQUIRE(kv_cache && page_table && old_seq_lens);
     CHITU_REQUIRE(batch >= 0 && num_pages >= 1 && page_size >= 1 && pages_per_seq >= 1 && q_lora_rank >= 128);
+    CHITU_REQUIRE(num_partials >= 0 && num_partials <= 16);
     if (kv_lora_rank != 512 || rope_dim != 64) return CHITU_ERR_UNSUPPORTED;
     if (q_lora_rank % 128 != 0 || q_lora_rank > kNormThreads * 8 * kNormMaxChunks) return CHITU_ERR_UNSUPPORTED;
+    if (num_partials > 0 && q_lora_rank > kQkvPostMaxStage) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(row_stride % 8 == 0 && row_stride >= q_lora_rank + 576);
     if (batch == 0) return CHITU_OK;
-    hipLaunchKernelGGL(mla_qkv_post_kernel, dim3((unsigned)batch, 2), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)qkv_a_bf16, row_stride, (int)q_lora_rank, (const bf16_t*)q_norm_weight_bf16, q_eps,
+    hipLaunchKernelGGL(mla_qkv_post_kernel, dim3((unsigned)batch, 2), dim3(256), 0, (hipStream_t)stream, qkv_a,
+                       (int)num_partials, (int)batch, row_stride, (int)q_lora_rank, (const bf16_t*)q_norm_weight_bf16, q_eps,
                        (fp8_t*)q_fp8, q_scales, (const bf16_t*)kv_norm_weight_bf16, kv_eps, cos, sin, (bf16_t*)kv_cache,
                        num_pages, (int)page_size, page_table, (int)pages_per_seq, old_seq_lens);
     CHITU_RETURN_LAUNCH_STATUS();

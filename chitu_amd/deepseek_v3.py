@@ -166,6 +166,15 @@ class RMSNormW(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.ones(dim, dtype=torch.bfloat16, device=device), requires_grad=False)
 
 
+def _wqkv_a_splits(bs: int, n: int, k: int) -> int:
+    """Cross-workgroup K split of the wqkv_a GEMM: worth it when its 16-row tiles leave most CUs idle, the K range
+    is long enough to halve, and the fp32 planes stay small (decode batches)."""
+    if os.environ.get("CHITU_WQKV_SPLIT", "1") == "0" or bs > 32 or k < 4096:
+        return 1
+    tiles = (n + 15) // 16
+    return 2 if tiles <= 160 else 1
+
+
 class AttentionDeepSeekV3(torch.nn.Module):
     """MLA, absorb-without-precomp, paged decode (model_deepseek_v3.py:394-703)."""
 
@@ -230,7 +239,13 @@ class AttentionDeepSeekV3(torch.nn.Module):
         kv_cache = cache.get_paged_kv_cache(self.layer_id)
         nblk = C // BLOCK
         if self.q_lora_rank > 0:
-            q_a_kv = self.wqkv_a(None, x_quant=x_quant)  # [bs, q_lora + C + R]
+            # wqkv_a: [bs, q_lora + C + R].  Its 2112 rows are 132 MFMA tiles -- half the chip -- so for decode batches
+            # the K range is cut in two (264 workgroups) and the fp32 halves are summed by the kernel that reads them
+            splits = _wqkv_a_splits(bs, self.wqkv_a.out_features, self.wqkv_a.in_features)
+            if splits > 1:
+                q_a_kv = ops.fp8_gemm_partials_deepseek_v3(x_quant[0], x_quant[1], self.wqkv_a.weight, self.wqkv_a.scale, splits)
+            else:
+                q_a_kv = self.wqkv_a(None, x_quant=x_quant)
             # q_norm + quant, and this token's [kv_norm(kv_c) | rope(k_pe)] row straight into its page
             qq, qs = ops.mla_qkv_post(q_a_kv, self.q_lora_rank, self.q_norm.weight, self.q_norm.eps, self.kv_norm.weight,
                                       self.kv_norm.eps, cos, sin, kv_cache, cache.get_gpu_block_table(),

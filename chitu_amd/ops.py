@@ -106,6 +106,25 @@ def fp8_gemm_deepseek_v3(a: torch.Tensor, a_s: torch.Tensor, b: torch.Tensor, b_
     return c
 
 
+def fp8_gemm_partials_deepseek_v3(a: torch.Tensor, a_s: torch.Tensor, b: torch.Tensor, b_s: torch.Tensor, num_splits: int):
+    """fp8_gemm_deepseek_v3 with the K range cut over `num_splits` workgroups per tile; returns the fp32 partial
+    planes [num_splits, M, N] (sum over dim 0, rounded once, = the GEMM output) for a consumer that folds the
+    sum into its own loads (mla_qkv_post(num_partials=...))."""
+    assert a.is_contiguous() and b.is_contiguous() and a_s.is_contiguous() and b_s.is_contiguous()
+    require_cuda(a, a_s, b, b_s)
+    assert a.element_size() == 1 and b.element_size() == 1 and a_s.dtype == torch.float32 and b_s.dtype == torch.float32
+    K = a.size(-1)
+    M = a.numel() // K
+    N = b.size(0)
+    parts = torch.empty(num_splits, M, N, dtype=torch.float32, device=a.device)
+    check(
+        _lib.lib().chitu_hip_fp8_gemm_blockscale_partials(ptr(a), ptr(a_s), ptr(b), ptr(b_s), ptr(parts), i64(M), i64(N),
+                                                          i64(K), i32(num_splits), stream_ptr()),
+        "fp8_gemm_partials_deepseek_v3",
+    )
+    return parts
+
+
 def soft_fp8_gemm_deepseek_v3(a: torch.Tensor, b: torch.Tensor, b_s: torch.Tensor):
     """FP8 weights decoded to bf16 on the fly, bf16 x bf16 dot (chitu/ops.py:487-511)."""
     assert a.is_contiguous() and b.is_contiguous(), "Input tensors must be contiguous"
@@ -473,18 +492,23 @@ def mla_qkv_post(q_a_kv, q_lora_rank, q_norm_weight, q_eps, kv_norm_weight, kv_e
                  old_seq_lens):
     """One launch for everything that reads wqkv_a's output [bs, q_lora + 512 + 64]: q_norm + act_quant
     (returns (q_fp8, q_scales), the wq_b GEMM input) and kv_norm + RoPE(k_pe) + page append.  q_pe is
-    rotated later by absorb_bmm_rope_fp8."""
+    rotated later by absorb_bmm_rope_fp8.  q_a_kv: the bf16 GEMM output, or the fp32 split-K planes
+    [S, bs, q_lora + 576] of fp8_gemm_partials_deepseek_v3 (summed in plane order, rounded once, as they load)."""
     require_cuda(q_a_kv, q_norm_weight, kv_norm_weight, cos, sin, kv_cache, page_table, old_seq_lens)
-    assert q_a_kv.dtype == torch.bfloat16 and q_a_kv.dim() == 2 and q_a_kv.stride(1) == 1
-    assert q_a_kv.shape[1] == q_lora_rank + 576 and kv_cache.dtype == torch.bfloat16 and kv_cache.shape[-1] == 576
+    if q_a_kv.dtype == torch.float32:
+        assert q_a_kv.dim() == 3 and q_a_kv.is_contiguous()
+        nparts, bs, stride = q_a_kv.shape[0], q_a_kv.shape[1], q_a_kv.shape[2]
+    else:
+        assert q_a_kv.dtype == torch.bfloat16 and q_a_kv.dim() == 2 and q_a_kv.stride(1) == 1
+        nparts, bs, stride = 0, q_a_kv.shape[0], q_a_kv.stride(0)
+    assert q_a_kv.shape[-1] == q_lora_rank + 576 and kv_cache.dtype == torch.bfloat16 and kv_cache.shape[-1] == 576
     assert kv_cache.is_contiguous() and page_table.is_contiguous() and page_table.dtype == torch.int32
     assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and old_seq_lens.dtype == torch.int32
-    bs = q_a_kv.shape[0]
     q = torch.empty(bs, q_lora_rank, dtype=torch.float8_e4m3fn, device=q_a_kv.device)
     s = torch.empty(bs, q_lora_rank // 128, dtype=torch.float32, device=q_a_kv.device)
     check(
         _lib.lib().chitu_hip_mla_qkv_post(
-            ptr(q_a_kv), i64(q_a_kv.stride(0)), i32(q_lora_rank), ptr(q_norm_weight), f32(q_eps), ptr(q), ptr(s),
+            ptr(q_a_kv), i32(nparts), i64(stride), i32(q_lora_rank), ptr(q_norm_weight), f32(q_eps), ptr(q), ptr(s),
             ptr(kv_norm_weight), f32(kv_eps), ptr(cos), ptr(sin), ptr(kv_cache), i64(kv_cache.shape[0]),
             i32(kv_cache.shape[1]), ptr(page_table), i32(page_table.shape[1]), ptr(old_seq_lens), i32(bs), i32(512),
             i32(64), stream_ptr(),

@@ -36,7 +36,7 @@ def generate_tp_rank_list(tp_size: int, pp_size: int):
     return torch.arange(tp_size * pp_size).reshape(pp_size, tp_size).tolist()
 
 
-def init_tp(tp_size: int, pp_size: int = 1):
+def init_tp(tp_size: int, pp_size: int):
     """Create the TP groups (ranks laid out [pp, tp], tensor_parallel.py:16-27)."""
     global tp_comm_group
     rank_list = generate_tp_rank_list(tp_size, pp_size)

@@ -86,6 +86,13 @@ int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_scale, const
                                   const float* b_scale, void* out, int out_dtype, int64_t M,
                                   int64_t N, int64_t K, void* workspace,
                                   int64_t workspace_bytes, void* stream);
+/* The same contraction with the K range cut over num_splits (2..16) workgroups per output tile and the fp32 partial
+ * planes as the OUTPUT: partials [num_splits, M, N], plane s = the contribution of its K blocks, no reduce launch.
+ * For the dense GEMMs whose N cannot fill 256 CUs on its own (wqkv_a: 2112 rows = 132 tiles); the consumer sums
+ * the planes in plane order (chitu_hip_mla_qkv_post with num_partials). */
+int chitu_hip_fp8_gemm_blockscale_partials(const void* a_fp8, const float* a_scale, const void* b_fp8,
+                                           const float* b_scale, float* partials, int64_t M, int64_t N,
+                                           int64_t K, int32_t num_splits, void* stream);
 
 /* ---- FP8-weight x bf16-activation GEMM ("soft fp8") ------------------------------------
  * Replaces soft_fp8_gemm_deepseek_v3 (chitu/ops.py:487-511, kernel triton_kernels.py:388-508):
@@ -375,8 +382,11 @@ int chitu_hip_mla_kv_prep(const void* kv_in_bf16, int64_t kv_row_stride, void* q
  * launch: q_norm + act_quant of q_a (= chitu_hip_rmsnorm quant_mode 1 -> q_fp8 [batch, q_lora_rank],
  * q_scales [batch, q_lora_rank/128], the input of the wq_b GEMM; model_deepseek_v3.py:480-487) and the
  * kv half of chitu_hip_mla_kv_prep (kv_norm + RoPE(k_pe) + page append).  q_pe is NOT rotated here
- * (it does not exist yet): use chitu_hip_absorb_bmm_rope_fp8 after wq_b. */
-int chitu_hip_mla_qkv_post(const void* qkv_a_bf16, int64_t row_stride, int32_t q_lora_rank,
+ * (it does not exist yet): use chitu_hip_absorb_bmm_rope_fp8 after wq_b.
+ *   qkv_a: num_partials == 0: the GEMM's bf16 output [batch, row_stride]; num_partials >= 1: the fp32 split-K
+ *   planes [num_partials, batch, row_stride] of chitu_hip_fp8_gemm_blockscale_partials -- each value is then
+ *   bf16(plane 0 + plane 1 + ...), the rounding the GEMM's own epilogue would apply (q_lora_rank <= 2048). */
+int chitu_hip_mla_qkv_post(const void* qkv_a, int32_t num_partials, int64_t row_stride, int32_t q_lora_rank,
                            const void* q_norm_weight_bf16, float q_eps, void* q_fp8, float* q_scales,
                            const void* kv_norm_weight_bf16, float kv_eps, const float* cos,
                            const float* sin, void* kv_cache, int64_t num_pages, int32_t page_size,

@@ -403,6 +403,32 @@ def test_qkv_post_and_absorb_rope_equal_the_separate_launches(bs):
     assert torch.equal(q2, q1) and torch.equal(ab, abs_ref)
 
 
+@pytest.mark.parametrize("bs,S", [(1, 2), (16, 2), (5, 3)])
+def test_qkv_post_reads_split_k_planes_like_the_rounded_sum(bs, S):
+    """mla_qkv_post(fp32 planes [S, bs, 2112]) == mla_qkv_post(bf16(plane 0 + plane 1 + ...)), bit for bit: the
+    cross-workgroup K split of wqkv_a changes where the partial sums are added, not what its consumers compute."""
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(90 + bs + S)
+    planes = torch.randn(S, bs, 1536 + 576, generator=g).cuda()
+    total = planes[0].clone()
+    for s in range(1, S):
+        total += planes[s]
+    q_a_kv = total.to(torch.bfloat16)
+    cos, sin = torch.randn(bs, 32, generator=g).cuda(), torch.randn(bs, 32, generator=g).cuda()
+    wq = (torch.rand(1536, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    wn = (torch.rand(512, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    pages = 2 * bs + 2
+    cache = torch.randn(pages, 64, 576, generator=g).to(torch.bfloat16).cuda()
+    table = torch.stack([torch.randperm(pages, generator=g)[:2] for _ in range(bs)]).to(torch.int32).cuda()
+    lens = torch.tensor([(37 * i + (63 if i % 2 else 64)) % 128 for i in range(bs)], dtype=torch.int32).cuda()
+    c1, c2 = cache.clone(), cache.clone()
+    q1, s1 = ops.mla_qkv_post(q_a_kv, 1536, wq, 1e-6, wn, 1e-6, cos, sin, c1, table, lens)
+    q2, s2 = ops.mla_qkv_post(planes, 1536, wq, 1e-6, wn, 1e-6, cos, sin, c2, table, lens)
+    assert np.array_equal(bits8(q1), bits8(q2)) and torch.equal(s1, s2) and torch.equal(c1, c2)
+    assert not torch.equal(c1, cache)
+
+
 @pytest.mark.parametrize("E,groups,topk,S,bias", [(256, (8, 4), 8, 16, True), (256, (8, 4), 8, 0, True), (256, (4, 2), 8, 3, True),
                                                   (256, (8, 4), 8, 16, False), (128, (1, 1), 6, 5, True), (64, (2, 1), 4, 0, True)])
 def test_gate_route_fast_path_equals_generic_kernel(E, groups, topk, S, bias, monkeypatch):

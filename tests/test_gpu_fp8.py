@@ -202,3 +202,32 @@ def test_arithmetic_shortcuts_selftest():
         torch.cuda.synchronize()
         f32_mismatch, fp8_mismatch, bf16_mismatch = bad.tolist()
         assert fp8_mismatch == 0 and bf16_mismatch == 0 and f32_mismatch == 0, (k, bad.tolist())
+
+
+@pytest.mark.parametrize("M,N,K,S", [(1, 2112, 7168, 2), (16, 2112, 7168, 2), (32, 2112, 7168, 2), (20, 512, 7168, 4),
+                                     (5, 1000, 384, 3), (70, 136, 512, 2)])
+def test_fp8_gemm_split_k_partial_planes(M, N, K, S):
+    """chitu_hip_fp8_gemm_blockscale_partials: plane s holds the contribution of its K blocks, the planes' fp32 sum
+    is the GEMM (vs the oracle <= 5e-3 after the bf16 rounding the consumer applies), run to run identical."""
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(M * 17 + N + K + S)
+    x = (torch.randn(M, K, generator=g) * 0.8).to(torch.bfloat16)
+    w, ws = randw(N, K, g)
+    xq, xs = ofp8.act_quant_deepseek_v3(x)
+    ref = ofp8.fp8_gemm_deepseek_v3(xq, xs, w, ws, torch.float32)
+    parts = ops.fp8_gemm_partials_deepseek_v3(xq.cuda(), xs.cuda(), w.cuda(), ws.cuda(), S)
+    assert tuple(parts.shape) == (S, M, N) and parts.dtype == torch.float32
+    total = parts[0].clone()
+    for s in range(1, S):
+        total += parts[s]
+    assert max_rel_to_peak(total.to(torch.bfloat16), ref) < 5e-3
+    # each plane is a partial contraction over a contiguous K range: plane s == the GEMM on that range alone
+    KB = K // 128
+    T = S * (8 if KB >= 8 * S else 4 if KB >= 4 * S else 2 if KB >= 2 * S else 1)
+    for s in range(S):
+        k0, k1 = (KB * (s * (T // S)) // T) * 128, (KB * ((s + 1) * (T // S)) // T) * 128
+        ref_s = ofp8.fp8_gemm_deepseek_v3(xq[:, k0:k1].contiguous(), xs[:, k0 // 128:k1 // 128].contiguous(),
+                                          w[:, k0:k1].contiguous(), ws[:, k0 // 128:k1 // 128].contiguous(), torch.float32)
+        assert max_rel_to_peak(parts[s], ref_s) < 1e-4, s
+    assert torch.equal(parts, ops.fp8_gemm_partials_deepseek_v3(xq.cuda(), xs.cuda(), w.cuda(), ws.cuda(), S))
