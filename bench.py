@@ -324,19 +324,24 @@ def roofline_dominant_kernel(model, routing, margs, bs, iters=3):
     a_bytes = bs * K + bs * (K // 128) * 4 + numel * (N // 2) * 2
     alg = w_bytes + s_bytes + a_bytes
     achieved = alg / (avg_ms * 1e-3) / 1e9
-    # HBM traffic per launch from the committed PMC pass (profiles/r01_pmc_moe_gemm.json: FETCH_SIZE,
-    # doubled per MI355X_MICROARCH.md), scaled by the distinct experts of the average launch.
-    traffic = None
+    # HBM traffic and MFMA utilisation of this kernel from the committed counter passes (tools/pmc_passes.sh ->
+    # tools/pmc_report.py -> profiles/r02_pmc_step.json: FETCH_SIZE doubled per MI355X_MICROARCH.md, WRITE_SIZE and
+    # SQ_VALU_MFMA_BUSY_CYCLES in their own passes), taken on an eager step of this same synthetic model at bs 16
+    traffic = mfma_util = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_moe_gemm.json")))["moe_gemm1_silu_kernel<1,3>"]
-        traffic = int((pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]) * distinct / pmc["distinct_experts"])
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_step.json")))["kernels"]
+        k = next(v for n, v in pmc.items() if "moe_gemm1_silu_kernel" in n)
+        traffic = int((k["hbm_read_MB"] + k.get("hbm_write_MB_uncalibrated", 0.0)) * 1e6)
+        mfma_util = k.get("mfma_util")
     except Exception:
         pass
     return {
         "kernel": "moe_gemm1_silu_kernel (routed experts W1, fp8 block-scaled grouped GEMM + SiLU-and-mul epilogue)",
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "traffic_source": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, profiles/r01_pmc_moe_gemm.json, scaled to this launch's distinct experts",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_util": mfma_util,
+        "traffic_source": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, per launch of this kernel "
+                          "in an eager bs-16 step of the same model (profiles/r02_pmc_step.json); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES "
+                          "/ (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs), its own pass",
         "avg_launch_us": round(avg_ms * 1e3, 2), "median_launch_us": round(ms[len(ms) // 2] * 1e3, 2),
         "algorithmic_bytes_per_launch": int(alg), "distinct_experts": round(distinct, 2),
         "distinct_experts_min_max": [min(pl[3] for pl in plans), max(pl[3] for pl in plans)],

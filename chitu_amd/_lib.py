@@ -116,3 +116,23 @@ def i32(v):
 
 def f32(v):
     return ctypes.c_float(float(v))
+
+
+DEBUG_OPTIONS = {"moe_gemm1_wk": 0, "moe_gemm1_nw": 1, "moe_gemm1_d": 2, "moe_gemm2_cfg": 3, "moe_i8_wk": 4,
+                 "gate_generic": 5, "gate_ticket": 6, "sample_radix": 7}
+
+
+class debug_option:
+    """`with debug_option("gate_generic", 1): ...` forces a launch variant of identical results
+    (chitu_hip_debug_option) for equivalence tests and tuning sweeps; restored to the heuristic on exit."""
+
+    def __init__(self, name: str, value: int):
+        self.opt, self.value = DEBUG_OPTIONS[name], int(value)
+
+    def __enter__(self):
+        check(lib().chitu_hip_debug_option(i32(self.opt), i32(self.value)), "debug_option")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().chitu_hip_debug_option(i32(self.opt), i32(-1)), "debug_option")
+        return False

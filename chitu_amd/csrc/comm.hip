@@ -90,19 +90,30 @@ __device__ __forceinline__ void wait_flag(const uint32_t* flag, uint32_t epoch, 
 }
 
 // Every storing wave drains its write-through stores, the workgroup meets, one lane per peer raises this
-// rank's flag there, one lane per source waits for that source's flag here, the workgroup meets again.
-__device__ __forceinline__ void exchange_flags(const CommPeers& peers, const CommGeom& g, int64_t flags_off, int slots,
-                                               int slot, uint32_t epoch, uint32_t* err) {
+// rank's flag there ...
+__device__ __forceinline__ void signal_peers(const CommPeers& peers, const CommGeom& g, int64_t flags_off, int slots,
+                                             int slot, uint32_t epoch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int tid = threadIdx.x;
-    if (tid < g.world && tid != g.rank) {
+    if (tid < g.world && tid != g.rank)
         sys_store(reinterpret_cast<uint32_t*>(peers.buf[tid] + flags_off) + (int64_t)g.rank * slots + slot, epoch);
+}
+// ... and one lane per source waits for that source's flag here, then the workgroup meets again.
+__device__ __forceinline__ void await_peers(const CommPeers& peers, const CommGeom& g, int64_t flags_off, int slots,
+                                            int slot, uint32_t epoch, uint32_t* err) {
+    const int tid = threadIdx.x;
+    if (tid < g.world && tid != g.rank)
         wait_flag(reinterpret_cast<const uint32_t*>(peers.buf[g.rank] + flags_off) + (int64_t)tid * slots + slot, epoch, err,
                   g.timeout_ticks);
-    }
     __syncthreads();
 }
+
+// `phase` of the two collectives: 0 = the whole collective in this launch; 1 = CONTRIBUTE only (push this rank's
+// data, raise its flags, return); 2 = COMPLETE only (wait for the peers, reduce / gather, advance the epoch), to
+// be issued after a phase-1 launch with the same arguments.  Split phases let a caller put work between the push
+// and the wait, and let every rank of a test live on one stream: all contributions first, then all completions,
+// no two kernels ever waiting for each other.
 
 // ---------------------------------------------------------------------------------------------
 // all-reduce (+ top-k sum in front, + residual add, RMSNorm, fp8 quant behind).  One workgroup per row,
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
     CommPeers peers, CommGeom g, uint32_t* state, const bf16_t* part, int64_t part_stride, int terms,
     int64_t term_stride, const bf16_t* x, int64_t x_stride, bf16_t* sum_out, int64_t sum_stride,
     const bf16_t* __restrict__ w, bf16_t* y, int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs, int dim,
-    float eps, float qeps) {
+    float eps, float qeps, int phase) {
     __shared__ float red[kCommThreads / 64];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n_chunks = dim >> 3;
@@ -140,14 +151,18 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
 
     // push this rank's row into its slot of every peer
     const uint32_t slot_off = (uint32_t)(((((int64_t)parity * kCommMaxRanks + g.rank) * g.max_rows + row) * g.max_dim + c * 8) * 2);
+    if (phase != 2) {
 #pragma unroll
-    for (int p = 0; p < kCommMaxRanks; ++p) {
-        if (p < g.world && p != g.rank && act) {
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[p] + g.data_ar, 0, g.data_ar_bytes, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(mine, rsrc, slot_off, 0, kCommAux);
+        for (int p = 0; p < kCommMaxRanks; ++p) {
+            if (p < g.world && p != g.rank && act) {
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[p] + g.data_ar, 0, g.data_ar_bytes, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(mine, rsrc, slot_off, 0, kCommAux);
+            }
         }
+        signal_peers(peers, g, g.flags_ar, g.max_rows, row, epoch);
+        if (phase == 1) return;
     }
-    exchange_flags(peers, g, g.flags_ar, g.max_rows, row, epoch, err);
+    await_peers(peers, g, g.flags_ar, g.max_rows, row, epoch, err);
 
     // reduce in rank order
     i32x4 theirs[kCommMaxRanks];
@@ -191,7 +206,8 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
 // along).  grid (chunks per row, rows); a workgroup moves 1024 x 8 elements of one row to every peer.
 template <bool OUT_F32>
 __global__ __launch_bounds__(kCommThreads) void allgather_kernel(CommPeers peers, CommGeom g, uint32_t* state,
-                                                                 const bf16_t* in, int64_t in_stride, int cols, void* out) {
+                                                                 const bf16_t* in, int64_t in_stride, int cols, void* out,
+                                                                 int phase) {
     const int row = blockIdx.y, tid = threadIdx.x;
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     const int col = (blockIdx.x * kCommThreads + tid) * 8;
@@ -203,14 +219,18 @@ __global__ __launch_bounds__(kCommThreads) void allgather_kernel(CommPeers peers
     i32x4 mine = {0, 0, 0, 0};
     if (act) mine = *reinterpret_cast<const i32x4*>(in + (int64_t)row * in_stride + col);
     const uint32_t in_slot = (uint32_t)(((int64_t)row * cols + col) * 2);
+    if (phase != 2) {
 #pragma unroll
-    for (int p = 0; p < kCommMaxRanks; ++p) {
-        if (p < g.world && p != g.rank && act) {
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[p] + g.data_ag, 0, g.data_ag_bytes, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(mine, rsrc, (uint32_t)(((int64_t)parity * kCommMaxRanks + g.rank) * g.ag_bytes) + in_slot, 0, kCommAux);
+        for (int p = 0; p < kCommMaxRanks; ++p) {
+            if (p < g.world && p != g.rank && act) {
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[p] + g.data_ag, 0, g.data_ag_bytes, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(mine, rsrc, (uint32_t)(((int64_t)parity * kCommMaxRanks + g.rank) * g.ag_bytes) + in_slot, 0, kCommAux);
+            }
         }
+        signal_peers(peers, g, g.flags_ag, g.max_blocks, blk, epoch);
+        if (phase == 1) return;
     }
-    exchange_flags(peers, g, g.flags_ag, g.max_blocks, blk, epoch, err);
+    await_peers(peers, g, g.flags_ag, g.max_blocks, blk, epoch, err);
     i32x4 theirs[kCommMaxRanks];
     {
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[g.rank] + g.data_ag, 0, g.data_ag_bytes, 0x00020000);
@@ -363,8 +383,8 @@ extern "C" int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf1
                                                 int64_t x_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
                                                 const void* weight_bf16, void* y_bf16, int64_t y_row_stride,
                                                 int64_t rows, int32_t dim, float eps, void* q_fp8, float* q_scales,
-                                                int32_t quant_mode, float quant_eps, void* stream) {
-    CHITU_REQUIRE(comm && part_bf16 && rows >= 0 && dim >= 8 && dim % 8 == 0);
+                                                int32_t quant_mode, float quant_eps, int32_t phase, void* stream) {
+    CHITU_REQUIRE(comm && part_bf16 && rows >= 0 && dim >= 8 && dim % 8 == 0 && phase >= 0 && phase <= 2);
     Comm* cm = (Comm*)comm;
     CHITU_REQUIRE(comm_ready(cm));
     if (rows > cm->g.max_rows || dim > cm->g.max_dim) return CHITU_ERR_UNSUPPORTED;
@@ -390,7 +410,7 @@ extern "C" int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf1
                        cm->g, cm->state, (const bf16_t*)part_bf16, part_row_stride, (int)terms, term_stride,        \
                        (const bf16_t*)x_bf16, x_row_stride, (bf16_t*)sum_out_bf16, sum_row_stride,                  \
                        (const bf16_t*)weight_bf16, (bf16_t*)y_bf16, y_row_stride, (fp8_t*)q_fp8, q_scales, (int)dim, \
-                       eps, quant_eps)
+                       eps, quant_eps, (int)phase)
     if (quant_mode == 0) LAUNCH(0);
     else if (quant_mode == 1) LAUNCH(1);
     else LAUNCH(2);
@@ -399,8 +419,8 @@ extern "C" int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf1
 }
 
 extern "C" int chitu_hip_comm_all_gather(void* comm, const void* in_bf16, int64_t in_row_stride, int64_t rows,
-                                         int64_t cols, void* out, int32_t out_dtype, void* stream) {
-    CHITU_REQUIRE(comm && in_bf16 && out && rows >= 0 && cols >= 8);
+                                         int64_t cols, void* out, int32_t out_dtype, int32_t phase, void* stream) {
+    CHITU_REQUIRE(comm && in_bf16 && out && rows >= 0 && cols >= 8 && phase >= 0 && phase <= 2);
     Comm* cm = (Comm*)comm;
     CHITU_REQUIRE(comm_ready(cm));
     CHITU_REQUIRE(out_dtype == 0 || out_dtype == 2);
@@ -412,9 +432,9 @@ extern "C" int chitu_hip_comm_all_gather(void* comm, const void* in_bf16, int64_
     const dim3 grid((unsigned)chunks, (unsigned)rows);
     if (out_dtype == 2)
         hipLaunchKernelGGL(allgather_kernel<true>, grid, dim3(kCommThreads), 0, st, cm->peers, cm->g, cm->state,
-                           (const bf16_t*)in_bf16, in_row_stride, (int)cols, out);
+                           (const bf16_t*)in_bf16, in_row_stride, (int)cols, out, (int)phase);
     else
         hipLaunchKernelGGL(allgather_kernel<false>, grid, dim3(kCommThreads), 0, st, cm->peers, cm->g, cm->state,
-                           (const bf16_t*)in_bf16, in_row_stride, (int)cols, out);
+                           (const bf16_t*)in_bf16, in_row_stride, (int)cols, out, (int)phase);
     CHITU_RETURN_LAUNCH_STATUS();
 }

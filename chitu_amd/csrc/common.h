@@ -24,6 +24,17 @@
 
 namespace chitu {
 
+// Launch-variant overrides (chitu_hip_debug_option): every op picks its launch variant (K-split width, ring depth,
+// fast / generic kernel ...) by a heuristic; tests and tuning sweeps force one through this table instead of the
+// process environment (no getenv on any launch path).  -1 = heuristic.  Defined in options.hip.
+enum DebugOption {
+    kOptMoeGemm1WK = 0, kOptMoeGemm1NW, kOptMoeGemm1D, kOptMoeGemm2Cfg, kOptMoeI8WK, kOptGateGeneric, kOptGateTicket,
+    kOptSampleRadix, kOptCount
+};
+extern int g_debug_options[kOptCount];
+inline int debug_option(DebugOption o) { return g_debug_options[o]; }
+inline void debug_override(DebugOption o, int& v) { if (g_debug_options[o] >= 0) v = g_debug_options[o]; }
+
 constexpr int kWave = 64;
 
 typedef uint16_t bf16_t;  // raw bits

@@ -16,7 +16,6 @@
 // partials are summed, in order, by the routing kernel itself (no separate reduce launch).  The same
 // GEMM entry point serves the LM head (N = vocab/tp, no split).
 #include "common.h"
-#include <stdlib.h>
 #include "gemm_common.h"
 #include "moe_align_device.h"
 
@@ -566,6 +565,17 @@ __global__ __launch_bounds__(1024) void gate_route_fast_kernel(
 // (moe_align_workgroup reading the ids from LDS): no ticket, no global round trip between routing and
 // sort.  Arithmetic, rounding points and tie rule are gate_route_fast_kernel's, so ids, weights and the
 // align outputs are bit-identical to the separate launches.
+// One wave fills p[0 .. n) with v: 16-byte stores over the aligned middle, scalar stores at the ragged ends.
+__device__ __forceinline__ void fill_i32_wave(int32_t* p, int64_t n, int32_t v, int lane) {
+    const int64_t head = min(n, (int64_t)((16 - ((uintptr_t)p & 15)) & 15) >> 2);
+    if (lane < head) p[lane] = v;
+    const int64_t quads = (n - head) >> 2;
+    const i32x4 v4 = {v, v, v, v};
+    for (int64_t i = lane; i < quads; i += 64) *reinterpret_cast<i32x4*>(p + head + i * 4) = v4;
+    const int64_t done = head + quads * 4;
+    if (done + lane < n) p[done + lane] = v;
+}
+
 template <int GS>  // experts per group: 32, or 0 = ungrouped
 __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     const void* __restrict__ logits, int S, int M, const bf16_t* __restrict__ bias, int n_groups, int topk_groups,
@@ -579,12 +589,14 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     int* align_lds = dyn_lds + nwaves * E + 2 * ((M * out_stride + 1) & ~1);
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
     // the sort's sentinels (fused_moe.py:493-502; expert_ids' unused tail = expert_map[0] under expert parallelism,
-    // :516-517) go out first: fire-and-forget stores that overlap the logits round trip
-    {
+    // :516-517) go out first: fire-and-forget stores that overlap the logits round trip.  Wave 0 issues them, the
+    // wave that later stores the sorted values: stores of ONE wave to one address land in program order, so no
+    // drain (s_waitcnt vmcnt) has to sit between the fill and the sort.
+    if (t == 0) {
         const int32_t tail_id = al.expert_map ? al.expert_map[0] : 0;
         const int32_t numel = M * out_stride;
-        for (int64_t i = threadIdx.x; i < al.sorted_cap; i += blockDim.x) al.sorted_ids[i] = numel;
-        for (int64_t i = threadIdx.x; i < al.expert_cap; i += blockDim.x) al.expert_ids[i] = tail_id;
+        fill_i32_wave(al.sorted_ids, al.sorted_cap, numel, lane);
+        fill_i32_wave(al.expert_ids, al.expert_cap, tail_id, lane);
     }
     if (t < M) {  // wave-uniform
         // ---- logits of experts 4*lane .. 4*lane+3: all loads up front
@@ -760,9 +772,9 @@ static int gate_route_launch(const void* logits, int32_t num_partials, int64_t t
     const int gs = n_groups > 1 ? num_experts / n_groups : 0;
     const bool fast = score_func == 1 && (gs == 0 || gs == 32 || gs == 64) && num_partials <= 16 &&
                       (threads / 64) * topk <= 64 && ((threads / 64) * topk) % 4 == 0 && n_groups <= 32 &&
-                      !getenv("CHITU_GATE_SLOW");
+                      debug_option(kOptGateGeneric) <= 0;
     if (fast && al.num_experts > 0 && num_experts == 256 && (gs == 0 || gs == 32) && tokens <= 16 &&
-        extra_count <= 32 && !getenv("CHITU_GATE_TICKET")) {
+        extra_count <= 32 && debug_option(kOptGateTicket) <= 0) {
         // one workgroup: a wave per token, then the sort (needs a thread per sorted-over expert)
         const int wg_threads = 64 * max((int)tokens, (max(num_experts, al.num_experts) + 63) / 64);
         const size_t ids_ints = 2 * (((size_t)tokens * out_stride + 1) & ~(size_t)1);

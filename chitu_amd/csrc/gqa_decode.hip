@@ -148,30 +148,56 @@ __global__ __launch_bounds__(64) void gqa_decode_kernel(
     }
 }
 
-// out[b,h,:] = sum_s w_s part_o[b,h,s,:] / sum_s w_s, w_s = exp(lse_s - max lse).  grid (batch*heads); block 32.
+// out[b,h,:] = sum_s w_s part_o[b,h,s,:] / sum_s w_s, w_s = exp(lse_s - max lse).  grid (batch*heads); one wave.
+// Nothing in here is a chain of dependent loads: the lse values are read one per lane, the weights travel by
+// shuffle, and the rows of part_o are read with data-independent addresses (8 in flight per lane); the two
+// halves of the wave take the even and the odd splits and are added at the end.
 __global__ __launch_bounds__(64) void gqa_merge_kernel(const float* __restrict__ part_o,
                                                        const float* __restrict__ part_lse,
                                                        bf16_t* __restrict__ out, int num_splits) {
     const int64_t bh = blockIdx.x;
-    if (threadIdx.x >= 32) return;
+    const int lane = threadIdx.x, half = lane >> 5, col = (lane & 31) * 4;
     const float* lse = part_lse + bh * num_splits;
-    float m = -INFINITY;
-    for (int s = 0; s < num_splits; ++s) m = __builtin_fmaxf(m, lse[s]);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
-    for (int s = 0; s < num_splits; ++s) {
-        const float l = lse[s];
-        if (l == -INFINITY) continue;
-        const float w = __expf(l - m);
-        wsum += w;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + (bh * num_splits + s) * kHd + threadIdx.x * 4);
+    float ls[4], m = -INFINITY;  // num_splits <= 256
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] += w * v[i];
+    for (int i = 0; i < 4; ++i) {
+        const int s = lane + 64 * i;
+        ls[i] = s < num_splits ? lse[s] : -INFINITY;
+        m = __builtin_fmaxf(m, ls[i]);
     }
+    m = wave_reduce_max(m);
+    float w[4], wsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w[i] = ls[i] == -INFINITY ? 0.f : __expf(ls[i] - m);
+        wsum += w[i];
+    }
+    wsum = wave_reduce_sum(wsum);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* rows = part_o + bh * num_splits * kHd + col;
+    for (int s0 = half; s0 < num_splits; s0 += 16) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(rows + (int64_t)min(s0 + 2 * u, num_splits - 1) * kHd);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + 2 * u;  // wave-uniform per half
+            const float ws_all = s < 64 ? w[0] : s < 128 ? w[1] : s < 192 ? w[2] : w[3];
+            const float ws = __shfl(ws_all, s & 63, 64);
+            if (s < num_splits && ws > 0.f) {  // an empty split's row is never used (it may hold anything)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += ws * v[u][i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] += __shfl_xor(acc[i], 32, 64);
+    if (half) return;
     const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
     i32x2 o2;
-    o2[0] = (int)((uint32_t)f32_to_bf16(acc[0] * inv) | ((uint32_t)f32_to_bf16(acc[1] * inv) << 16));
-    o2[1] = (int)((uint32_t)f32_to_bf16(acc[2] * inv) | ((uint32_t)f32_to_bf16(acc[3] * inv) << 16));
-    *reinterpret_cast<i32x2*>(out + bh * kHd + threadIdx.x * 4) = o2;
+    o2[0] = (int)f32x2_to_bf16x2(acc[0] * inv, acc[1] * inv);
+    o2[1] = (int)f32x2_to_bf16x2(acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<i32x2*>(out + bh * kHd + col) = o2;
 }
 
 }  // namespace chitu

@@ -376,6 +376,48 @@ extern "C" int chitu_hip_mla_qkv_post(const void* qkv_a, int32_t num_partials, i
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
+// ---- the decode step's prologue in one launch: vocabulary-parallel embedding lookup (ids outside this rank's
+// row range give a zero row, chitu/tensor_parallel.py:199-208) and the gather of every sequence's rotary row
+// (prepare_freqs_cis_decode, chitu/models/model.py:429-448).  One workgroup per token.
+namespace chitu {
+__global__ __launch_bounds__(256) void embed_rope_gather_kernel(
+    const int64_t* __restrict__ tokens, const bf16_t* __restrict__ table, int64_t vocab_start, int64_t vocab_local, int dim,
+    bf16_t* __restrict__ h, const int32_t* __restrict__ positions, const float* __restrict__ cos_table,
+    const float* __restrict__ sin_table, int64_t table_rows, int half, float* __restrict__ cos_out, float* __restrict__ sin_out) {
+    const int b = blockIdx.x;
+    const int64_t local = tokens[b] - vocab_start;
+    const bool mine = local >= 0 && local < vocab_local;
+    const bf16_t* src = table + (mine ? local : 0) * dim;
+    for (int c = threadIdx.x; c < (dim >> 3); c += 256) {
+        i32x4 v = {0, 0, 0, 0};
+        if (mine) v = *reinterpret_cast<const i32x4*>(src + c * 8);
+        *reinterpret_cast<i32x4*>(h + (int64_t)b * dim + c * 8) = v;
+    }
+    if (cos_out) {
+        const int64_t pos = min((int64_t)max(positions[b], 0), table_rows - 1);
+        for (int i = threadIdx.x; i < half; i += 256) {
+            cos_out[(int64_t)b * half + i] = cos_table[pos * half + i];
+            sin_out[(int64_t)b * half + i] = sin_table[pos * half + i];
+        }
+    }
+}
+}  // namespace chitu
+
+extern "C" int chitu_hip_embed_rope_gather(const int64_t* tokens, const void* embed_bf16, int64_t vocab_start,
+                                           int64_t vocab_local, int32_t dim, void* h_bf16, const int32_t* positions,
+                                           const float* cos_table, const float* sin_table, int64_t table_rows,
+                                           int32_t half, float* cos_out, float* sin_out, int32_t batch, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(tokens && embed_bf16 && h_bf16 && vocab_local >= 1 && dim >= 8 && batch >= 0);
+    if (dim % 8 != 0) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(!cos_out || (positions && cos_table && sin_table && sin_out && table_rows >= 1 && half >= 1));
+    if (batch == 0) return CHITU_OK;
+    hipLaunchKernelGGL(embed_rope_gather_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, tokens,
+                       (const bf16_t*)embed_bf16, vocab_start, vocab_local, (int)dim, (bf16_t*)h_bf16, positions, cos_table,
+                       sin_table, table_rows, (int)half, cos_out, sin_out);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
 extern "C" int chitu_hip_gqa_qkv_post(void* qkv_bf16, int64_t row_stride, int32_t q_heads, int32_t kv_heads,
                                       int32_t head_dim, const float* cos, const float* sin, int32_t layout,
                                       void* k_cache, void* v_cache, int64_t num_pages, int32_t page_size,

@@ -20,7 +20,11 @@
 // sized on the host from the batch only (graph-static); a split's token range is derived from
 // the device-side sequence length, empty splits publish LSE = -inf.  Stage 2 merges splits.
 #include "common.h"
-#include <stdlib.h>
+// Profiling aid, compile-time only: a probe build (hipcc -DCHITU_MLA_PHASE_MASK=<bits>) drops phases of the tile loop
+// (1: KV loads, 2: QK^T, 8: PV, 16: LDS staging) to price them; such a build computes garbage and is never shipped.
+#ifndef CHITU_MLA_PHASE_MASK
+#define CHITU_MLA_PHASE_MASK 0
+#endif
 
 namespace chitu {
 
@@ -43,7 +47,8 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     int64_t qp_sb, int64_t qp_sh, const bf16_t* __restrict__ cache, int64_t num_pages, int page_size,
     const int32_t* __restrict__ block_table, int table_stride, const int32_t* __restrict__ seqlens,
     float scale, float* __restrict__ part_o, float* __restrict__ part_lse, bf16_t* __restrict__ out,
-    int H, int num_splits, int dbg) {
+    int H, int num_splits) {
+    constexpr int dbg = CHITU_MLA_PHASE_MASK;  // 0 in every shipped build (see the macro)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* kv_lds = smem;                                   // [64][1168]
     uint8_t* q_lds = smem + kTile * kRowB;                    // [16][1168]
@@ -311,12 +316,11 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    static const int dbg = getenv("CHITU_MLA_DBG") ? atoi(getenv("CHITU_MLA_DBG")) : 0;  // profiling aid: skip phases
     const dim3 grid((unsigned)num_splits, (unsigned)batch, (unsigned)((heads + 15) / 16));
     hipLaunchKernelGGL(mla_decode_kernel, grid, dim3(256), lds, st, (const bf16_t*)q_nope, qn_stride_b,
                        qn_stride_h, (const bf16_t*)q_pe, qp_stride_b, qp_stride_h, (const bf16_t*)kv_cache,
                        num_pages, (int)page_size, block_table, (int)table_stride, seqlens, softmax_scale,
-                       part_o, part_lse, (bf16_t*)out_bf16, (int)heads, (int)num_splits, dbg);
+                       part_o, part_lse, (bf16_t*)out_bf16, (int)heads, (int)num_splits);
     if (num_splits > 1 && out_bf16)
         hipLaunchKernelGGL(mla_merge_kernel, dim3((unsigned)(batch * heads)), dim3(128), 0, st, part_o,
                            part_lse, (bf16_t*)out_bf16, (int)num_splits);

@@ -22,7 +22,6 @@
 // fp32 over bf16 values.  No atomics anywhere: results are run-to-run identical.
 #include "common.h"
 #include "gemm_common.h"
-#include <stdlib.h>
 
 namespace chitu {
 
@@ -588,9 +587,9 @@ extern "C" int chitu_hip_moe_gemm1_fp8(const void* a_fp8, const float* a_scale, 
     // grid alone fills the chip (>= 2048 waves); below that K is split over the workgroup's waves
     int WK = wgs <= 512 ? 8 : wgs <= 1024 ? 4 : wgs <= 2048 ? 2 : 1;
     int NW = 1, D = 3;  // sweep on MI355X: D=3 5.7 TB/s, D=2 5.4, D=4 5.2; NW>1 (shared L1 activations) loses 5-20%
-    if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);  // tuning knobs (tools/bench_kernels.py)
-    if (const char* ov = getenv("CHITU_MOE_GEMM1_NW")) NW = atoi(ov);
-    if (const char* ov = getenv("CHITU_MOE_GEMM1_D")) D = atoi(ov);
+    debug_override(kOptMoeGemm1WK, WK);  // variant overrides (tests, tools/bench_kernels.py)
+    debug_override(kOptMoeGemm1NW, NW);
+    debug_override(kOptMoeGemm1D, D);
     while (WK > 1 && WK > KB) WK >>= 1;
     if (WK > 1) NW = 1;
     hipStream_t st = (hipStream_t)stream;
@@ -704,10 +703,10 @@ extern "C" int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_sc
     // (37.5; WK 1: 50.9); bs 16+ -> WK 1, D 3 (61.9; WK 2: 69.0).  Few workgroups: split K over more waves
     // and keep the ring shallow so every workgroup is resident at once; many: one long stream per wave.
     int WK = wgs <= 640 ? 8 : wgs <= 1536 ? 4 : wgs <= 3200 ? 2 : 1;
-    if (const char* ov = getenv("CHITU_MOE_GEMM1_WK")) WK = atoi(ov);  // tuning knobs
+    debug_override(kOptMoeGemm1WK, WK);
     while (WK > 1 && WK > KB) WK >>= 1;
     int D = WK >= 4 ? 2 : 3;
-    if (const char* ov = getenv("CHITU_MOE_GEMM1_D")) D = atoi(ov);
+    debug_override(kOptMoeGemm1D, D);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)n_tiles, (unsigned)max_mblocks);
 #define LAUNCH1S(WKV, DV)                                                                                     \
@@ -750,7 +749,7 @@ extern "C" int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_
     // its 4x fewer workgroups still fill the chip several times over
     const bool many = (int64_t)n_tiles * mbs > 50000;
     int cfg = many ? 24 : 21;  // NT*10 + ROUNDS
-    if (const char* ov = getenv("CHITU_MOE_GEMM2_CFG")) cfg = atoi(ov);  // tuning knob (tools/bench_kernels.py)
+    debug_override(kOptMoeGemm2Cfg, cfg);
     switch (KB) {
         case 1: LAUNCH2Q(1, 2, 1); break;
         case 2:

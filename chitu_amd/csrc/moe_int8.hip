@@ -14,7 +14,6 @@
 // Activations are bf16 here (the reference's W8A8Linear emits fp16; the rounding points are the same).
 #include "common.h"
 #include "gemm_common.h"
-#include <stdlib.h>
 
 namespace chitu {
 
@@ -221,7 +220,7 @@ __global__ __launch_bounds__(64 * WK) void moe_i8_gemm2_kernel(
 
 static int pick_wk(int64_t wgs, int KB) {
     int WK = wgs <= 640 ? 8 : wgs <= 1536 ? 4 : wgs <= 3200 ? 2 : 1;
-    if (const char* ov = getenv("CHITU_MOE_I8_WK")) WK = atoi(ov);
+    debug_override(kOptMoeI8WK, WK);
     while (WK > 1 && WK > KB) WK >>= 1;
     return WK;
 }

@@ -21,7 +21,6 @@
 //
 // One workgroup (1024 threads) per row; rows are independent.
 #include "common.h"
-#include <stdlib.h>
 
 namespace chitu {
 
@@ -723,7 +722,7 @@ extern "C" int chitu_hip_sample(const void* logits, int act_dtype, int64_t row_s
     // greedy for every row: top_ks == NULL; otherwise all four per-row arrays are required
     if (top_ks != nullptr) CHITU_REQUIRE(top_ps && uniforms && (probs_mode || temperatures));
     if (rows == 0) return CHITU_OK;
-    const int use_candidates = getenv("CHITU_SAMPLE_RADIX") ? 0 : 1;  // A/B and test knob: radix descent only
+    const int use_candidates = chitu::debug_option(chitu::kOptSampleRadix) > 0 ? 0 : 1;  // test / A-B override: radix descent only
 #define LAUNCH(DT)                                                                                          \
     hipLaunchKernelGGL(chitu::sample_kernel<DT>, dim3((unsigned)rows), dim3(chitu::kSampleThreads), 0,      \
                        (hipStream_t)stream, logits, row_stride, (int)vocab, temperatures, top_ks, top_ps,   \

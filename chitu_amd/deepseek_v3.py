@@ -167,9 +167,11 @@ class RMSNormW(torch.nn.Module):
 
 
 def _wqkv_a_splits(bs: int, n: int, k: int) -> int:
-    """Cross-workgroup K split of the wqkv_a GEMM: worth it when its 16-row tiles leave most CUs idle, the K range
-    is long enough to halve, and the fp32 planes stay small (decode batches)."""
-    if os.environ.get("CHITU_WQKV_SPLIT", "1") == "0" or bs > 32 or k < 4096:
+    """Cross-workgroup K split of the wqkv_a GEMM (its 2112 rows are 132 MFMA tiles: half the chip), the fp32
+    halves summed by the kernel that reads them.  Built, parity-tested and measured NEUTRAL on the R1 step (same-box
+    A/B, profiles/r02_ab_tail_kernels.txt: 264 workgroups last as long as 132 -- the launch is bound by its chain
+    of dependent round trips, not by CU count), so it is off unless CHITU_WQKV_SPLIT=1 asks for it."""
+    if os.environ.get("CHITU_WQKV_SPLIT", "0") != "1" or bs > 32 or k < 4096:
         return 1
     tiles = (n + 15) // 16
     return 2 if tiles <= 160 else 1
@@ -239,8 +241,7 @@ class AttentionDeepSeekV3(torch.nn.Module):
         kv_cache = cache.get_paged_kv_cache(self.layer_id)
         nblk = C // BLOCK
         if self.q_lora_rank > 0:
-            # wqkv_a: [bs, q_lora + C + R].  Its 2112 rows are 132 MFMA tiles -- half the chip -- so for decode batches
-            # the K range is cut in two (264 workgroups) and the fp32 halves are summed by the kernel that reads them
+            # wqkv_a: [bs, q_lora + C + R] (optionally as split-K planes, see _wqkv_a_splits)
             splits = _wqkv_a_splits(bs, self.wqkv_a.out_features, self.wqkv_a.in_features)
             if splits > 1:
                 q_a_kv = ops.fp8_gemm_partials_deepseek_v3(x_quant[0], x_quant[1], self.wqkv_a.weight, self.wqkv_a.scale, splits)
@@ -515,9 +516,13 @@ class DeepSeekV3Decoder(torch.nn.Module):
 
     def decode_eager(self, tokens):
         """tokens [bs] int64 -> logits [bs, vocab] fp32 (decode_single_device, model.py:468-475)."""
-        pos = self.cache.get_gpu_seq_lens_excl_this_decode().long()
-        cos, sin = self.cos_table[pos], self.sin_table[pos]  # prepare_freqs_cis_decode, model.py:429-448
-        h, pending = self.embed(tokens), None
+        # embedding rows of this rank's vocabulary slice + every sequence's rotary row (prepare_freqs_cis_decode,
+        # model.py:429-448): one launch
+        h, cos, sin = ops.embed_rope_gather(tokens, self.embed_weight, self.vocab_start if self.vocab_local != self.args.vocab_size else 0,
+                                            self.cache.get_gpu_seq_lens_excl_this_decode(), self.cos_table, self.sin_table)
+        if self.vocab_local != self.args.vocab_size:
+            h = tp.all_reduce(h)  # tensor_parallel.py:199-208
+        pending = None
         for layer in self.layers:
             h, pending = layer(h, pending, cos, sin)
         h = add_norm(h, pending, self.norm)[1]

@@ -488,6 +488,32 @@ def mla_merge_absorb_uv_quant_fp8(partials, num_splits, batch, w, scale, scale_o
     return q, s
 
 
+def embed_rope_gather(tokens, embed_weight, vocab_start, positions=None, cos_table=None, sin_table=None):
+    """The decode step's prologue in one launch: h = vocabulary-parallel embedding rows (zero for ids outside
+    [vocab_start, vocab_start + rows), tensor_parallel.py:199-208 without the all-reduce) and, when positions is
+    given, (cos, sin) = the rotary rows of positions[:bs] (model.py:429-448).  Returns (h, cos, sin)."""
+    require_cuda(tokens, embed_weight, positions, cos_table, sin_table)
+    assert tokens.dtype == torch.int64 and tokens.dim() == 1 and tokens.is_contiguous()
+    assert embed_weight.dtype == torch.bfloat16 and embed_weight.is_contiguous()
+    bs, dim = tokens.shape[0], embed_weight.shape[1]
+    h = torch.empty(bs, dim, dtype=torch.bfloat16, device=tokens.device)
+    cos = sin = None
+    half = rows = 0
+    if positions is not None:
+        assert positions.dtype == torch.int32 and positions.is_contiguous() and positions.numel() >= bs
+        assert cos_table.dtype == torch.float32 and cos_table.is_contiguous() and sin_table.is_contiguous()
+        rows, half = cos_table.shape
+        cos = torch.empty(bs, half, dtype=torch.float32, device=tokens.device)
+        sin = torch.empty(bs, half, dtype=torch.float32, device=tokens.device)
+    check(
+        _lib.lib().chitu_hip_embed_rope_gather(ptr(tokens), ptr(embed_weight), i64(vocab_start), i64(embed_weight.shape[0]),
+                                               i32(dim), ptr(h), ptr(positions), ptr(cos_table), ptr(sin_table), i64(rows),
+                                               i32(half), ptr(cos), ptr(sin), i32(bs), stream_ptr()),
+        "embed_rope_gather",
+    )
+    return h, cos, sin
+
+
 def mla_qkv_post(q_a_kv, q_lora_rank, q_norm_weight, q_eps, kv_norm_weight, kv_eps, cos, sin, kv_cache, page_table,
                  old_seq_lens):
     """One launch for everything that reads wqkv_a's output [bs, q_lora + 512 + 64]: q_norm + act_quant

@@ -90,11 +90,14 @@ class XgmiComm:
         return rows <= self.max_rows and dim <= self.max_dim and dim % 8 == 0 and terms <= 16
 
     def allreduce_rmsnorm(self, part: torch.Tensor, x: Optional[torch.Tensor] = None, weight: Optional[torch.Tensor] = None,
-                          eps: float = 1e-6, out_bf16: bool = True, quant: Optional[str] = None, out: Optional[torch.Tensor] = None):
+                          eps: float = 1e-6, out_bf16: bool = True, quant: Optional[str] = None, out: Optional[torch.Tensor] = None,
+                          phase: int = 0, into=None):
         """part: this rank's partial, [rows, dim] or [rows, terms, dim] (terms summed first, chitu_hip_moe_sum's
         rounding).  Returns what ops.rms_norm(x, weight, eps, out_bf16, quant, add=<all-reduced part>) returns:
         (x_new, y[, q, s]) -- with x None, x_new is the all-reduced tensor itself; with weight None only
-        x_new is returned (a plain all-reduce, `out` may alias `part` for the in-place form)."""
+        x_new is returned (a plain all-reduce, `out` may alias `part` for the in-place form).
+        phase: 0 = whole collective; 1 = contribute only (returns the output tensors, not yet valid); 2 = complete
+        (pass the tuple phase 1 returned as `into`)."""
         require_cuda(part, x, weight)
         assert part.dtype == torch.bfloat16 and part.stride(-1) == 1
         dim = part.shape[-1]
@@ -106,14 +109,17 @@ class XgmiComm:
             rows, terms, term_stride, part_stride = part.shape[0], 1, 0, part.stride(0)
         if x is not None:
             assert x.dtype == torch.bfloat16 and x.shape == (rows, dim) and x.stride(-1) == 1
-        sum_out = out if out is not None else torch.empty(rows, dim, dtype=torch.bfloat16, device=part.device)
-        assert sum_out.shape == (rows, dim) and sum_out.dtype == torch.bfloat16 and sum_out.stride(-1) == 1
         y = q = s = None
+        if into is not None:
+            sum_out, y, q, s = (tuple(into) + (None,) * 4)[:4] if isinstance(into, tuple) else (into, None, None, None)
+        else:
+            sum_out = out if out is not None else torch.empty(rows, dim, dtype=torch.bfloat16, device=part.device)
+        assert sum_out.shape == (rows, dim) and sum_out.dtype == torch.bfloat16 and sum_out.stride(-1) == 1
         if weight is not None:
             assert weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.numel() == dim
-            if out_bf16:
+            if out_bf16 and y is None:
                 y = torch.empty(rows, dim, dtype=torch.bfloat16, device=part.device)
-            if quant is not None:
+            if quant is not None and q is None:
                 q = torch.empty(rows, dim, dtype=torch.float8_e4m3fn, device=part.device)
                 s = torch.empty(rows, dim // 128, dtype=torch.float32, device=part.device)
         else:
@@ -122,7 +128,7 @@ class XgmiComm:
             _lib.lib().chitu_hip_comm_allreduce_rmsnorm(
                 self._h, ptr(part), i64(part_stride), i32(terms), i64(term_stride), ptr(x),
                 i64(x.stride(0) if x is not None else 0), ptr(sum_out), i64(sum_out.stride(0)), ptr(weight), ptr(y), i64(dim),
-                i64(rows), i32(dim), f32(eps), ptr(q), ptr(s), i32(_QUANT_MODE[quant]), f32(1e-10), stream_ptr()),
+                i64(rows), i32(dim), f32(eps), ptr(q), ptr(s), i32(_QUANT_MODE[quant]), f32(1e-10), i32(phase), stream_ptr()),
             "comm_allreduce_rmsnorm")
         if weight is None:
             return sum_out
@@ -137,13 +143,14 @@ class XgmiComm:
     def gather_fits(self, rows: int, cols: int) -> bool:
         return cols % 8 == 0 and rows * cols * 2 <= self.gather_bytes
 
-    def all_gather_last_dim(self, y: torch.Tensor, out_dtype=torch.bfloat16) -> torch.Tensor:
-        """[rows, cols] bf16 per rank -> [rows, world * cols] (rank-major along the last dim) in bf16 or f32."""
+    def all_gather_last_dim(self, y: torch.Tensor, out_dtype=torch.bfloat16, phase: int = 0, into=None) -> torch.Tensor:
+        """[rows, cols] bf16 per rank -> [rows, world * cols] (rank-major along the last dim) in bf16 or f32.
+        phase / into: as allreduce_rmsnorm."""
         require_cuda(y)
         assert y.dim() == 2 and y.dtype == torch.bfloat16 and y.stride(-1) == 1
         rows, cols = y.shape
-        out = torch.empty(rows, self.world * cols, dtype=out_dtype, device=y.device)
+        out = into if into is not None else torch.empty(rows, self.world * cols, dtype=out_dtype, device=y.device)
         check(_lib.lib().chitu_hip_comm_all_gather(self._h, ptr(y), i64(y.stride(0)), i64(rows), i64(cols), ptr(out),
-                                                   i32({torch.bfloat16: 0, torch.float32: 2}[out_dtype]), stream_ptr()),
+                                                   i32({torch.bfloat16: 0, torch.float32: 2}[out.dtype]), i32(phase), stream_ptr()),
               "comm_all_gather")
         return out

@@ -198,6 +198,27 @@ int chitu_hip_bf16_gemm_silu(const void* x_bf16, const void* w13_bf16, void* out
  *   out[r, :] = bf16( bf16(silu(x[r, :d])) * x[r, d:2d] ),  x [rows, 2d] bf16, out [rows, d] bf16, d % 8 == 0. */
 int chitu_hip_silu_and_mul(const void* x_bf16, void* out_bf16, int64_t rows, int64_t d, void* stream);
 
+/* ---- decode-step prologue: embedding lookup + rotary-row gather in one launch -----------------------
+ * Replaces VocabParallelEmbedding.forward's mask / lookup / zero-fill (chitu/tensor_parallel.py:199-208; the
+ * all-reduce that follows stays the caller's) and prepare_freqs_cis_decode's gather of the rotary row of every
+ * sequence's current position (chitu/models/model.py:429-448):
+ *   h[b, :] = vocab_start <= tokens[b] < vocab_start + vocab_local ? embed[tokens[b] - vocab_start, :] : 0
+ *   cos_out[b, :] = cos_table[positions[b], :], sin_out likewise ([table_rows, half] f32; skipped when cos_out NULL)
+ *   tokens [batch] i64, embed [vocab_local, dim] bf16 (dim % 8 == 0), h [batch, dim] bf16, positions [batch] i32. */
+int chitu_hip_embed_rope_gather(const int64_t* tokens, const void* embed_bf16, int64_t vocab_start,
+                                int64_t vocab_local, int32_t dim, void* h_bf16, const int32_t* positions,
+                                const float* cos_table, const float* sin_table, int64_t table_rows,
+                                int32_t half, float* cos_out, float* sin_out, int32_t batch, void* stream);
+
+/* ---- launch-variant override (tests, tuning sweeps) -------------------------------------------------
+ * Several ops choose between launch variants of IDENTICAL results (K-split width, ring depth, key-based vs
+ * generic routing kernel, candidate vs radix sampler ...) by a shape heuristic.  This entry forces one, so the
+ * equivalence tests can run every variant and a sweep can time them; value -1 restores the heuristic.  Process-wide,
+ * not thread-safe, never needed in production.  option: 0 MoE GEMM1 K-split waves, 1 GEMM1 tiles per workgroup,
+ * 2 GEMM1 ring depth, 3 GEMM2 config (NT*10 + ROUNDS), 4 int8 MoE K-split waves, 5 generic routing kernel (1),
+ * 6 ticket-based route + align (1), 7 radix-only sampler (1). */
+int chitu_hip_debug_option(int32_t option, int32_t value);
+
 /* ---- arithmetic self-test ----------------------------------------------------------------------
  * The quantising kernels divide a group's values by its scale with a refined-reciprocal +
  * residual-correction sequence instead of the IEEE division expansion, and round to bf16 with
@@ -484,7 +505,10 @@ int chitu_hip_sample(const void* logits, int act_dtype, int64_t row_stride, int6
  *     rows <= max_rows, dim <= max_dim, dim % 8 == 0 (CHITU_ERR_UNSUPPORTED otherwise: use the library path).
  *   comm_all_gather: out[row, r*cols + j] = in_r[row, j] (rank-major concat of the last dimension);
  *     in bf16 [rows, cols] (row stride given, cols % 8 == 0, rows*cols*2 <= gather_bytes); out_dtype 0 = bf16,
- *     2 = f32 (the logits' `.float()`, models/model.py:475, rides along); out [rows, world*cols] dense. */
+ *     2 = f32 (the logits' `.float()`, models/model.py:475, rides along); out [rows, world*cols] dense.
+ *   phase (both): 0 = the whole collective; 1 = contribute only (push this rank's data, signal, return);
+ *     2 = complete only (wait for the peers, reduce / gather, advance the call counter) -- issue it after a
+ *     phase-1 launch with the same arguments.  Split phases let work sit between the push and the wait. */
 int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_rows, int32_t max_dim,
                           int64_t gather_bytes, int32_t timeout_ms, void** comm_out);
 int chitu_hip_comm_ipc_handle(void* comm, void* handle_out_64);
@@ -498,9 +522,9 @@ int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf16, int64_t 
                                      int64_t x_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
                                      const void* weight_bf16, void* y_bf16, int64_t y_row_stride,
                                      int64_t rows, int32_t dim, float eps, void* q_fp8, float* q_scales,
-                                     int32_t quant_mode, float quant_eps, void* stream);
+                                     int32_t quant_mode, float quant_eps, int32_t phase, void* stream);
 int chitu_hip_comm_all_gather(void* comm, const void* in_bf16, int64_t in_row_stride, int64_t rows,
-                              int64_t cols, void* out, int32_t out_dtype, void* stream);
+                              int64_t cols, void* out, int32_t out_dtype, int32_t phase, void* stream);
 
 #ifdef __cplusplus
 }

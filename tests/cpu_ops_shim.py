@@ -172,6 +172,17 @@ class CpuGqaBackend:
         return ogqa.attn_varlen_causal(q, k, v, cu_seqlens_q).to(torch.bfloat16)
 
 
+def embed_rope_gather(tokens, embed_weight, vocab_start, positions=None, cos_table=None, sin_table=None):
+    """tensor_parallel.py:199-208 (lookup with foreign ids zeroed, no all-reduce) + model.py:429-448 (rotary rows)."""
+    local = tokens - vocab_start
+    foreign = (local < 0) | (local >= embed_weight.shape[0])
+    h = torch.nn.functional.embedding(local.masked_fill(foreign, 0), embed_weight).masked_fill(foreign.unsqueeze(-1), 0)
+    if positions is None:
+        return h, None, None
+    pos = positions[: tokens.shape[0]].long()
+    return h, cos_table[pos], sin_table[pos]
+
+
 def install_llama(monkeypatch_setattr):
     from chitu_amd import ops
 
@@ -184,7 +195,8 @@ def install(monkeypatch_setattr):
     from chitu_amd import fused_moe, ops
 
     for name in ("rms_norm", "act_quant_deepseek_v3", "fp8_gemm_deepseek_v3", "mla_kv_prep", "absorb_bmm_fp8",
-                 "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear", "mla_qkv_post", "absorb_bmm_rope_fp8"):
+                 "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear", "mla_qkv_post", "absorb_bmm_rope_fp8",
+                 "embed_rope_gather"):
         monkeypatch_setattr(ops, name, globals()[name])
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)
     monkeypatch_setattr(fused_moe, "silu_and_mul_quant", silu_and_mul_quant)

@@ -448,16 +448,13 @@ def test_gate_route_fast_path_equals_generic_kernel(E, groups, topk, S, bias, mo
             logits = ((part * 4).round() / 4 if coarse else part).float().cuda()
         b = ((torch.randn(E, generator=g) * (0.25 if coarse else 0.05)).to(torch.bfloat16).cuda()) if bias else None
         outs = []
-        for slow in (False, True):
-            if slow:
-                monkeypatch.setenv("CHITU_GATE_SLOW", "1")
-            else:
-                monkeypatch.delenv("CHITU_GATE_SLOW", raising=False)
+        for slow in (0, 1):
             w = torch.zeros(M, topk + 2, dtype=torch.bfloat16, device="cuda")
             ids = torch.zeros(M, topk + 2, dtype=torch.int64, device="cuda")
-            rc = _lib.lib().chitu_hip_gate_route(ptr(logits), i32(S), i64(M), i32(E), ptr(b), i32(groups[0]), i32(groups[1]),
-                                                 i32(topk), i32(1), f32(2.5), ptr(w), ptr(ids), i32(topk + 2), i32(E),
-                                                 f32(1.0), i32(2), stream_ptr())
+            with _lib.debug_option("gate_generic", slow):
+                rc = _lib.lib().chitu_hip_gate_route(ptr(logits), i32(S), i64(M), i32(E), ptr(b), i32(groups[0]), i32(groups[1]),
+                                                     i32(topk), i32(1), f32(2.5), ptr(w), ptr(ids), i32(topk + 2), i32(E),
+                                                     f32(1.0), i32(2), stream_ptr())
             assert rc == 0
             torch.cuda.synchronize()
             outs.append((w.cpu(), ids.cpu()))

@@ -75,3 +75,27 @@ def test_rope_strided_views(rtype):
     rq, rk = okv.apply_rotary_pos_emb(q_pe, k_pe, cos, sin, rtype)
     oq, ok = ops.apply_rotary_pos_emb(q_full.cuda()[..., 128:], kv_full.cuda()[..., 512:], cos.cuda(), sin.cuda(), rtype)
     assert torch.equal(oq.cpu(), rq) and torch.equal(ok.cpu(), rk)
+
+
+@pytest.mark.parametrize("bs,dim,vocab_start,rows", [(1, 7168, 0, 16160), (16, 7168, 32320, 16160), (5, 512, 100, 64)])
+def test_embed_rope_gather_is_the_masked_lookup_and_the_table_rows(bs, dim, vocab_start, rows):
+    """chitu_hip_embed_rope_gather == VocabParallelEmbedding's mask / lookup / zero-fill (tensor_parallel.py:199-208)
+    + the rotary-row gather of prepare_freqs_cis_decode (model.py:429-448), bit for bit."""
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(bs + dim)
+    table = torch.randn(rows, dim, generator=g).to(torch.bfloat16)
+    toks = torch.randint(vocab_start - 5, vocab_start + rows + 5, (bs,), generator=g)
+    toks[0] = vocab_start  # first and last row of the slice, and ids on both sides of it
+    if bs > 2:
+        toks[1], toks[2] = vocab_start + rows - 1, vocab_start + rows
+    cos_t, sin_t = torch.randn(300, 32, generator=g), torch.randn(300, 32, generator=g)
+    pos = torch.randint(0, 300, (bs + 3,), generator=g).to(torch.int32)  # the cache's buffer is longer than the batch
+    h, c, s = ops.embed_rope_gather(toks.cuda(), table.cuda(), vocab_start, pos.cuda(), cos_t.cuda(), sin_t.cuda())
+    local = toks - vocab_start
+    foreign = (local < 0) | (local >= rows)
+    want = torch.nn.functional.embedding(local.masked_fill(foreign, 0), table).masked_fill(foreign.unsqueeze(-1), 0)
+    assert torch.equal(h.cpu(), want) and foreign.any() and not foreign.all()
+    assert torch.equal(c.cpu(), cos_t[pos[:bs].long()]) and torch.equal(s.cpu(), sin_t[pos[:bs].long()])
+    h2, c2, s2 = ops.embed_rope_gather(toks.cuda(), table.cuda(), vocab_start)
+    assert torch.equal(h2, h) and c2 is None and s2 is None

@@ -113,16 +113,17 @@ def test_two_launch_expert_path_is_bit_identical_to_three_launch(M, E, topk, K, 
     emap[E // 2:] = -1
     # the two forms pick their K split (waves per workgroup) from different launch heuristics; with the
     # same split the fp32 summation order, and therefore every bit, is the same
-    for wk in ("1", "2", "8"):
-        monkeypatch.setenv("CHITU_MOE_GEMM1_WK", wk)
-        outs = {}
-        for fuse in ("1", "0"):
-            monkeypatch.setenv("CHITU_MOE_FUSE_SILU", fuse)
-            outs[fuse] = (run_hip(*args), run_hip(*args, expert_map=emap.cuda(), global_num_experts=E))
+    from chitu_amd._lib import debug_option
+
+    for wk in (1, 2, 8):
+        with debug_option("moe_gemm1_wk", wk):
+            outs = {}
+            for fuse in ("1", "0"):
+                monkeypatch.setenv("CHITU_MOE_FUSE_SILU", fuse)
+                outs[fuse] = (run_hip(*args), run_hip(*args, expert_map=emap.cuda(), global_num_experts=E))
         assert torch.equal(outs["1"][0], outs["0"][0]), wk
         assert torch.equal(outs["1"][1], outs["0"][1]), wk
     # default heuristics: same function up to the summation order
-    monkeypatch.delenv("CHITU_MOE_GEMM1_WK")
     monkeypatch.setenv("CHITU_MOE_FUSE_SILU", "1")
     a = run_hip(*args)
     monkeypatch.setenv("CHITU_MOE_FUSE_SILU", "0")

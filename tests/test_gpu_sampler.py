@@ -16,12 +16,14 @@ pytestmark = pytest.mark.gpu
 def sampler_path(request, monkeypatch):
     """Every test runs twice: with the short candidate-list path enabled (the default; it declines where it
     cannot prove the list complete and the radix descent runs) and with the radix descent alone
-    (CHITU_SAMPLE_RADIX, read by chitu_hip_sample at every call).  Both implement one integer specification."""
+    (launch-variant override "sample_radix", chitu_hip_debug_option).  Both implement one integer specification."""
+    from chitu_amd._lib import debug_option
+
     if request.param == "radix":
-        monkeypatch.setenv("CHITU_SAMPLE_RADIX", "1")
+        with debug_option("sample_radix", 1):
+            yield request.param
     else:
-        monkeypatch.delenv("CHITU_SAMPLE_RADIX", raising=False)
-    return request.param
+        yield request.param
 
 
 def _responses(g):

@@ -78,7 +78,7 @@ if want("moe"):
         mmb = min(eid.numel(), numel)
         fns = [(lambda l=l: lib.chitu_hip_moe_gemm1_fp8(ptr(xq), ptr(xs), ptr(w1[l]), ptr(w1s[l]), ptr(sid), ptr(eid), ptr(npost),
                                                          ptr(c1), i64(numel), i32(topk), i64(2 * I), i64(K), i64(mmb), stream_ptr())) for l in range(L)]
-        timeit(f"moe_gemm1 bs={bs} distinct={distinct} WK={os.environ.get('CHITU_MOE_GEMM1_WK','auto')}", fns, distinct * 2 * I * K)
+        timeit(f"moe_gemm1 bs={bs} distinct={distinct} WK={os.environ.get('CHITU_MOE_GEMM1_WK','auto')} (apply with chitu_amd._lib.debug_option)", fns, distinct * 2 * I * K)
         hq, hs = fused_moe.silu_and_mul_quant(c1, mode="group")
         c3 = torch.empty(numel, K, dtype=torch.bfloat16, device=dev)
         wts = torch.rand(bs, topk, device=dev, generator=gen).to(torch.bfloat16)
