@@ -89,6 +89,10 @@ def absorb_uv_quant_fp8(x, w, scale, scale_offset, sh, sk):
 def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale, extra_expert_id=-1,
                      extra_weight=1.0, extra_count=1, align=None):
     # align (the fused route + sort launch) is a launch-count optimisation: the 2-tuple makes the caller sort itself
+    if score_func == "softmax_renorm":  # Mixtral: softmax -> top-k -> renormalise (model_hf_mixtral.py:60-75)
+        from oracle import mixtral as omix
+
+        return omix.route(x, weight, topk)
     w, i = ods.gate(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale)
     if extra_expert_id >= 0:
         w = torch.cat([w, torch.full((w.shape[0], extra_count), extra_weight, dtype=w.dtype)], 1)
@@ -102,9 +106,14 @@ def bf16_linear(x, weight, out_dtype=None):
 
 def fused_experts(hidden_states, w1, w2, topk_weights, topk_ids, inplace=False, use_fp8_w8a8=False,
                   global_num_experts=-1, w1_scale=None, w2_scale=None, block_shape=None, a1_quant=None,
-                  expert_map=None, **kw):
-    out = omoe.fused_experts_fp8(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale,
-                                 expert_map=expert_map)
+                  expert_map=None, use_int8_w8a8=False, **kw):
+    if use_int8_w8a8:
+        from oracle import w8a8 as ow
+
+        out = ow.fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale)
+    else:
+        out = omoe.fused_experts_fp8(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale,
+                                     expert_map=expert_map)
     if inplace:
         hidden_states.copy_(out)
         return hidden_states
@@ -184,10 +193,11 @@ def embed_rope_gather(tokens, embed_weight, vocab_start, positions=None, cos_tab
 
 
 def install_llama(monkeypatch_setattr):
-    from chitu_amd import ops
+    from chitu_amd import fused_moe, ops
 
-    for name in ("rms_norm", "bf16_linear", "gqa_qkv_post", "bf16_linear_silu", "apply_rotary_pos_emb"):
+    for name in ("rms_norm", "bf16_linear", "gqa_qkv_post", "bf16_linear_silu", "apply_rotary_pos_emb", "gate_deepseek_v3"):
         monkeypatch_setattr(ops, name, globals()[name])
+    monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)  # Mixtral's INT8 experts ride on the Llama wiring
 
 
 def install(monkeypatch_setattr):

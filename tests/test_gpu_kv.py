@@ -95,7 +95,7 @@ def test_embed_rope_gather_is_the_masked_lookup_and_the_table_rows(bs, dim, voca
     local = toks - vocab_start
     foreign = (local < 0) | (local >= rows)
     want = torch.nn.functional.embedding(local.masked_fill(foreign, 0), table).masked_fill(foreign.unsqueeze(-1), 0)
-    assert torch.equal(h.cpu(), want) and foreign.any() and not foreign.all()
+    assert torch.equal(h.cpu(), want) and not foreign.all() and (bs < 3 or foreign.any())
     assert torch.equal(c.cpu(), cos_t[pos[:bs].long()]) and torch.equal(s.cpu(), sin_t[pos[:bs].long()])
     h2, c2, s2 = ops.embed_rope_gather(toks.cuda(), table.cuda(), vocab_start)
     assert torch.equal(h2, h) and c2 is None and s2 is None

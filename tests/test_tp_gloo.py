@@ -365,3 +365,97 @@ def _llama_tp(rank, world):
 @pytest.mark.parametrize("world", [1, 2])
 def test_llama_wiring_reproduces_the_reference_cpu_run(world):
     _run(_llama_tp, world)
+
+
+def _mixtral_tp(rank, world):
+    """BASELINE config 4's parallelism at test size: chitu_amd/mixtral.py under tensor parallelism -- attention heads
+    and every expert's width split over the ranks (w13 rows per gate / up half, w2 columns; per-channel scales follow
+    their channels, w2's stay whole), router replicated, two all-reduces per layer -- two decode steps."""
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.mixtral import MixtralArgs, MixtralDecoder
+    from oracle import w8a8 as ow
+    from tests import cpu_ops_shim
+
+    cpu_ops_shim.install_llama(setattr)
+    args = MixtralArgs(dim=512, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=512, ffn_dim=256, num_local_experts=4,
+                       num_experts_per_tok=2)
+    hq, hkv, hd = args.n_heads, args.n_kv_heads, args.head_dim
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=2, block_size=64, max_seq_len=128, device="cpu",
+                                n_local_kv_heads=hkv // world, head_dim=hd, dtype=torch.bfloat16)
+    model = MixtralDecoder(args, cache, cpu_ops_shim.CpuGqaBackend(), max_position_embeddings=128, device="cpu")
+    g = torch.Generator().manual_seed(21)
+    full = {}
+    D = args.dim
+    shapes = {"embed_weight": (512, D), "head_weight": (512, D), "norm": (D,)}
+    for i in range(args.n_layers):
+        pre = f"layers.{i}."
+        shapes.update({pre + "attn.wqkv": ((hq + 2 * hkv) * hd, D), pre + "attn.wo": (D, hq * hd), pre + "attn_norm": (D,),
+                       pre + "ffn_norm": (D,), pre + "ffn.gate": (4, D)})
+    for k, shp in shapes.items():
+        full[k] = torch.ones(shp, dtype=torch.bfloat16) if k.endswith("norm") else \
+            (torch.randn(shp, generator=g) * (1.0 if k == "embed_weight" else shp[-1] ** -0.5)).to(torch.bfloat16)
+    for i in range(args.n_layers):
+        pre = f"layers.{i}.ffn."
+        q13, s13, q2, s2 = [], [], [], []
+        for e in range(4):
+            a, b = ow.quant_weight(torch.randn(2 * args.ffn_dim, D, generator=g) * D ** -0.5)
+            c, d = ow.quant_weight(torch.randn(D, args.ffn_dim, generator=g) * args.ffn_dim ** -0.5)
+            q13.append(a), s13.append(b.view(-1)), q2.append(c), s2.append(d.view(-1))
+        full[pre + "w13"], full[pre + "w13_scale"] = torch.stack(q13), torch.stack(s13)
+        full[pre + "w2"], full[pre + "w2_scale"] = torch.stack(q2), torch.stack(s2)
+
+    def chunk(t, dim):
+        c = t.shape[dim] // world
+        return t.narrow(dim, rank * c, c)
+
+    for k, p in model.named_parameters():
+        t = full[k]
+        if k.endswith("attn.wqkv"):
+            q, kk, v = t[: hq * hd], t[hq * hd : (hq + hkv) * hd], t[(hq + hkv) * hd :]
+            t = torch.cat([chunk(q, 0), chunk(kk, 0), chunk(v, 0)], 0)
+        elif k.endswith("ffn.w13") or k.endswith("ffn.w13_scale"):
+            i = t.shape[1] // 2
+            t = torch.cat([chunk(t[:, :i], 1), chunk(t[:, i:], 1)], 1)
+        elif k.endswith("ffn.w2"):
+            t = chunk(t, 2)
+        elif k.endswith("attn.wo"):
+            t = chunk(t, 1)
+        elif k in ("embed_weight", "head_weight"):
+            t = chunk(t, 0)
+        assert p.shape == t.shape, (k, p.shape, t.shape)
+        p.data.copy_(t)
+    reqs = ["a", "b"]
+    for r, n in zip(reqs, (5, 64)):
+        cache.register_sequence(r, n)
+        for blk in cache.block_table[r]:
+            kv = (torch.randn(2, args.n_layers, 64, hkv, hd, generator=g) * 0.5).to(torch.bfloat16)
+            cache.paged_k_cache[:, blk] = chunk(kv[0], 2)
+            cache.paged_v_cache[:, blk] = chunk(kv[1], 2)
+    tokens, outs = torch.tensor([3, 200]), []
+    for _ in range(2):
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        with torch.inference_mode():
+            logits = model.decode(tokens, use_graph=False)
+        assert logits.shape == (2, args.vocab_size)
+        outs.append(logits.float().clone())
+        tokens = logits.argmax(-1)
+        cache.finalize_cache_single_decode(reqs)
+    for t in outs:
+        ref = t.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(ref, t)
+    if rank == 0:
+        torch.save({"logits": outs}, os.environ["TP_OUT"] + f".mx{world}")
+
+
+def test_mixtral_int8_decode_step_tp2_matches_tp1(tmp_path):
+    base = str(tmp_path / "mx")
+    os.environ["TP_OUT"] = base
+    _run(_mixtral_tp, 1)
+    _run(_mixtral_tp, 2)
+    l1, l2 = torch.load(base + ".mx1")["logits"], torch.load(base + ".mx2")["logits"]
+    # first step: same tokens on both sides; a rank quantises ITS slice of the experts' hidden activations per token
+    # (W8A8Linear under row parallelism), so TP = 2 differs from TP = 1 by int8 rounding, not bit for bit
+    err = ((l1[0] - l2[0]).abs().max() / l1[0].abs().max()).item()
+    assert err < 5e-2, err
