@@ -283,3 +283,4 @@ extern "C" int chitu_hip_silu_and_mul(const void* x_bf16, void* out_bf16, int64_
                        (const bf16_t*)x_bf16, (bf16_t*)out_bf16, rows, (int)d);
     CHITU_RETURN_LAUNCH_STATUS();
 }
+

@@ -204,10 +204,12 @@ class LlamaDecoder(torch.nn.Module):
         return torch.stack(out, dim=1)
 
     def decode_eager(self, tokens):
-        bs = tokens.shape[0]
-        pos = self.cache.get_gpu_seq_lens_excl_this_decode()[:bs].long()
-        cos, sin = self.cos_table[pos], self.sin_table[pos]
-        h, pending = self.embed(tokens), None
+        # embedding rows of this rank's vocabulary slice + every sequence's rotary row: one launch
+        h, cos, sin = ops.embed_rope_gather(tokens, self.embed_weight, self.vocab_start if self.vocab_local != self.args.vocab_size else 0,
+                                            self.cache.get_gpu_seq_lens_excl_this_decode(), self.cos_table, self.sin_table)
+        if self.vocab_local != self.args.vocab_size:
+            h = tp.all_reduce(h)
+        pending = None
         for layer in self.layers:
             h, pending = layer(h, pending, cos, sin)
         h = ops.rms_norm(h, self.norm, self.args.norm_eps, add=pending)[1]

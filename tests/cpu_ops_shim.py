@@ -195,7 +195,8 @@ def embed_rope_gather(tokens, embed_weight, vocab_start, positions=None, cos_tab
 def install_llama(monkeypatch_setattr):
     from chitu_amd import fused_moe, ops
 
-    for name in ("rms_norm", "bf16_linear", "gqa_qkv_post", "bf16_linear_silu", "apply_rotary_pos_emb", "gate_deepseek_v3"):
+    for name in ("rms_norm", "bf16_linear", "gqa_qkv_post", "bf16_linear_silu", "apply_rotary_pos_emb", "gate_deepseek_v3",
+                 "embed_rope_gather"):
         monkeypatch_setattr(ops, name, globals()[name])
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)  # Mixtral's INT8 experts ride on the Llama wiring
 
