@@ -72,6 +72,39 @@ def test_vs_oracle(bs, H, lens, splits):
     assert err < REL_TOL, err
 
 
+@pytest.mark.parametrize("lens", [[8192, 5000], [32768, 20001, 9]])
+def test_long_contexts_vs_oracle(lens):
+    """Contexts where the KV stream dominates (8k / 32k tokens: 128 / 512 tiles per sequence, many tiles per split,
+    the running-max rescale taken hundreds of times), ragged, with the default split heuristic and a forced one;
+    also through the fused split-merge + W_UV + quant launch the decode step uses."""
+    from chitu_amd import ops
+    from oracle import fp8 as ofp8
+
+    bs, H = len(lens), 16
+    pages = sum((l + 63) // 64 for l in lens) + 2
+    q_nope, q_pe, cache, table, sl = make_case(bs, H, lens, pages, seed=len(lens) + lens[0])
+    scale = 0.1352
+    ref = omla.mla_decode(q_nope, q_pe, cache, table, sl, scale)
+    be = backend(H)
+    dev = [t.cuda() for t in (q_nope, q_pe, cache, sl, table)]
+    for splits in (None, 5):
+        out = be.mla_decode(dev[0], dev[1], dev[2], dev[3], dev[4], scale, num_splits=splits)
+        err = max_rel_to_peak(out, ref)
+        assert err < REL_TOL, (splits, err)
+    part = be.mla_decode(dev[0], dev[1], dev[2], dev[3], dev[4], scale, return_partials=True)
+    assert isinstance(part, tuple) and part[1] >= 2
+    g = torch.Generator().manual_seed(3)
+    w = (torch.randn(H, 256, 512, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    sc = torch.rand(H * 2, 4, generator=g) * 0.02 + 0.01
+    w_uv = w.cuda()[:, 128:]
+    q, s_ = ops.mla_merge_absorb_uv_quant_fp8(part[0], part[1], bs, w_uv, sc.cuda(), 4, 8, 1)
+    # oracle: W_UV projection of the oracle's attention output (model_deepseek_v3.py:697), then act_quant
+    wd = ofp8.weight_dequant_deepseek_v3(w.view(H * 256, 512), sc).view(H, 256, 512)[:, 128:]
+    proj = torch.einsum("bhc,hdc->bhd", ref.float(), wd.float()).to(torch.bfloat16).reshape(bs, H * 128)
+    got = (q.float().view(bs, H, 128) * s_.view(bs, H, 1)).reshape(bs, H * 128)
+    assert max_rel_to_peak(got, proj) < 4e-2  # one fp8 quantisation step (2^-4 relative) on top of the attention bar
+
+
 def test_garbage_beyond_seqlen_is_ignored_and_zero_length():
     """Rows past seqlens (stale page content, even NaN) must not leak into the output."""
     q_nope, q_pe, cache, table, sl = make_case(2, 16, [70, 130], 8, seed=5)
