@@ -217,7 +217,7 @@ class AttentionDeepSeekV3(torch.nn.Module):
         bypass the counter (`.data` fills: init_synthetic_, checkpoint.load_deepseek_v3) call
         `refresh_derived_layouts`."""
         wt = self.wkv_b.weight
-        key = (wt.data_ptr(), wt._version)
+        key = (wt.data_ptr(), None if wt.is_inference() else wt._version)  # inference tensors carry no version counter
         if self._w_uk_t is None or self._w_uk_key != key:
             H = self.n_local_heads
             w = wt.view(torch.uint8).view(H, self.qk_nope_head_dim + self.v_head_dim, self.kv_lora_rank)

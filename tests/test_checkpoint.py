@@ -227,3 +227,35 @@ def test_two_shared_experts_become_two_slots_of_the_routed_width():
         assert torch.equal(out["layers.1.ffn.w2.scale"][nr + j], st["layers.1.ffn.shared_experts.w2.scale"][:, j * (I // 128):(j + 1) * (I // 128)])
     with pytest.raises(ValueError):  # the wide MLP handed over as ONE slot does not have the routed experts' shape
         ck.preprocess_deepseek_v3(st, nr, n_shared=1)
+
+
+def test_transposed_w_uk_tracks_the_weights_and_keeps_its_buffer():
+    """The derived [H, kv_lora, nope] copy of W_UK is rebuilt IN PLACE when wkv_b changes through a tracked path
+    (copy_ / load_state_dict: version counter) and after `refresh_derived_layouts` (writers that go through `.data`),
+    so a captured graph keeps reading valid bytes; a model built under inference_mode (no version counters) works."""
+    from chitu_amd.deepseek_v3 import DeepSeekV3Decoder, refresh_derived_layouts
+
+    model = DeepSeekV3Decoder(_args(1), None, None, max_position_embeddings=64, device="cpu")
+    attn = model.layers[0].attn
+    w = attn.wkv_b.weight
+    with torch.no_grad():
+        w.copy_(torch.randint(0, 120, w.shape, dtype=torch.uint8).view(w.dtype))
+    H = attn.n_local_heads
+
+    def expect():
+        return w.view(torch.uint8).view(H, 256, attn.kv_lora_rank)[:, :128].transpose(1, 2).contiguous()
+
+    t1 = attn.w_uk_transposed()
+    ptr = t1.data_ptr()
+    assert torch.equal(t1.view(torch.uint8), expect())
+    with torch.no_grad():
+        w.copy_(torch.randint(0, 120, w.shape, dtype=torch.uint8).view(w.dtype))  # tracked write
+    t2 = attn.w_uk_transposed()
+    assert t2.data_ptr() == ptr and torch.equal(t2.view(torch.uint8), expect())
+    w.data.view(torch.uint8).fill_(7)  # untracked write
+    refresh_derived_layouts(model)
+    assert attn.w_uk_transposed().data_ptr() == ptr and torch.equal(attn.w_uk_transposed().view(torch.uint8), expect())
+    with torch.inference_mode():
+        m2 = DeepSeekV3Decoder(_args(1), None, None, max_position_embeddings=64, device="cpu")
+        m2.layers[0].attn.wkv_b.weight.view(torch.uint8).fill_(3)
+        assert int(m2.layers[0].attn.w_uk_transposed().view(torch.uint8).max()) == 3
