@@ -473,20 +473,9 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
 
 
 def add_norm(x, pending, norm, out_bf16=True, quant=None):
-    """(x_new, y, q, s) with x_new = x + pending and y / (q, s) = RMSNorm(x_new) [quantised]; entries not asked
-    for are None.  pending: None | a tensor ([rows, dim], or [rows, terms, dim]: terms summed first) | a
-    tp.PendingAllReduce (partial of this rank: all-reduced over xGMI inside the same launch)."""
-    if isinstance(pending, tp.PendingAllReduce):
-        res = tp.xgmi_comm().allreduce_rmsnorm(pending.part, x, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant)
-    elif pending is None:
-        res = (x,) + _as_tuple(ops.rms_norm(x, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant))
-    else:
-        res = ops.rms_norm(x, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant, add=pending)
-    return tuple(res) + (None,) * (4 - len(res))
-
-
-def _as_tuple(r):
-    return r if isinstance(r, tuple) else (r,)
+    """tensor_parallel.add_norm on an RMSNormW module: residual add (+ the all-reduce of a deferred partial) + norm
+    [+ fp8 quant] in one launch; returns (x_new, y, q, s)."""
+    return tp.add_norm(x, pending, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant)
 
 
 class DeepSeekV3Decoder(torch.nn.Module):

@@ -118,16 +118,13 @@ class LlamaBlock(torch.nn.Module):
     def forward(self, x, pending, cos, sin, varlens=None):
         """(x, pending) -> (x', pending'): residual adds folded into the RMSNorm that consumes them;
         varlens given = prefill."""
-        if pending is None:
-            hn = ops.rms_norm(x, self.attn_norm, self.eps)
-        else:
-            x, hn = ops.rms_norm(x, self.attn_norm, self.eps, add=pending)
+        x, hn = tp.add_norm(x, pending, self.attn_norm, self.eps)[:2]
         if varlens is None:
-            a = tp.all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+            a = tp.defer_all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
         else:
-            a = tp.all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
-        x, hn = ops.rms_norm(x, self.ffn_norm, self.eps, add=a)
-        return x, tp.all_reduce(self.ffn(hn))
+            a = tp.defer_all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
+        x, hn = tp.add_norm(x, a, self.ffn_norm, self.eps)[:2]
+        return x, tp.defer_all_reduce(self.ffn(hn))
 
 
 class LlamaDecoder(torch.nn.Module):
@@ -175,7 +172,7 @@ class LlamaDecoder(torch.nn.Module):
         for layer in self.layers:
             h, pending = layer(h, pending, cos, sin, varlens)
         last = torch.tensor([p - 1 for p in varlens.cpu_prefix_lens[1:]], dtype=torch.int64, device=self.device)
-        h = ops.rms_norm(h[last], self.norm, self.args.norm_eps, add=pending[last].contiguous())[1]
+        h = ops.rms_norm(h[last], self.norm, self.args.norm_eps, add=tp.resolve(pending)[last].contiguous())[1]
         self.cache.finalize_cache_all_prefill(req_ids, varlens)
         return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()
 
@@ -212,8 +209,8 @@ class LlamaDecoder(torch.nn.Module):
         pending = None
         for layer in self.layers:
             h, pending = layer(h, pending, cos, sin)
-        h = ops.rms_norm(h, self.norm, self.args.norm_eps, add=pending)[1]
-        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight)).float()
+        h = tp.add_norm(h, pending, self.norm, self.args.norm_eps)[1]
+        return tp.all_gather_last_dim(ops.bf16_linear(h, self.head_weight), out_dtype=torch.float32)
 
     @torch.inference_mode()
     def decode(self, tokens, use_graph=True):

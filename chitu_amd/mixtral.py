@@ -66,16 +66,13 @@ class MixtralBlock(torch.nn.Module):
         self.eps = args.norm_eps
 
     def forward(self, x, pending, cos, sin, varlens=None):
-        if pending is None:
-            hn = ops.rms_norm(x, self.attn_norm, self.eps)
-        else:
-            x, hn = ops.rms_norm(x, self.attn_norm, self.eps, add=pending)
+        x, hn = tp.add_norm(x, pending, self.attn_norm, self.eps)[:2]
         if varlens is None:
-            a = tp.all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+            a = tp.defer_all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
         else:
-            a = tp.all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
-        x, hn = ops.rms_norm(x, self.ffn_norm, self.eps, add=a)
-        return x, tp.all_reduce(self.ffn(hn))
+            a = tp.defer_all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
+        x, hn = tp.add_norm(x, a, self.ffn_norm, self.eps)[:2]
+        return x, tp.defer_all_reduce(self.ffn(hn))
 
 
 class MixtralDecoder(LlamaDecoder):

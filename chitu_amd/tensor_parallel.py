@@ -188,6 +188,23 @@ def defer_all_reduce(t: torch.Tensor):
     return all_reduce(t)
 
 
+def add_norm(x, pending, weight, eps, out_bf16=True, quant=None):
+    """(x_new, y, q, s) with x_new = x + pending and y / (q, s) = RMSNorm(x_new) [fp8-quantised]; entries not asked
+    for are None.  pending: None | a tensor ([rows, dim], or [rows, terms, dim]: terms summed first) | a
+    PendingAllReduce (this rank's partial: all-reduced over xGMI inside the same launch).  The one place where a
+    residual add, its norm and -- under tensor parallelism -- the all-reduce in front of them meet."""
+    from . import ops
+
+    if isinstance(pending, PendingAllReduce):
+        res = _xgmi.allreduce_rmsnorm(pending.part, x, weight, eps, out_bf16=out_bf16, quant=quant)
+    elif pending is None:
+        r = ops.rms_norm(x, weight, eps, out_bf16=out_bf16, quant=quant)
+        res = (x,) + (r if isinstance(r, tuple) else (r,))
+    else:
+        res = ops.rms_norm(x, weight, eps, out_bf16=out_bf16, quant=quant, add=pending)
+    return tuple(res) + (None,) * (4 - len(res))
+
+
 def defers_topk_sum(rows: int, dim: int, terms: int) -> bool:
     """May the fused MoE leave its top-k sum to the consumer of defer_all_reduce()?  Yes when nothing sits
     between the experts and the next norm (one rank) or when the in-graph all-reduce takes the terms."""

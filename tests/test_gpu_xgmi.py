@@ -409,3 +409,66 @@ def test_tp_decode_step_one_graph_on_xgmi_equals_eager_on_library():
     """World 2 only: beyond two ranks the library's bf16 sum depends on its (unspecified) order, and this random
     tiny model amplifies one flipped bit per layer, so there is no tight bar to hold a run to."""
     _spawn(_decode_worker, 2, timeout=240)
+
+
+def _mixtral_worker(rank, world):
+    """BASELINE config 4's parallelism (Mixtral, INT8 W8A8 experts, tensor parallel) on the in-graph collectives:
+    a tiny Mixtral under TP = world, eager launches + library all-reduce vs ONE hipGraph on xGMI (every all-reduce
+    folded into the norm that consumes it), same rank-local weights and KV, teacher-forced tokens."""
+    from chitu_amd import graphs
+    from chitu_amd import tensor_parallel as tp
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.mixtral import MixtralArgs, MixtralDecoder, init_synthetic_
+
+    args = MixtralArgs(dim=512, n_layers=2, n_heads=4 * world, n_kv_heads=world, vocab_size=1024, ffn_dim=256 * world,
+                       num_local_experts=4, num_experts_per_tok=2)
+    args_head_dim = args.dim // args.n_heads
+    if args_head_dim != 128:  # gqa_decode: head_dim 128 -> widen the model instead of the heads
+        args = MixtralArgs(dim=128 * 4 * world, n_layers=2, n_heads=4 * world, n_kv_heads=world, vocab_size=1024,
+                           ffn_dim=256 * world, num_local_experts=4, num_experts_per_tok=2)
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=4, block_size=256, max_seq_len=512, device="cuda",
+                                n_local_kv_heads=args.n_kv_heads // world, head_dim=args.head_dim, dtype=torch.bfloat16)
+    model = MixtralDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads // world, max_seq_len=512),
+                           max_position_embeddings=512, device="cuda")
+    init_synthetic_(model, seed=300 + rank)
+    starts = (250, 3, 300)
+
+    def fresh(tag):
+        reqs = [f"{tag}{i}" for i in range(3)]
+        g = torch.Generator().manual_seed(7)
+        for r, n in zip(reqs, starts):
+            cache.register_sequence(r, n)
+            for blk in cache.block_table[r]:
+                cache.paged_k_cache[:, blk] = (torch.randn(args.n_layers, 256, 1, 128, generator=g) * 0.5).to(torch.bfloat16).cuda()
+                cache.paged_v_cache[:, blk] = (torch.randn(args.n_layers, 256, 1, 128, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        return reqs
+
+    def run(reqs, use_graph, forced=None, steps=8):
+        toks = torch.tensor([5, 17, 900], dtype=torch.int64, device="cuda")
+        logits_all, toks_all = [], []
+        for step in range(steps):
+            cache.prepare_cache_decode(reqs)
+            cache.prepare_block_table_for_decode(reqs)
+            logits = model.decode(toks, use_graph=use_graph).clone()
+            cache.finalize_cache_single_decode(reqs)
+            logits_all.append(logits)
+            toks = logits.argmax(-1) if forced is None else forced[step]
+            toks_all.append(toks.clone())
+        return logits_all, toks_all
+
+    ra = fresh("lib")
+    l_lib, t_lib = run(ra, False)
+    for r in ra:
+        cache.finalize_cache_all_decode(r)
+    assert tp.enable_xgmi(max_rows=16, max_dim=2048, gather_bytes=16 * args.vocab_size * 2, timeout_ms=8000)
+    assert graphs.graph_mode(True) == "full"
+    rb = fresh("xg")
+    l_x, _ = run(rb, True, forced=t_lib)
+    assert tp.xgmi_comm().status() == 0
+    for step, (a, b) in enumerate(zip(l_lib, l_x)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), step
+
+
+def test_mixtral_int8_tp2_one_graph_on_xgmi_equals_eager_on_library():
+    _spawn(_mixtral_worker, 2, timeout=240)
