@@ -565,17 +565,6 @@ __global__ __launch_bounds__(1024) void gate_route_fast_kernel(
 // (moe_align_workgroup reading the ids from LDS): no ticket, no global round trip between routing and
 // sort.  Arithmetic, rounding points and tie rule are gate_route_fast_kernel's, so ids, weights and the
 // align outputs are bit-identical to the separate launches.
-// One wave fills p[0 .. n) with v: 16-byte stores over the aligned middle, scalar stores at the ragged ends.
-__device__ __forceinline__ void fill_i32_wave(int32_t* p, int64_t n, int32_t v, int lane) {
-    const int64_t head = min(n, (int64_t)((16 - ((uintptr_t)p & 15)) & 15) >> 2);
-    if (lane < head) p[lane] = v;
-    const int64_t quads = (n - head) >> 2;
-    const i32x4 v4 = {v, v, v, v};
-    for (int64_t i = lane; i < quads; i += 64) *reinterpret_cast<i32x4*>(p + head + i * 4) = v4;
-    const int64_t done = head + quads * 4;
-    if (done + lane < n) p[done + lane] = v;
-}
-
 template <int GS>  // experts per group: 32, or 0 = ungrouped
 __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     const void* __restrict__ logits, int S, int M, const bf16_t* __restrict__ bias, int n_groups, int topk_groups,
@@ -588,16 +577,6 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     int64_t* ids_lds = reinterpret_cast<int64_t*>(dyn_lds + nwaves * E);     // [M * out_stride]
     int* align_lds = dyn_lds + nwaves * E + 2 * ((M * out_stride + 1) & ~1);
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
-    // the sort's sentinels (fused_moe.py:493-502; expert_ids' unused tail = expert_map[0] under expert parallelism,
-    // :516-517) go out first: fire-and-forget stores that overlap the logits round trip.  Wave 0 issues them, the
-    // wave that later stores the sorted values: stores of ONE wave to one address land in program order, so no
-    // drain (s_waitcnt vmcnt) has to sit between the fill and the sort.
-    if (t == 0) {
-        const int32_t tail_id = al.expert_map ? al.expert_map[0] : 0;
-        const int32_t numel = M * out_stride;
-        fill_i32_wave(al.sorted_ids, al.sorted_cap, numel, lane);
-        fill_i32_wave(al.expert_ids, al.expert_cap, tail_id, lane);
-    }
     if (t < M) {  // wave-uniform
         // ---- logits of experts 4*lane .. 4*lane+3: all loads up front
         float lg[4];
@@ -688,17 +667,10 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
             ids_lds[t * out_stride + topk + lane] = extra_id + lane;
         }
     }
-    __syncthreads();  // ids of every token in LDS; every wave's sentinel stores drained (vmcnt(0) precedes the barrier)
-    // the sort of <= a few hundred ids is one wave's work: wave-local steps only, the other waves are done
-#ifdef CHITU_AB_WORKGROUP_ALIGN  // A/B build only (tools/ab_bench.sh): the sort on the whole workgroup
+    __syncthreads();
     moe_align_workgroup<int64_t>(ids_lds, (int64_t)M * out_stride, al.num_experts, al.block_size, al.sorted_ids,
                                  al.sorted_cap, al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, 1,
                                  al.expert_map, align_lds, (int)blockDim.x);
-#else
-    if (t == 0)
-        moe_align_wave<int64_t>(ids_lds, M * out_stride, al.num_experts, al.block_size, al.sorted_ids, al.sorted_cap,
-                                al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, al.expert_map, align_lds);
-#endif
 }
 
 }  // namespace chitu

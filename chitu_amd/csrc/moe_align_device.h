@@ -124,92 +124,4 @@ __device__ __forceinline__ void moe_align_workgroup(
     }
 }
 
-// The same sort run by ONE WAVE, for a handful of ids (decode batches: 16 tokens x 9 slots): every step is
-// wave-local (LDS atomics, a DPP/shuffle scan over lane-owned expert ranges, ballot match-any for the stable
-// ranks), so nothing waits at a workgroup barrier.  The caller has ALREADY filled the sentinels
-// (sorted_ids = numel, expert_ids = expert_map ? expert_map[0] : 0 over their whole capacity) and made that fill
-// visible (a workgroup barrier) before calling; outputs are bit-identical to moe_align_workgroup(fill = 1).
-// lds: 2 * E ints (counts | cursor).  Call from one full wave; E <= 64 * kAlignWaveMaxPerLane.
-constexpr int kAlignWaveMaxPerLane = 16;
-template <typename id_t>
-__device__ __forceinline__ void moe_align_wave(
-    const id_t* ids, int numel, int E, int block_size, int32_t* __restrict__ sorted_ids, int64_t sorted_cap,
-    int32_t* __restrict__ expert_ids, int64_t expert_cap, int32_t* __restrict__ num_post_pad,
-    int32_t* __restrict__ cumsum, const int32_t* __restrict__ expert_map, int* lds) {
-    int* counts = lds;
-    int* cursor = lds + E;
-    const int lane = threadIdx.x & 63;
-    for (int e = lane; e < E; e += 64) counts[e] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < numel; i += 64) {
-        const int64_t e = (int64_t)ids[i];
-        if (e >= 0 && e < E) atomicAdd(&counts[(int)e], 1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // lane owns experts [lane * per, lane * per + per)
-    const int per = (E + 63) >> 6;
-    int padded[kAlignWaveMaxPerLane];
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < kAlignWaveMaxPerLane; ++k) {
-        const int e = lane * per + k;
-        padded[k] = (k < per && e < E) ? ((counts[e] + block_size - 1) / block_size) * block_size : 0;
-        mine += padded[k];
-    }
-    int incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-    }
-    int start = incl - mine;
-#pragma unroll
-    for (int k = 0; k < kAlignWaveMaxPerLane; ++k) {
-        const int e = lane * per + k;
-        if (k < per && e < E) {
-            const int32_t own_id = expert_map ? expert_map[e] : (int32_t)e;
-            cursor[e] = start;
-            cumsum[e + 1] = start + padded[k];
-            for (int i = start; i < start + padded[k]; i += block_size) {
-                const int b = i / block_size;
-                if (b < expert_cap) expert_ids[b] = own_id;
-            }
-            start += padded[k];
-        }
-    }
-    if (lane == 63) *num_post_pad = incl;
-    if (lane == 0) cumsum[0] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int nbits = 0;
-    while ((1 << nbits) < E) ++nbits;
-    for (int base = 0; base < numel; base += 64) {
-        const int i = base + lane;
-        int64_t e64 = -1;
-        if (i < numel) e64 = (int64_t)ids[i];
-        const bool valid = (e64 >= 0 && e64 < E);
-        const int e = valid ? (int)e64 : 0;
-        unsigned long long same = __ballot(valid);
-        for (int b = 0; b < nbits; ++b) {
-            const bool bit = (e >> b) & 1;
-            const unsigned long long bal = __ballot(valid && bit);
-            same &= bit ? bal : ~bal;
-        }
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const int rank = __popcll(same & lt);
-        int pos = 0;
-        if (valid) {
-            pos = cursor[e] + rank;
-            if (pos < sorted_cap) sorted_ids[pos] = (int32_t)i;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) cursor[e] += __popcll(same);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 }  // namespace chitu
