@@ -668,9 +668,13 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
         }
     }
     __syncthreads();
+    // the sort needs a thread per expert, not a wave per token: the other waves leave (a finished wave no longer
+    // counts at s_barrier), so the sort's barriers and per-wave histograms span 5 waves instead of up to 16
+    const int sort_waves = min((int)(blockDim.x >> 6), max((al.num_experts + 63) >> 6, (M * out_stride + 63) >> 6));
+    if (t >= sort_waves) return;
     moe_align_workgroup<int64_t>(ids_lds, (int64_t)M * out_stride, al.num_experts, al.block_size, al.sorted_ids,
                                  al.sorted_cap, al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, 1,
-                                 al.expert_map, align_lds, (int)blockDim.x);
+                                 al.expert_map, align_lds, sort_waves * 64);
 }
 
 }  // namespace chitu
