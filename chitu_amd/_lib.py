@@ -119,7 +119,7 @@ def f32(v):
 
 
 DEBUG_OPTIONS = {"moe_gemm1_wk": 0, "moe_gemm1_nw": 1, "moe_gemm1_d": 2, "moe_gemm2_cfg": 3, "moe_i8_wk": 4,
-                 "gate_generic": 5, "gate_ticket": 6, "sample_radix": 7}
+                 "gate_generic": 5, "gate_ticket": 6, "sample_radix": 7, "fp8_gemm_wk": 8, "fp8_gemm_deep": 9}
 
 
 class debug_option:

@@ -244,6 +244,8 @@ extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_s
     hipStream_t st = (hipStream_t)stream;
     SplitPlan plan = plan_split((int)N, (int)K);
     if (plan.S > 1 && (!workspace || workspace_bytes < (int64_t)plan.S * M * N * 4)) plan.S = 1;
+    debug_override(kOptFp8GemmWK, plan.WK);
+    while (plan.WK > 1 && plan.WK * plan.S > (int)(K / 128)) plan.WK >>= 1;
     const dim3 grid((unsigned)((N + 15) / 16), (unsigned)plan.S);
     float* partial = (float*)workspace;
     for (int64_t mb = 0; mb < M; mb += 64) {
@@ -251,7 +253,7 @@ extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_s
         const int mbase = (int)mb;
         if (rem <= 16) {
             const int per_wave = (int)(K / 128) / (plan.WK * plan.S);
-            if (plan.WK == 8 && per_wave > 4 && per_wave <= 8)
+            if (plan.WK == 8 && per_wave > 4 && per_wave <= 8 && debug_option(kOptFp8GemmDeep) != 0)
                 hipLaunchKernelGGL((fp8_gemm_kernel<1, 8, true>), grid, dim3(512), 0, st, (const fp8_t*)a_fp8, a_scale,
                                    (const fp8_t*)b_fp8, b_scale, out, out_dtype, partial, (int)M, (int)N, (int)K,
                                    plan.S, mbase);

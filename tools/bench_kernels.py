@@ -12,7 +12,12 @@ ap.add_argument("--bs", type=int, nargs="+", default=[1, 16])
 ap.add_argument("--layers", type=int, default=8)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--only", type=str, default="")
+ap.add_argument("--opt", type=str, default="", help="launch-variant overrides, e.g. fp8_gemm_wk=8,fp8_gemm_deep=0")
 a = ap.parse_args()
+for kv in filter(None, a.opt.split(",")):
+    k, v = kv.split("=")
+    _lib.check(_lib.lib().chitu_hip_debug_option(i32(_lib.DEBUG_OPTIONS[k]), i32(int(v))), "debug_option")
+    print(f"# override {k} = {v}")
 torch.cuda.set_device(0)
 dev = "cuda"
 gen = torch.Generator(device=dev).manual_seed(0)
