@@ -184,7 +184,25 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
     // ---- merge: out[t] = sum_s w_s * part_o[bh, s, t] / sum_s w_s, w_s = exp(lse_s - max lse)
     // (same operation order as mla_merge_kernel).  Lane s of every wave holds lse_s / w_s; the
     // partial rows are requested 16 at a time, not one round trip per row.
-    {
+    if (S <= 16) {
+        // the usual decode shape: all S partial rows are requested BEFORE the lse values are looked at (their
+        // addresses do not depend on them), so the launch pays one memory round trip, not two; same sums, same order
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = part_o[(bh * S + min(i, S - 1)) * K + tid];
+        const float l = lane < S ? part_lse[bh * S + lane] : -INFINITY;
+        const float m = wave_reduce_max(l);
+        const float wl = l == -INFINITY ? 0.f : __expf(l - m);
+        float acc = 0.f, wsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float ws = i < S ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), i)) : 0.f;
+            wsum += ws;
+            acc += ws * (ws != 0.f ? v[i] : 0.f);
+        }
+        const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+        xs[tid] = f32_to_bf16(acc * inv);
+    } else {
         const float* lse = part_lse + bh * S;
         float m = -INFINITY;
         for (int s0 = 0; s0 < S; s0 += 64) {
