@@ -35,6 +35,24 @@ extern int g_debug_options[kOptCount];
 inline int debug_option(DebugOption o) { return g_debug_options[o]; }
 inline void debug_override(DebugOption o, int& v) { if (g_debug_options[o] >= 0) v = g_debug_options[o]; }
 
+// Phase probes (probe builds only: hipcc -DCHITU_PROBE): CHITU_PROBE_MARK(i) stores the 100 MHz wall clock into slot i
+// of a device array from thread 0 of workgroup 0; tools/probe_phases.py reads it back.  Compiles to nothing otherwise.
+#ifdef CHITU_PROBE
+static __device__ unsigned long long g_probe_marks[32];  // one copy per translation unit (no relocatable device code)
+#define CHITU_PROBE_READER(tu)                                                                                     \
+    extern "C" int chitu_hip_probe_read_##tu(unsigned long long* out32) {                                          \
+        (void)hipDeviceSynchronize();                                                                              \
+        return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(chitu::g_probe_marks), sizeof(unsigned long long) * 32);        \
+    }
+#define CHITU_PROBE_MARK(i)                                                                            \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) g_probe_marks[i] = wall_clock64(); \
+    } while (0)
+#else
+#define CHITU_PROBE_MARK(i) do {} while (0)
+#define CHITU_PROBE_READER(tu)
+#endif
+
 constexpr int kWave = 64;
 
 typedef uint16_t bf16_t;  // raw bits

@@ -577,6 +577,7 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     int64_t* ids_lds = reinterpret_cast<int64_t*>(dyn_lds + nwaves * E);     // [M * out_stride]
     int* align_lds = dyn_lds + nwaves * E + 2 * ((M * out_stride + 1) & ~1);
     const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+    CHITU_PROBE_MARK(0);
     if (t < M) {  // wave-uniform
         // ---- logits of experts 4*lane .. 4*lane+3: all loads up front
         float lg[4];
@@ -609,6 +610,8 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
         }
         float orig[4], sel[4];
         uint32_t key[4];
+        if (lg[0] == 12345.678f) CHITU_PROBE_MARK(9);  // (probe builds: forces the logits wait here)
+        CHITU_PROBE_MARK(1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             orig[c] = bf16r(1.0f / (1.0f + expf(-lg[c])));  // original_scores
@@ -667,7 +670,9 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
             ids_lds[t * out_stride + topk + lane] = extra_id + lane;
         }
     }
+    CHITU_PROBE_MARK(2);
     __syncthreads();
+    CHITU_PROBE_MARK(3);
     // the sort needs a thread per expert, not a wave per token: the other waves leave (a finished wave no longer
     // counts at s_barrier), so the sort's barriers and per-wave histograms span 5 waves instead of up to 16
     const int sort_waves = min((int)(blockDim.x >> 6), max((al.num_experts + 63) >> 6, (M * out_stride + 63) >> 6));
@@ -675,6 +680,7 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     moe_align_workgroup<int64_t>(ids_lds, (int64_t)M * out_stride, al.num_experts, al.block_size, al.sorted_ids,
                                  al.sorted_cap, al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, 1,
                                  al.expert_map, align_lds, sort_waves * 64);
+    CHITU_PROBE_MARK(4);
 }
 
 }  // namespace chitu
@@ -860,3 +866,5 @@ extern "C" int chitu_hip_bf16_gemm_silu(const void* x_bf16, const void* w13_bf16
 #undef LAUNCHS
     CHITU_RETURN_LAUNCH_STATUS();
 }
+
+CHITU_PROBE_READER(gate)

@@ -60,49 +60,71 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int split = blockIdx.x, b = blockIdx.y, hb = blockIdx.z;
-    const int L = seqlens[b];
-    const int n_tiles = (L + kTile - 1) / kTile;
-    const int tile0 = (int)((long)n_tiles * split / num_splits);
-    const int tile1 = (int)((long)n_tiles * (split + 1) / num_splits);
     const int h0 = hb * 16;
     const int32_t* tbl = block_table + (int64_t)b * table_stride;
+    CHITU_PROBE_MARK(8);
+    // The prologue is ONE chain of dependent loads -- seqlens -> page id -> KV rows -- and everything else rides in
+    // its shadow: seqlens is requested first, then Q (independent of it), then the wait; every load below is
+    // unconditional (indices clamped, the unwanted values dropped when they are stored to LDS), so the code is
+    // straight-line and the compiler's s_waitcnt counts past the loads that are not needed yet.
+    const int L = seqlens[b];
+    // Q (A operand of QK^T; 16 heads x 576, same padded stride as the KV rows): 1152 chunks, <= 5 per thread
+    i32x4 qreg[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int c = min(tid + i * 256, 16 * 72 - 1);
+        const int row = c / 72, col = c % 72;
+        const int h = min(h0 + row, H - 1);
+        const bf16_t* src = col < 64 ? q_nope + b * qn_sb + h * qn_sh + col * 8
+                                     : q_pe + b * qp_sb + h * qp_sh + (col - 64) * 8;
+        qreg[i] = *reinterpret_cast<const i32x4*>(src);
+    }
+    if (L == -12345) CHITU_PROBE_MARK(15);  // (probe builds: forces the seqlens wait here)
+    CHITU_PROBE_MARK(9);
+    const int n_tiles = (L + kTile - 1) / kTile;
+    // 32-bit unsigned quotients (a 64-bit division is a software LOOP on this chain; the launcher bounds
+    // tiles * splits below 2^31)
+    const int tile0 = (int)((unsigned)n_tiles * (unsigned)split / (unsigned)num_splits);
+    const int tile1 = (int)((unsigned)n_tiles * (unsigned)(split + 1) / (unsigned)num_splits);
 
-    // this split's page ids -> LDS once (a per-tile table lookup is a dependent global load on the
-    // critical path of every tile)
-    // The FIRST tile's page id is read directly (one dependent load) so its KV loads leave as early
-    // as possible -- with one tile per split, the usual decode shape, that chain is the kernel; the
-    // LDS copy for the following tiles is filled in the shadow of those loads.
+    // this split's page ids: the first tile's straight from the table (it heads the chain), the following tiles'
+    // (two per thread, up to kMaxTilesLds) parked in LDS so that no later tile pays a table lookup
     const bool pages_in_lds = (tile1 - tile0) <= kMaxTilesLds;
+    const int max_page_idx = table_stride - 1;
+    const int first_pg = tbl[min((tile0 * kTile) / page_size, max_page_idx)];
+    int pg_ahead[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) pg_ahead[i] = tbl[min(((tile0 + tid + i * 256) * kTile) / page_size, max_page_idx)];
     auto page_src = [&](int64_t page, int t0) -> const bf16_t* {
         if (page < 0 || page >= num_pages) page = 0;  // corrupt table: stay in bounds
         return cache + (page * page_size + (t0 % page_size)) * (int64_t)kD;
     };
     auto tile_src = [&](int tile) -> const bf16_t* {
         const int t0 = tile * kTile;
-        return page_src(pages_in_lds ? pages_lds[tile - tile0] : tbl[t0 / page_size], t0);
+        return page_src(pages_in_lds ? pages_lds[tile - tile0] : tbl[min(t0 / page_size, max_page_idx)], t0);
     };
-    // this thread's 18 chunks of a tile: chunk c = tid + i*256 -> (row, col)
+    // this thread's 18 chunks of a tile: chunk c = tid + i*256 -> (row, col); rows past the sequence end read the
+    // tile's last valid row instead (unconditional loads) and are zeroed when staged
     i32x4 pf[18];
     auto issue = [&](const bf16_t* src, int valid) {
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             const int c = tid + i * 256;
-            const int row = c / 72, col = c % 72;
-            pf[i] = i32x4{0, 0, 0, 0};  // rows past the sequence end are staged as zeros
-            if (row < valid && !(dbg & 1)) pf[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(src + row * kD + col * 8));
+            const int row = min(c / 72, valid - 1), col = c % 72;
+            if (!(dbg & 1)) pf[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(src + row * kD + col * 8));
         }
     };
-    if (tile0 < tile1) issue(page_src(tbl[(tile0 * kTile) / page_size], tile0 * kTile), min(kTile, L - tile0 * kTile));
-    if (pages_in_lds)  // visible to all waves after the loop's first barrier
-        for (int i = tid; i < tile1 - tile0; i += 256) pages_lds[i] = tbl[((tile0 + i) * kTile) / page_size];
-
-    // Q -> LDS (A operand of QK^T; 16 heads x 576, same padded stride as the KV rows)
-    for (int c = tid; c < 16 * 72; c += 256) {
-        const int row = c / 72, col = c % 72;
-        const int h = min(h0 + row, H - 1);
-        const bf16_t* src = col < 64 ? q_nope + b * qn_sb + h * qn_sh + col * 8
-                                     : q_pe + b * qp_sb + h * qp_sh + (col - 64) * 8;
-        *reinterpret_cast<i32x4*>(q_lds + row * kRowB + col * 16) = *reinterpret_cast<const i32x4*>(src);
+    if (tile0 < tile1) issue(page_src(first_pg, tile0 * kTile), min(kTile, L - tile0 * kTile));
+    // ---- only now the first stores: Q and the page list (visible to all waves after the loop's first barrier)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int c = tid + i * 256;
+        if (c < 16 * 72) *reinterpret_cast<i32x4*>(q_lds + (c / 72) * kRowB + (c % 72) * 16) = qreg[i];
+    }
+    if (pages_in_lds) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (tid + i * 256 < tile1 - tile0) pages_lds[tid + i * 256] = pg_ahead[i];
     }
 
     f32x4 o[8];
@@ -122,10 +144,12 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             const int c = tid + i * 256;
-            *reinterpret_cast<i32x4*>(kv_lds + (c / 72) * kRowB + (c % 72) * 16) = pf[i];
+            const i32x4 zero = {0, 0, 0, 0};
+            *reinterpret_cast<i32x4*>(kv_lds + (c / 72) * kRowB + (c % 72) * 16) = (c / 72) < valid ? pf[i] : zero;
         }
         }
         __syncthreads();
+        CHITU_PROBE_MARK(10);
         if (tile + 1 < tile1) issue(tile_src(tile + 1), min(kTile, L - (tile + 1) * kTile));
 
         // ---- S = Q K^T for this wave's 16 tokens (two accumulators: no 18-deep dependent chain)
@@ -144,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
             }
         }
         // lane holds S[head 4g+r][token wave*16+j]
+        CHITU_PROBE_MARK(11);
         const bool tok_ok = (wave * 16 + j) < valid;
         float sv[4], mx[4];
 #pragma unroll
@@ -204,6 +229,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     }
 
     // ---- epilogue: lane holds O[head 4g+r][col wave*128 + c*16 + j]
+    CHITU_PROBE_MARK(12);
     const bool empty = tile1 <= tile0;
     if (num_splits == 1) {
 #pragma unroll
@@ -239,6 +265,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
             *reinterpret_cast<f32x4*>(part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c4 * 4) =
                 *reinterpret_cast<const f32x4*>(o_lds + hr * kC + c4 * 4);
     }
+    CHITU_PROBE_MARK(13);
 }
 
 // Stage 2: out[b,h,:] = sum_s w_s * part_o[b,h,s,:] / sum_s w_s, w_s = exp(lse_s - max lse).
@@ -300,6 +327,8 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
     if (kv_lora_rank != kC || rope_dim != kR) return CHITU_ERR_UNSUPPORTED;
     if (page_size < kTile || page_size % kTile != 0) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(num_splits >= 1 && num_splits <= 256);
+    // the kernel's split arithmetic is 32-bit: tiles the table can address x (splits + 1) must stay below 2^31
+    CHITU_REQUIRE((int64_t)table_stride * (page_size / kTile) * (num_splits + 1) < (1ll << 31));
     if (batch == 0) return CHITU_OK;
     float* part_o = nullptr;
     float* part_lse = nullptr;
@@ -326,3 +355,5 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
                            part_lse, (bf16_t*)out_bf16, (int)num_splits);
     CHITU_RETURN_LAUNCH_STATUS();
 }
+
+CHITU_PROBE_READER(mla_decode)

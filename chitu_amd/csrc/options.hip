@@ -10,3 +10,4 @@ extern "C" int chitu_hip_debug_option(int32_t option, int32_t value) {
     chitu::g_debug_options[option] = value;
     return CHITU_OK;
 }
+

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Phase timing INSIDE the latency-bound kernels (probe build: every .hip compiled with -DCHITU_PROBE, see common.h):
+    make -C chitu_amd/csrc probe            -> build_probe/libchitu_hip_probe.so
+    CHITU_HIP_LIB=build_probe/libchitu_hip_probe.so python tools/probe_phases.py [bs=16]
+Runs eager decode steps of an 8-layer R1 rank shard (so the kernels see the step's real inputs and a cold cache) and
+prints, for workgroup 0 of the LAST launch of each probed kernel, the 100 MHz wall-clock deltas between its marks."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from chitu_amd import _lib  # noqa: E402
+
+NAMES = {
+    ("gate", "gate_route_align_wg_kernel"): [(0, "start"), (1, "logits loaded + summed"), (2, "routing done (ids in LDS)"), (3, "workgroup barrier"),
+                                   (4, "sort done")],
+    ("mla_decode", "mla_decode_kernel"): [(8, "start"), (9, "seqlens loaded"), (10, "first KV tile staged in LDS"), (11, "QK^T done"),
+                          (12, "tile loop done (softmax, PV)"), (13, "partials stored")],
+}
+
+
+@torch.inference_mode()
+def main():
+    bs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+
+    class A:
+        layers, ctx, steps, warmup, bs, no_bs1, router_std = 8, 1024, 4, 2, 16, True, None
+
+    A.bs = bs
+    margs, model, cache = bench.build_model(A, 0)
+    reqs = [f"p{i}" for i in range(bs)]
+    for r in reqs:
+        cache.register_sequence(r, 1024)
+    tokens = torch.randint(100, 1000, (bs,), device="cuda")
+    for _ in range(3):
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        tokens = model.decode(tokens, use_graph=False).argmax(-1)
+        cache.finalize_cache_single_decode(reqs)
+    for (tu, k), marks in NAMES.items():
+        buf = (ctypes.c_ulonglong * 32)()
+        rc = getattr(_lib.lib(), f"chitu_hip_probe_read_{tu}")(buf)
+        assert rc == 0, rc
+        t0 = buf[marks[0][0]]
+        print(k)
+        prev = t0
+        for idx, name in marks[1:]:
+            t = buf[idx]
+            print(f"   +{(t - prev) * 0.01:6.2f} us  -> {name}   (at {(t - t0) * 0.01:6.2f} us)")
+            prev = t
+
+
+if __name__ == "__main__":
+    main()
