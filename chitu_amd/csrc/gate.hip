@@ -456,6 +456,13 @@ __device__ __forceinline__ uint32_t row16_max_u32(uint32_t v) {
     v = max(v, dpp_u32<0x121>(v));
     return v;
 }
+// max over each aligned group of 8 lanes (DPP: xor 1, xor 2 inside the quads, then the half-row mirror brings the other quad)
+__device__ __forceinline__ uint32_t group8_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_max_u32_uniform(uint32_t v) {
     v = row16_max_u32(v);
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
@@ -619,29 +626,32 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
             key[c] = score_key(sel[c], lane * 4 + c);
         }
         *reinterpret_cast<f32x4*>(&orig_lds[t * E + lane * 4]) = f32x4{orig[0], orig[1], orig[2], orig[3]};
+        if (key[0] == 0xdeadbeefu) CHITU_PROBE_MARK(9);
+        CHITU_PROBE_MARK(5);
         if (GS == 32) {
             // group score = sum of the group's top-2 (bias) or its max (no bias), :827-831; group = 8 lanes
-            uint32_t k1 = max(max(key[0], key[1]), max(key[2], key[3]));
-#pragma unroll
-            for (int off = 1; off < 8; off <<= 1) k1 = max(k1, (uint32_t)__shfl_xor((int)k1, off, 64));
+            // maxima over the group's 8 lanes on the VALU (DPP quad permutes + half-row mirror), not through LDS
+            const uint32_t k1 = group8_max_u32(max(max(key[0], key[1]), max(key[2], key[3])));
             uint32_t k2 = 0u;
 #pragma unroll
             for (int c = 0; c < 4; ++c) k2 = max(k2, key[c] == k1 ? 0u : key[c]);
-#pragma unroll
-            for (int off = 1; off < 8; off <<= 1) k2 = max(k2, (uint32_t)__shfl_xor((int)k2, off, 64));
+            k2 = group8_max_u32(k2);
             const float m1 = key_score(k1), m2 = key_score(k2);
             const float mine = bias ? bf16r(m1 + m2) : m1;
             const int grp = lane >> 3;
             int rank = 0;
-            for (int g2 = 0; g2 < n_groups; ++g2) {
-                const float o = __shfl(mine, g2 * 8, 64);
-                rank += (o > mine) || (o == mine && g2 < grp);
+#pragma unroll
+            for (int g2 = 0; g2 < 8; ++g2) {  // E = 256, GS = 32: exactly 8 groups; lane reads, not LDS permutes
+                const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), g2 * 8));
+                rank += (g2 < n_groups) && ((o > mine) || (o == mine && g2 < grp));
             }
             if (rank >= topk_groups) {  // scores * mask
 #pragma unroll
                 for (int c = 0; c < 4; ++c) key[c] = score_key(0.f, lane * 4 + c);
             }
         }
+        if (key[0] == 0xdeadbeefu) CHITU_PROBE_MARK(9);
+        CHITU_PROBE_MARK(6);
         // ---- top-k: topk rounds of a wave-wide maximum; round r's winner is slot r (descending score)
         uint32_t mine_k = 0u;
         for (int r = 0; r < topk; ++r) {
@@ -651,12 +661,20 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
             for (int c = 0; c < 4; ++c)
                 if (key[c] == m) key[c] = 0u;
         }
+        if (mine_k == 0xdeadbeefu) CHITU_PROBE_MARK(9);
+        CHITU_PROBE_MARK(7);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-local LDS hand-off (orig_lds)
         __builtin_amdgcn_wave_barrier();
         const int we = 0xffff - (int)(mine_k & 0xffffu);
         const float ws = lane < topk ? orig_lds[t * E + (we & (E - 1))] : 0.f;
         float sum = 0.f;
-        for (int i = 0; i < topk; ++i) sum += __shfl(ws, i, 64);
+        if (topk <= 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)  // same left-to-right sum, by lane reads
+                if (i < topk) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ws), i));
+        } else {
+            for (int i = 0; i < topk; ++i) sum += __shfl(ws, i, 64);
+        }
         if (lane < topk) {
             float w = bf16r(ws / bf16r(sum));  // weights /= weights.sum(-1, keepdim=True)
             w = bf16r(w * route_scale);       // weights *= route_scale

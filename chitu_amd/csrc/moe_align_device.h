@@ -39,6 +39,7 @@ __device__ __forceinline__ void moe_align_workgroup(
         for (int64_t i = tid; i < expert_cap; i += nthreads) expert_ids[i] = 0;
     }
     __syncthreads();
+    CHITU_PROBE_MARK(20);
 
     // Pass 1: per-expert totals (order-free, LDS atomics are exact for integers).
     for (int64_t i = tid; i < numel; i += nthreads) {
@@ -46,6 +47,7 @@ __device__ __forceinline__ void moe_align_workgroup(
         if (e >= 0 && e < E) atomicAdd(&counts[(int)e], 1);
     }
     __syncthreads();
+    CHITU_PROBE_MARK(21);
 
     // Pass 2: exclusive scan of padded counts -> segment starts; thread t owns expert t.
     int padded = 0;
@@ -82,6 +84,7 @@ __device__ __forceinline__ void moe_align_workgroup(
         for (int64_t b = total / block_size + tid; b < expert_cap; b += nthreads) expert_ids[b] = tail_id;
     }
     __syncthreads();
+    CHITU_PROBE_MARK(22);
 
     // Pass 3: stable scatter, 1024 tokens per round.
     int nbits = 0;

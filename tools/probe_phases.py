@@ -15,8 +15,10 @@ import bench  # noqa: E402
 from chitu_amd import _lib  # noqa: E402
 
 NAMES = {
-    ("gate", "gate_route_align_wg_kernel"): [(0, "start"), (1, "logits loaded + summed"), (2, "routing done (ids in LDS)"), (3, "workgroup barrier"),
-                                   (4, "sort done")],
+    ("gate", "gate_route_align_wg_kernel"): [(0, "start"), (1, "logits loaded + summed"), (5, "scores (sigmoid, bias, keys)"),
+                                              (6, "group selection"), (7, "top-k rounds"), (2, "weights normalised, ids in LDS"),
+                                              (3, "workgroup barrier (slowest token wave)"), (20, "sort: sentinels + zeroing"),
+                                              (21, "sort: counts"), (22, "sort: scan + expert ids"), (4, "sort: scatter; done")],
     ("mla_decode", "mla_decode_kernel"): [(8, "start"), (9, "seqlens loaded"), (10, "first KV tile staged in LDS"), (11, "QK^T done"),
                           (12, "tile loop done (softmax, PV)"), (13, "partials stored")],
 }
