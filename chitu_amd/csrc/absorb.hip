@@ -171,6 +171,7 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
     __shared__ float red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b = blockIdx.y;
+    CHITU_PROBE_MARK(0);
     const int64_t bh = (int64_t)b * H + h;
     const fp8_t* wp = W + (int64_t)h * w_sh + (int64_t)(wave * 16 + j) * K + g * 16;
     const float* sp = scale + s_off + h * s_sh;
@@ -229,7 +230,9 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
         const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
         xs[tid] = f32_to_bf16(acc * inv);
     }
+    CHITU_PROBE_MARK(1);  // merged row in LDS
     __syncthreads();
+    CHITU_PROBE_MARK(2);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
@@ -247,6 +250,7 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
     amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
     amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
     if (lane == 0) red[wave] = amax;
+    CHITU_PROBE_MARK(3);  // projection done (W tile had arrived)
     __syncthreads();
     amax = red[0];
 #pragma unroll
@@ -261,6 +265,7 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
 #pragma unroll
         for (int k = 0; k < 4; ++k) t[k] = v[k] / sc;
     }
+    CHITU_PROBE_MARK(4);
     if (j != 0) return;
     const uint32_t packed = f32x2_to_fp8x2(t[0], t[1]) | (f32x2_to_fp8x2(t[2], t[3]) << 16);
     *reinterpret_cast<uint32_t*>(q + bh * 128 + wave * 16 + g * 4) = packed;
@@ -361,3 +366,5 @@ extern "C" int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, in
                        scale, scale_offset, scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales, (int)heads);
     CHITU_RETURN_LAUNCH_STATUS();
 }
+
+CHITU_PROBE_READER(absorb)

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
     const float* __restrict__ WS, void* __restrict__ out, int out_dt, float* __restrict__ partial,
     int M, int N, int K, int S, int m_base) {
     __shared__ float red[WK > 1 ? WK * MT * 256 : 1];
+    if (DEEP) CHITU_PROBE_MARK(0);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -99,17 +100,27 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
 #pragma unroll
     for (int d = 0; d < D; ++d)
         if (kb0 + d < kb1) load(ring[d], kb0 + d);
+    if (DEEP) CHITU_PROBE_MARK(1);  // all loads issued
     for (int kb = kb0; kb < kb1; kb += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if (kb + d < kb1) {
                 compute(ring[d]);
+                if (DEEP && kb == kb0 && d == 0) {
+                    if (acc[0][0] == 1.2345e30f) CHITU_PROBE_MARK(9);
+                    CHITU_PROBE_MARK(2);  // first K block multiplied (its loads have arrived)
+                }
                 if (kb + d + D < kb1) load(ring[d], kb + d + D);
             }
         }
     }
+    if (DEEP) {
+        if (acc[0][0] == 1.2345e30f) CHITU_PROBE_MARK(9);
+        CHITU_PROBE_MARK(3);  // K loop done
+    }
 
     gemm_epilogue_v2<MT, WK>(acc, red, out, out_dt, partial, M, N, S, m_base, n0);
+    if (DEEP) CHITU_PROBE_MARK(4);
 }
 
 // out[m][n] = sum_s partial[s][m][n] in s order, then cast.
@@ -349,3 +360,5 @@ extern "C" int chitu_hip_soft_fp8_gemm(const void* a_bf16, const void* b_fp8, co
     }
     CHITU_RETURN_LAUNCH_STATUS();
 }
+
+CHITU_PROBE_READER(fp8_gemm)

@@ -38,7 +38,10 @@ __global__ __launch_bounds__(64) void gqa_decode_kernel(
     const int G = Hq / Hkv;  // q heads per kv head (<= 16)
     const int L = seqlens[b];
     const int n16 = (L + 15) >> 4;
-    const int s0i = (int)((long)n16 * split / num_splits), s1i = (int)((long)n16 * (split + 1) / num_splits);
+    // 32-bit unsigned quotients: a 64-bit division is a software loop on the kernel's critical chain (the launcher bounds
+    // 16-token steps x splits below 2^31)
+    const int s0i = (int)((unsigned)n16 * (unsigned)split / (unsigned)num_splits);
+    const int s1i = (int)((unsigned)n16 * (unsigned)(split + 1) / (unsigned)num_splits);
     const int32_t* tbl = table + (int64_t)b * table_stride;
     const int64_t tok_stride = (int64_t)Hkv * kHd;
 
@@ -216,6 +219,7 @@ extern "C" int chitu_hip_gqa_decode(const void* q_bf16, int64_t q_stride_b, int6
     if (head_dim != kHd || q_heads / kv_heads > 16) return CHITU_ERR_UNSUPPORTED;
     if (page_size < 16 || page_size % 16 != 0) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(q_stride_b % 8 == 0 && q_stride_h % 8 == 0);
+    CHITU_REQUIRE((int64_t)table_stride * (page_size / 16) * (num_splits + 1) < (1ll << 31));  // 32-bit split arithmetic
     if (batch == 0) return CHITU_OK;
     float* part_o = nullptr;
     float* part_lse = nullptr;

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kNormWideThreads) void rmsnorm_add_kernel(
     bf16_t* sum_out, int64_t sum_stride, const bf16_t* __restrict__ w, bf16_t* y, int64_t y_stride,
     fp8_t* __restrict__ q, float* __restrict__ qs, int dim, float eps, float qeps) {
     __shared__ float red[kNormWideThreads / 64];
+    if (QMODE == 2 && MAXT == 1) CHITU_PROBE_MARK(0);
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n_chunks = dim >> 3;
     const bool act = tid < n_chunks;
@@ -51,7 +52,12 @@ __global__ __launch_bounds__(kNormWideThreads) void rmsnorm_add_kernel(
     i32x4 sraw;
     add_bf16x8(xraw, a, v, sraw);
     if (act && sum_out) *reinterpret_cast<i32x4*>(sum_out + (int64_t)row * sum_stride + tid * 8) = sraw;
+    if (QMODE == 2 && MAXT == 1) {
+        if (v[0] == 1.2345e30f) CHITU_PROBE_MARK(9);
+        CHITU_PROBE_MARK(1);  // inputs arrived, residual added
+    }
     rmsnorm_wide_finish<QMODE>(v, act, row, wraw, y, y_stride, q, qs, dim, eps, qeps, red);
+    if (QMODE == 2 && MAXT == 1) CHITU_PROBE_MARK(2);
 }
 
 }  // namespace chitu
@@ -107,3 +113,5 @@ extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const
 #undef LAUNCH
     CHITU_RETURN_LAUNCH_STATUS();
 }
+
+CHITU_PROBE_READER(norm)

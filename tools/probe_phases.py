@@ -19,6 +19,11 @@ NAMES = {
                                               (6, "group selection"), (7, "top-k rounds"), (2, "weights normalised, ids in LDS"),
                                               (3, "workgroup barrier (slowest token wave)"), (20, "sort: sentinels + zeroing"),
                                               (21, "sort: counts"), (22, "sort: scan + expert ids"), (4, "sort: scatter; done")],
+    ("fp8_gemm", "fp8_gemm_kernel<1,8,DEEP> (wqkv_a)"): [(0, "start"), (1, "all loads issued"), (2, "first K block multiplied"),
+                                                          (3, "K loop done"), (4, "LDS reduce + stores issued")],
+    ("absorb", "mla_merge_uv_quant_kernel"): [(0, "start"), (1, "merged row written to LDS"), (2, "barrier"), (3, "W_UV projection done"),
+                                              (4, "group scale + quotients")],
+    ("norm", "rmsnorm_add_kernel<group quant, 1 term> (ffn_norm)"): [(0, "start"), (1, "inputs arrived, residual added"), (2, "norm + quant + stores issued")],
     ("mla_decode", "mla_decode_kernel"): [(8, "start"), (9, "seqlens loaded"), (10, "first KV tile staged in LDS"), (11, "QK^T done"),
                           (12, "tile loop done (softmax, PV)"), (13, "partials stored")],
 }
