@@ -119,7 +119,16 @@ def f32(v):
 
 
 DEBUG_OPTIONS = {"moe_gemm1_wk": 0, "moe_gemm1_nw": 1, "moe_gemm1_d": 2, "moe_gemm2_cfg": 3, "moe_i8_wk": 4,
-                 "gate_generic": 5, "gate_ticket": 6, "sample_radix": 7, "fp8_gemm_wk": 8, "fp8_gemm_deep": 9}
+                 "gate_generic": 5, "gate_ticket": 6, "sample_radix": 7, "fp8_gemm_wk": 8, "fp8_gemm_deep": 9,
+                 "bf16_gemm_wk": 10, "bf16_gemm_deep": 11, "bf16_silu_wk": 12}
+
+
+def apply_debug_options_from_env():
+    """Tools only (tools/run_extra.py, tools/bench_kernels.py): CHITU_DEBUG_OPTIONS="name=value,..." forces launch
+    variants for a sweep.  The product never calls this."""
+    for kv in filter(None, os.environ.get("CHITU_DEBUG_OPTIONS", "").split(",")):
+        k, v = kv.split("=")
+        check(lib().chitu_hip_debug_option(i32(DEBUG_OPTIONS[k]), i32(int(v))), "debug_option")
 
 
 class debug_option:

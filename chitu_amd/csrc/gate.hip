@@ -719,6 +719,8 @@ extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void*
     const int S = num_splits;
     int WK = 8;
     while (WK > 1 && (WK * S > KB || (int64_t)tiles * S * WK > 4096)) WK >>= 1;
+    debug_override(kOptBf16GemmWK, WK);
+    while (WK > 1 && WK * S > KB) WK >>= 1;
     const dim3 grid((unsigned)tiles, (unsigned)S);
 #define LAUNCH(MT, WKV)                                                                            \
     hipLaunchKernelGGL((bf16_gemm_kernel<MT, WKV>), grid, dim3(64 * WKV), 0, st, (const bf16_t*)x_bf16, \
@@ -734,7 +736,7 @@ extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void*
     for (int64_t mb = 0; mb < M; mb += 32) {
         const int mbase = (int)mb;
         if (M - mb <= 16) {
-            if (WK == 8 && per_wave > 4 && per_wave <= 8)
+            if (WK == 8 && per_wave > 4 && per_wave <= 8 && debug_option(kOptBf16GemmDeep) != 0)
                 hipLaunchKernelGGL((bf16_gemm_kernel<1, 8, true>), grid, dim3(512), 0, st, (const bf16_t*)x_bf16,
                                    (const bf16_t*)w_bf16, out, out_dtype, partials, (int)M, (int)N, (int)K, S, mbase);
             else
@@ -865,6 +867,8 @@ extern "C" int chitu_hip_bf16_gemm_silu(const void* x_bf16, const void* w13_bf16
     const int tiles = (int)((inter + 15) / 16);
     int WK = 8;
     while (WK > 1 && (WK > KB || (int64_t)tiles * WK > 4096)) WK >>= 1;
+    debug_override(kOptBf16SiluWK, WK);
+    while (WK > 1 && WK > KB) WK >>= 1;
     const dim3 grid((unsigned)tiles);
 #define LAUNCHS(MT, WKV)                                                                                        \
     hipLaunchKernelGGL((bf16_gemm_silu_kernel<MT, WKV>), grid, dim3(64 * WKV), 0, st, (const bf16_t*)x_bf16,    \

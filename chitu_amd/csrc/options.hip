@@ -2,7 +2,7 @@
 #include "common.h"
 
 namespace chitu {
-int g_debug_options[kOptCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int g_debug_options[kOptCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 }
 
 extern "C" int chitu_hip_debug_option(int32_t option, int32_t value) {

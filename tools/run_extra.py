@@ -6,6 +6,9 @@ import torch
 import bench
 
 torch.cuda.set_device(0)
+from chitu_amd import _lib
+
+_lib.apply_debug_options_from_env()
 which, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 16
 fn = {"mixtral": bench.mixtral_extra, "llama": bench.llama3_8b_extra, "v2lite": bench.v2_lite_extra,
       "ep8": bench.ep8_rank_extra}[which]
