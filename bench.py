@@ -157,6 +157,59 @@ def time_collectives(bs, dim, vocab_local, iters=200):
     return out
 
 
+class DeviceStateSampler:
+    """rocm-smi clocks / power of the local GPU sampled from a host thread WHILE a measurement runs (boxes of the pool
+    differ by up to 10 % on the latency-bound launches: the line carries what the device was doing).  Host-side only."""
+
+    def __init__(self, device_index):
+        import threading
+
+        self.dev, self.rows, self.stop = str(device_index), [], threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import subprocess
+
+        while not self.stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", self.dev, "--showclocks", "--showpower", "--csv"], capture_output=True,
+                                     text=True, timeout=5).stdout.strip().splitlines()
+                if len(out) >= 2:
+                    self.rows.append(dict(zip(out[0].split(","), out[-1].split(","))))
+            except Exception:  # noqa: BLE001 -- diagnostics only
+                pass
+            self.stop.wait(0.2)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.thread.join(timeout=10)
+        return False
+
+    def summary(self):
+        import re
+
+        def nums(key_part):
+            vals = []
+            for r in self.rows:
+                for k, v in r.items():
+                    if key_part in k.lower():
+                        m = re.search(r"([0-9.]+)", v or "")
+                        if m:
+                            vals.append(float(m.group(1)))
+            return vals
+
+        out = {"samples": len(self.rows)}
+        for name, key in (("sclk_mhz", "sclk"), ("mclk_mhz", "mclk"), ("fclk_mhz", "fclk"), ("power_w", "power")):
+            v = nums(key)
+            if v:
+                out[name] = {"min": min(v), "max": max(v)}
+        return out
+
+
 def barrier_sync(world):
     torch.cuda.synchronize()
     if world > 1:
@@ -601,7 +654,8 @@ def main():
         if ok.item() == 0:
             use_graph, graph_mode = False, "off (full capture refused)"
             model.graphs, model.static_tokens, model.static_out, model.graph_pool = {}, {}, {}, None
-    dt = measure(model, cache, a.bs, a.ctx, a.steps, a.warmup, world, use_graph, "m")
+    with DeviceStateSampler(local if not dinfo["shared_device"] else 0) as dev_state:
+        dt = measure(model, cache, a.bs, a.ctx, a.steps, a.warmup, world, use_graph, "m")
     ms_per_step = dt / a.steps * 1e3
     node_tok_s = a.bs * a.steps / dt
     value = node_tok_s * world / SHARD
@@ -678,6 +732,7 @@ def main():
             "step_hbm_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "step_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof, "cpu_baseline": cpu, "build_s": round(build_s, 1),
+            "device_state_during_timed_steps": dev_state.summary(),
         }
         res.update(extra)
         if a.layers != 61 or a.router_std is not None or dinfo["shared_device"]:

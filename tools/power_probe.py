@@ -16,7 +16,7 @@ def sample(stop, out):
             out.append(repr(e))
         time.sleep(0.3)
 
-ns = types.SimpleNamespace(layers=61, ctx=1024, steps=8, warmup=2, bs=16)
+ns = types.SimpleNamespace(layers=61, ctx=1024, steps=8, warmup=2, bs=16, no_bs1=True, router_std=None)
 torch.cuda.set_device(0)
 margs, model, cache = bench.build_model(ns, 0)
 hdr = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showpower", "--csv"], capture_output=True, text=True).stdout.strip().splitlines()[0]
