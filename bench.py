@@ -158,8 +158,8 @@ def time_collectives(bs, dim, vocab_local, iters=200):
 
 
 class DeviceStateSampler:
-    """rocm-smi clocks / power of the local GPU sampled from a host thread WHILE a measurement runs (boxes of the pool
-    differ by up to 10 % on the latency-bound launches: the line carries what the device was doing).  Host-side only."""
+    """rocm-smi clocks / power of the local GPU sampled from a host thread while a replica of the timed loop runs
+    (boxes of the pool differ by up to 10 % on the latency-bound launches: the line carries what the device was doing)."""
 
     def __init__(self, device_index):
         import threading
@@ -198,7 +198,7 @@ class DeviceStateSampler:
                 for k, v in r.items():
                     if key_part in k.lower():
                         m = re.search(r"([0-9.]+)", v or "")
-                        if m:
+                        if m and "level" not in k.lower() and float(m.group(1)) > 10:  # clock speeds / watts, not level indices
                             vals.append(float(m.group(1)))
             return vals
 
@@ -654,9 +654,11 @@ def main():
         if ok.item() == 0:
             use_graph, graph_mode = False, "off (full capture refused)"
             model.graphs, model.static_tokens, model.static_out, model.graph_pool = {}, {}, {}, None
-    with DeviceStateSampler(local if not dinfo["shared_device"] else 0) as dev_state:
-        dt = measure(model, cache, a.bs, a.ctx, a.steps, a.warmup, world, use_graph, "m")
+    dt = measure(model, cache, a.bs, a.ctx, a.steps, a.warmup, world, use_graph, "m")
     ms_per_step = dt / a.steps * 1e3
+    # the same loop once more, NOT part of any reported time, with rocm-smi sampled beside it
+    with DeviceStateSampler(local if not dinfo["shared_device"] else 0) as dev_state:
+        measure(model, cache, a.bs, a.ctx, max(a.steps, 96), 0, world, use_graph, "d")
     node_tok_s = a.bs * a.steps / dt
     value = node_tok_s * world / SHARD
 
@@ -732,7 +734,7 @@ def main():
             "step_hbm_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "step_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof, "cpu_baseline": cpu, "build_s": round(build_s, 1),
-            "device_state_during_timed_steps": dev_state.summary(),
+            "device_state_under_load": dev_state.summary(),
         }
         res.update(extra)
         if a.layers != 61 or a.router_std is not None or dinfo["shared_device"]:
