@@ -737,7 +737,9 @@ def main():
             "device_state_under_load": dev_state.summary(),
         }
         res.update(extra)
-        if a.layers != 61 or a.router_std is not None or dinfo["shared_device"]:
+        if coll and coll.get("xgmi_error_word"):
+            res["invalid"] = "an xGMI collective timed out (error word != 0): the step's results and timings are void"
+        elif a.layers != 61 or a.router_std is not None or dinfo["shared_device"]:
             res["invalid"] = ("debug run: " + ", ".join(
                 w for w, c in (("reduced layer count", a.layers != 61), ("non-default synthetic router", a.router_std is not None),
                                ("all ranks share one GPU (functional check of the N > 1 path)", dinfo["shared_device"])) if c))
