@@ -261,9 +261,13 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     for (int i = 0; i < 8; ++i) {
         const int chunk = tid + i * 256;
         const int hr = chunk >> 7, c4 = chunk & 127;
-        if (h0 + hr < H)
-            *reinterpret_cast<f32x4*>(part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c4 * 4) =
-                *reinterpret_cast<const f32x4*>(o_lds + hr * kC + c4 * 4);
+        if (h0 + hr < H) {
+            // write-through (sc1): 8.4 MB of partials left DIRTY in the L2s would be flushed by the end-of-kernel
+            // release, in front of the launch that reads them back; streamed out here they overlap the other workgroups
+            const f32x4 v = *reinterpret_cast<const f32x4*>(o_lds + hr * kC + c4 * 4);
+            float* dst = part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c4 * 4;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+        }
     }
     CHITU_PROBE_MARK(13);
 }
