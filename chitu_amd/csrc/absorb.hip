@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
     const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sk, fp8_t* __restrict__ q,
     float* __restrict__ qs, int batch, int H, int K) {
     __shared__ float red[8][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, m0 = blockIdx.y * 16;
     const int m = min(m0 + j, batch - 1);
     const fp8_t* wp = W + (int64_t)h * w_sh + (int64_t)(wave * 16 + j) * K + g * 16;

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
     __shared__ float red[WK > 1 ? WK * MT * 256 : 1];
     if (DEEP) CHITU_PROBE_MARK(0);
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // wave-uniform by construction; saying so (readfirstlane) lets the compiler keep the K-range arithmetic in SGPRs
+    // and fetch the weight block scales with scalar loads instead of one vector load per K block
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int KB = K >> 7;
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(64 * WK) void soft_fp8_gemm_kernel(
     int m_base) {
     __shared__ float red[WK > 1 ? WK * MT * 256 : 1];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int KB = (K + 127) >> 7;

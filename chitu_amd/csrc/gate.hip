@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_kernel(const bf16_t* __rest
                                                             float* __restrict__ partial, int M, int N,
                                                             int K, int S, int m_base) {
     __shared__ float red[WK > 1 ? WK * MT * 256 : 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int KB = K >> 6;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_silu_kernel(const bf16_t* _
                                                                  bf16_t* __restrict__ out, int M, int inter, int K,
                                                                  int m_base) {
     __shared__ float red[WK > 1 ? WK * MT * 512 : 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int KB = K >> 6;

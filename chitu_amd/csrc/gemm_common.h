@@ -12,7 +12,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT], float* red, void
                                               float* partial, int M, int N, int S, int m_base,
                                               int n0) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     auto store = [&](int mt, const f32x4& v) {
         const int m = m_base + mt * 16 + j;
@@ -117,7 +117,7 @@ template <int MT, int WK>
 __device__ __forceinline__ void gemm_epilogue_v2(f32x4 (&acc)[MT], float* red, void* out, int out_dt,
                                                  float* partial, int M, int N, int S, int m_base, int n0) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     auto store = [&](int mt, const f32x4& v) {
         const int m = m_base + mt * 16 + j;

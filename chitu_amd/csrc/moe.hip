@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64 * WK * NW) void moe_gemm1_kernel(
     __shared__ float red[WK > 1 ? WK * 256 : 1];
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = (NW > 1 ? blockIdx.x * NW + wave : blockIdx.x) * 16;
     if (NW > 1 && n0 >= N) return;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_silu_kernel(
     __shared__ float red[WK > 1 ? WK * 512 : 1];
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int N = 2 * I;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void moe_gemm2_kernel(
     int mul_weight) {
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int KB = I >> 7;
     const int slot = sorted_ids[mb * 16 + j];
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void moe_gemm2_q_kernel(
     __shared__ i32x4 xq_lds[2 * KB][64];
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int slot = sorted_ids[mb * 16 + j];
     const bool valid = slot < numel;
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm2_generic_kernel(
     __shared__ float red[WK > 1 ? WK * 256 : 1];
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int KB = I >> 7;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64 * WK) void moe_i8_gemm1_silu_kernel(
     __shared__ int red[WK > 1 ? WK * 512 : 1];
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int N = 2 * I;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * WK) void moe_i8_gemm2_kernel(
     __shared__ int red[WK > 1 ? WK * 256 : 1];
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int KB = I >> 7;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * WK) void w8a8_int8_gemm_kernel(
     const float* __restrict__ WS, const void* __restrict__ bias, int bias_dt, void* __restrict__ out,
     int out_dt, int M, int N, int K, int m_base) {
     __shared__ int red[WK > 1 ? WK * MT * 256 : 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int KB = K >> 7;
