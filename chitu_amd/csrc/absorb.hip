@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
     constexpr int K = 512, KC = 8;
     __shared__ __attribute__((aligned(16))) bf16_t xs[K];
     __shared__ float red[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, g = lane >> 4;
     const int h = blockIdx.x, b = blockIdx.y;
     CHITU_PROBE_MARK(0);
     const int64_t bh = (int64_t)b * H + h;

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     float* orig_lds = reinterpret_cast<float*>(dyn_lds);                      // [nwaves][E]
     int64_t* ids_lds = reinterpret_cast<int64_t*>(dyn_lds + nwaves * E);     // [M * out_stride]
     int* align_lds = dyn_lds + nwaves * E + 2 * ((M * out_stride + 1) & ~1);
-    const int lane = threadIdx.x & 63, t = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the wave's token: wave-uniform
     CHITU_PROBE_MARK(0);
     if (t < M) {  // wave-uniform
         // ---- logits of experts 4*lane .. 4*lane+3: all loads up front

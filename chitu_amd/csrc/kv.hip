@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void mla_kv_prep_kernel(
     float eps, bf16_t* __restrict__ cache, int64_t num_pages, int page_size, const int32_t* __restrict__ table,
     int pages_per_seq, const int32_t* __restrict__ old_lens) {
 #pragma clang fp contract(off)
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const bf16_t* src = kv_in + (int64_t)b * kv_stride;
     const float* cb = cos + (int64_t)b * 32;
     const float* sb = sin + (int64_t)b * 32;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void mla_kv_row(int b, const bf16_t* src, const bf16_
                                            const int32_t* __restrict__ table, int pages_per_seq,
                                            const int32_t* __restrict__ old_lens) {
 #pragma clang fp contract(off)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (wave > 1) return;
     bf16_t* row = nullptr;
     {

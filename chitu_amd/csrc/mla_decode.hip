@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     float* red_sum = red_max + 64;                                                      // [4][16]
     int* pages_lds = reinterpret_cast<int*>(red_sum + 64);                              // [kMaxTilesLds]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int split = blockIdx.x, b = blockIdx.y, hb = blockIdx.z;
     const int h0 = hb * 16;

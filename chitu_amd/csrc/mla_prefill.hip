@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_kernel(
     float* red_max = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(p_lds) + 16 * kPStride * 2);  // [4][16]
     float* red_sum = red_max + 64;                                                                      // [4][16]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: SGPR index math
     const int j = lane & 15, g = lane >> 4;
     const int seq = blockIdx.y, hb = blockIdx.z;
     const int s0 = cu_seqlens[seq], s1 = cu_seqlens[seq + 1];

@@ -28,7 +28,7 @@ __device__ __forceinline__ void moe_align_workgroup(
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     for (int i = tid; i < E; i += nthreads) counts[i] = 0;
     for (int i = tid; i < nwaves * E; i += nthreads) wave_hist[i] = 0;
