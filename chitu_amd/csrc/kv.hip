@@ -7,6 +7,7 @@
 //   chitu/ops.py:51-91, 124-326       launchers + torch RoPE
 #include "common.h"
 #include "norm_common.h"
+#include "mla_kv_row.h"
 
 namespace chitu {
 
@@ -190,54 +191,6 @@ __global__ __launch_bounds__(256) void gqa_qkv_post_kernel(
         const bf16_e* vsrc = row + (hq + hkv) * d;
         for (int idx = threadIdx.x; idx < hkv * d / 8; idx += 256)
             *reinterpret_cast<i32x4*>(v_cache + dst_row + idx * 8) = *reinterpret_cast<const i32x4*>(vsrc + idx * 8);
-    }
-}
-
-// kv_norm(kv_c) + RoPE(k_pe) of one token written straight into its page row (waves 0 and 1 of a
-// workgroup); src = [kv_c (512) | k_pe (64)].
-__device__ __forceinline__ void mla_kv_row(int b, const bf16_t* src, const bf16_t* __restrict__ kv_norm_w, float kv_eps,
-                                           const float* __restrict__ cos, const float* __restrict__ sin,
-                                           bf16_t* __restrict__ cache, int64_t num_pages, int page_size,
-                                           const int32_t* __restrict__ table, int pages_per_seq,
-                                           const int32_t* __restrict__ old_lens) {
-#pragma clang fp contract(off)
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    if (wave > 1) return;
-    bf16_t* row = nullptr;
-    {
-        const int L = old_lens[b];
-        const int pidx = L / page_size;
-        if (L >= 0 && pidx < pages_per_seq) {
-            const int64_t page = table[(int64_t)b * pages_per_seq + pidx];
-            if (page >= 0 && page < num_pages) row = cache + (page * page_size + (L % page_size)) * 576;
-        }
-    }
-    if (wave == 0) {
-        const i32x4 raw = *reinterpret_cast<const i32x4*>(src + lane * 8);
-        const i32x4 wraw = *reinterpret_cast<const i32x4*>(kv_norm_w + lane * 8);
-        float v[8], ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t u = (uint32_t)raw[k];
-            v[2 * k] = __uint_as_float(u << 16);
-            v[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) ss += v[k] * v[k];
-        ss = wave_reduce_sum(ss);
-        const float rr = rsqrtf(ss / 512.0f + kv_eps);
-        i32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t u = (uint32_t)wraw[k];
-            o[k] = (int)f32x2_to_bf16x2((v[2 * k] * rr) * __uint_as_float(u << 16),
-                                        (v[2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
-        }
-        if (row) *reinterpret_cast<i32x4*>(row + lane * 8) = o;
-    } else if (lane < 32 && row) {
-        const float x0 = bf16_to_f32(src[512 + 2 * lane]), x1 = bf16_to_f32(src[512 + 2 * lane + 1]);
-        const float c = cos[(int64_t)b * 32 + lane], s = sin[(int64_t)b * 32 + lane];
-        *reinterpret_cast<uint32_t*>(row + 512 + 2 * lane) = f32x2_to_bf16x2(x0 * c - x1 * s, x1 * c + x0 * s);
     }
 }
 

@@ -166,6 +166,11 @@ class RMSNormW(torch.nn.Module):
         self.weight = torch.nn.Parameter(torch.ones(dim, dtype=torch.bfloat16, device=device), requires_grad=False)
 
 
+# q_norm + act_quant + wq_b GEMM + KV append as one launch (ops.mla_q_proj); CHITU_Q_PROJ_FUSED=0 keeps the two
+# launches apart (A/B timing, tests of the unfused pair).
+FUSE_Q_PROJ = os.environ.get("CHITU_Q_PROJ_FUSED", "1") != "0"
+
+
 def _wqkv_a_splits(bs: int, n: int, k: int) -> int:
     """Cross-workgroup K split of the wqkv_a GEMM (its 2112 rows are 132 MFMA tiles: half the chip), the fp32
     halves summed by the kernel that reads them.  Built, parity-tested and measured NEUTRAL on the R1 step (same-box
@@ -232,9 +237,10 @@ class AttentionDeepSeekV3(torch.nn.Module):
     def decode_forward_paged(self, x_quant, cos, sin):
         """x_quant = fp8 (q, s) of attn_norm(x), [bs, dim].  Returns wo(attn) before the all-reduce.
 
-        7 launches (the reference's decode_forward_paged + _run_linear issue ~25): wqkv_a GEMM,
-        [q_norm + quant | kv_norm + RoPE(k_pe) + page append], wq_b GEMM, [W_UK absorb | RoPE(q_pe)],
-        MLA decode, [split merge + W_UV absorb + quant], wo GEMM."""
+        6 launches (the reference's decode_forward_paged + _run_linear issue ~25): wqkv_a GEMM,
+        [q_norm + quant -> wq_b GEMM | kv_norm + RoPE(k_pe) + page append], [W_UK absorb | RoPE(q_pe)],
+        MLA decode, [split merge + W_UV absorb + quant], wo GEMM.  (7 with batches above 32: the q_norm / kv
+        launch and the wq_b GEMM apart.)"""
         H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
         bs = x_quant[0].shape[0]
         cache = self.cache
@@ -247,11 +253,20 @@ class AttentionDeepSeekV3(torch.nn.Module):
                 q_a_kv = ops.fp8_gemm_partials_deepseek_v3(x_quant[0], x_quant[1], self.wqkv_a.weight, self.wqkv_a.scale, splits)
             else:
                 q_a_kv = self.wqkv_a(None, x_quant=x_quant)
-            # q_norm + quant, and this token's [kv_norm(kv_c) | rope(k_pe)] row straight into its page
-            qq, qs = ops.mla_qkv_post(q_a_kv, self.q_lora_rank, self.q_norm.weight, self.q_norm.eps, self.kv_norm.weight,
-                                      self.kv_norm.eps, cos, sin, kv_cache, cache.get_gpu_block_table(),
-                                      cache.get_gpu_seq_lens_excl_this_decode())
-            q = self.wq_b(None, x_quant=(qq, qs)).view(bs, H, self.qk_head_dim)
+            if FUSE_Q_PROJ and splits == 1 and ops.mla_q_proj_fits(bs, self.q_lora_rank):
+                # ONE launch: q_norm + act_quant as the prologue of the wq_b GEMM, and this token's
+                # [kv_norm(kv_c) | rope(k_pe)] row straight into its page on extra workgroups of the same grid
+                q = ops.mla_q_proj(q_a_kv, self.q_lora_rank, self.q_norm.weight, self.q_norm.eps, self.wq_b.weight,
+                                   self.wq_b.scale, self.kv_norm.weight, self.kv_norm.eps, cos, sin, kv_cache,
+                                   cache.get_gpu_block_table(), cache.get_gpu_seq_lens_excl_this_decode(),
+                                   out_dtype=torch.bfloat16)
+            else:
+                # q_norm + quant, and this token's [kv_norm(kv_c) | rope(k_pe)] row straight into its page
+                qq, qs = ops.mla_qkv_post(q_a_kv, self.q_lora_rank, self.q_norm.weight, self.q_norm.eps, self.kv_norm.weight,
+                                          self.kv_norm.eps, cos, sin, kv_cache, cache.get_gpu_block_table(),
+                                          cache.get_gpu_seq_lens_excl_this_decode())
+                q = self.wq_b(None, x_quant=(qq, qs))
+            q = q.view(bs, H, self.qk_head_dim)
             q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
             # q_nope' = q_nope . W_UK  (einsum "shd,hdc->shc", :529-531), wkv_b dequantised in registers;
             # q_pe rotated in place by the same launch

@@ -544,6 +544,41 @@ def mla_qkv_post(q_a_kv, q_lora_rank, q_norm_weight, q_eps, kv_norm_weight, kv_e
     return q, s
 
 
+def mla_q_proj_fits(bs: int, q_lora_rank: int) -> bool:
+    """Shapes chitu_hip_mla_q_proj takes (decode batches up to two 16-token tiles, q_lora_rank <= 8 waves x 2 K blocks)."""
+    return 0 < bs <= 32 and q_lora_rank % 128 == 0 and 128 <= q_lora_rank <= 2048
+
+
+def mla_q_proj(q_a_kv, q_lora_rank, q_norm_weight, q_eps, wq_b, wq_b_scale, kv_norm_weight, kv_eps, cos, sin, kv_cache,
+               page_table, old_seq_lens, out_dtype=None):
+    """mla_qkv_post + the wq_b GEMM in ONE launch: q = fp8_gemm(act_quant(q_norm(q_a)), wq_b) [bs, N] with the norm and
+    the quantisation as the GEMM's prologue (model_deepseek_v3.py:488), and each token's [kv_norm(kv_c) | RoPE(k_pe)] row
+    appended to its page (:493-496, :684-686) by extra workgroups of the same grid.  q_a_kv: wqkv_a's bf16 output
+    [bs, q_lora + 576]; check mla_q_proj_fits first."""
+    require_cuda(q_a_kv, q_norm_weight, wq_b, wq_b_scale, kv_norm_weight, cos, sin, kv_cache, page_table, old_seq_lens)
+    assert q_a_kv.dtype == torch.bfloat16 and q_a_kv.dim() == 2 and q_a_kv.stride(1) == 1
+    bs = q_a_kv.shape[0]
+    assert mla_q_proj_fits(bs, q_lora_rank), "use mla_qkv_post + fp8_gemm_deepseek_v3 for this shape"
+    assert q_a_kv.shape[-1] == q_lora_rank + 576 and kv_cache.dtype == torch.bfloat16 and kv_cache.shape[-1] == 576
+    assert kv_cache.is_contiguous() and page_table.is_contiguous() and page_table.dtype == torch.int32
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and old_seq_lens.dtype == torch.int32
+    assert wq_b.element_size() == 1 and wq_b.is_contiguous() and wq_b.shape[1] == q_lora_rank
+    assert wq_b_scale.dtype == torch.float32 and wq_b_scale.is_contiguous()
+    N = wq_b.shape[0]
+    assert wq_b_scale.shape == ((N + 127) // 128, q_lora_rank // 128)
+    out = torch.empty(bs, N, dtype=out_dtype or torch.get_default_dtype(), device=q_a_kv.device)
+    check(
+        _lib.lib().chitu_hip_mla_q_proj(
+            ptr(q_a_kv), i64(q_a_kv.stride(0)), i32(q_lora_rank), ptr(q_norm_weight), f32(q_eps), ptr(wq_b), ptr(wq_b_scale),
+            ptr(out), float_dtype_code(out.dtype), i64(N), ptr(kv_norm_weight), f32(kv_eps), ptr(cos), ptr(sin),
+            ptr(kv_cache), i64(kv_cache.shape[0]), i32(kv_cache.shape[1]), ptr(page_table), i32(page_table.shape[1]),
+            ptr(old_seq_lens), i32(bs), i32(512), i32(64), stream_ptr(),
+        ),
+        "mla_q_proj",
+    )
+    return out
+
+
 def absorb_bmm_rope_fp8(x, w, scale, scale_offset, scale_stride_h, scale_stride_n, scale_stride_k, q_pe, cos, sin):
     """absorb_bmm_fp8 + in-place RoPE of q_pe [B, H, 64] in the same launch."""
     require_cuda(x, w, scale, q_pe, cos, sin)

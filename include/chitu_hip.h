@@ -416,6 +416,23 @@ int chitu_hip_mla_qkv_post(const void* qkv_a, int32_t num_partials, int64_t row_
                            const int32_t* old_seq_lens, int32_t batch, int32_t kv_lora_rank,
                            int32_t rope_dim, void* stream);
 
+/* chitu_hip_mla_qkv_post AND the wq_b GEMM in one launch (decode, batch <= 32, q_lora_rank <= 2048):
+ *   out[batch, N] = fp8_gemm(act_quant(q_norm(qkv_a[:, :q_lora_rank])), wq_b)   (model_deepseek_v3.py:488 with the
+ *   linear's act_quant + fp8 GEMM, triton_kernels.py:194-216 / :302-365), and every token's
+ *   [kv_norm(kv_c) | RoPE(k_pe)] row appended to its page (model_deepseek_v3.py:493-496, :684-686).
+ * q_norm + act_quant run as the GEMM's prologue in every workgroup (per element the arithmetic of
+ * chitu_hip_rmsnorm quant_mode 1; the mean square is summed in this kernel's own fixed order, so the rounded norm
+ * can differ from chitu_hip_mla_qkv_post's in the last bf16 bit of a few elements).  wq_b [N, q_lora_rank] e4m3 with
+ * scales [ceil(N/128), q_lora_rank/128]; out_dtype 0 bf16 / 1 f16 / 2 f32.  Other shapes: CHITU_ERR_UNSUPPORTED
+ * (use chitu_hip_mla_qkv_post + chitu_hip_fp8_gemm_blockscale). */
+int chitu_hip_mla_q_proj(const void* qkv_a_bf16, int64_t row_stride, int32_t q_lora_rank,
+                         const void* q_norm_weight_bf16, float q_eps, const void* wq_b_fp8,
+                         const float* wq_b_scale, void* out, int32_t out_dtype, int64_t N,
+                         const void* kv_norm_weight_bf16, float kv_eps, const float* cos, const float* sin,
+                         void* kv_cache, int64_t num_pages, int32_t page_size, const int32_t* page_table,
+                         int32_t pages_per_seq, const int32_t* old_seq_lens, int32_t batch,
+                         int32_t kv_lora_rank, int32_t rope_dim, void* stream);
+
 /* ---- W_UV absorb projection fused with the FP8 quantisation of wo's input ---------------------
  * chitu_hip_absorb_bmm_fp8 for N = 128 (einsum "bshc,hdc->bshd", model_deepseek_v3.py:697) followed by
  * act_quant_deepseek_v3 of the bf16-rounded result (model_deepseek_v3.py:98-100 inside wo):

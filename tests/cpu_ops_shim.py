@@ -57,6 +57,17 @@ def mla_qkv_post(q_a_kv, q_lora_rank, q_norm_weight, q_eps, kv_norm_weight, kv_e
     return qq, qs
 
 
+def mla_q_proj_fits(bs, q_lora_rank):
+    return 0 < bs <= 32 and q_lora_rank % 128 == 0 and 128 <= q_lora_rank <= 2048
+
+
+def mla_q_proj(q_a_kv, q_lora_rank, q_norm_weight, q_eps, wq_b, wq_b_scale, kv_norm_weight, kv_eps, cos, sin, kv_cache,
+               page_table, old_seq_lens, out_dtype=None):
+    qq, qs = mla_qkv_post(q_a_kv, q_lora_rank, q_norm_weight, q_eps, kv_norm_weight, kv_eps, cos, sin, kv_cache, page_table,
+                          old_seq_lens)
+    return fp8_gemm_deepseek_v3(qq, qs, wq_b, wq_b_scale, out_dtype=out_dtype)
+
+
 def absorb_bmm_rope_fp8(x, w, scale, scale_offset, sh, sn, sk, q_pe, cos, sin):
     qo, _ = okv.apply_rotary_pos_emb(q_pe, q_pe[:, 0], cos, sin, "llama")
     q_pe.copy_(qo)
@@ -206,7 +217,7 @@ def install(monkeypatch_setattr):
     from chitu_amd import fused_moe, ops
 
     for name in ("rms_norm", "act_quant_deepseek_v3", "fp8_gemm_deepseek_v3", "mla_kv_prep", "absorb_bmm_fp8",
-                 "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear", "mla_qkv_post", "absorb_bmm_rope_fp8",
+                 "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear", "mla_qkv_post", "mla_q_proj", "mla_q_proj_fits", "absorb_bmm_rope_fp8",
                  "embed_rope_gather"):
         monkeypatch_setattr(ops, name, globals()[name])
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)

@@ -429,6 +429,83 @@ def test_qkv_post_reads_split_k_planes_like_the_rounded_sum(bs, S):
     assert not torch.equal(c1, cache)
 
 
+def _q_proj_case(bs, ql, seed):
+    g = torch.Generator().manual_seed(seed)
+    q_a_kv = (torch.randn(bs, ql + 576, generator=g) * (0.2 + torch.rand(bs, 1, generator=g) * 3)).to(torch.bfloat16).cuda()
+    cos, sin = torch.randn(bs, 32, generator=g).cuda(), torch.randn(bs, 32, generator=g).cuda()
+    wq = (torch.rand(ql, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    wn = (torch.rand(512, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    pages = 2 * bs + 2
+    cache = torch.randn(pages, 64, 576, generator=g).to(torch.bfloat16).cuda()
+    table = torch.randperm(pages, generator=g)[: 2 * bs].view(bs, 2).to(torch.int32).cuda()  # no page shared by two sequences
+    lens = torch.tensor([(37 * i + (63 if i % 2 else 64)) % 128 for i in range(bs)], dtype=torch.int32).cuda()
+    return g, q_a_kv, cos, sin, wq, wn, cache, table, lens
+
+
+@pytest.mark.parametrize("bs", [1, 5, 16, 17, 32])
+@pytest.mark.parametrize("ql,N", [(1536, 3072), (512, 200), (2048, 1536), (128, 64)])
+def test_q_proj_one_launch_vs_the_separate_launches_and_the_oracle(bs, ql, N):
+    """mla_q_proj (q_norm + act_quant as the wq_b GEMM's prologue, KV append on extra workgroups) against
+    mla_qkv_post + fp8_gemm_deepseek_v3: the page rows bit for bit (same code); q (fp32) within 2e-3 of the pair's peak (the
+    mean square is summed in another order: the last bit of a few bf16 norms, hence one fp8 step on a few inputs) and
+    within 1e-2 of the CPU oracle's rms_norm -> act_quant -> fp8 GEMM."""
+    from chitu_amd import ops
+    from oracle import fp8 as ofp8
+
+    g, q_a_kv, cos, sin, wq, wn, cache, table, lens = _q_proj_case(bs, ql, 300 + bs + ql)
+    w = (torch.randn(N, ql, generator=g) * 0.5).to(torch.float8_e4m3fn).cuda()
+    ws = (torch.rand((N + 127) // 128, ql // 128, generator=g) * 0.02 + 0.01).cuda()
+    c1, c2 = cache.clone(), cache.clone()
+    qq, qs = ops.mla_qkv_post(q_a_kv, ql, wq, 1e-6, wn, 1e-6, cos, sin, c1, table, lens)
+    ref = ops.fp8_gemm_deepseek_v3(qq, qs, w, ws, out_dtype=torch.float32)
+    out = ops.mla_q_proj(q_a_kv, ql, wq, 1e-6, w, ws, wn, 1e-6, cos, sin, c2, table, lens, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    bad = (c1 != c2).nonzero()
+    assert bad.shape[0] == 0, (bad.shape[0], bad[:8].tolist(), table.tolist(), lens.tolist(),
+                               [(c1[tuple(i)].item(), c2[tuple(i)].item(), cache[tuple(i)].item()) for i in bad[:8].tolist()])
+    assert not torch.equal(c2, cache)
+    assert max_rel_to_peak(out, ref) < 2e-3  # fp32 outputs: a bf16 output's own last bit would be 4e-3 of the peak
+    out = ops.mla_q_proj(q_a_kv, ql, wq, 1e-6, w, ws, wn, 1e-6, cos, sin, c2, table, lens, out_dtype=torch.bfloat16)
+    y = torch.nn.functional.rms_norm(q_a_kv[:, :ql].cpu().float(), (ql,), wq.cpu().float(), 1e-6).to(torch.bfloat16)
+    oq, os_ = ofp8.act_quant_deepseek_v3(y)
+    o_ref = ofp8.fp8_gemm_deepseek_v3(oq, os_, w.cpu(), ws.cpu(), torch.bfloat16)
+    assert max_rel_to_peak(out, o_ref) < 1e-2
+
+
+@pytest.mark.parametrize("bs", [1, 16, 23])
+def test_q_proj_prologue_quantises_like_act_quant(bs):
+    """The prologue seen through an identity wq_b (fp8 1.0 on the diagonal, scales 1.0, fp32 output): what comes out is
+    fp8(y / s) * s of the normalised row, i.e. the dequantised act_quant -- equal to the unfused launch's (q, s) on all
+    but a few elements (those whose bf16 norm sits on a rounding boundary of the mean square's last bit), and never
+    further away than one fp8 step."""
+    from chitu_amd import ops
+
+    ql = 1536
+    g, q_a_kv, cos, sin, wq, wn, cache, table, lens = _q_proj_case(bs, ql, 700 + bs)
+    w = torch.eye(ql).to(torch.float8_e4m3fn).cuda()
+    ws = torch.ones(ql // 128, ql // 128).cuda()
+    c1, c2 = cache.clone(), cache.clone()
+    qq, qs = ops.mla_qkv_post(q_a_kv, ql, wq, 1e-6, wn, 1e-6, cos, sin, c1, table, lens)
+    deq = qq.float().view(bs, ql // 128, 128) * qs[:, :, None]
+    out = ops.mla_q_proj(q_a_kv, ql, wq, 1e-6, w, ws, wn, 1e-6, cos, sin, c2, table, lens, out_dtype=torch.float32)
+    out = out.view(bs, ql // 128, 128)
+    diff = (out != deq)
+    assert diff.float().mean().item() < 0.01, diff.float().mean().item()
+    # one e4m3 step is at most 2^-3 of the value's binade: <= 1/8 * |v| (+ the scale's own last-bit change)
+    assert ((out - deq).abs() <= 0.13 * deq.abs().clamp_min(1e-30) + 1e-6 * qs[:, :, None]).all()
+    assert torch.equal(c1, c2)
+
+
+def test_q_proj_unsupported_shapes_say_so():
+    from chitu_amd import ops
+
+    assert not ops.mla_q_proj_fits(33, 1536) and not ops.mla_q_proj_fits(16, 2176) and not ops.mla_q_proj_fits(0, 1536)
+    g, q_a_kv, cos, sin, wq, wn, cache, table, lens = _q_proj_case(33, 1536, 9)
+    w = torch.zeros(64, 1536).to(torch.float8_e4m3fn).cuda()
+    with pytest.raises(AssertionError):
+        ops.mla_q_proj(q_a_kv, 1536, wq, 1e-6, w, torch.ones(1, 12).cuda(), wn, 1e-6, cos, sin, cache, table, lens)
+
+
 @pytest.mark.parametrize("E,groups,topk,S,bias", [(256, (8, 4), 8, 16, True), (256, (8, 4), 8, 0, True), (256, (4, 2), 8, 3, True),
                                                   (256, (8, 4), 8, 16, False), (128, (1, 1), 6, 5, True), (64, (2, 1), 4, 0, True)])
 def test_gate_route_fast_path_equals_generic_kernel(E, groups, topk, S, bias, monkeypatch):

@@ -24,6 +24,10 @@ NAMES = {
     ("absorb", "mla_merge_uv_quant_kernel"): [(0, "start"), (1, "merged row written to LDS"), (2, "barrier"), (3, "W_UV projection done"),
                                               (4, "group scale + quotients")],
     ("norm", "rmsnorm_add_kernel<group quant, 1 term> (ffn_norm)"): [(0, "start"), (1, "inputs arrived, residual added"), (2, "norm + quant + stores issued")],
+    ("mla_q_proj", "mla_q_proj_kernel<1> (first GEMM workgroup)"): [(0, "start"), (1, "all loads issued"), (2, "activation rows arrived, partial mean squares in LDS"),
+                                                                    (3, "barrier, row sums, rsqrt"), (4, "first K block: norm + quant + MFMAs (weights arrived)"),
+                                                                    (5, "all K blocks"), (6, "LDS reduce + stores issued")],
+    ("mla_q_proj", "mla_q_proj_kernel<1> (first KV workgroup)"): [(10, "start"), (11, "page row written")],
     ("mla_decode", "mla_decode_kernel"): [(8, "start"), (9, "seqlens loaded"), (10, "first KV tile staged in LDS"), (11, "QK^T done"),
                           (12, "tile loop done (softmax, PV)"), (13, "partials stored")],
 }

@@ -11,8 +11,9 @@ con = sqlite3.connect(db)
 rows = con.execute("select name, start, end from kernels order by start").fetchall()
 al = [i for i, r in enumerate(rows) if "gate_route" in r[0]]
 tail = int(sys.argv[4]) if len(sys.argv) > 4 else 2 * nmoe
-first, last = al[-tail - nmoe * steps], al[-tail]
-t0, t1 = rows[first][1], rows[last][1]
+first = al[-tail - nmoe * steps]
+t0 = rows[first][1]
+t1 = rows[al[-tail]][1] if tail > 0 else rows[-1][2] + 1  # tail 0 (bench.py --no-roofline): up to the last dispatch
 sel = [r for r in rows if t0 <= r[1] < t1]
 agg = {}
 for n, s, e in sel:
