@@ -77,6 +77,7 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_kernel(const bf16_t* __rest
         }
     };
     // DEEP (single token tile, <= 8 K blocks per wave): the wave's whole K range in one round trip
+    // (a ring of 8 for the long-K form was measured: slower, Llama-3-8B bs 1 3.46 -> 3.50 ms/step)
     constexpr int D = DEEP ? 8 : MT >= 4 ? 2 : 4;
     Bf16Stage<MT> ring[D];
 #pragma unroll

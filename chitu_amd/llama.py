@@ -6,10 +6,12 @@ FeedForward:201-214, TransformerBlock, Transformer.decode:538-622; models/model_
 wqkv / w13 layout of the original Meta checkpoints, rotary_type "llama" = interleaved pairs).
 
 Per layer and step, 7 launches: add+RMSNorm, wqkv GEMM, [RoPE(q, k) + append K, V], paged GQA decode
-(+ merge when the KV range is split), wo GEMM, add+RMSNorm, [w13 GEMM + SiluAndMul], w2 GEMM.
+(+ merge when the KV range is split), wo GEMM, add+RMSNorm, [w13 GEMM + SiluAndMul], w2 GEMM -- 5 at batch 1,
+where both add+RMSNorm steps run as the prologue of the GEMM behind them (bf16_norm_gemm.hip).
 All GEMMs are the weight-streaming skinny bf16 kernel (gate.hip); the whole step replays as one hipGraph.
 """
 
+import os
 from dataclasses import dataclass
 
 import torch
@@ -52,6 +54,18 @@ def _param(*shape, device=None):
     return torch.nn.Parameter(torch.empty(*shape, dtype=torch.bfloat16, device=device), requires_grad=False)
 
 
+# Decode batches up to this size run a layer's two residual-add + RMSNorm steps as the prologue of the GEMMs behind
+# them (ops.bf16_linear_add_norm / bf16_linear_silu_add_norm: bit-identical, two launches fewer per layer).  0 = off.
+FUSE_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_NORM_MAX_BS", "1"))
+
+
+def _fuses_norm(x, pending, n_out) -> bool:
+    """pending must be a plain [bs, dim] tensor: not None (first layer), not a partial whose all-reduce the norm launch
+    itself performs (tensor_parallel.PendingAllReduce, the in-graph xGMI form)."""
+    return (isinstance(pending, torch.Tensor) and pending.dim() == 2 and x.shape[0] <= FUSE_NORM_MAX_BS
+            and ops.bf16_add_norm_fits(x.shape[0], n_out, x.shape[1]))
+
+
 class LlamaAttention(torch.nn.Module):
     def __init__(self, args, layer_id, cache, attn_backend, device=None, rotary_type="llama"):
         super().__init__()
@@ -66,8 +80,12 @@ class LlamaAttention(torch.nn.Module):
 
     def decode_forward_paged(self, x, cos, sin):
         """x = attn_norm(h) bf16 [bs, dim] -> wo(attention) before the all-reduce (model.py:167-198)."""
-        bs = x.shape[0]
-        qkv = ops.bf16_linear(x, self.wqkv).view(bs, self.hq + 2 * self.hkv, self.hd)
+        return self.decode_from_qkv(ops.bf16_linear(x, self.wqkv), cos, sin)
+
+    def decode_from_qkv(self, qkv, cos, sin):
+        """The merged projection's output [bs, (hq + 2 hkv) * hd] -> wo(attention) before the all-reduce."""
+        bs = qkv.shape[0]
+        qkv = qkv.view(bs, self.hq + 2 * self.hkv, self.hd)
         k_cache, v_cache = self.cache.get_paged_kv_cache(self.layer_id)
         table = self.cache.get_gpu_block_table()
         # RoPE(q, k) + append of k and v to their pages: one launch
@@ -118,11 +136,22 @@ class LlamaBlock(torch.nn.Module):
     def forward(self, x, pending, cos, sin, varlens=None):
         """(x, pending) -> (x', pending'): residual adds folded into the RMSNorm that consumes them;
         varlens given = prefill."""
-        x, hn = tp.add_norm(x, pending, self.attn_norm, self.eps)[:2]
-        if varlens is None:
-            a = tp.defer_all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+        if varlens is None and _fuses_norm(x, pending, self.attn.wqkv.shape[0]):
+            # small decode batches: the add + norm run as the prologue of the projection that consumes them
+            x, qkv = ops.bf16_linear_add_norm(x, pending, self.attn_norm, self.eps, self.attn.wqkv)
+            a = tp.defer_all_reduce(self.attn.decode_from_qkv(qkv, cos, sin))
         else:
-            a = tp.defer_all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
+            x, hn = tp.add_norm(x, pending, self.attn_norm, self.eps)[:2]
+            if varlens is None:
+                a = tp.defer_all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+            else:
+                a = tp.defer_all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
+        return self.ffn_part(x, a, varlens)
+
+    def ffn_part(self, x, a, varlens):
+        if varlens is None and _fuses_norm(x, a, self.ffn.inter):
+            x, h = ops.bf16_linear_silu_add_norm(x, a, self.ffn_norm, self.eps, self.ffn.w13)
+            return x, tp.defer_all_reduce(ops.bf16_linear(h, self.ffn.w2))
         x, hn = tp.add_norm(x, a, self.ffn_norm, self.eps)[:2]
         return x, tp.defer_all_reduce(self.ffn(hn))
 

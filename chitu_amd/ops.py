@@ -361,6 +361,60 @@ def bf16_linear_silu(x: torch.Tensor, w13: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def bf16_add_norm_fits(M: int, N: int, K: int) -> bool:
+    """Shapes chitu_hip_bf16_gemm_add_norm / chitu_hip_bf16_gemm_silu_add_norm take (N = output rows of the GEMM, or the
+    SwiGLU width): 1-4 tokens, a hidden size the wide norm form covers, and a K split of at least 4 waves."""
+    if not (1 <= M <= 4 and K % 64 == 0 and 512 <= K <= 8192 and M * K <= 24576):
+        return False
+    tiles, wk = (N + 15) // 16, 8
+    while wk > 1 and (wk > K // 64 or tiles * wk > 4096):
+        wk >>= 1
+    return wk >= 4
+
+
+def bf16_linear_add_norm(x, add, norm_weight, eps, weight, out_dtype=None):
+    """(x_new, F.linear(rms_norm(x_new), weight)) with x_new = x + add, ONE launch (the add and the norm run as the
+    GEMM's prologue in every workgroup; bit-identical to rms_norm(x, add=add) followed by bf16_linear).
+    x, add [M, K] bf16 with M <= 4: check bf16_add_norm_fits first."""
+    require_cuda(x, add, norm_weight, weight)
+    assert x.dtype == torch.bfloat16 and add.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+    assert x.dim() == 2 and add.shape == x.shape and x.stride(1) == 1 and add.stride(1) == 1 and weight.is_contiguous()
+    assert norm_weight.dtype == torch.bfloat16 and norm_weight.is_contiguous() and norm_weight.numel() == x.shape[1]
+    M, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K and bf16_add_norm_fits(M, N, K), "use rms_norm(add=) + bf16_linear for this shape"
+    x_new = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(M, N, dtype=out_dtype or torch.bfloat16, device=x.device)
+    check(
+        _lib.lib().chitu_hip_bf16_gemm_add_norm(ptr(x), i64(x.stride(0)), ptr(add), i64(add.stride(0)), ptr(x_new), i64(K),
+                                                ptr(norm_weight), f32(eps), ptr(weight), ptr(out), float_dtype_code(out.dtype),
+                                                i64(M), i64(N), i64(K), stream_ptr()),
+        "bf16_linear_add_norm",
+    )
+    return x_new, out
+
+
+def bf16_linear_silu_add_norm(x, add, norm_weight, eps, w13):
+    """(x_new, silu(y w1^T) * (y w3^T)) with x_new = x + add, y = rms_norm(x_new), ONE launch; bit-identical to
+    rms_norm(x, add=add) followed by bf16_linear_silu.  Check bf16_add_norm_fits(M, inter, K) first."""
+    require_cuda(x, add, norm_weight, w13)
+    assert x.dtype == torch.bfloat16 and add.dtype == torch.bfloat16 and w13.dtype == torch.bfloat16
+    assert x.dim() == 2 and add.shape == x.shape and x.stride(1) == 1 and add.stride(1) == 1 and w13.is_contiguous()
+    assert norm_weight.dtype == torch.bfloat16 and norm_weight.is_contiguous() and norm_weight.numel() == x.shape[1]
+    M, K = x.shape
+    inter = w13.shape[0] // 2
+    assert w13.shape == (2 * inter, K) and bf16_add_norm_fits(M, inter, K), "use rms_norm(add=) + bf16_linear_silu for this shape"
+    x_new = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(M, inter, dtype=torch.bfloat16, device=x.device)
+    check(
+        _lib.lib().chitu_hip_bf16_gemm_silu_add_norm(ptr(x), i64(x.stride(0)), ptr(add), i64(add.stride(0)), ptr(x_new), i64(K),
+                                                     ptr(norm_weight), f32(eps), ptr(w13), ptr(out), i64(M), i64(inter), i64(K),
+                                                     stream_ptr()),
+        "bf16_linear_silu_add_norm",
+    )
+    return x_new, out
+
+
 def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     """silu(x[..., :d]) * x[..., d:] on bf16 (SiluAndMul, fused_moe.py:24-39; Llama's F.silu(w1 x) * w3 x)."""
     require_cuda(x)

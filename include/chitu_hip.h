@@ -194,6 +194,26 @@ int chitu_hip_gqa_qkv_post(void* qkv_bf16, int64_t row_stride, int32_t q_heads, 
 int chitu_hip_bf16_gemm_silu(const void* x_bf16, const void* w13_bf16, void* out_bf16, int64_t M, int64_t inter,
                              int64_t K, void* stream);
 
+/* ---- residual add + RMSNorm as the prologue of the bf16 GEMM that consumes it (decode batches of 1-4 rows) -------
+ * TransformerBlock (models/model.py:246-251): h = x + attention(attention_norm(x)); out = h + ffn(ffn_norm(h)) --
+ * the add and the norm (RMSNorm.forward, models/model.py:29-78) in front of a layer's qkv projection and of its
+ * gate/up projection, folded into those launches:
+ *   sum_out[m] = bf16(x[m] + add[m])                       (the new residual stream; may alias x or add)
+ *   y[m]       = bf16((sum_out[m] * rsqrt(mean(sum_out[m]^2) + eps)) * norm_weight)
+ *   out        = y . w^T                                   (chitu_hip_bf16_gemm_add_norm)
+ *   out        = silu(y . w1^T) * (y . w3^T)               (chitu_hip_bf16_gemm_silu_add_norm, w13 = [w1; w3])
+ * Bit-identical to chitu_hip_rmsnorm(add = ...) followed by chitu_hip_bf16_gemm / chitu_hip_bf16_gemm_silu (same
+ * summation orders).  M <= 4, K % 64 == 0, 512 <= K <= 8192, M * K <= 24576 and at least 4 waves of K split for the
+ * shape; anything else: CHITU_ERR_UNSUPPORTED (use the two launches).  Row strides in elements, multiples of 8. */
+int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
+                                 int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                 const void* norm_weight_bf16, float eps, const void* w_bf16, void* out,
+                                 int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* stream);
+int chitu_hip_bf16_gemm_silu_add_norm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
+                                      int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                      const void* norm_weight_bf16, float eps, const void* w13_bf16,
+                                      void* out_bf16, int64_t M, int64_t inter, int64_t K, void* stream);
+
 /* ---- SiluAndMul (unquantised MLPs: Llama FeedForward, models/model.py:212-214; fused_moe.py:24-39)
  *   out[r, :] = bf16( bf16(silu(x[r, :d])) * x[r, d:2d] ),  x [rows, 2d] bf16, out [rows, d] bf16, d % 8 == 0. */
 int chitu_hip_silu_and_mul(const void* x_bf16, void* out_bf16, int64_t rows, int64_t d, void* stream);

@@ -169,6 +169,20 @@ def bf16_linear_silu(x, w13):
     return F.silu(h[..., :d]) * h[..., d:]
 
 
+def bf16_add_norm_fits(M, N, K):
+    return 1 <= M <= 4 and K % 64 == 0 and 512 <= K <= 8192 and M * K <= 24576
+
+
+def bf16_linear_add_norm(x, add, norm_weight, eps, weight, out_dtype=None):
+    x_new, y = rms_norm(x, norm_weight, eps, add=add)
+    return x_new, bf16_linear(y, weight, out_dtype)
+
+
+def bf16_linear_silu_add_norm(x, add, norm_weight, eps, w13):
+    x_new, y = rms_norm(x, norm_weight, eps, add=add)
+    return x_new, bf16_linear_silu(y, w13)
+
+
 def apply_rotary_pos_emb(q, k, cos, sin, rotary_type="hf-llama"):
     return okv.apply_rotary_pos_emb(q, k, cos, sin, rotary_type)
 
@@ -207,7 +221,7 @@ def install_llama(monkeypatch_setattr):
     from chitu_amd import fused_moe, ops
 
     for name in ("rms_norm", "bf16_linear", "gqa_qkv_post", "bf16_linear_silu", "apply_rotary_pos_emb", "gate_deepseek_v3",
-                 "embed_rope_gather"):
+                 "embed_rope_gather", "bf16_add_norm_fits", "bf16_linear_add_norm", "bf16_linear_silu_add_norm"):
         monkeypatch_setattr(ops, name, globals()[name])
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)  # Mixtral's INT8 experts ride on the Llama wiring
 

@@ -138,6 +138,68 @@ def test_gate_up_gemm_with_silu_epilogue_equals_gemm_then_silu(M, inter, K):
     assert max_rel_to_peak(out, cpu) < 1e-2
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,inter,K", [(6144, 14336, 4096), (12288, 11008, 4096), (256, 2048, 1024), (100, 200, 512), (1024, 1024, 8192)])
+def test_add_norm_as_gemm_prologue_is_bit_identical_to_the_separate_launches(M, N, inter, K):
+    """bf16_linear_add_norm / bf16_linear_silu_add_norm (residual add + RMSNorm redone by every workgroup of the GEMM
+    that consumes it) == rms_norm(x, add=...) followed by bf16_linear / bf16_linear_silu, bit for bit: new residual
+    stream, projection, SwiGLU output.  Shapes: Llama-3-8B and Llama-2-7B layers, small ones, the 8192-wide limit."""
+    from chitu_amd import ops
+
+    if not ops.bf16_add_norm_fits(M, min(N, inter), K) or not ops.bf16_add_norm_fits(M, max(N, inter), K):
+        with pytest.raises(AssertionError):
+            ops.bf16_linear_add_norm(torch.zeros(M, K, dtype=torch.bfloat16, device="cuda"), torch.zeros(M, K, dtype=torch.bfloat16, device="cuda"),
+                                     torch.ones(K, dtype=torch.bfloat16, device="cuda"), 1e-5,
+                                     torch.zeros(N if not ops.bf16_add_norm_fits(M, N, K) else inter, K, dtype=torch.bfloat16, device="cuda"))
+        return
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M + 2, K, generator=g) * 2).to(torch.bfloat16).cuda()[1 : M + 1]  # a view: row stride K, offset base
+    add = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    nw = (1 + 0.2 * torch.randn(K, generator=g)).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    w13 = (torch.randn(2 * inter, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    x_ref, y = ops.rms_norm(x, nw, 1e-5, add=add)
+    o_ref, h_ref = ops.bf16_linear(y, w), ops.bf16_linear_silu(y, w13)
+    x1, o = ops.bf16_linear_add_norm(x, add, nw, 1e-5, w)
+    x2, h = ops.bf16_linear_silu_add_norm(x, add, nw, 1e-5, w13)
+    assert torch.equal(x1, x_ref) and torch.equal(x2, x_ref)
+    assert torch.equal(o, o_ref), (o.float() - o_ref.float()).abs().max().item()
+    assert torch.equal(h, h_ref), (h.float() - h_ref.float()).abs().max().item()
+    o32 = ops.bf16_linear_add_norm(x, add, nw, 1e-5, w, out_dtype=torch.float32)[1]
+    assert torch.equal(o32, ops.bf16_linear(y, w, out_dtype=torch.float32))
+
+
+@pytest.mark.parametrize("bs", [1, 2])
+def test_decode_with_norms_in_the_gemm_prologues_equals_decode_without(bs, monkeypatch):
+    """A whole decode step (eager and graph replay) with the add + norm steps fused into the GEMMs behind them against
+    the same step with every norm as its own launch: identical logits and KV pages."""
+    from chitu_amd import llama
+
+    args = tiny_args(2)
+    model, cache = build(args)
+    reqs = [f"q{i}" for i in range(bs)]
+    gen = torch.Generator().manual_seed(11)
+    for r, n in zip(reqs, (300, 17)):
+        cache.register_sequence(r, n)
+    cache.paged_k_cache.normal_(0, 0.5)
+    cache.paged_v_cache.normal_(0, 0.5)
+    tokens = torch.randint(0, args.vocab_size, (bs,), generator=gen).cuda()
+    cache.prepare_cache_decode(reqs)
+    cache.prepare_block_table_for_decode(reqs)
+    snap_k, snap_v = cache.paged_k_cache.clone(), cache.paged_v_cache.clone()
+    res = {}
+    for fuse in (0, 4):
+        monkeypatch.setattr(llama, "FUSE_NORM_MAX_BS", fuse)
+        model.graphs.clear()
+        for mode in (False, True):
+            cache.paged_k_cache.copy_(snap_k)
+            cache.paged_v_cache.copy_(snap_v)
+            res[(fuse, mode)] = (model.decode(tokens, use_graph=mode).clone(), cache.paged_k_cache.clone(), cache.paged_v_cache.clone())
+    base = res[(0, False)]
+    for key, val in res.items():
+        assert all(torch.equal(a, b) for a, b in zip(val, base)), key
+
+
 def test_prefill_equals_token_by_token_decode_and_generate():
     args = tiny_args(2)
     model, cache = build(args)
