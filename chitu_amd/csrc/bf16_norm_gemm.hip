@@ -115,14 +115,30 @@ __device__ __forceinline__ void add_norm_finish(AddNormRegs<WK, MR>& r, bf16_t* 
     __syncthreads();
 }
 
+// QKV epilogue (the merged q|k|v projection of a GQA / MHA layer, interleaved-pair rotary): what
+// gqa_qkv_post_kernel (kv.hip) does to the projection's bf16 output, done on the accumulators instead -- q heads
+// rotated into `out`, k heads rotated into the token's page row of k_cache, v heads copied into v_cache
+// (Attention.decode_forward_paged, models/model.py:167-198).  A 16-column tile lies inside one head (head_dim % 16
+// == 0) and holds whole rotary pairs (2i, 2i + 1), so each lane rotates its own two pairs.
+struct QkvPostArgs {
+    const float* cos;  // [M, head_dim / 2]
+    const float* sin;
+    bf16_t* k_cache;   // [num_pages, page_size, hkv, head_dim]
+    bf16_t* v_cache;
+    int64_t num_pages;
+    const int32_t* table;  // [M, pages_per_seq]
+    const int32_t* old_lens;
+    int page_size, pages_per_seq, hq, hkv, d;
+};
+
 // ---------------------------------------------------------------- add + norm -> out = y . W^T
 // K loop, K split and accumulation order of bf16_gemm_kernel<1, WK> (gate.hip); D = ring depth (8: the wave's whole
 // K range in one round trip, the form chitu_hip_bf16_gemm picks for <= 8 blocks per wave).
-template <int WK, int D, int MR>
+template <int WK, int D, int MR, bool QKV = false>
 __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
     const bf16_t* x, int64_t x_stride, const bf16_t* add, int64_t add_stride, bf16_t* sum_out, int64_t sum_stride,
     const bf16_t* __restrict__ nw, float eps, const bf16_t* __restrict__ W, void* __restrict__ out, int out_dt, int M,
-    int N, int K) {
+    int N, int K, QkvPostArgs qa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ float red[WK > 1 ? WK * 256 : 1];
     __shared__ float nred[kFusedNormMaxRows * 16];
@@ -132,6 +148,19 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
     const int n0 = blockIdx.x * 16;
     const int KB = K >> 6;
     const int kb0 = (int)((long)KB * wave / WK), kb1 = (int)((long)KB * (wave + 1) / WK);
+    // QKV: the token's rotary factors and page row, requested first (their round trips hide behind everything else)
+    float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
+    int old_len = -1;
+    const int tok = min(j, M - 1);
+    const int head = QKV ? n0 / qa.d : 0, hcol = QKV ? n0 - head * qa.d : 0;  // workgroup-uniform
+    if (QKV && wave == 0) {
+        if (head < qa.hq + qa.hkv) {
+            const int half = qa.d >> 1, i0 = (hcol >> 1) + g;
+            rc[0] = qa.cos[(int64_t)tok * half + i0], rs[0] = qa.sin[(int64_t)tok * half + i0];
+            rc[1] = qa.cos[(int64_t)tok * half + i0 + 4], rs[1] = qa.sin[(int64_t)tok * half + i0 + 4];
+        }
+        if (head >= qa.hq) old_len = qa.old_lens[tok];
+    }
     AddNormRegs<WK, MR> regs;
     add_norm_issue<WK, MR>(regs, x, x_stride, add, add_stride, nw, M, K >> 3);
     const int eoff = ((j & 1) * 4 + g) * 8;
@@ -174,7 +203,58 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
         }
     }
     f32x4 acc[1] = {f32x4{e0[0] + o0[1], e0[2] + o0[3], e1[0] + o1[1], e1[2] + o1[3]}};
-    gemm_epilogue_v2<1, WK>(acc, red, out, out_dt, nullptr, M, N, 1, 0, n0);
+    if (!QKV) {
+        gemm_epilogue_v2<1, WK>(acc, red, out, out_dt, nullptr, M, N, 1, 0, n0);
+        return;
+    }
+    // ---- QKV: the page row's address (one more dependent load, issued before the reduce), K-split reduce in wave
+    // order (gemm_epilogue_v2's), then rotate / scatter
+    int64_t dst_row = -1;
+    if (wave == 0 && head >= qa.hq) {
+        const int pidx = old_len / qa.page_size;
+        if (old_len >= 0 && pidx < qa.pages_per_seq) {
+            const int64_t page = qa.table[(int64_t)tok * qa.pages_per_seq + pidx];
+            if (page >= 0 && page < qa.num_pages) dst_row = (page * qa.page_size + (old_len % qa.page_size)) * (int64_t)qa.hkv * qa.d;
+        }
+    }
+    f32x4 sum = acc[0];
+    if (WK > 1) {
+        *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc[0];
+        __syncthreads();
+        if (wave != 0) return;
+        sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < WK; ++w) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&red[(w * 64 + lane) * 4]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] += v[r];
+        }
+    }
+    if (j >= M) return;
+    {
+#pragma clang fp contract(off)
+        uint32_t pk[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // the projection's bf16 output, then RoPE in fp32 with one rounding: gqa_qkv_post_kernel's arithmetic
+            const float x0 = round_bf16(sum[2 * h]), x1 = round_bf16(sum[2 * h + 1]);
+            if (head < qa.hq + qa.hkv) {
+                const float c = rc[h], sn = rs[h];
+                pk[h] = (uint32_t)f32_to_bf16(x0 * c - x1 * sn) | ((uint32_t)f32_to_bf16(x1 * c + x0 * sn) << 16);
+            } else {
+                pk[h] = (uint32_t)f32_to_bf16(x0) | ((uint32_t)f32_to_bf16(x1) << 16);
+            }
+        }
+        bf16_t* dst = nullptr;
+        if (head < qa.hq) dst = (bf16_t*)out + (size_t)j * N + n0;
+        else if (dst_row >= 0)
+            dst = (head < qa.hq + qa.hkv ? qa.k_cache + dst_row + (size_t)(head - qa.hq) * qa.d
+                                         : qa.v_cache + dst_row + (size_t)(head - qa.hq - qa.hkv) * qa.d) + hcol;
+        if (dst) {
+            *reinterpret_cast<uint32_t*>(dst + 2 * g) = pk[0];
+            *reinterpret_cast<uint32_t*>(dst + 8 + 2 * g) = pk[1];
+        }
+    }
 }
 
 // ---------------------------------------------------------------- add + norm -> h = silu(y . W1^T) * (y . W3^T)
@@ -316,7 +396,53 @@ extern "C" int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_st
     hipLaunchKernelGGL((bf16_gemm_add_norm_kernel<WKV, DV, MRV>), dim3((unsigned)tiles), dim3(64 * WKV), lds, st,        \
                        (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)add_bf16, add_row_stride, (bf16_t*)sum_out_bf16, \
                        sum_row_stride, (const bf16_t*)norm_weight_bf16, eps, (const bf16_t*)w_bf16, out, (int)out_dtype, \
-                       (int)M, (int)N, (int)K)
+                       (int)M, (int)N, (int)K, QkvPostArgs{})
+#define LAUNCH(WKV, DV)                          \
+    do {                                         \
+        if (M == 1) LAUNCH_MR(WKV, DV, 1);       \
+        else if (M == 2) LAUNCH_MR(WKV, DV, 2);  \
+        else LAUNCH_MR(WKV, DV, 4);              \
+    } while (0)
+    if (WK == 8) {
+        if (per_wave <= 8) LAUNCH(8, 8);
+        else LAUNCH(8, 4);
+    } else {
+        if (per_wave <= 8) LAUNCH(4, 8);
+        else LAUNCH(4, 4);
+    }
+#undef LAUNCH
+#undef LAUNCH_MR
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_bf16_gemm_add_norm_qkv_post(
+    const void* x_bf16, int64_t x_row_stride, const void* add_bf16, int64_t add_row_stride, void* sum_out_bf16,
+    int64_t sum_row_stride, const void* norm_weight_bf16, float eps, const void* wqkv_bf16, void* qkv_out_bf16, int64_t M,
+    int64_t K, int32_t q_heads, int32_t kv_heads, int32_t head_dim, const float* cos, const float* sin, void* k_cache,
+    void* v_cache, int64_t num_pages, int32_t page_size, const int32_t* page_table, int32_t pages_per_seq,
+    const int32_t* old_seq_lens, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && add_bf16 && sum_out_bf16 && norm_weight_bf16 && wqkv_bf16 && qkv_out_bf16);
+    CHITU_REQUIRE(cos && sin && k_cache && v_cache && page_table && old_seq_lens);
+    CHITU_REQUIRE(M >= 0 && K >= 64 && K < (1 << 30) && q_heads >= 1 && kv_heads >= 1 && head_dim >= 16);
+    CHITU_REQUIRE(num_pages >= 1 && page_size >= 1 && pages_per_seq >= 1);
+    CHITU_REQUIRE(x_row_stride % 8 == 0 && add_row_stride % 8 == 0 && sum_row_stride % 8 == 0);
+    if (M == 0) return CHITU_OK;
+    const int64_t N = (int64_t)(q_heads + 2 * kv_heads) * head_dim;
+    if (!fused_norm_shape_ok(M, K) || head_dim % 16 != 0 || N >= (1 << 30)) return CHITU_ERR_UNSUPPORTED;
+    const int KB = (int)(K / 64), tiles = (int)(N / 16);
+    const int WK = gemm_wk(tiles, KB);
+    if (WK < 4) return CHITU_ERR_UNSUPPORTED;
+    const int per_wave = KB / WK;
+    const size_t lds = (size_t)M * K * 2;
+    hipStream_t st = (hipStream_t)stream;
+    const QkvPostArgs qa{cos, sin, (bf16_t*)k_cache, (bf16_t*)v_cache, num_pages, page_table, old_seq_lens,
+                         (int)page_size, (int)pages_per_seq, (int)q_heads, (int)kv_heads, (int)head_dim};
+#define LAUNCH_MR(WKV, DV, MRV)                                                                                          \
+    hipLaunchKernelGGL((bf16_gemm_add_norm_kernel<WKV, DV, MRV, true>), dim3((unsigned)tiles), dim3(64 * WKV), lds, st,  \
+                       (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)add_bf16, add_row_stride, (bf16_t*)sum_out_bf16, \
+                       sum_row_stride, (const bf16_t*)norm_weight_bf16, eps, (const bf16_t*)wqkv_bf16, qkv_out_bf16, 0,   \
+                       (int)M, (int)N, (int)K, qa)
 #define LAUNCH(WKV, DV)                          \
     do {                                         \
         if (M == 1) LAUNCH_MR(WKV, DV, 1);       \

@@ -6,8 +6,9 @@ FeedForward:201-214, TransformerBlock, Transformer.decode:538-622; models/model_
 wqkv / w13 layout of the original Meta checkpoints, rotary_type "llama" = interleaved pairs).
 
 Per layer and step, 7 launches: add+RMSNorm, wqkv GEMM, [RoPE(q, k) + append K, V], paged GQA decode
-(+ merge when the KV range is split), wo GEMM, add+RMSNorm, [w13 GEMM + SiluAndMul], w2 GEMM -- 5 at batch 1,
-where both add+RMSNorm steps run as the prologue of the GEMM behind them (bf16_norm_gemm.hip).
+(+ merge when the KV range is split), wo GEMM, add+RMSNorm, [w13 GEMM + SiluAndMul], w2 GEMM -- 4 at batch 1-2,
+where both add+RMSNorm steps run as the prologue of the GEMM behind them and RoPE + the K / V append as the
+epilogue of the qkv projection (bf16_norm_gemm.hip).
 All GEMMs are the weight-streaming skinny bf16 kernel (gate.hip); the whole step replays as one hipGraph.
 """
 
@@ -55,8 +56,11 @@ def _param(*shape, device=None):
 
 
 # Decode batches up to this size run a layer's two residual-add + RMSNorm steps as the prologue of the GEMMs behind
-# them (ops.bf16_linear_add_norm / bf16_linear_silu_add_norm: bit-identical, two launches fewer per layer).  0 = off.
-FUSE_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_NORM_MAX_BS", "1"))
+# them, and RoPE + the K / V page append as the epilogue of the qkv projection (ops.bf16_linear_add_norm[_qkv_post] /
+# bf16_linear_silu_add_norm: bit-identical, three launches fewer per layer).  Measured on Llama-3-8B (tools/llama_ab.py,
+# profiles/r02_ab_llama_norm_prologue.txt): bs 1 3.45 -> 3.20 ms/step, bs 2 3.57 -> 3.44, bs 4 3.70 -> 3.84 (the
+# four-row prologue costs more registers and LDS traffic than the launches it saves).  0 = off.
+FUSE_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_NORM_MAX_BS", "2"))
 
 
 def _fuses_norm(x, pending, n_out) -> bool:
@@ -87,15 +91,32 @@ class LlamaAttention(torch.nn.Module):
         bs = qkv.shape[0]
         qkv = qkv.view(bs, self.hq + 2 * self.hkv, self.hd)
         k_cache, v_cache = self.cache.get_paged_kv_cache(self.layer_id)
-        table = self.cache.get_gpu_block_table()
         # RoPE(q, k) + append of k and v to their pages: one launch
-        q = ops.gqa_qkv_post(qkv, self.hq, self.hkv, cos, sin, k_cache, v_cache, table,
+        q = ops.gqa_qkv_post(qkv, self.hq, self.hkv, cos, sin, k_cache, v_cache, self.cache.get_gpu_block_table(),
                              self.cache.get_gpu_seq_lens_excl_this_decode(), rotary_type=self.rotary_type)
+        return self.decode_from_q(q)
+
+    def decode_from_q(self, q):
+        """Rotated q heads [bs, hq, hd] (this token's k and v already in their pages) -> wo(attention)."""
+        bs = q.shape[0]
+        k_cache, v_cache = self.cache.get_paged_kv_cache(self.layer_id)
+        table = self.cache.get_gpu_block_table()
         o = self.attn_backend.attn_with_kvcache(
             q.unsqueeze(1), k_cache, v_cache, None, None,
             cache_seqlens=self.cache.get_gpu_seq_lens_incl_this_decode()[:bs], block_table=table[:bs])
         return ops.bf16_linear(o.view(bs, self.hq * self.hd), self.wo)
 
+    def decode_from_residual(self, x, pending, norm_weight, eps, cos, sin):
+        """Small decode batches: residual add + attn_norm + wqkv projection [+ RoPE and the K / V page append when the
+        rotary pairs are interleaved] in ONE launch.  Returns (x + pending, wo(attention) before the all-reduce)."""
+        if self.rotary_type == "llama":
+            k_cache, v_cache = self.cache.get_paged_kv_cache(self.layer_id)
+            x, qkv = ops.bf16_linear_add_norm_qkv_post(
+                x, pending, norm_weight, eps, self.wqkv, self.hq, self.hkv, cos, sin, k_cache, v_cache,
+                self.cache.get_gpu_block_table(), self.cache.get_gpu_seq_lens_excl_this_decode())
+            return x, self.decode_from_q(qkv[:, : self.hq])
+        x, qkv = ops.bf16_linear_add_norm(x, pending, norm_weight, eps, self.wqkv)
+        return x, self.decode_from_qkv(qkv, cos, sin)
 
     def prefill_forward(self, x, cos, sin, varlens):
         """models/model.py:104-132: projections on all T prompt tokens, RoPE, page writes by the cache
@@ -138,8 +159,8 @@ class LlamaBlock(torch.nn.Module):
         varlens given = prefill."""
         if varlens is None and _fuses_norm(x, pending, self.attn.wqkv.shape[0]):
             # small decode batches: the add + norm run as the prologue of the projection that consumes them
-            x, qkv = ops.bf16_linear_add_norm(x, pending, self.attn_norm, self.eps, self.attn.wqkv)
-            a = tp.defer_all_reduce(self.attn.decode_from_qkv(qkv, cos, sin))
+            x, a = self.attn.decode_from_residual(x, pending, self.attn_norm, self.eps, cos, sin)
+            a = tp.defer_all_reduce(a)
         else:
             x, hn = tp.add_norm(x, pending, self.attn_norm, self.eps)[:2]
             if varlens is None:

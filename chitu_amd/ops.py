@@ -394,6 +394,36 @@ def bf16_linear_add_norm(x, add, norm_weight, eps, weight, out_dtype=None):
     return x_new, out
 
 
+def bf16_linear_add_norm_qkv_post(x, add, norm_weight, eps, wqkv, q_heads, kv_heads, cos, sin, k_cache, v_cache,
+                                  page_table, old_seq_lens):
+    """bf16_linear_add_norm on the merged q|k|v projection with gqa_qkv_post (rotary_type "llama") in its epilogue: returns
+    (x_new, qkv [M, q_heads + 2*kv_heads, head_dim]) where only the q heads of qkv are written (rotated); the rotated k
+    heads and the v heads are in their page rows.  Bit-identical to rms_norm(add=) + bf16_linear + gqa_qkv_post."""
+    require_cuda(x, add, norm_weight, wqkv, cos, sin, k_cache, v_cache, page_table, old_seq_lens)
+    assert x.dtype == torch.bfloat16 and add.dtype == torch.bfloat16 and wqkv.dtype == torch.bfloat16
+    assert x.dim() == 2 and add.shape == x.shape and x.stride(1) == 1 and add.stride(1) == 1 and wqkv.is_contiguous()
+    assert norm_weight.dtype == torch.bfloat16 and norm_weight.is_contiguous() and norm_weight.numel() == x.shape[1]
+    M, K = x.shape
+    N = wqkv.shape[0]
+    d = N // (q_heads + 2 * kv_heads)
+    assert N == (q_heads + 2 * kv_heads) * d and d % 16 == 0 and wqkv.shape[1] == K and bf16_add_norm_fits(M, N, K)
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == v_cache.shape and k_cache.dtype == torch.bfloat16
+    assert tuple(k_cache.shape[2:]) == (kv_heads, d) and page_table.dtype == torch.int32 and page_table.is_contiguous()
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous() and cos.shape == (M, d // 2)
+    assert old_seq_lens.dtype == torch.int32 and page_table.shape[0] >= M
+    x_new = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
+    qkv = torch.empty(M, q_heads + 2 * kv_heads, d, dtype=torch.bfloat16, device=x.device)
+    check(
+        _lib.lib().chitu_hip_bf16_gemm_add_norm_qkv_post(
+            ptr(x), i64(x.stride(0)), ptr(add), i64(add.stride(0)), ptr(x_new), i64(K), ptr(norm_weight), f32(eps), ptr(wqkv),
+            ptr(qkv), i64(M), i64(K), i32(q_heads), i32(kv_heads), i32(d), ptr(cos), ptr(sin), ptr(k_cache), ptr(v_cache),
+            i64(k_cache.shape[0]), i32(k_cache.shape[1]), ptr(page_table), i32(page_table.shape[1]), ptr(old_seq_lens),
+            stream_ptr()),
+        "bf16_linear_add_norm_qkv_post",
+    )
+    return x_new, qkv
+
+
 def bf16_linear_silu_add_norm(x, add, norm_weight, eps, w13):
     """(x_new, silu(y w1^T) * (y w3^T)) with x_new = x + add, y = rms_norm(x_new), ONE launch; bit-identical to
     rms_norm(x, add=add) followed by bf16_linear_silu.  Check bf16_add_norm_fits(M, inter, K) first."""

@@ -209,6 +209,19 @@ int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_stride, const
                                  int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
                                  const void* norm_weight_bf16, float eps, const void* w_bf16, void* out,
                                  int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* stream);
+/* chitu_hip_bf16_gemm_add_norm for the merged q|k|v projection of a GQA / MHA layer with chitu_hip_gqa_qkv_post
+ * (layout 0: interleaved rotary pairs) applied in the epilogue: qkv_out [M, (q_heads + 2*kv_heads) * head_dim] receives
+ * the ROTATED q heads only; the rotated k heads and the v heads go straight into the token's page rows of k_cache /
+ * v_cache (Attention.decode_forward_paged, models/model.py:167-198).  Bit-identical to the three separate launches.
+ * head_dim % 16 == 0; other limits as chitu_hip_bf16_gemm_add_norm. */
+int chitu_hip_bf16_gemm_add_norm_qkv_post(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
+                                          int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                          const void* norm_weight_bf16, float eps, const void* wqkv_bf16,
+                                          void* qkv_out_bf16, int64_t M, int64_t K, int32_t q_heads, int32_t kv_heads,
+                                          int32_t head_dim, const float* cos, const float* sin, void* k_cache,
+                                          void* v_cache, int64_t num_pages, int32_t page_size,
+                                          const int32_t* page_table, int32_t pages_per_seq,
+                                          const int32_t* old_seq_lens, void* stream);
 int chitu_hip_bf16_gemm_silu_add_norm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
                                       int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
                                       const void* norm_weight_bf16, float eps, const void* w13_bf16,

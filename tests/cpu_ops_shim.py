@@ -178,6 +178,16 @@ def bf16_linear_add_norm(x, add, norm_weight, eps, weight, out_dtype=None):
     return x_new, bf16_linear(y, weight, out_dtype)
 
 
+def bf16_linear_add_norm_qkv_post(x, add, norm_weight, eps, wqkv, q_heads, kv_heads, cos, sin, k_cache, v_cache,
+                                  page_table, old_seq_lens):
+    x_new, y = rms_norm(x, norm_weight, eps, add=add)
+    d = wqkv.shape[0] // (q_heads + 2 * kv_heads)
+    qkv = bf16_linear(y, wqkv).view(x.shape[0], q_heads + 2 * kv_heads, d)
+    qkv = qkv.clone()
+    qkv[:, :q_heads] = gqa_qkv_post(qkv, q_heads, kv_heads, cos, sin, k_cache, v_cache, page_table, old_seq_lens, rotary_type="llama")
+    return x_new, qkv
+
+
 def bf16_linear_silu_add_norm(x, add, norm_weight, eps, w13):
     x_new, y = rms_norm(x, norm_weight, eps, add=add)
     return x_new, bf16_linear_silu(y, w13)
@@ -221,7 +231,8 @@ def install_llama(monkeypatch_setattr):
     from chitu_amd import fused_moe, ops
 
     for name in ("rms_norm", "bf16_linear", "gqa_qkv_post", "bf16_linear_silu", "apply_rotary_pos_emb", "gate_deepseek_v3",
-                 "embed_rope_gather", "bf16_add_norm_fits", "bf16_linear_add_norm", "bf16_linear_silu_add_norm"):
+                 "embed_rope_gather", "bf16_add_norm_fits", "bf16_linear_add_norm", "bf16_linear_silu_add_norm",
+                 "bf16_linear_add_norm_qkv_post"):
         monkeypatch_setattr(ops, name, globals()[name])
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)  # Mixtral's INT8 experts ride on the Llama wiring
 

@@ -169,6 +169,34 @@ def test_add_norm_as_gemm_prologue_is_bit_identical_to_the_separate_launches(M, 
     assert torch.equal(o32, ops.bf16_linear(y, w, out_dtype=torch.float32))
 
 
+@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("hq,hkv,d,K", [(32, 8, 128, 4096), (32, 32, 128, 4096), (8, 2, 128, 1024), (4, 4, 64, 512)])
+def test_qkv_projection_with_norm_prologue_and_rope_append_epilogue(M, hq, hkv, d, K):
+    """bf16_linear_add_norm_qkv_post == rms_norm(add=) + bf16_linear + gqa_qkv_post (rotary "llama"), bit for bit:
+    residual stream, rotated q heads, both caches (ragged lengths across page boundaries)."""
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(M + hq + K)
+    x = (torch.randn(M, K, generator=g) * 2).to(torch.bfloat16).cuda()
+    add = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    nw = (1 + 0.2 * torch.randn(K, generator=g)).to(torch.bfloat16).cuda()
+    w = (torch.randn((hq + 2 * hkv) * d, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    cos, sin = torch.randn(M, d // 2, generator=g).cuda(), torch.randn(M, d // 2, generator=g).cuda()
+    pages, page = 2 * M + 1, 16
+    kc = torch.randn(pages, page, hkv, d, generator=g).to(torch.bfloat16).cuda()
+    vc = torch.randn(pages, page, hkv, d, generator=g).to(torch.bfloat16).cuda()
+    table = torch.randperm(pages, generator=g)[: 2 * M].view(M, 2).to(torch.int32).cuda()
+    lens = torch.tensor([(11 * i + (15 if i % 2 else 16)) % 32 for i in range(M)], dtype=torch.int32).cuda()
+    x_ref, y = ops.rms_norm(x, nw, 1e-5, add=add)
+    qkv_ref = ops.bf16_linear(y, w).view(M, hq + 2 * hkv, d)
+    k1, v1 = kc.clone(), vc.clone()
+    q_ref = ops.gqa_qkv_post(qkv_ref, hq, hkv, cos, sin, k1, v1, table, lens, rotary_type="llama")
+    k2, v2 = kc.clone(), vc.clone()
+    x2, qkv = ops.bf16_linear_add_norm_qkv_post(x, add, nw, 1e-5, w, hq, hkv, cos, sin, k2, v2, table, lens)
+    assert torch.equal(x2, x_ref) and torch.equal(qkv[:, :hq], q_ref)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2) and not torch.equal(k2, kc) and not torch.equal(v2, vc)
+
+
 @pytest.mark.parametrize("bs", [1, 2])
 def test_decode_with_norms_in_the_gemm_prologues_equals_decode_without(bs, monkeypatch):
     """A whole decode step (eager and graph replay) with the add + norm steps fused into the GEMMs behind them against
