@@ -175,6 +175,16 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
         }
     }
     add_norm_finish<WK, MR>(regs, sum_out, sum_stride, blockIdx.x == 0, M, K, eps, ybuf, nred);
+    // QKV: the page row's address -- old_len arrived with the prologue's loads; its dependent table load is issued here
+    // so that the round trip runs under the K loop, not after it
+    int64_t dst_row = -1;
+    if (QKV && wave == 0 && head >= qa.hq) {
+        const int pidx = old_len / qa.page_size;
+        if (old_len >= 0 && pidx < qa.pages_per_seq) {
+            const int64_t page = qa.table[(int64_t)tok * qa.pages_per_seq + pidx];
+            if (page >= 0 && page < qa.num_pages) dst_row = (page * qa.page_size + (old_len % qa.page_size)) * (int64_t)qa.hkv * qa.d;
+        }
+    }
     const bf16_t* yp = ybuf + (size_t)min(j, M - 1) * K + g * 8;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -207,16 +217,7 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
         gemm_epilogue_v2<1, WK>(acc, red, out, out_dt, nullptr, M, N, 1, 0, n0);
         return;
     }
-    // ---- QKV: the page row's address (one more dependent load, issued before the reduce), K-split reduce in wave
-    // order (gemm_epilogue_v2's), then rotate / scatter
-    int64_t dst_row = -1;
-    if (wave == 0 && head >= qa.hq) {
-        const int pidx = old_len / qa.page_size;
-        if (old_len >= 0 && pidx < qa.pages_per_seq) {
-            const int64_t page = qa.table[(int64_t)tok * qa.pages_per_seq + pidx];
-            if (page >= 0 && page < qa.num_pages) dst_row = (page * qa.page_size + (old_len % qa.page_size)) * (int64_t)qa.hkv * qa.d;
-        }
-    }
+    // ---- QKV: K-split reduce in wave order (gemm_epilogue_v2's), then rotate / scatter
     f32x4 sum = acc[0];
     if (WK > 1) {
         *reinterpret_cast<f32x4*>(&red[(wave * 64 + lane) * 4]) = acc[0];
