@@ -209,6 +209,9 @@ void launch_splitk_reduce(const float* partial, void* out, int out_dt, int S, in
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, partial, out, out_dt, S, MN);
 }
 
+// from this many token rows on, the W8A8 GEMM is tiled for compute (fp8_gemm_tiled.hip) instead of streamed per 64 rows
+constexpr int kTiledMinRows = 128;
+
 struct SplitPlan {
     int WK, S;
 };
@@ -255,6 +258,11 @@ extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_s
     if (K % 128 != 0) return CHITU_ERR_UNSUPPORTED;  // act_quant's contract, ops.py:345-348
     if (M == 0) return CHITU_OK;
     hipStream_t st = (hipStream_t)stream;
+    if (M >= kTiledMinRows && debug_option(kOptFp8GemmTiled) != 0) {
+        // prefill-sized M: a GEMM, not a weight stream (fp8_gemm_tiled.hip)
+        launch_fp8_gemm_tiled((const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, out, out_dtype, M, N, K, st);
+        CHITU_RETURN_LAUNCH_STATUS();
+    }
     SplitPlan plan = plan_split((int)N, (int)K);
     if (plan.S > 1 && (!workspace || workspace_bytes < (int64_t)plan.S * M * N * 4)) plan.S = 1;
     debug_override(kOptFp8GemmWK, plan.WK);

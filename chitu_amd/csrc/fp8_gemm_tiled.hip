@@ -1,0 +1,165 @@
+// Compute-shaped W8A8 block-scaled GEMM for PREFILL (hundreds to thousands of token rows), gfx950.
+//
+// Replaces (reference, read-only), for M >= 128:
+//   chitu/triton_kernels.py:302-365  fp8_gemm_deepseek_v3_kernel   (W8A8, fp32 128x128 / 1x128 block scales)
+//   chitu/ops.py:453-483             its launcher
+// The decode kernel (fp8_gemm.hip) streams the weight matrix once per 64 token rows: right when the op is
+// a weight stream (M <= 64), 32 passes over the same 15 MB at M = 2048 (profiles/r02_prefill_*: the dense
+// projections were 54 % of a prefill layer, at ~1 % of the MFMA peak).  Here the op is tiled like a GEMM:
+//
+//   workgroup = 128 weight rows x 128 tokens, 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles
+//   (v_mfma_f32_16x16x32_fp8_fp8, weights = A operand, tokens = B operand, as in the decode kernels);
+//   K advances in the quantisation's own 128-wide blocks: both operand tiles (16 KB each) go global -> registers ->
+//   LDS (rows padded to 144 B: the 16 rows a wave-load touches start in 16 different bank groups), double-buffered,
+//   the next block's global loads in flight while the current one is multiplied; per block every 16 x 16 tile is a
+//   fresh 4-MFMA dot that is folded in as (dot * a_s[token]) * b_s -- the reference's order (triton_kernels.py:357);
+//   b_s is one scalar per workgroup and block (128-row tiles are scale-block aligned), a_s one value per lane and
+//   token tile.
+// Bound: MFMA (this instruction runs at the bf16 rate, ~2.5 PFLOP/s dense); per block a wave issues 64 MFMAs against
+// 16 ds_read_b128 and ~130 VALU instructions of scale folding.
+#include "common.h"
+#include "gemm_common.h"
+
+namespace chitu {
+
+constexpr int kTileN = 128, kTileM = 128, kTileK = 128;
+constexpr int kLdsRow = kTileK + 16;  // bytes per staged row
+
+struct TileRegs {
+    i32x4 w[4], x[4];
+    float xs[4];
+    float ws;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fp8_gemm_tiled_kernel(
+    const fp8_t* __restrict__ X, const float* __restrict__ XS, const fp8_t* __restrict__ W, const float* __restrict__ WS,
+    void* __restrict__ out, int out_dt, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][kTileN * kLdsRow];
+    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kTileM * kLdsRow];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int n0 = blockIdx.x * kTileN, m0 = blockIdx.y * kTileM;
+    const int KB = K >> 7;
+
+    // staging role: thread t moves 16 B of rows (t / 8) + 32 i at byte (t % 8) * 16, i < 4, of both tiles
+    const int srow = tid >> 3, scol = (tid & 7) * 16;
+    const fp8_t* wg[4];
+    const fp8_t* xg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wg[i] = W + (size_t)min(n0 + srow + 32 * i, N - 1) * K + scol;
+        xg[i] = X + (size_t)min(m0 + srow + 32 * i, M - 1) * K + scol;
+    }
+    // the token of this lane's column in each of the wave's 4 token tiles: its per-block activation scale
+    const float* xsp[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xsp[mt] = XS + (size_t)min(m0 + wm * 64 + mt * 16 + j, M - 1) * KB;
+    const float* wsp = WS + (size_t)(n0 >> 7) * KB;
+
+    auto fetch = [&](TileRegs& r, int kb) {
+        const int off = kb << 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r.w[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wg[i] + off));
+            r.x[i] = *reinterpret_cast<const i32x4*>(xg[i] + off);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) r.xs[mt] = xsp[mt][kb];
+        r.ws = wsp[kb];
+    };
+    auto stage = [&](const TileRegs& r, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<i32x4*>(&sW[buf][(srow + 32 * i) * kLdsRow + scol]) = r.w[i];
+            *reinterpret_cast<i32x4*>(&sX[buf][(srow + 32 * i) * kLdsRow + scol]) = r.x[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    TileRegs cur, nxt;
+    fetch(cur, 0);
+    stage(cur, 0);
+    __syncthreads();
+    for (int kb = 0; kb < KB; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < KB) fetch(nxt, kb + 1);
+        // fragments: lane (j, g) takes bytes [g*16, g*16+16) of both 64-byte halves of row j of each tile -- the same
+        // k subset for the weight rows and the token rows, which is all the dot product needs
+        i32x4 wa[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint8_t* wr = &sW[buf][(wn * 64 + t * 16 + j) * kLdsRow + g * 16];
+            wa[t][0] = *reinterpret_cast<const i32x4*>(wr);
+            wa[t][1] = *reinterpret_cast<const i32x4*>(wr + 64);
+        }
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16 + j) * kLdsRow + g * 16];
+            const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr), xb1 = *reinterpret_cast<const i32x4*>(xr + 64);
+            const float sc = cur.xs[mt];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][0]), frag_lo(xb0), z, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][0]), frag_hi(xb0), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][1]), frag_lo(xb1), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][1]), frag_hi(xb1), d, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * cur.ws;
+            }
+        }
+        if (kb + 1 < KB) {
+            stage(nxt, buf ^ 1);
+            cur = nxt;
+        }
+        __syncthreads();
+    }
+
+    // C tile (nt, mt): lane holds weight rows n = 4g .. 4g+3 of token column j -> 4 consecutive outputs of one token
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + j;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+            if (n >= N) continue;
+            const f32x4 v = acc[nt][mt];
+            if (out_dt == 2) {
+                float* dst = (float*)out + (size_t)m * N + n;
+                if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+                else
+                    for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = v[r];
+            } else {
+                uint16_t h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = out_dt == 0 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
+                uint16_t* dst = (uint16_t*)out + (size_t)m * N + n;
+                if (n + 3 < N && (N & 3) == 0) {
+                    i32x2 o;
+                    o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
+                    o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                    *reinterpret_cast<i32x2*>(dst) = o;
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = h[r];
+                }
+            }
+        }
+    }
+}
+
+// chitu_hip_fp8_gemm_blockscale's large-M form (declared in gemm_common.h, called from fp8_gemm.hip)
+void launch_fp8_gemm_tiled(const fp8_t* a, const float* a_s, const fp8_t* b, const float* b_s, void* out, int out_dt,
+                           int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    const dim3 grid((unsigned)((N + kTileN - 1) / kTileN), (unsigned)((M + kTileM - 1) / kTileM));
+    hipLaunchKernelGGL(fp8_gemm_tiled_kernel, grid, dim3(256), 0, st, a, a_s, b, b_s, out, out_dt, (int)M, (int)N, (int)K);
+}
+
+}  // namespace chitu

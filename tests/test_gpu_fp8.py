@@ -231,3 +231,30 @@ def test_fp8_gemm_split_k_partial_planes(M, N, K, S):
                                           w[:, k0:k1].contiguous(), ws[:, k0 // 128:k1 // 128].contiguous(), torch.float32)
         assert max_rel_to_peak(parts[s], ref_s) < 1e-4, s
     assert torch.equal(parts, ops.fp8_gemm_partials_deepseek_v3(xq.cuda(), xs.cuda(), w.cuda(), ws.cuda(), S))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 2112, 7168), (2048, 3072, 1536), (1000, 7168, 2048), (129, 200, 128), (333, 136, 384),
+                                   (4096, 512, 7168)])
+def test_fp8_gemm_tiled_prefill_form_vs_streaming_form_and_oracle(M, N, K):
+    """M >= 128 takes the compute-shaped kernel (fp8_gemm_tiled.hip: 128 x 128 tiles through LDS).  Against the
+    weight-streaming kernel forced on the same inputs (launch-variant option fp8_gemm_tiled = 0): fp32 outputs agree to
+    summation order inside a 128-block (<= 1e-5 of the peak); against the CPU oracle on the small shapes: <= 5e-3 after
+    the bf16 rounding.  Ragged edges (M, N not multiples of 128 / 16) included; run to run identical."""
+    from chitu_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.8).to(torch.bfloat16)
+    w, ws = randw(N, K, g)
+    xq, xs = ofp8.act_quant_deepseek_v3(x)
+    xq, xs, w, ws = xq.cuda(), xs.cuda(), w.cuda(), ws.cuda()
+    tiled = ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.float32)
+    with _lib.debug_option("fp8_gemm_tiled", 0):
+        streamed = ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.float32)
+    assert tuple(tiled.shape) == (M, N) and torch.isfinite(tiled).all()
+    assert max_rel_to_peak(tiled, streamed) < 1e-5
+    assert torch.equal(tiled, ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.float32))
+    b16 = ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.bfloat16)
+    assert max_rel_to_peak(b16, streamed) < 5e-3
+    if M * N * K <= 2e8:
+        ref = ofp8.fp8_gemm_deepseek_v3(xq.cpu(), xs.cpu(), w.cpu(), ws.cpu(), torch.float32)
+        assert max_rel_to_peak(b16, ref) < 5e-3
