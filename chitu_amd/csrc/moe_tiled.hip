@@ -1,0 +1,247 @@
+// Fused MoE for PREFILL-sized batches: the two grouped FP8 GEMMs tiled for compute (64 sorted slots x 128 weight rows
+// per workgroup), gfx950.
+//
+// Replaces (reference, read-only), for hundreds of tokens and more:
+//   chitu/fused_moe.py:62-307     fused_moe_kernel (Triton grouped GEMM, BLOCK_SIZE_M = 64 tiles -- the tile height
+//                                 this file uses too: moe_align_block_size is run with block 64 here)
+//   chitu/fused_moe.py:24-39      SiluAndMul (fused into GEMM1's epilogue)
+// The decode kernels (moe.hip) give every 16-slot tile its own stream of the expert's weights: right when an expert
+// sees 1-3 tokens, 4.2 GB of L2 -> CU traffic per layer at 2048 prompt tokens (64 tokens per expert:
+// profiles/r02_prefill_*: 1.3 ms of a 2.0 ms layer).  Here a workgroup stages a 64-slot activation tile (rows gathered
+// through sorted_token_ids) and a 128-row weight tile of the tile's expert in LDS per 128-wide K block, double-buffered
+// like fp8_gemm_tiled.hip, and every wave multiplies 2 weight-row tiles x 4 slot tiles per block.
+//   GEMM1 + SiLU:  the 128 weight rows are 64 gate rows [n0, n0+64) and the 64 up rows [I+n0, I+n0+64) of W1 [E, 2I, K];
+//                  wave w owns gate rows 16w.. and the matching up rows, so g and u of one output meet in one lane:
+//                  h = bf16(bf16(silu(bf16(g))) * bf16(u)) -> bf16 [numel, I]   (moe_gemm1_silu_kernel's rounding points)
+//   GEMM2:         128 rows of W2 [E, N, I]; out[slot, n] = bf16(acc * routed_weight[slot]) (moe_gemm2_kernel's)
+// Scales: (dot * a_s[slot row]) * w_s per K block, the reference's order (fused_moe.py:281).
+#include "common.h"
+#include "gemm_common.h"
+
+namespace chitu {
+
+constexpr int kMoeTileM = 64;            // slots per tile = the moe_align block size of this path
+constexpr int kMoeLdsRow = 128 + 16;     // bytes per staged row
+
+__device__ __forceinline__ float moe_tiled_routed_weight(const void* topk_w, int w_dt, int slot) {
+    if (w_dt == 0) return bf16_to_f32(((const bf16_t*)topk_w)[slot]);
+    if (w_dt == 1) return f16_to_f32(((const uint16_t*)topk_w)[slot]);
+    return ((const float*)topk_w)[slot];
+}
+
+struct MoeTileRegs {
+    i32x4 w[4], x[2];
+    float xs[4];
+    float ws0, ws1;
+};
+
+// grid (weight-row tiles, max m-blocks); block 256.
+//   SILU: Nw = 2I rows per expert, blockIdx.x covers output columns [64 bx, 64 bx + 64); `out` = h [numel, I].
+//   else: Nw = N rows per expert, blockIdx.x covers rows [128 bx, +128); `out` = [numel, Nw] scaled by the routed weight.
+// row_div: activation row of slot s = s / row_div (topk for GEMM1: the token; 1 for GEMM2: the slot's own h row).
+template <bool SILU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void moe_gemm_tiled_kernel(
+    const fp8_t* __restrict__ Xq, const float* __restrict__ Xs, const fp8_t* __restrict__ W, const float* __restrict__ Ws,
+    const int32_t* __restrict__ sorted_ids, const int32_t* __restrict__ expert_ids,
+    const int32_t* __restrict__ num_post_pad, bf16_t* __restrict__ out, const void* __restrict__ topk_w, int w_dt,
+    int numel, int row_div, int Nw, int K) {
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][128 * kMoeLdsRow];
+    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kMoeTileM * kMoeLdsRow];
+    const int mb = blockIdx.y;
+    if (mb * kMoeTileM >= *num_post_pad) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int e = expert_ids[mb];
+    const int I = Nw >> 1;
+    const int n0 = SILU ? blockIdx.x * 64 : blockIdx.x * 128;
+    const int KB = K >> 7;
+
+    // this lane's output slots (token column j of each of the 4 slot tiles)
+    int slot[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) slot[mt] = sorted_ids[mb * kMoeTileM + mt * 16 + j];
+    if (e < 0) {  // another rank's expert (expert parallelism): its slots are zero-filled, fused_moe.py:40-59
+        const int cols = SILU ? 64 : 128, ldo = SILU ? I : Nw;
+        for (int idx = tid; idx < kMoeTileM * (cols / 8); idx += 256) {
+            const int r = idx / (cols / 8), c = idx % (cols / 8);
+            const int s = sorted_ids[mb * kMoeTileM + r];
+            if (s < numel && n0 + c * 8 + 7 < ldo) *reinterpret_cast<i32x4*>(out + (size_t)s * ldo + n0 + c * 8) = i32x4{0, 0, 0, 0};
+        }
+        return;
+    }
+
+    // staging roles: weights 128 rows (4 x 16 B per thread), activations 64 gathered rows (2 x 16 B per thread)
+    const int srow = tid >> 3, scol = (tid & 7) * 16;
+    const fp8_t* wg[4];
+    const fp8_t* xg[2];
+    const fp8_t* We = W + (size_t)e * Nw * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = srow + 32 * i;  // tile row
+        const int row = SILU ? (r < 64 ? n0 + r : I + n0 + (r - 64)) : n0 + r;
+        wg[i] = We + (size_t)min(row, Nw - 1) * K + scol;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = sorted_ids[mb * kMoeTileM + srow + 32 * i];
+        xg[i] = Xq + (size_t)(min(s, numel - 1) / row_div) * K + scol;  // padded slots re-read a valid row (never stored)
+    }
+    const float* xsp[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xsp[mt] = Xs + (size_t)(min(slot[mt], numel - 1) / row_div) * KB;
+    const float* wsb = Ws + (size_t)e * ((Nw + 127) >> 7) * KB;
+    const float* wsp0 = wsb + (size_t)(n0 >> 7) * KB;
+    const float* wsp1 = SILU ? wsb + (size_t)((I + n0) >> 7) * KB : wsp0;
+
+    auto fetch = [&](MoeTileRegs& r, int kb) {
+        const int off = kb << 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.w[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wg[i] + off));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r.x[i] = *reinterpret_cast<const i32x4*>(xg[i] + off);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) r.xs[mt] = xsp[mt][kb];
+        r.ws0 = wsp0[kb];
+        r.ws1 = wsp1[kb];
+    };
+    auto stage = [&](const MoeTileRegs& r, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(&sW[buf][(srow + 32 * i) * kMoeLdsRow + scol]) = r.w[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<i32x4*>(&sX[buf][(srow + 32 * i) * kMoeLdsRow + scol]) = r.x[i];
+    };
+
+    // the wave's two weight-row tiles inside the staged 128 rows
+    const int wrow0 = SILU ? 16 * wave : 32 * wave, wrow1 = SILU ? 64 + 16 * wave : 32 * wave + 16;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    MoeTileRegs cur, nxt;
+    fetch(cur, 0);
+    stage(cur, 0);
+    __syncthreads();
+    for (int kb = 0; kb < KB; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < KB) fetch(nxt, kb + 1);
+        i32x4 wa[2][2];
+        {
+            const uint8_t* w0 = &sW[buf][(wrow0 + j) * kMoeLdsRow + g * 16];
+            const uint8_t* w1 = &sW[buf][(wrow1 + j) * kMoeLdsRow + g * 16];
+            wa[0][0] = *reinterpret_cast<const i32x4*>(w0);
+            wa[0][1] = *reinterpret_cast<const i32x4*>(w0 + 64);
+            wa[1][0] = *reinterpret_cast<const i32x4*>(w1);
+            wa[1][1] = *reinterpret_cast<const i32x4*>(w1 + 64);
+        }
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const uint8_t* xr = &sX[buf][(mt * 16 + j) * kMoeLdsRow + g * 16];
+            const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr), xb1 = *reinterpret_cast<const i32x4*>(xr + 64);
+            const float sc = cur.xs[mt];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][0]), frag_lo(xb0), z, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][0]), frag_hi(xb0), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][1]), frag_lo(xb1), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][1]), frag_hi(xb1), d, 0, 0, 0);
+                const float wsc = nt == 0 ? cur.ws0 : cur.ws1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * wsc;
+            }
+        }
+        if (kb + 1 < KB) {
+            stage(nxt, buf ^ 1);
+            cur = nxt;
+        }
+        __syncthreads();
+    }
+
+    // C tile (nt, mt): lane holds weight rows 4g .. 4g+3 of the tile for slot column j
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int s = slot[mt];
+        if (s >= numel) continue;
+        if (SILU) {
+            const int n = n0 + 16 * wave + 4 * g;  // output column of r = 0
+            uint16_t h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gv = round_bf16(acc[0][mt][r]), uv = round_bf16(acc[1][mt][r]);  // GEMM1's bf16 output (c1)
+                const float sl = round_bf16(gv / (1.0f + expf(-gv)));
+                h[r] = f32_to_bf16(sl * uv);
+            }
+            bf16_t* dst = out + (size_t)s * I + n;
+            if (n + 3 < I) {
+                i32x2 o;
+                o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
+                o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                *reinterpret_cast<i32x2*>(dst) = o;
+            } else {
+                for (int r = 0; r < 4 && n + r < I; ++r) dst[r] = h[r];
+            }
+        } else {
+            const float rw = topk_w ? moe_tiled_routed_weight(topk_w, w_dt, s) : 1.0f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + 32 * wave + 16 * nt + 4 * g;
+                uint16_t h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = f32_to_bf16(acc[nt][mt][r] * rw);
+                bf16_t* dst = out + (size_t)s * Nw + n;
+                if (n + 3 < Nw) {
+                    i32x2 o;
+                    o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
+                    o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                    *reinterpret_cast<i32x2*>(dst) = o;
+                } else {
+                    for (int r = 0; r < 4 && n + r < Nw; ++r) dst[r] = h[r];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace chitu
+
+extern "C" int chitu_hip_moe_gemm1_silu_fp8_tiled(const void* a_fp8, const float* a_scale, const void* w1_fp8,
+                                                  const float* w1_scale, const int32_t* sorted_token_ids,
+                                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                                                  void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size,
+                                                  int64_t K, int64_t max_mblocks, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(a_fp8 && a_scale && w1_fp8 && w1_scale && sorted_token_ids && expert_ids && num_tokens_post_pad && h_bf16);
+    CHITU_REQUIRE(numel >= 0 && numel < (1ll << 31) && topk >= 1 && inter_size >= 1 && K >= 128 && max_mblocks >= 0);
+    if (K % 128 != 0 || inter_size % 128 != 0 || inter_size >= (1 << 29) || K >= (1 << 30)) return CHITU_ERR_UNSUPPORTED;
+    if (numel == 0 || max_mblocks == 0) return CHITU_OK;
+    CHITU_REQUIRE(max_mblocks <= 65535);
+    const dim3 grid((unsigned)(inter_size / 64), (unsigned)max_mblocks);
+    hipLaunchKernelGGL((moe_gemm_tiled_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const fp8_t*)a_fp8, a_scale,
+                       (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)h_bf16,
+                       (const void*)nullptr, 0, (int)numel, (int)topk, (int)(2 * inter_size), (int)K);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_moe_gemm2_fp8_tiled(const void* h_fp8, const float* h_scale, const void* w2_fp8,
+                                             const float* w2_scale, const int32_t* sorted_token_ids,
+                                             const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                                             const void* topk_weights, int weights_dtype, int32_t mul_routed_weight,
+                                             void* out_bf16, int64_t numel, int64_t N, int64_t inter_size,
+                                             int64_t max_mblocks, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(h_fp8 && h_scale && w2_fp8 && w2_scale && sorted_token_ids && expert_ids && num_tokens_post_pad && out_bf16);
+    CHITU_REQUIRE(numel >= 0 && numel < (1ll << 31) && N >= 1 && inter_size >= 128 && max_mblocks >= 0);
+    CHITU_REQUIRE(!mul_routed_weight || (topk_weights && weights_dtype >= 0 && weights_dtype <= 2));
+    if (inter_size % 128 != 0 || N % 8 != 0 || N >= (1 << 30) || inter_size >= (1 << 30)) return CHITU_ERR_UNSUPPORTED;
+    if (numel == 0 || max_mblocks == 0) return CHITU_OK;
+    CHITU_REQUIRE(max_mblocks <= 65535);
+    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)max_mblocks);
+    hipLaunchKernelGGL((moe_gemm_tiled_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const fp8_t*)h_fp8, h_scale,
+                       (const fp8_t*)w2_fp8, w2_scale, sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)out_bf16,
+                       mul_routed_weight ? topk_weights : (const void*)nullptr, (int)weights_dtype, (int)numel, 1, (int)N,
+                       (int)inter_size);
+    CHITU_RETURN_LAUNCH_STATUS();
+}

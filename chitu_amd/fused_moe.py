@@ -140,6 +140,14 @@ def per_token_group_quant_fp8(
 
 
 _MOE_BLOCK_M = 16  # one MFMA tile of sorted slots (the reference's BLOCK_SIZE_M=64 is >90% padding in decode)
+# Prefill: once the experts see dozens of tokens each, the grouped GEMMs are tiled for compute -- moe_align with the
+# reference's block 64, 64-slot x 128-row tiles through LDS (csrc/moe_tiled.hip).  Taken from _MOE_TILED_MIN_TOKENS tokens
+# on (0 = never) when the average expert holds at least _MOE_TILED_MIN_PER_EXPERT slots (below that the 64-slot tiles are
+# mostly padding: R1 rank shard, 128 prompt tokens = 4 slots per expert: 0.50 -> 0.56 ms per layer; 512 tokens = 16:
+# neutral; 2048 tokens = 64: 2.03 -> 1.70 ms).
+_MOE_TILED_MIN_TOKENS = int(os.environ.get("CHITU_MOE_TILED_MIN_TOKENS", "128"))
+_MOE_TILED_MIN_PER_EXPERT = 24
+_MOE_TILED_BLOCK_M = 64
 
 
 class SiluAndMul(torch.nn.Module):
@@ -275,8 +283,11 @@ def fused_experts_impl(
     def rnd(n):
         return (n + 255) // 256 * 256
 
-    cap = numel + global_num_experts * (_MOE_BLOCK_M - 1)
-    nblk = ceil_div(cap, _MOE_BLOCK_M)
+    tiled = (_MOE_TILED_MIN_TOKENS > 0 and num_tokens >= _MOE_TILED_MIN_TOKENS and aligned is None and I % 128 == 0
+             and Nout % 8 == 0 and numel >= _MOE_TILED_MIN_PER_EXPERT * global_num_experts)
+    block_m = _MOE_TILED_BLOCK_M if tiled else _MOE_BLOCK_M
+    cap = numel + global_num_experts * (block_m - 1)
+    nblk = ceil_div(cap, block_m)
     KB = K // 128
     sizes = [
         ("sorted", cap * 4), ("experts", nblk * 4), ("npost", 4), ("cumsum", (global_num_experts + 1) * 4),
@@ -303,7 +314,7 @@ def fused_experts_impl(
         check(
             lib.chitu_hip_moe_align_block_size_mapped(
                 ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel), i32(global_num_experts),
-                i32(_MOE_BLOCK_M), P("sorted"), i64(cap), P("experts"), i64(nblk), P("npost"), P("cumsum"),
+                i32(block_m), P("sorted"), i64(cap), P("experts"), i64(nblk), P("npost"), P("cumsum"),
                 i32(1), ptr(emap), st,
             ),
             "moe_align_block_size",
@@ -329,7 +340,30 @@ def fused_experts_impl(
         assert aq.is_contiguous() and as_.is_contiguous() and aq.numel() == num_tokens * K
         assert as_.dtype == torch.float32 and as_.numel() == num_tokens * KB
         a1q_p, a1s_p = ptr(aq), ptr(as_)
-    if I % 128 == 0 and I <= 512 and os.environ.get("CHITU_MOE_FUSE_SILU", "1") != "0":
+    if tiled:
+        # prefill: GEMM1 + SiLU-and-mul tiled, per-token-group quant of h, GEMM2 tiled (csrc/moe_tiled.hip)
+        assert nblk <= 65535
+        check(
+            lib.chitu_hip_moe_gemm1_silu_fp8_tiled(
+                a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("c1"),
+                i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), st,
+            ),
+            "moe gemm1 (tiled, silu fused)",
+        )
+        check(
+            lib.chitu_hip_act_quant_fp8(P("c1"), float_dtype_code(torch.bfloat16), i64(numel), i64(I), i32(128), i32(1),
+                                        f32(1e-10), P("a2q"), P("a2s"), st),
+            "moe quant2",
+        )
+        check(
+            lib.chitu_hip_moe_gemm2_fp8_tiled(
+                P("a2q"), P("a2s"), ptr(w2), ptr(w2_scale), sorted_p, experts_ptr, npost_p,
+                ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel), i64(Nout),
+                i64(I), i64(max_mblocks), st,
+            ),
+            "moe gemm2 (tiled)",
+        )
+    elif I % 128 == 0 and I <= 512 and os.environ.get("CHITU_MOE_FUSE_SILU", "1") != "0":
         # two launches: GEMM1 with SiLU-and-mul in its epilogue (gate and up tile of the same columns
         # in one wave), GEMM2 with the fp8 re-quantisation of h in its prologue
         check(

@@ -167,6 +167,24 @@ int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_scale, const 
                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
                                  void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size, int64_t K,
                                  int64_t max_mblocks, void* stream);
+/* The same two grouped GEMMs tiled for PREFILL-sized batches (64 sorted slots x 128 weight rows per workgroup through
+ * LDS, fused_moe.py:62-307 with its BLOCK_SIZE_M = 64): sorted_token_ids / expert_ids / num_tokens_post_pad must come from
+ * chitu_hip_moe_align_block_size with block_size 64; max_mblocks <= 65535.
+ *   gemm1_silu_tiled: h[slot, :] = bf16(bf16(silu(bf16(gate))) * bf16(up)) as bf16 [numel, I]; I % 128 == 0, K % 128 == 0.
+ *   gemm2_tiled: out[slot, :] = bf16((h_fp8[slot] . W2[e]^T, block-scaled) * routed_weight[slot]); h quantised by the
+ *   caller (chitu_hip_act_quant_fp8 mode 1); I % 128 == 0, N % 8 == 0.
+ * Same rounding points as the decode kernels; the order of the sum inside a 128-block differs (<= 1e-5 of the result). */
+int chitu_hip_moe_gemm1_silu_fp8_tiled(const void* a_fp8, const float* a_scale, const void* w1_fp8,
+                                       const float* w1_scale, const int32_t* sorted_token_ids,
+                                       const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                                       void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size, int64_t K,
+                                       int64_t max_mblocks, void* stream);
+int chitu_hip_moe_gemm2_fp8_tiled(const void* h_fp8, const float* h_scale, const void* w2_fp8,
+                                  const float* w2_scale, const int32_t* sorted_token_ids,
+                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                                  const void* topk_weights, int weights_dtype, int32_t mul_routed_weight,
+                                  void* out_bf16, int64_t numel, int64_t N, int64_t inter_size,
+                                  int64_t max_mblocks, void* stream);
 int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_fp8, const float* w2_scale,
                                   const int32_t* sorted_token_ids, const int32_t* expert_ids,
                                   const int32_t* num_tokens_post_pad, const void* topk_weights,
