@@ -88,24 +88,29 @@ class PagedKVCacheManager:
 
     # ---- prefill: write whole pages (chitu/cache_manager.py:93-142)
     def finalize_cache_bylayer_prefill(self, xk, xv, req_ids, varlen, layer_id):
-        for idx, req_id in enumerate(req_ids):
-            n_prepared = (varlen.cpu_lens[idx] + self.block_size - 1) // self.block_size
-            if layer_id == self.begin_layer_id:
+        """Write the prompt tokens' rows of one layer into their pages (cache_manager.py:93-142).  The pages are taken and
+        the destination row of every token is worked out once, at the first layer; each layer is then ONE scatter
+        (index_copy_) per cache instead of a slice copy per page."""
+        if layer_id == self.begin_layer_id:
+            rows = []
+            for idx, req_id in enumerate(req_ids):
+                n_prepared = (varlen.cpu_lens[idx] + self.block_size - 1) // self.block_size
                 self.seq_lens[req_id] = varlen.cpu_lens[idx]
                 self.block_table[req_id] = [self.get_free_block() for _ in range(n_prepared)]
-            block_ids = self.block_table[req_id]
-            start_pos = varlen.cpu_prefix_lens[idx]
-            end_pos = varlen.cpu_prefix_lens[idx + 1]
-            li = layer_id - self.begin_layer_id
-            for chunk_id in range(n_prepared):
-                blk = block_ids[chunk_id]
-                n = min(self.block_size, end_pos - start_pos)
-                if self.kv_shape_per_sample is not None:
-                    self.paged_kv_cache[li][blk][:n] = xk[start_pos : start_pos + n]
-                else:
-                    self.paged_k_cache[li][blk][:n] = xk[start_pos : start_pos + n]
-                    self.paged_v_cache[li][blk][:n] = xv[start_pos : start_pos + n]
-                start_pos += n
+                n_tok = varlen.cpu_prefix_lens[idx + 1] - varlen.cpu_prefix_lens[idx]
+                for t in range(n_tok):
+                    rows.append(self.block_table[req_id][t // self.block_size] * self.block_size + t % self.block_size)
+            dev = (self.paged_kv_cache if self.kv_shape_per_sample is not None else self.paged_k_cache).device
+            self._prefill_rows = torch.tensor(rows, dtype=torch.int64).to(dev)
+        li = layer_id - self.begin_layer_id
+        rows = self._prefill_rows
+        if self.kv_shape_per_sample is not None:
+            c = self.paged_kv_cache[li]
+            c.view(-1, *c.shape[2:]).index_copy_(0, rows, xk[: rows.numel()].to(c.dtype))
+        else:
+            ck, cv = self.paged_k_cache[li], self.paged_v_cache[li]
+            ck.view(-1, *ck.shape[2:]).index_copy_(0, rows, xk[: rows.numel()].to(ck.dtype))
+            cv.view(-1, *cv.shape[2:]).index_copy_(0, rows, xv[: rows.numel()].to(cv.dtype))
 
     def register_sequence(self, req_id, length):
         """Allocate pages for a sequence of `length` cached tokens without writing data

@@ -1,0 +1,136 @@
+// Compute-shaped bf16 GEMM for PREFILL-sized M (router scores, every linear of an unquantised model, the LM head over
+// a whole prompt), gfx950.  Same tiling as fp8_gemm_tiled.hip -- 128 weight rows x 128 tokens per workgroup, 4 waves as
+// 2 x 2, both operand tiles staged through LDS per 128-byte K block (64 bf16), double-buffered -- without block scales:
+// the 16 accumulator tiles of a wave run across the whole K range (v_mfma_f32_16x16x32_bf16, weights = A operand).
+//
+// Replaces (reference, read-only), for M >= 128: torch.nn.functional.linear on bf16 weights as used by
+//   chitu/models/model_deepseek_v3.py:810-812  GateDeepSeekV3.forward  (scores = linear(x, weight))
+//   chitu/models/model.py:104-132, 201-214     Attention / FeedForward projections in prefill
+// The skinny kernel (gate.hip: bf16_gemm_kernel) streams the weight matrix once per 32 token rows: 64 launches of
+// 4.7 us for the router of a 2048-token prompt (profiles/r02_prefill_*), one launch here.
+#include "common.h"
+#include "gemm_common.h"
+
+namespace chitu {
+
+constexpr int kBTile = 128;
+constexpr int kBLdsRow = 128 + 16;  // bytes per staged row (64 bf16 + pad)
+
+struct BTileRegs {
+    i32x4 w[4], x[4];
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bf16_gemm_tiled_kernel(
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ out, int out_dt, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][kBTile * kBLdsRow];
+    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kBTile * kBLdsRow];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int n0 = blockIdx.x * kBTile, m0 = blockIdx.y * kBTile;
+    const int KB = K >> 6;  // blocks of 64 elements = 128 bytes
+
+    const int srow = tid >> 3, scol = (tid & 7) * 8;  // 8 bf16 = 16 bytes
+    const bf16_t* wg[4];
+    const bf16_t* xg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wg[i] = W + (size_t)min(n0 + srow + 32 * i, N - 1) * K + scol;
+        xg[i] = X + (size_t)min(m0 + srow + 32 * i, M - 1) * K + scol;
+    }
+    auto fetch = [&](BTileRegs& r, int kb) {
+        const int off = kb << 6;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r.w[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wg[i] + off));
+            r.x[i] = *reinterpret_cast<const i32x4*>(xg[i] + off);
+        }
+    };
+    auto stage = [&](const BTileRegs& r, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<i32x4*>(&sW[buf][(srow + 32 * i) * kBLdsRow + scol * 2]) = r.w[i];
+            *reinterpret_cast<i32x4*>(&sX[buf][(srow + 32 * i) * kBLdsRow + scol * 2]) = r.x[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    BTileRegs cur, nxt;
+    fetch(cur, 0);
+    stage(cur, 0);
+    __syncthreads();
+    for (int kb = 0; kb < KB; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < KB) fetch(nxt, kb + 1);
+        // lane (j, g): elements [8g, 8g+8) of each 32-element half of row j -- one MFMA operand per half
+        s16x8 wa[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint8_t* wr = &sW[buf][(wn * 64 + t * 16 + j) * kBLdsRow + g * 16];
+            wa[t][0] = *reinterpret_cast<const s16x8*>(wr);
+            wa[t][1] = *reinterpret_cast<const s16x8*>(wr + 64);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16 + j) * kBLdsRow + g * 16];
+            const s16x8 xb0 = *reinterpret_cast<const s16x8*>(xr), xb1 = *reinterpret_cast<const s16x8*>(xr + 64);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nt][0], xb0, acc[nt][mt], 0, 0, 0);
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nt][1], xb1, acc[nt][mt], 0, 0, 0);
+            }
+        }
+        if (kb + 1 < KB) {
+            stage(nxt, buf ^ 1);
+            cur = nxt;
+        }
+        __syncthreads();
+    }
+
+    // C tile (nt, mt): lane holds weight rows n = 4g .. 4g+3 of token column j -> 4 consecutive outputs of one token
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + j;
+        if (m >= M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + 4 * g;
+            if (n >= N) continue;
+            const f32x4 v = acc[nt][mt];
+            if (out_dt == 2) {
+                float* dst = (float*)out + (size_t)m * N + n;
+                if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+                else
+                    for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = v[r];
+            } else {
+                uint16_t h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = out_dt == 0 ? f32_to_bf16(v[r]) : f32_to_f16(v[r]);
+                uint16_t* dst = (uint16_t*)out + (size_t)m * N + n;
+                if (n + 3 < N && (N & 3) == 0) {
+                    i32x2 o;
+                    o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
+                    o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                    *reinterpret_cast<i32x2*>(dst) = o;
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = h[r];
+                }
+            }
+        }
+    }
+}
+
+// chitu_hip_bf16_gemm's large-M form (declared in gemm_common.h, called from gate.hip)
+void launch_bf16_gemm_tiled(const bf16_t* x, const bf16_t* w, void* out, int out_dt, int64_t M, int64_t N, int64_t K,
+                            hipStream_t st) {
+    const dim3 grid((unsigned)((N + kBTile - 1) / kBTile), (unsigned)((M + kBTile - 1) / kBTile));
+    hipLaunchKernelGGL(bf16_gemm_tiled_kernel, grid, dim3(256), 0, st, x, w, out, out_dt, (int)M, (int)N, (int)K);
+}
+
+}  // namespace chitu

@@ -171,6 +171,10 @@ __device__ __forceinline__ void gemm_epilogue_v2(f32x4 (&acc)[MT], float* red, v
 void launch_fp8_gemm_tiled(const fp8_t* a, const float* a_s, const fp8_t* b, const float* b_s, void* out, int out_dt,
                            int64_t M, int64_t N, int64_t K, hipStream_t st);
 
+// The same for bf16 weights (router scores, unquantised linears) at prefill-sized M.  Defined in bf16_gemm_tiled.hip.
+void launch_bf16_gemm_tiled(const bf16_t* x, const bf16_t* w, void* out, int out_dt, int64_t M, int64_t N, int64_t K,
+                            hipStream_t st);
+
 // out[m][n] = sum_s partial[s][m][n] (s ascending), cast to out_dt.  Defined in fp8_gemm.hip.
 void launch_splitk_reduce(const float* partial, void* out, int out_dt, int S, int64_t MN, hipStream_t st);
 

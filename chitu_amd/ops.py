@@ -489,7 +489,8 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
     assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous() and weight.is_contiguous()
     M, K = x.shape
     E = weight.shape[0]
-    splits = _GATE_SPLITS if K % (64 * _GATE_SPLITS) == 0 else 1
+    # decode: K cut over 16 workgroups per tile, the routing launch sums the fp32 planes; prefill-sized M: one tiled GEMM
+    splits = _GATE_SPLITS if K % (64 * _GATE_SPLITS) == 0 and M < 256 else 1
     cols = topk + (extra_count if extra_expert_id >= 0 else 0)
     w_out = torch.empty(M, cols, dtype=torch.bfloat16, device=x.device)
     ids = torch.empty(M, cols, dtype=torch.int64, device=x.device)

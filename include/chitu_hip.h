@@ -269,7 +269,8 @@ int chitu_hip_embed_rope_gather(const int64_t* tokens, const void* embed_bf16, i
  * 2 GEMM1 ring depth, 3 GEMM2 config (NT*10 + ROUNDS), 4 int8 MoE K-split waves, 5 generic routing kernel (1),
  * 6 ticket-based route + align (1), 7 radix-only sampler (1), 8 dense fp8 GEMM K-split waves, 9 its whole-K-in-flight
  * form for <= 8 blocks per wave (0 = off), 10 / 11 the same two for the bf16 GEMM, 12 K-split waves of the bf16 SwiGLU GEMM,
- * 13 the tiled (compute-shaped) form of the dense fp8 GEMM for M >= 128 (0 = keep streaming the weights per 64 rows). */
+ * 13 the tiled (compute-shaped) form of the dense fp8 GEMM for M >= 128 (0 = keep streaming the weights per 64 rows),
+ * 14 the same for the bf16 GEMM (0 = per 32 rows). */
 int chitu_hip_debug_option(int32_t option, int32_t value);
 
 /* ---- arithmetic self-test ----------------------------------------------------------------------

@@ -228,6 +228,27 @@ def test_decode_with_norms_in_the_gemm_prologues_equals_decode_without(bs, monke
         assert all(torch.equal(a, b) for a, b in zip(val, base)), key
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 1024, 7168), (2048, 256, 7168), (1000, 6144, 4096), (257, 200, 512), (300, 4096, 14336)])
+def test_bf16_gemm_tiled_prefill_form_vs_streaming_form(M, N, K):
+    """M >= 128 takes the compute-shaped bf16 kernel (bf16_gemm_tiled.hip); against the weight-streaming kernel forced on
+    the same inputs: fp32 outputs agree to summation order (<= 1e-4 of the peak), bf16 outputs to their last bit, and the
+    result is torch's F.linear up to that bit; ragged edges included; run to run identical."""
+    from chitu_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    tiled = ops.bf16_linear(x, w, out_dtype=torch.float32)
+    with _lib.debug_option("bf16_gemm_tiled", 0):
+        streamed = ops.bf16_linear(x, w, out_dtype=torch.float32)
+    assert tuple(tiled.shape) == (M, N) and torch.isfinite(tiled).all()
+    assert max_rel_to_peak(tiled, streamed) < 1e-4
+    assert torch.equal(tiled, ops.bf16_linear(x, w, out_dtype=torch.float32))
+    ref = torch.nn.functional.linear(x.float(), w.float())
+    assert max_rel_to_peak(tiled, ref) < 1e-4
+    assert max_rel_to_peak(ops.bf16_linear(x, w), ref) < 8e-3  # one bf16 ulp of the peak binade
+
+
 def test_prefill_equals_token_by_token_decode_and_generate():
     args = tiny_args(2)
     model, cache = build(args)
