@@ -320,6 +320,7 @@ def algorithmic_bytes_per_step(margs, bs, ctx, distinct):
     return margs.n_layers * attn + margs.n_dense_layers * dense + n_moe * moe + head + kv
 
 
+@torch.inference_mode()  # like the decode step: the capture touches state created under inference mode
 def roofline_dominant_kernel(model, routing, margs, bs, iters=3):
     """Time the dominant kernel -- the routed-expert GEMM1 with SiLU-and-mul in its epilogue
     (chitu_hip_moe_gemm1_silu_fp8 -> moe_gemm1_silu_kernel: ~2/3 of all bytes at bs=16) -- live with

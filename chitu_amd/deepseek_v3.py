@@ -169,6 +169,9 @@ class RMSNormW(torch.nn.Module):
 # q_norm + act_quant + wq_b GEMM + KV append as one launch (ops.mla_q_proj); CHITU_Q_PROJ_FUSED=0 keeps the two
 # launches apart (A/B timing, tests of the unfused pair).
 FUSE_Q_PROJ = os.environ.get("CHITU_Q_PROJ_FUSED", "1") != "0"
+# ... up to one 16-token tile: with two tiles every workgroup redoes the norm + quant of 32 rows and the kernel is out of
+# registers (bench bs 32: 14.7 ms/step with the two launches, 15.1 with the fused one)
+_Q_PROJ_MAX_BS = 16
 
 
 def _wqkv_a_splits(bs: int, n: int, k: int) -> int:
@@ -239,7 +242,7 @@ class AttentionDeepSeekV3(torch.nn.Module):
 
         6 launches (the reference's decode_forward_paged + _run_linear issue ~25): wqkv_a GEMM,
         [q_norm + quant -> wq_b GEMM | kv_norm + RoPE(k_pe) + page append], [W_UK absorb | RoPE(q_pe)],
-        MLA decode, [split merge + W_UV absorb + quant], wo GEMM.  (7 with batches above 32: the q_norm / kv
+        MLA decode, [split merge + W_UV absorb + quant], wo GEMM.  (7 with batches above 16: the q_norm / kv
         launch and the wq_b GEMM apart.)"""
         H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
         bs = x_quant[0].shape[0]
@@ -253,7 +256,7 @@ class AttentionDeepSeekV3(torch.nn.Module):
                 q_a_kv = ops.fp8_gemm_partials_deepseek_v3(x_quant[0], x_quant[1], self.wqkv_a.weight, self.wqkv_a.scale, splits)
             else:
                 q_a_kv = self.wqkv_a(None, x_quant=x_quant)
-            if FUSE_Q_PROJ and splits == 1 and ops.mla_q_proj_fits(bs, self.q_lora_rank):
+            if FUSE_Q_PROJ and splits == 1 and bs <= _Q_PROJ_MAX_BS and ops.mla_q_proj_fits(bs, self.q_lora_rank):
                 # ONE launch: q_norm + act_quant as the prologue of the wq_b GEMM, and this token's
                 # [kv_norm(kv_c) | rope(k_pe)] row straight into its page on extra workgroups of the same grid
                 q = ops.mla_q_proj(q_a_kv, self.q_lora_rank, self.q_norm.weight, self.q_norm.eps, self.wq_b.weight,
