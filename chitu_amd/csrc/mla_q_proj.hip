@@ -7,7 +7,8 @@
 //   chitu/triton_kernels.py:194-216            act_quant_deepseek_v3_kernel  (the fp8 input of wq_b)
 //   chitu/triton_kernels.py:302-365            fp8_gemm_deepseek_v3_kernel
 // and, in this library, the pair chitu_hip_mla_qkv_post + chitu_hip_fp8_gemm_blockscale (kept: prefill, batches
-// above 32, q_lora_rank above 2048, the split-K planes of wqkv_a).
+// above 32, q_lora_rank above 2048, the split-K planes of wqkv_a; the model takes this launch for one token tile,
+// batch <= 16: with two tiles a workgroup redoes the norm + quant of 32 rows and the pair was the faster form).
 //
 // Why: at decode batch sizes both launches are a few microseconds of dependent memory round trips behind a launch
 // (4.8 us each for 0.1 MB and 4.7 MB) and the norm + quant of a [<= 32, 1536] matrix is
