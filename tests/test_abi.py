@@ -56,3 +56,37 @@ def test_ops_fail_loudly_without_device_tensors():
         fused_moe.moe_align_block_size(torch.zeros(4, 2, dtype=torch.int64), 4, 4)
     with pytest.raises(HipCallError):
         ops.act_quant_deepseek_v3(torch.zeros(2, 128, dtype=torch.bfloat16))
+
+
+def test_fused_launch_shape_limits_agree_between_python_and_c():
+    """ops.bf16_add_norm_fits / ops.mla_q_proj_fits (what the models ask before taking a fused launch) and the C entry
+    points' own limits are the same boundary: every shape the Python side calls unfit is refused by the library with
+    CHITU_ERR_UNSUPPORTED before anything is launched (argument checks run on the host, so this needs no GPU; the
+    pointers are never dereferenced)."""
+    from chitu_amd import _lib, ops
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.c_void_p(ctypes.addressof(buf))
+    i32, i64, f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    unfit = 0
+    for M in (1, 2, 3, 4, 5):
+        for K in (256, 512, 520, 4096, 7168, 8192, 8256):
+            for N in (16, 256, 6144, 100000):
+                if ops.bf16_add_norm_fits(M, N, K):
+                    continue
+                unfit += 1
+                rc = lib.chitu_hip_bf16_gemm_add_norm(p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, f32(1e-5), p, p,
+                                                      i32(0), i64(M), i64(N), i64(K), None)
+                assert rc == -2, (M, N, K, rc)
+                rc = lib.chitu_hip_bf16_gemm_silu_add_norm(p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, f32(1e-5),
+                                                           p, p, i64(M), i64(N), i64(K), None)
+                assert rc == -2, (M, N, K, rc)
+    assert unfit > 20
+    for bs, ql in ((33, 1536), (64, 1536), (16, 2176), (16, 1600), (1, 4096)):
+        assert not ops.mla_q_proj_fits(bs, ql)
+        rc = lib.chitu_hip_mla_q_proj(p, i64(ql + 576 + (8 - (ql + 576) % 8) % 8), i32(ql), p, f32(1e-6), p, p, p, i32(0), i64(3072),
+                                      p, f32(1e-6), p, p, p, i64(4), i32(64), p, i32(2), p, i32(bs), i32(512), i32(64), None)
+        assert rc == -2, (bs, ql, rc)
