@@ -98,10 +98,11 @@ class PagedKVCacheManager:
                 self.seq_lens[req_id] = varlen.cpu_lens[idx]
                 self.block_table[req_id] = [self.get_free_block() for _ in range(n_prepared)]
                 n_tok = varlen.cpu_prefix_lens[idx + 1] - varlen.cpu_prefix_lens[idx]
-                for t in range(n_tok):
-                    rows.append(self.block_table[req_id][t // self.block_size] * self.block_size + t % self.block_size)
+                t = torch.arange(n_tok, dtype=torch.int64)
+                blocks = torch.tensor(self.block_table[req_id], dtype=torch.int64)
+                rows.append(blocks[t // self.block_size] * self.block_size + t % self.block_size)
             dev = (self.paged_kv_cache if self.kv_shape_per_sample is not None else self.paged_k_cache).device
-            self._prefill_rows = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self._prefill_rows = (torch.cat(rows) if rows else torch.zeros(0, dtype=torch.int64)).to(dev)
         li = layer_id - self.begin_layer_id
         rows = self._prefill_rows
         if self.kv_shape_per_sample is not None:
