@@ -25,8 +25,9 @@
 // all peers) beats a two-hop reduce-scatter + all-gather until the per-link bytes dominate the extra hop.
 //
 // Replay safety.  Kernel arguments are frozen in a hipGraph, so the call counter lives in device memory:
-// epoch[slot] (local, ordinary memory) counts the calls that used `slot` (a row of the all-reduce, a
-// workgroup of the all-gather); the flag value of a call is its epoch, the data slot is epoch & 1.  A rank
+// epoch (local, ordinary memory) counts calls -- per ROW for the all-reduce (a row's data slot has a fixed address),
+// per CALL for the all-gather (its data layout depends on the call's shape, so the parity must flip for the whole
+// buffer at once); the flag value of a call is its epoch, the data slot is epoch & 1.  A rank
 // can only be one call ahead of a peer on a slot (it needs the peer's flag of call c to finish call c), so
 // a flag is awaited as `flag - epoch >= 0` and two data slots suffice: a writer of call c + 2 has seen
 // every peer's flag of call c + 1, which a peer stores in a kernel that starts after its kernel of call c
@@ -54,13 +55,15 @@ struct CommGeom {
     int64_t flags_ar, flags_ag, data_ar, data_ag, ag_bytes;
     uint32_t data_ar_bytes, data_ag_bytes;  // whole regions (buffer descriptors)
     uint64_t timeout_ticks;
+    uint32_t* host_err;  // pinned host word (device-visible): set together with the device error word, so the host can
+                         // notice a timed-out collective between two steps WITHOUT synchronising the stream
 };
 
 struct Comm {
     CommGeom g;
     CommPeers peers;
     bool ipc_opened[kCommMaxRanks];
-    uint32_t* state;  // device, ordinary memory: epoch_ar[max_rows] | epoch_ag[max_blocks] | err[4]
+    uint32_t* state;  // device, ordinary memory: epoch_ar[max_rows] | epoch_ag (word 0: the all-gather CALL counter) [max_blocks] | err[4]
     int64_t total;
 };
 
@@ -72,7 +75,8 @@ __device__ __forceinline__ void sys_store(uint32_t* p, uint32_t v) {
 }
 
 // One lane: wait until *flag has reached `epoch` (peers may already be one call ahead).  Bounded.
-__device__ __forceinline__ void wait_flag(const uint32_t* flag, uint32_t epoch, uint32_t* err, uint64_t timeout) {
+__device__ __forceinline__ void wait_flag(const uint32_t* flag, uint32_t epoch, uint32_t* err, uint64_t timeout,
+                                          uint32_t* host_err) {
     if ((int32_t)(sys_load(flag) - epoch) >= 0) return;
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;  // sticky
     const uint64_t t0 = wall_clock64();
@@ -83,6 +87,7 @@ __device__ __forceinline__ void wait_flag(const uint32_t* flag, uint32_t epoch, 
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
             if (wall_clock64() - t0 > timeout) {
                 __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sys_store(host_err, 1u);  // the copy the host polls between steps (XgmiComm.poll_error)
                 return;
             }
         }
@@ -105,7 +110,7 @@ __device__ __forceinline__ void await_peers(const CommPeers& peers, const CommGe
     const int tid = threadIdx.x;
     if (tid < g.world && tid != g.rank)
         wait_flag(reinterpret_cast<const uint32_t*>(peers.buf[g.rank] + flags_off) + (int64_t)tid * slots + slot, epoch, err,
-                  g.timeout_ticks);
+                  g.timeout_ticks, g.host_err);
     __syncthreads();
 }
 
@@ -212,9 +217,14 @@ __global__ __launch_bounds__(kCommThreads) void allgather_kernel(CommPeers peers
     const int blk = blockIdx.y * gridDim.x + blockIdx.x;
     const int col = (blockIdx.x * kCommThreads + tid) * 8;
     const bool act = col < cols;
+    // ONE counter per comm for the all-gather calls: every workgroup of a call reads the same value (the previous
+    // call's kernel has finished), so the data-slot parity alternates per CALL whatever the (rows, cols) of the calls
+    // are -- with a per-workgroup counter, calls of different shapes could map different workgroups with different
+    // parities onto overlapping bytes.  The flags stay per workgroup; a workgroup index an earlier call did not use
+    // holds an older epoch, which `flag - epoch >= 0` treats as "not there yet".
     uint32_t* epoch_ag = state + g.max_rows;
     uint32_t* err = state + g.max_rows + g.max_blocks;
-    const uint32_t epoch = epoch_ag[blk] + 1;
+    const uint32_t epoch = epoch_ag[0] + 1;
     const int parity = (int)(epoch & 1u);
     i32x4 mine = {0, 0, 0, 0};
     if (act) mine = *reinterpret_cast<const i32x4*>(in + (int64_t)row * in_stride + col);
@@ -241,7 +251,14 @@ __global__ __launch_bounds__(kCommThreads) void allgather_kernel(CommPeers peers
                 rsrc, act ? (uint32_t)(((int64_t)parity * kCommMaxRanks + src) * g.ag_bytes) + in_slot : 0u, 0, kCommAux);
         }
     }
-    if (tid == 0) epoch_ag[blk] = epoch;
+    // advanced by the call's LAST workgroup to get here (ticket in word 1; the next call is a later kernel)
+    if (tid == 0) {
+        const uint32_t n = gridDim.x * gridDim.y;
+        if (__hip_atomic_fetch_add(&epoch_ag[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n - 1) {
+            __hip_atomic_store(&epoch_ag[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&epoch_ag[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (!act) return;
     const int64_t out_row = (int64_t)row * g.world * cols;
 #pragma unroll
@@ -279,10 +296,12 @@ extern "C" int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_ro
     CHITU_REQUIRE(max_rows >= 1 && max_dim >= 8 && max_dim % 8 == 0 && max_dim <= kCommThreads * 8 && gather_bytes >= 0);
     CHITU_REQUIRE(timeout_ms >= 1);
     Comm* cm = new Comm();
+    cm->state = nullptr;
     CommGeom& g = cm->g;
+    g.host_err = nullptr;
     g.rank = rank, g.world = world, g.max_rows = max_rows, g.max_dim = max_dim;
     g.ag_bytes = align_up(gather_bytes, 256);
-    g.max_blocks = (int)(g.ag_bytes / (kCommThreads * 16)) + max_rows;  // a row's last chunk may be partial
+    g.max_blocks = (int)(g.ag_bytes / (kCommThreads * 16)) + max_rows + 2;  // a row's last chunk may be partial; >= 2 state words
     const int64_t ar = (int64_t)2 * kCommMaxRanks * max_rows * max_dim * 2, ag = (int64_t)2 * kCommMaxRanks * g.ag_bytes;
     if (ar >= (1ll << 32) || ag >= (1ll << 32)) {
         delete cm;
@@ -302,9 +321,13 @@ extern "C" int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_ro
     const size_t state_bytes = ((size_t)max_rows + g.max_blocks + 4) * 4;
     if (e == hipSuccess) e = hipMalloc((void**)&cm->state, state_bytes);
     if (e == hipSuccess) e = hipMemset(cm->state, 0, state_bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&g.host_err, 64, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) *g.host_err = 0;
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         if (p) (void)hipFree(p);
+        if (cm->state) (void)hipFree(cm->state);
+        if (g.host_err) (void)hipHostFree(g.host_err);
         delete cm;
         return (int)e;
     }
@@ -360,6 +383,15 @@ extern "C" int chitu_hip_comm_status(void* comm, uint32_t* err_out) {
     return e == hipSuccess ? CHITU_OK : (int)e;
 }
 
+// Non-blocking: the pinned host copy of the error word (set by the kernel that timed out, visible as soon as that
+// store has crossed the bus).  No stream is synchronised; 0 only means "nothing reported yet".
+extern "C" int chitu_hip_comm_poll_error(void* comm, uint32_t* err_out) {
+    CHITU_REQUIRE(comm && err_out);
+    Comm* cm = (Comm*)comm;
+    *err_out = *(volatile uint32_t*)cm->g.host_err;
+    return CHITU_OK;
+}
+
 extern "C" int chitu_hip_comm_destroy(void* comm) {
     CHITU_REQUIRE(comm);
     Comm* cm = (Comm*)comm;
@@ -368,6 +400,7 @@ extern "C" int chitu_hip_comm_destroy(void* comm) {
         if (cm->ipc_opened[i]) (void)hipIpcCloseMemHandle(cm->peers.buf[i]);
     (void)hipFree(cm->peers.buf[cm->g.rank]);
     (void)hipFree(cm->state);
+    (void)hipHostFree(cm->g.host_err);
     delete cm;
     return CHITU_OK;
 }

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void gqa_decode_kernel(
     const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
     const int split = blockIdx.x, b = blockIdx.y / Hkv, kvh = blockIdx.y % Hkv;
     const int G = Hq / Hkv;  // q heads per kv head (<= 16)
-    const int L = seqlens[b];
+    const int L = max(seqlens[b], 0);  // a corrupt negative length is an empty sequence, not a huge unsigned range
     const int n16 = (L + 15) >> 4;
     // 32-bit unsigned quotients: a 64-bit division is a software loop on the kernel's critical chain (the launcher bounds
     // 16-token steps x splits below 2^31)
@@ -178,13 +178,16 @@ __global__ __launch_bounds__(64) void gqa_merge_kernel(const float* __restrict__
     wsum = wave_reduce_sum(wsum);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const float* rows = part_o + bh * num_splits * kHd + col;
-    for (int s0 = half; s0 < num_splits; s0 += 16) {
+    // The trip count is the SAME for both halves (s0 is wave-uniform, the half enters through `s`): the __shfl below
+    // is a ds_bpermute, which returns 0 for a source lane that has left the loop, so a half that exits one
+    // iteration early (num_splits % 16 == 1) would drop the weights the other half still fetches from its lanes.
+    for (int s0 = 0; s0 < num_splits; s0 += 16) {
         f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(rows + (int64_t)min(s0 + 2 * u, num_splits - 1) * kHd);
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(rows + (int64_t)min(s0 + half + 2 * u, num_splits - 1) * kHd);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int s = s0 + 2 * u;  // wave-uniform per half
+            const int s = s0 + half + 2 * u;  // uniform per half
             const float ws_all = s < 64 ? w[0] : s < 128 ? w[1] : s < 192 ? w[2] : w[3];
             const float ws = __shfl(ws_all, s & 63, 64);
             if (s < num_splits && ws > 0.f) {  // an empty split's row is never used (it may hold anything)

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     // its shadow: seqlens is requested first, then Q (independent of it), then the wait; every load below is
     // unconditional (indices clamped, the unwanted values dropped when they are stored to LDS), so the code is
     // straight-line and the compiler's s_waitcnt counts past the loads that are not needed yet.
-    const int L = seqlens[b];
+    const int L = max(seqlens[b], 0);  // a corrupt negative length is an empty sequence (the unsigned split arithmetic below)
     // Q (A operand of QK^T; 16 heads x 576, same padded stride as the KV rows): 1152 chunks, <= 5 per thread
     i32x4 qreg[5];
 #pragma unroll

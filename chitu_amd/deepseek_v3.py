@@ -579,7 +579,12 @@ class DeepSeekV3Decoder(torch.nn.Module):
             out.append(tok)
         for r in req_ids:
             self.cache.finalize_cache_all_decode(r)
-        return torch.stack(out, dim=1)
+        tokens_out = torch.stack(out, dim=1)
+        if tp.xgmi_comm() is not None:
+            # the tokens are about to leave the engine: make sure no collective behind them gave up on a peer
+            torch.cuda.current_stream().synchronize()
+            tp.check_comm()
+        return tokens_out
 
     def embed(self, tokens):
         """tensor_parallel.py:199-208: mask ids outside this rank's vocab slice, lookup, all-reduce."""
@@ -606,6 +611,7 @@ class DeepSeekV3Decoder(torch.nn.Module):
         every all-reduce / all-gather, the pieces are hipGraphs and the collectives are issued between them
         (RCCL never has to be capturable; 2 x layers + 2 host calls per step, far below the pieces' GPU
         time); "piecewise" / "full" force a mode."""
+        tp.check_comm()  # a collective of an earlier step that timed out: raise instead of decoding garbage
         self.prepare_decoding_attn()
         bs = tokens.shape[0]
         if not use_graph:

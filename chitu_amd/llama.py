@@ -248,7 +248,12 @@ class LlamaDecoder(torch.nn.Module):
             out.append(tok)
         for r in req_ids:
             self.cache.finalize_cache_all_decode(r)
-        return torch.stack(out, dim=1)
+        tokens_out = torch.stack(out, dim=1)
+        if tp.xgmi_comm() is not None:
+            # the tokens are about to leave the engine: make sure no collective behind them gave up on a peer
+            torch.cuda.current_stream().synchronize()
+            tp.check_comm()
+        return tokens_out
 
     def decode_eager(self, tokens):
         # embedding rows of this rank's vocabulary slice + every sequence's rotary row: one launch
@@ -266,6 +271,7 @@ class LlamaDecoder(torch.nn.Module):
     def decode(self, tokens, use_graph=True):
         """Eager, or the step captured per batch size: one hipGraph, or -- on a rank with collectives --
         hipGraph pieces with the collectives between them (chitu_amd/graphs.py)."""
+        tp.check_comm()  # a collective of an earlier step that timed out: raise instead of decoding garbage
         bs = tokens.shape[0]
         if not use_graph:
             return self.decode_eager(tokens)

@@ -22,6 +22,7 @@ __all__ = [
     "RowParallelLinear",
     "VocabParallelEmbedding",
     "enable_xgmi",
+    "check_comm",
     "all_reduce",
     "all_gather_last_dim",
 ]
@@ -80,49 +81,81 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
                 selftest: bool = True) -> bool:
     """Switch the TP group's decode-sized collectives to the in-graph xGMI kernels: every rank creates its
     buffer, the IPC handles travel over the process group, and (selftest) one all-reduce and one all-gather are
-    checked against the library's on every rank.  All ranks agree on the outcome (an all-reduce of the verdicts);
-    on any failure the library path stays in place and False is returned.  Collective over the TP group."""
+    checked against the library's on every rank.  Collective over the TP group, in STAGES (create, map, all-reduce
+    self-test, all-gather self-test): every rank takes part in every collective of a stage whatever happened to it
+    locally, the ranks agree on the stage's verdict (MIN over the group), and only a unanimous success moves on --
+    so a failure on some ranks (IPC refused on one GPU, a mismatch on one rank) can never leave the others inside a
+    collective nobody else enters.  On any failure the library path stays in place on EVERY rank and False is returned."""
     global _xgmi
     if get_tp_size() <= 1 or not torch.cuda.is_available():
         return False
     from .xgmi import XgmiComm
 
     group, rank, world = get_tp_group(), get_tp_rank(), get_tp_size()
-    ok, comm, why = 1, None, ""
-    try:
-        comm = XgmiComm.from_group(group, max_rows=max_rows, max_dim=max_dim, gather_bytes=gather_bytes,
-                                   timeout_ms=timeout_ms)
-        if selftest:
-            # the library's answer is computed where its backend works (gloo: host tensors)
-            lib_dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-            gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
-            dim = min(max_dim, 1024)
-            for rows in (1, min(max_rows, 5)):
-                part = torch.randn(rows, dim, device="cuda", generator=gen).to(torch.bfloat16)
-                want = part.float().to(lib_dev)
-                dist.all_reduce(want, group=group)  # fp32 sum: order-free up to rounding
-                got = comm.allreduce_rmsnorm(part).float().to(lib_dev)
-                if comm.status() != 0 or not torch.allclose(got, want, rtol=2e-2, atol=2e-2):
-                    ok, why = 0, "all-reduce self-test mismatch / timeout"
-            if ok and gather_bytes >= 2 * 32 * 2:
-                y = torch.randn(2, 32, device="cuda", generator=gen).to(torch.bfloat16)
-                ref = [torch.empty(2, 32, dtype=torch.float32, device=lib_dev) for _ in range(world)]
-                dist.all_gather(ref, y.float().to(lib_dev), group=group)
-                got = comm.all_gather_last_dim(y).float().to(lib_dev)
-                if comm.status() != 0 or not torch.equal(got, torch.cat(ref, dim=-1)):
-                    ok, why = 0, "all-gather self-test mismatch / timeout"
-    except Exception as e:  # noqa: BLE001 -- any setup failure means: keep the library path
-        ok, why = 0, repr(e)
-    verdict = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
-    if int(verdict.item()) != 1:
+    lib_dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"  # the library's answer is computed where its backend works
+
+    def unanimous(ok: bool) -> bool:
+        verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device=lib_dev)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+        return int(verdict.item()) == 1
+
+    def give_up(comm, why):
         if why:
             print(f"[chitu_amd] rank {rank}: xGMI collectives not enabled ({why}); using the library path", flush=True)
         if comm is not None:
             comm.close()
         return False
+
+    try:  # stages 1 + 2 (create, map): from_group is collective-safe and raises on every rank or on none
+        comm = XgmiComm.from_group(group, max_rows=max_rows, max_dim=max_dim, gather_bytes=gather_bytes, timeout_ms=timeout_ms)
+    except RuntimeError as e:
+        return give_up(None, str(e))
+    if selftest:
+        gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
+        dim = min(max_dim, 1024)
+        for rows in (1, min(max_rows, 5)):  # stage 3: the library's collective is entered by every rank, unconditionally
+            part = torch.randn(rows, dim, device="cuda", generator=gen).to(torch.bfloat16)
+            want = part.float().to(lib_dev)
+            dist.all_reduce(want, group=group)  # fp32 sum: order-free up to rounding
+            ok, why = True, ""
+            try:
+                got = comm.allreduce_rmsnorm(part).float().to(lib_dev)
+                if comm.status() != 0 or not torch.allclose(got, want, rtol=2e-2, atol=2e-2):
+                    ok, why = False, "all-reduce self-test mismatch / timeout"
+            except Exception as e:  # noqa: BLE001 -- a local failure is a vote, not an exit
+                ok, why = False, repr(e)
+            if not unanimous(ok):
+                return give_up(comm, why)
+        if gather_bytes >= 2 * 32 * 2:  # stage 4
+            y = torch.randn(2, 32, device="cuda", generator=gen).to(torch.bfloat16)
+            ref = [torch.empty(2, 32, dtype=torch.float32, device=lib_dev) for _ in range(world)]
+            dist.all_gather(ref, y.float().to(lib_dev), group=group)
+            ok, why = True, ""
+            try:
+                got = comm.all_gather_last_dim(y).float().to(lib_dev)
+                if comm.status() != 0 or not torch.equal(got, torch.cat(ref, dim=-1)):
+                    ok, why = False, "all-gather self-test mismatch / timeout"
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, repr(e)
+            if not unanimous(ok):
+                return give_up(comm, why)
     _xgmi = comm
     return True
+
+
+class CollectiveTimeout(RuntimeError):
+    """An in-graph collective gave up waiting for a peer (csrc/comm.hip: bounded spins, sticky error word)."""
+
+
+def check_comm():
+    """Raise CollectiveTimeout if a collective of an EARLIER step timed out.  The kernels cannot raise: a timed-out wait
+    sets the error word, reduces whatever is in the slots and every later collective skips its wait, so the tokens that
+    follow are garbage -- the reference, in that situation, has NCCL's watchdog abort the process.  This is the host
+    side of that contract: a non-blocking read of the pinned copy of the error word, called by the decoders before
+    every step (and, blocking, at the end of generate()), so a stalled peer becomes an exception within one step."""
+    if _xgmi is not None and _xgmi.poll_error() != 0:
+        raise CollectiveTimeout(
+            f"rank {get_tp_rank()}: an xGMI collective timed out waiting for a peer; every result since is invalid")
 
 
 def disable_xgmi():

@@ -61,23 +61,56 @@ class XgmiComm:
     @classmethod
     def from_group(cls, group=None, **kw) -> "XgmiComm":
         """One rank per process: create, exchange the IPC handles over `group` (host objects, any backend),
-        map every peer.  Collective over the group; returns when every rank has mapped every buffer."""
+        map every peer.  Collective over the group and COLLECTIVE-SAFE: a rank whose own stage failed still takes
+        part in every exchange (sending a failure marker), all ranks agree on the outcome of each stage before the
+        next one starts, and either every rank returns a comm or every rank raises RuntimeError -- no rank is ever
+        left alone inside a collective the others have skipped."""
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        comm = cls(rank, world, **kw)
+
+        def agree(ok: bool, what: str, why: str = ""):
+            votes = [None] * world
+            dist.all_gather_object(votes, (bool(ok), why), group=group)
+            bad = [(r, w) for r, (o, w) in enumerate(votes) if not o]
+            if bad:
+                raise RuntimeError(f"xGMI setup failed at '{what}' on rank(s) " + ", ".join(f"{r}: {w}" for r, w in bad))
+
+        comm, handle, why = None, None, ""
+        try:
+            comm = cls(rank, world, **kw)
+            handle = comm.ipc_handle()
+        except Exception as e:  # noqa: BLE001 -- reported to every rank below
+            why = repr(e)
         handles = [None] * world
-        dist.all_gather_object(handles, comm.ipc_handle(), group=group)
-        for peer, h in enumerate(handles):
-            if peer != rank:
-                comm.open_peer(peer, h)
-        dist.barrier(group=group)
+        dist.all_gather_object(handles, handle, group=group)  # a failed rank contributes None
+        try:
+            agree(handle is not None, "create", why)
+            why = ""
+            try:
+                for peer, h in enumerate(handles):
+                    if peer != rank:
+                        comm.open_peer(peer, h)
+            except Exception as e:  # noqa: BLE001
+                why = repr(e)
+            agree(not why, "open_peer", why)
+        except RuntimeError:
+            if comm is not None:
+                comm.close()
+            raise
         return comm
 
     def status(self) -> int:
         """Blocking: 0 = fine, bit 0 = some wait timed out (sticky)."""
         err = ctypes.c_uint32()
         check(_lib.lib().chitu_hip_comm_status(self._h, ctypes.byref(err)), "comm_status")
+        return err.value
+
+    def poll_error(self) -> int:
+        """Non-blocking: the host-visible copy of the error word (0 = nothing reported so far).  Cheap enough to
+        be read before every decode step; no stream is synchronised."""
+        err = ctypes.c_uint32()
+        check(_lib.lib().chitu_hip_comm_poll_error(self._h, ctypes.byref(err)), "comm_poll_error")
         return err.value
 
     def close(self):

@@ -565,6 +565,9 @@ int chitu_hip_sample(const void* logits, int act_dtype, int64_t row_stride, int6
  *     store).  comm_local_ptr / comm_set_peer: the same for ranks that share one process (raw pointers).
  *     Every rank must have created (and thereby zeroed) its buffer before any peer launches a collective.
  *   comm_status: blocking read of the error word (0 = fine, bit 0 = a wait timed out).
+ *   comm_poll_error: NON-blocking read of the pinned host copy of that word (the kernel that times out stores
+ *     both); a serving loop calls it between steps -- where the reference would see NCCL's watchdog abort the
+ *     process (its all_reduce never returns garbage silently) -- without synchronising the stream.
  * COLLECTIVES (enqueue only; every rank of the group must issue the same sequence of calls):
  *   comm_allreduce_rmsnorm -- one launch for [top-k sum ->] all-reduce -> residual add -> RMSNorm -> fp8 quant:
  *     part_r = terms > 1 ? bf16(sum_k float(part[row*part_row_stride + k*term_stride + :])) : part[row]
@@ -587,6 +590,7 @@ int chitu_hip_comm_open_peer(void* comm, int32_t peer, const void* handle_64);
 int chitu_hip_comm_local_ptr(void* comm, void** ptr_out);
 int chitu_hip_comm_set_peer(void* comm, int32_t peer, void* ptr);
 int chitu_hip_comm_status(void* comm, uint32_t* err_out);
+int chitu_hip_comm_poll_error(void* comm, uint32_t* err_out);
 int chitu_hip_comm_destroy(void* comm);
 int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf16, int64_t part_row_stride,
                                      int32_t terms, int64_t term_stride, const void* x_bf16,

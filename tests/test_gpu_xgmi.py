@@ -186,6 +186,28 @@ def test_split_phase_chain_in_place_and_all_gather(world):
         c.close()
 
 
+def test_all_gather_calls_of_changing_shapes_share_one_comm():
+    """The gather's data slots are addressed by (row, cols) of the CALL, so the two-slot parity has to flip per call,
+    not per workgroup: calls whose shapes (and workgroup counts) differ are interleaved here -- with a per-workgroup
+    counter, workgroup 1 of the wide call and workgroup 0 of the narrow ones would disagree on the parity of
+    overlapping bytes.  Split-phase, 4 ranks on one stream, values distinct per call and rank."""
+    world = 4
+    comms = _local_world(world, max_rows=8, max_dim=1024, gather_bytes=8 * 16384 * 2)
+    shapes = [(1, 16384), (3, 8200 - 8), (8, 64), (2, 8192 + 8), (1, 16384), (8, 64), (8, 64), (5, 12000)]
+    for it, (rows, cols) in enumerate(shapes * 2):
+        ys = [((torch.arange(rows * cols, dtype=torch.float32).reshape(rows, cols) % 251) + 1000 * r + 7 * it).to(torch.bfloat16).cuda()
+              for r in range(world)]
+        g = [comms[r].all_gather_last_dim(ys[r], torch.bfloat16, phase=1) for r in range(world)]
+        g = [comms[r].all_gather_last_dim(ys[r], torch.bfloat16, phase=2, into=g[r]) for r in range(world)]
+        torch.cuda.synchronize()
+        want = ocomm.all_gather_last_dim([y.cpu() for y in ys], torch.bfloat16)
+        for r in range(world):
+            assert torch.equal(g[r].cpu(), want), (it, rows, cols, r)
+    assert [c.status() for c in comms] == [0] * world
+    for c in comms:
+        c.close()
+
+
 def test_missing_peer_times_out_instead_of_hanging():
     """Rank 1 never launches: rank 0's wait gives up after the timeout, the error word is sticky and later
     launches return at once."""
@@ -202,11 +224,24 @@ def test_missing_peer_times_out_instead_of_hanging():
     torch.cuda.synchronize()
     first = time.time() - t0
     assert comms[0].status() == 1 and 0.2 < first < 5.0
+    # the host-visible copy needs no synchronisation: it is what the decoders poll before every step
+    assert comms[0].poll_error() == 1 and comms[1].poll_error() == 0
     t0 = time.time()
     for _ in range(20):
         comms[0].allreduce_rmsnorm(part)
     torch.cuda.synchronize()
     assert time.time() - t0 < 0.3 and comms[1].status() == 0
+    # ... and the seam the decoders call turns it into an exception
+    from chitu_amd import tensor_parallel as tp
+
+    tp._xgmi = comms[0]
+    try:
+        with pytest.raises(tp.CollectiveTimeout):
+            tp.check_comm()
+        tp._xgmi = comms[1]
+        tp.check_comm()
+    finally:
+        tp._xgmi = None
     for c in comms:
         c.close()
 
