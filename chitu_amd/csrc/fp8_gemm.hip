@@ -146,17 +146,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // b = bf16( bits(((w&0x80)<<24)|((w&0x7f)<<20)) * (b_s * 2^120) ), acc += dot_bf16(a, b)
 // (triton_kernels.py:453-488).  Weights = A operand of v_mfma_f32_16x16x32_bf16; a lane's
 // 16-B weight load feeds two MFMAs, the bf16 activation fragment uses the same k order.
-__device__ __forceinline__ s16x8 soft_decode8(uint32_t w0, uint32_t w1, float s2) {
-    s16x8 r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t byte = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
-        const uint32_t bits = ((byte & 0x80u) << 24) | ((byte & 0x7fu) << 20);
-        r[i] = (short)f32_to_bf16(__uint_as_float(bits) * s2);
-    }
-    return r;
-}
-
 template <int MT, int WK>
 __global__ __launch_bounds__(64 * WK) void soft_fp8_gemm_kernel(
     const bf16_t* __restrict__ X, const fp8_t* __restrict__ W, const float* __restrict__ WS,

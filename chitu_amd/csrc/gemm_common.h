@@ -167,6 +167,20 @@ __device__ __forceinline__ void gemm_epilogue_v2(f32x4 (&acc)[MT], float* red, v
     }
 }
 
+// soft-fp8 decode of 8 e4m3 bytes to the bf16 values the reference multiplies with (triton_kernels.py:453-488,
+// fused_moe.py:232-276): bits -> f32 by bit placement, x (scale * 2^120) in f32, one rounding to bf16.  NaN codes
+// come out as +-480 * scale, like the reference's.
+__device__ __forceinline__ s16x8 soft_decode8(uint32_t w0, uint32_t w1, float s2) {
+    s16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t byte = ((i < 4 ? w0 : w1) >> (8 * (i & 3))) & 0xffu;
+        const uint32_t bits = ((byte & 0x80u) << 24) | ((byte & 0x7fu) << 20);
+        r[i] = (short)f32_to_bf16(__uint_as_float(bits) * s2);
+    }
+    return r;
+}
+
 // The compute-shaped (128 x 128 tile) form of the W8A8 block-scaled GEMM for prefill-sized M.  Defined in fp8_gemm_tiled.hip.
 void launch_fp8_gemm_tiled(const fp8_t* a, const float* a_s, const fp8_t* b, const float* b_s, void* out, int out_dt,
                            int64_t M, int64_t N, int64_t K, hipStream_t st);

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
             // release, in front of the launch that reads them back; streamed out here they overlap the other workgroups
             const f32x4 v = *reinterpret_cast<const f32x4*>(o_lds + hr * kC + c4 * 4);
             float* dst = part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c4 * 4;
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         }
     }
     CHITU_PROBE_MARK(13);

@@ -223,7 +223,9 @@ def fused_experts_impl(
 ):
     """out[t] = sum_j w[t,j] * W2[e_tj] . (silu(W1[e_tj] x_t)[:I] * (W1[e_tj] x_t)[I:])
 
-    FP8 W8A8 with [128,128] block scales (the DeepSeek-V3/R1 path, fused_moe.py:1130-1307).
+    Modes (fused_moe.py:1130-1307, the branches of fused_moe_kernel:216-298): FP8 W8A8 with [128,128] block scales
+    (use_fp8_w8a8=True: the DeepSeek-V3/R1 path, described below), the same weights with bf16 activations
+    (soft_fp8=True) and bf16 experts (use_fp8_w8a8=False) -- `_fused_experts_bf16_act` --, INT8 W8A8 (use_int8_w8a8).
     Launches: align(16) -> [quant ->] grouped GEMM1 (+ silu*mul) -> grouped GEMM2 (requant +, x routed
     weight) -> top-k sum.  Scratch lives in a persistent workspace (graph-capture safe).
     a1_quant=(q, s): the per-128-group fp8 form of hidden_states if the producer (fused RMSNorm)
@@ -247,12 +249,16 @@ def fused_experts_impl(
         assert aligned is None, "aligned= is wired for the fp8 path only"
         return _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts,
                                    expert_map, w1_scale, w2_scale, reduce_topk)
-    if not use_fp8_w8a8 or soft_fp8 or use_int8_w8a16 or use_int4_w4a16:
+    if use_int8_w8a16 or use_int4_w4a16:
         raise NotImplementedError(
-            "chitu_amd.fused_moe implements the fp8_w8a8 block-scaled path (use_fp8_w8a8=True, "
-            "block_shape=[128,128], soft_fp8=False) and the int8 W8A8 path (use_int8_w8a8=True); other modes "
-            "are not built"
+            "chitu_amd.fused_moe implements the modes the reference's DeepSeek MoE drives (bf16 experts, fp8_w8a8 "
+            "block-scaled experts with soft_fp8 on or off) and int8 W8A8 (use_int8_w8a8=True); the weight-only "
+            "int8 / int4 modes are not built"
         )
+    if not use_fp8_w8a8 or soft_fp8:
+        return _fused_experts_bf16_act(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts,
+                                       expert_map, w1_scale if use_fp8_w8a8 else None,
+                                       w2_scale if use_fp8_w8a8 else None, block_shape, reduce_topk, aligned)
     assert block_shape is not None and list(block_shape) == [128, 128], "block_shape must be [128, 128]"
     assert w1_scale is not None and w2_scale is not None
     assert a1_scale is None and a2_scale is None, "dynamic per-token-group activation scales only"
@@ -463,6 +469,79 @@ def _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, 
     check(lib.chitu_hip_moe_i8_gemm2(P("aq"), P("as"), ptr(w2), ptr(w2_scale), P("sorted"), P("experts"), P("npost"),
                                      ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel),
                                      i64(Nout), i64(I), i64(max_mblocks), st), "moe int8 gemm2")
+    if not reduce_topk:
+        c3_off = off["c3"] - base
+        return ws[c3_off : c3_off + numel * Nout * 2].view(torch.bfloat16).view(num_tokens, topk, Nout)
+    check(lib.chitu_hip_moe_sum(P("c3"), ptr(out), i64(num_tokens), i32(topk), i64(Nout), st), "moe sum")
+    return out
+
+
+def _fused_experts_bf16_act(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts, expert_map,
+                            w1_scale, w2_scale, block_shape, reduce_topk, aligned):
+    """bf16 activations: bf16 experts (w*_scale None; use_fp8_w8a8=False, fused_moe.py:298) or fp8 experts decoded to
+    bf16 in registers (soft_fp8=True, fused_moe.py:232-276).  align(16) -> grouped GEMM1 with SiluAndMul in its epilogue
+    -> grouped GEMM2 (x routed weight) -> top-k sum: the reference's four steps (fused_moe.py:1230-1305) with its
+    rounding points (bf16 after each GEMM, SiluAndMul on bf16 tensors), no activation quantisation."""
+    soft = w1_scale is not None
+    assert hidden_states.dtype == torch.bfloat16, "bf16 activations"
+    if soft:
+        assert block_shape is not None and list(block_shape) == [128, 128], "block_shape must be [128, 128]"
+        assert w2_scale is not None and w1.element_size() == 1 and w2.element_size() == 1
+        assert w1_scale.dtype == torch.float32 and w2_scale.dtype == torch.float32
+        assert w1_scale.is_contiguous() and w2_scale.is_contiguous()
+    else:
+        assert w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16, "bf16 expert weights"
+    require_cuda(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale)
+    num_tokens, K = hidden_states.shape
+    E, N, _ = w1.shape
+    I = N // 2
+    assert w2.shape[0] == E and w2.shape[2] == I, "w2 must be [E, hidden_out, N/2]"
+    Nout = w2.shape[1]
+    assert K % 128 == 0 and I % 128 == 0, "K and the expert width must be multiples of 128"
+    if global_num_experts == -1:
+        global_num_experts = E
+    topk = topk_ids.shape[1]
+    dev = hidden_states.device
+    out = hidden_states if inplace else torch.empty_like(hidden_states)
+    if num_tokens == 0:
+        return out
+    numel = num_tokens * topk
+    topk_ids = topk_ids.contiguous()
+    topk_weights = topk_weights.contiguous()
+    cap = numel + global_num_experts * (_MOE_BLOCK_M - 1)
+    nblk = ceil_div(cap, _MOE_BLOCK_M)
+    rnd = lambda n: (n + 255) // 256 * 256
+    sizes = [("sorted", cap * 4), ("experts", nblk * 4), ("npost", 4), ("cumsum", (global_num_experts + 1) * 4),
+             ("h", numel * I * 2), ("c3", numel * Nout * 2)]
+    ws = workspace.get(sum(rnd(n) for _, n in sizes), dev, "moe")
+    base, off, cur = ws.data_ptr(), {}, 0
+    for name, n in sizes:
+        off[name] = base + cur
+        cur += rnd(n)
+    import ctypes as _ct
+
+    P = lambda name: _ct.c_void_p(off[name])
+    lib, st = _lib.lib(), stream_ptr()
+    max_mblocks = min(nblk, numel)
+    if aligned is None:
+        emap = _expert_map_i32(expert_map, global_num_experts, dev)
+        check(lib.chitu_hip_moe_align_block_size_mapped(ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel),
+                                                        i32(global_num_experts), i32(_MOE_BLOCK_M), P("sorted"), i64(cap),
+                                                        P("experts"), i64(nblk), P("npost"), P("cumsum"), i32(1), ptr(emap), st),
+              "moe_align_block_size")
+        sorted_p, experts_ptr, npost_p = P("sorted"), P("experts"), P("npost")
+    else:
+        a_sorted, a_experts, a_npost = aligned
+        require_cuda(a_sorted, a_experts, a_npost)
+        assert a_sorted.numel() == cap and a_experts.numel() == nblk, "aligned buffers must come from block 16 over global_num_experts"
+        sorted_p, experts_ptr, npost_p = ptr(a_sorted), ptr(a_experts), ptr(a_npost)
+    kind = i32(1 if soft else 0)
+    check(lib.chitu_hip_moe_gemm_bf16(ptr(hidden_states), i32(topk), ptr(w1), ptr(w1_scale), kind, sorted_p, experts_ptr,
+                                      npost_p, ptr(None), i32(0), i32(0), i32(1), P("h"), i64(numel), i64(I), i64(K),
+                                      i64(max_mblocks), st), "moe gemm1 (bf16 activations, silu fused)")
+    check(lib.chitu_hip_moe_gemm_bf16(P("h"), i32(1), ptr(w2), ptr(w2_scale), kind, sorted_p, experts_ptr, npost_p,
+                                      ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), i32(0), P("c3"),
+                                      i64(numel), i64(Nout), i64(I), i64(max_mblocks), st), "moe gemm2 (bf16 activations)")
     if not reduce_topk:
         c3_off = off["c3"] - base
         return ws[c3_off : c3_off + numel * Nout * 2].view(torch.bfloat16).view(num_tokens, topk, Nout)

@@ -194,6 +194,27 @@ int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_fp8, const 
 int chitu_hip_moe_sum(const void* c3_bf16, void* out_bf16, int64_t tokens, int32_t topk, int64_t N,
                       void* stream);
 
+/* ---- fused MoE with bf16 ACTIVATIONS: bf16 experts and soft-fp8 experts (csrc/moe_bf16.hip) --------
+ * The two modes of fused_moe_kernel (chitu/fused_moe.py:62-307) that do not quantise the activations:
+ *   weight_kind 0 -- bf16 weights, `accumulator += tl.dot(a, b)` (:298): fused_experts(use_fp8_w8a8=False), what the
+ *     reference's MoEDeepSeekV3.forward runs for scale-less checkpoints (model_deepseek_v3.py:950-956) and, on every
+ *     non-NVIDIA device, for soft-fp8 ones after weight_dequant_soft_fp8 (:975-993);
+ *   weight_kind 1 -- fp8 e4m3fn weights + [128,128] block scales decoded to bf16 in registers,
+ *     b = bf16(bits(((w & 0x80) << 24) | ((w & 0x7f) << 20)) * (scale * 2^120)) (:232-276): fused_experts(
+ *     use_fp8_w8a8=True, soft_fp8=True), the NVIDIA branch (:968-974) -- same values as kind 0 on the dequantised weights.
+ * One grouped GEMM over moe_align (block 16) output, fp32 accumulation over the whole K, one rounding to bf16:
+ *   out[slot, :] = bf16( (a[slot / a_div, :] . w[e, :, :]^T) * (mul_routed_weight ? topk_weights[slot] : 1) )
+ *   a bf16 [rows, K] (a_div = topk for the first GEMM, 1 for the second); w [E, Nw, K]; w_scale [E, ceil(Nw/128), K/128]
+ *   (kind 1 only); out bf16 [numel, n_out]; expert -1 (expert_map: another rank's) writes zeros.
+ *   silu = 1: Nw = 2*n_out (gate rows | up rows) and out = bf16(bf16(silu(bf16(g))) * bf16(u)) -- GEMM1 followed by
+ *   SiluAndMul on bf16 tensors (fused_moe.py:24-39, :1262-1265) in one launch; silu = 0: Nw = n_out.
+ *   K % 128 == 0; kind 1 with silu: n_out % 128 == 0.  Sum over the top-k with chitu_hip_moe_sum. */
+int chitu_hip_moe_gemm_bf16(const void* a_bf16, int32_t a_div, const void* w, const float* w_scale,
+                            int32_t weight_kind, const int32_t* sorted_token_ids, const int32_t* expert_ids,
+                            const int32_t* num_tokens_post_pad, const void* topk_weights, int32_t weights_dtype,
+                            int32_t mul_routed_weight, int32_t silu, void* out_bf16, int64_t numel, int64_t n_out,
+                            int64_t K, int64_t max_mblocks, void* stream);
+
 /* ---- GQA / MHA decode: RoPE(q in place, k) + paged append of k and v in one launch ----------------
  * Replaces apply_rotary_pos_emb (ops.py:311-326) + the two in-place appends of attn_with_kvcache
  * (attn_backend.py:108-115) in Attention.decode_forward_paged (models/model.py:167-198), same arithmetic.

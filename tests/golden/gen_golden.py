@@ -167,6 +167,26 @@ def gen_fused_moe():
     )
 
 
+def gen_fused_moe_bf16():
+    """The unquantised branch of the reference's fused MoE (use_fp8_w8a8=False), run in fp16 (rounding points live:
+    GEMM outputs, SiluAndMul and the top-k sum round to fp16; the interpreter's float -> fp16 cast is numpy's RNE) and
+    in fp32 (pure algorithm).  bf16 tl.dot is broken in the Triton interpreter, so bf16 itself cannot be
+    generated; the oracle is dtype-generic and pinned on these two."""
+    from chitu.fused_moe import fused_experts_impl
+
+    g = torch.Generator().manual_seed(14)
+    M, E, topk, K, I = 7, 8, 3, 256, 128
+    x32 = (torch.randn(M, K, generator=g) * 0.5).to(torch.float16).float()
+    w1_32 = (torch.randn(E, 2 * I, K, generator=g) * 0.1).to(torch.float16).float()
+    w2_32 = (torch.randn(E, K, I, generator=g) * 0.1).to(torch.float16).float()
+    ids = torch.stack([torch.randperm(E, generator=g)[:topk] for _ in range(M)])
+    wts32 = torch.rand(M, topk, generator=g).to(torch.float16).float()
+    out16 = fused_experts_impl(x32.half(), w1_32.half(), w2_32.half(), wts32.half(), ids, inplace=False, use_fp8_w8a8=False)
+    out32 = fused_experts_impl(x32.clone(), w1_32, w2_32, wts32, ids, inplace=False, use_fp8_w8a8=False)
+    save("fused_moe_bf16", x=x32.numpy(), w1=w1_32.numpy(), w2=w2_32.numpy(), ids=ids.numpy(), wts=wts32.numpy(),
+         out16=out16.float().numpy(), out32=out32.numpy())
+
+
 # ---------------------------------------------------------------- MLA paged decode (fp32-held bf16 values)
 def gen_mla_decode():
     from chitu.triton_decode_attention import _mla_attn_kernel, _mla_softmax_reducev
@@ -306,6 +326,7 @@ GENS = {
     "group_quant": gen_group_quant,
     "append_rope": gen_append_rope,
     "fused_moe": gen_fused_moe,
+    "fused_moe_bf16": gen_fused_moe_bf16,
     "mla_decode": gen_mla_decode,
     "gqa_decode": gen_gqa_decode,
     "mla_prefill": gen_mla_prefill,

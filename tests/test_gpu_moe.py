@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import moe as omoe
-from tests.util import bf16, fp8, golden, max_rel_to_peak
+from tests.util import assert_close_elementwise, bf16, fp8, golden, max_rel_to_peak
 
 pytestmark = pytest.mark.gpu
 
@@ -69,6 +69,86 @@ def test_vs_oracle(M, E, topk, K, I):
     err = max_rel_to_peak(out, ref)
     assert err < REL_TOL, err
     assert ((out.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item() < 5e-3
+
+
+# ---------------------------------------------------------------- bf16-activation modes (fused_moe.py:232-276, :298)
+def run_hip_bf16_act(x, w1, w2, ids, wts, w1s=None, w2s=None, **kw):
+    from chitu_amd import fused_moe
+
+    soft = w1s is not None
+    out = fused_moe.fused_experts(
+        x.cuda().clone(), w1.cuda(), w2.cuda(), wts.cuda(), ids.cuda(), inplace=False, use_fp8_w8a8=soft,
+        w1_scale=w1s.cuda() if soft else None, w2_scale=w2s.cuda() if soft else None, block_shape=[128, 128],
+        soft_fp8=soft, **kw)
+    return out.cpu()
+
+
+BF16_SHAPES = [
+    (1, 32, 8, 7168, 256),    # R1 TP=8 per-expert shapes, bs 1
+    (16, 32, 8, 7168, 256),   # bs 16
+    (33, 16, 4, 512, 128),    # more than one 16-slot tile per expert
+    (5, 8, 2, 256, 128),
+    (7, 8, 3, 384, 640),
+    (4, 64, 6, 2048, 1408 - 1408 % 128),  # V2-Lite-like (1280-wide here: the expert width must keep 128-blocks whole)
+]
+
+
+@pytest.mark.parametrize("M,E,topk,K,I", BF16_SHAPES)
+def test_bf16_experts_vs_oracle(M, E, topk, K, I):
+    """fused_experts(use_fp8_w8a8=False): bf16 weights, bf16 activations -- the reference's MoE for scale-less checkpoints
+    (model_deepseek_v3.py:950-956).  Oracle pinned by the reference's own run (tests/golden/fused_moe_bf16.npz)."""
+    g = torch.Generator().manual_seed(M * 1000 + E + 5)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    w1 = (torch.randn(E, 2 * I, K, generator=g) * K ** -0.5).to(torch.bfloat16)
+    w2 = (torch.randn(E, K, I, generator=g) * I ** -0.5).to(torch.bfloat16)
+    ids = torch.stack([torch.randperm(E, generator=g)[:topk] for _ in range(M)])
+    wts = torch.rand(M, topk, generator=g).to(torch.bfloat16)
+    out = run_hip_bf16_act(x, w1, w2, ids, wts)
+    ref = omoe.fused_experts_bf16(x, w1, w2, wts, ids)
+    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close_elementwise(out, ref, what="bf16 experts")
+    assert torch.equal(out, run_hip_bf16_act(x, w1, w2, ids, wts))  # deterministic
+
+
+@pytest.mark.parametrize("M,E,topk,K,I", BF16_SHAPES)
+def test_soft_fp8_experts_vs_oracle_and_vs_dequantised_bf16(M, E, topk, K, I):
+    """fused_experts(use_fp8_w8a8=True, soft_fp8=True): fp8 weights decoded to bf16 in registers, bf16 activations
+    (fused_moe.py:232-276; the README's `infer.soft_fp8=True`).  Must be the bf16 mode on weight_dequant_soft_fp8's
+    output (what the reference runs on non-NVIDIA devices, model_deepseek_v3.py:975-993): same decode bit for bit,
+    so only the K-block order of the fp32 sum differs."""
+    from chitu_amd import ops
+
+    x, w1, w2, w1s, w2s, ids, wts = make_case(M, E, topk, K, I, seed=M * 1000 + E + 9)
+    out = run_hip_bf16_act(x, w1, w2, ids, wts, w1s, w2s)
+    ref = omoe.fused_experts_soft_fp8(x, w1, w2, wts, ids, w1s, w2s)
+    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close_elementwise(out, ref, what="soft-fp8 experts")
+    torch.set_default_dtype(torch.bfloat16)  # the dequant's output dtype is torch's default, as in the reference (ops.py:413)
+    try:
+        w1d = torch.stack([ops.weight_dequant_soft_fp8_deepseek_v3(w1[e].cuda(), w1s[e].cuda()) for e in range(E)])
+        w2d = torch.stack([ops.weight_dequant_soft_fp8_deepseek_v3(w2[e].cuda(), w2s[e].cuda()) for e in range(E)])
+    finally:
+        torch.set_default_dtype(torch.float32)
+    via_bf16 = run_hip_bf16_act(x, w1d.cpu(), w2d.cpu(), ids, wts)
+    assert max_rel_to_peak(out, via_bf16) < 4e-3  # one bf16 flip of an intermediate at most
+
+
+def test_bf16_act_modes_expert_map_and_unreduced_output():
+    x, w1, w2, w1s, w2s, ids, wts = make_case(6, 8, 2, 256, 128, seed=19)
+    emap = torch.tensor([0, 1, 2, 3, -1, -1, -1, -1], dtype=torch.int32)
+    wts_masked = torch.where(ids < 4, wts.float(), torch.zeros(())).to(wts.dtype)
+    out = run_hip_bf16_act(x, w1[:4].contiguous(), w2[:4].contiguous(), ids, wts, w1s[:4].contiguous(), w2s[:4].contiguous(),
+                           expert_map=emap.cuda(), global_num_experts=8)
+    ref = omoe.fused_experts_soft_fp8(x, w1, w2, wts_masked, ids, w1s, w2s)
+    assert max_rel_to_peak(out, ref) < REL_TOL
+    un = run_hip_bf16_act(x, w1, w2, ids, wts, w1s, w2s, reduce_topk=False)
+    assert tuple(un.shape) == (6, 2, 256)
+    assert torch.equal(un.float().sum(1).to(torch.bfloat16), run_hip_bf16_act(x, w1, w2, ids, wts, w1s, w2s))
+    from chitu_amd import fused_moe
+
+    for bad in ({"use_int8_w8a16": True}, {"use_int4_w4a16": True}):
+        with pytest.raises(NotImplementedError):
+            fused_moe.fused_experts(x.cuda(), w1.cuda(), w2.cuda(), wts.cuda(), ids.cuda(), **bad)
 
 
 def test_inplace_fp32_weights_and_determinism():

@@ -151,6 +151,31 @@ def test_fused_moe_bit_exact_under_interpreter_casts(interpreter_casts):
     assert mism < 0.02, mism  # fp32 dot summation order inside tl.dot is the only freedom left
 
 
+def test_fused_moe_unquantised_branch_vs_reference_fixture():
+    """oracle.moe.fused_experts_bf16 (dtype-generic) against the reference's fused_experts_impl(use_fp8_w8a8=False) run
+    in fp16 (every rounding point live) and in fp32 (the algorithm alone): tests/golden/gen_golden.py fused_moe_bf16."""
+    g = golden("fused_moe_bf16")
+    x, w1, w2, wts = (torch.from_numpy(g[k]) for k in ("x", "w1", "w2", "wts"))
+    ids = torch.from_numpy(g["ids"])
+    o32 = omoe.fused_experts_bf16(x, w1, w2, wts, ids)
+    assert max_rel_to_peak(o32, torch.from_numpy(g["out32"])) < 1e-5  # fp32: summation order only
+    o16 = omoe.fused_experts_bf16(x.half(), w1.half(), w2.half(), wts.half(), ids)
+    ref16 = torch.from_numpy(g["out16"])
+    assert max_rel_to_peak(o16, ref16) < 2e-3
+    assert (o16.float() != ref16).float().mean() < 0.05  # a last-bit fp16 flip where an fp32 sum lands on a tie
+    # the soft-fp8 branch = the same arithmetic on soft-dequantised weights (model_deepseek_v3.py:975-993)
+    gq = golden("fused_moe_fp8")
+    xb, w1q, w2q = bf16(gq["x"]), fp8(gq["w1"]), fp8(gq["w2"])
+    w1s, w2s = torch.from_numpy(gq["w1s"]), torch.from_numpy(gq["w2s"])
+    soft = omoe.fused_experts_soft_fp8(xb, w1q, w2q, bf16(gq["wts"]), torch.from_numpy(gq["ids"]), w1s, w2s)
+    w1d = torch.stack([ofp8.weight_dequant_soft_fp8_deepseek_v3(w1q[e], w1s[e]) for e in range(w1q.shape[0])])
+    w2d = torch.stack([ofp8.weight_dequant_soft_fp8_deepseek_v3(w2q[e], w2s[e]) for e in range(w2q.shape[0])])
+    assert torch.equal(soft, omoe.fused_experts_bf16(xb, w1d, w2d, bf16(gq["wts"]), torch.from_numpy(gq["ids"])))
+    # ... and differs from the W8A8 branch only by the activation quantisation (a few % of the peak at these sizes)
+    hard = omoe.fused_experts_fp8(xb, w1q, w2q, bf16(gq["wts"]), torch.from_numpy(gq["ids"]), w1s, w2s)
+    assert max_rel_to_peak(soft, hard) < 0.1
+
+
 def test_fp8_gemm_and_dequant():
     g = golden("fp8_linear")
     c = ofp8.fp8_gemm_deepseek_v3(fp8(g["xq"]), torch.from_numpy(g["xs"]), fp8(g["w"]), torch.from_numpy(g["ws"]))
