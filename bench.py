@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--ctx", type=int, default=1024)
     ap.add_argument("--layers", type=int, default=61, help="debug only: fewer layers => result flagged invalid")
     ap.add_argument("--router-std", type=float, default=None, help="debug only: synthetic router weight std (result flagged invalid)")
+    ap.add_argument("--opt", type=str, default="", help="debug only: launch-variant overrides name=value,... (chitu_hip_debug_option; same results by construction, still reported in the line)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 and bs=32 measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -639,6 +640,12 @@ def mixtral_extra(steps, warmup, ctx):
 def main():
     a = parse()
     rank, world, local, dinfo = setup_dist(a.gpus)
+    if a.opt:  # A/B of launch variants on one box (tools): identical results, different kernels
+        from chitu_amd import _lib
+
+        for kv in a.opt.split(","):
+            k, v = kv.split("=")
+            _lib.check(_lib.lib().chitu_hip_debug_option(_lib.i32(_lib.DEBUG_OPTIONS[k]), _lib.i32(int(v))), "debug_option")
     use_graph = not a.no_graph
     if dinfo["shared_device"]:
         # all ranks on one GPU: keep the layers that fit (1.45 GB per layer and rank); flagged invalid below
@@ -759,6 +766,8 @@ def main():
             "device_state_under_load": dev_state.summary(),
         }
         res.update(extra)
+        if a.opt:
+            res["launch_variant_overrides"] = a.opt
         if coll and coll.get("xgmi_error_word"):
             res["invalid"] = "an xGMI collective timed out (error word != 0): the step's results and timings are void"
         elif a.layers != 61 or a.router_std is not None or dinfo["shared_device"]:

@@ -124,7 +124,7 @@ class HipAttnBackend(AttnBackend):
         partials = return_partials and num_splits > 1
         if out is None and not partials:
             out = torch.empty(B, H, C, dtype=torch.bfloat16, device=q_nope.device)
-        need = B * H * num_splits * (C + 1) * 4 if num_splits > 1 else 0
+        need = B * H * num_splits * (C * 2 + 4) if num_splits > 1 else 0  # bf16 partial rows + fp32 LSE
         ws = workspace.get(max(need, 1), q_nope.device, "mla")
         check(
             _lib.lib().chitu_hip_mla_decode(

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
 // into LDS while the 64 KB W_UV[h] tile (requested first) is in flight; wave w then owns output
 // columns [16w, 16w+16).  The MFMA tile's 16 token columns all carry token b (LDS broadcast).
 __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
-    const float* __restrict__ part_o, const float* __restrict__ part_lse, int S, const fp8_t* __restrict__ W,
+    const bf16_t* __restrict__ part_o, const float* __restrict__ part_lse, int S, const fp8_t* __restrict__ W,
     int64_t w_sh, const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sk,
     fp8_t* __restrict__ q, float* __restrict__ qs, int H) {
     constexpr int K = 512, KC = 8;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
         // addresses do not depend on them), so the launch pays one memory round trip, not two; same sums, same order
         float v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = part_o[(bh * S + min(i, S - 1)) * K + tid];
+        for (int i = 0; i < 16; ++i) v[i] = bf16_to_f32(part_o[(bh * S + min(i, S - 1)) * K + tid]);
         const float l = lane < S ? part_lse[bh * S + lane] : -INFINITY;
         const float m = wave_reduce_max(l);
         const float wl = l == -INFINITY ? 0.f : __expf(l - m);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
             for (int i0 = 0; i0 < n; i0 += 16) {
                 float v[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) v[i] = part_o[(bh * S + s0 + min(i0 + i, n - 1)) * K + tid];
+                for (int i = 0; i < 16; ++i) v[i] = bf16_to_f32(part_o[(bh * S + s0 + min(i0 + i, n - 1)) * K + tid]);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const float ws = i0 + i < n ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (i0 + i) & 63)) : 0.f;
@@ -359,8 +359,8 @@ extern "C" int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, in
     CHITU_REQUIRE(batch >= 0 && heads >= 1 && num_splits >= 2 && num_splits <= 256 && w_stride_h % 16 == 0);
     if (K != 512) return CHITU_ERR_UNSUPPORTED;
     if (batch == 0) return CHITU_OK;
-    const float* part_o = (const float*)workspace;
-    const float* part_lse = part_o + (int64_t)batch * heads * num_splits * 512;
+    const bf16_t* part_o = (const bf16_t*)workspace;  // chitu_hip_mla_decode's layout: bf16 rows | fp32 LSE
+    const float* part_lse = (const float*)(part_o + (int64_t)batch * heads * num_splits * 512);
     hipLaunchKernelGGL(mla_merge_uv_quant_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(512), 0,
                        (hipStream_t)stream, part_o, part_lse, (int)num_splits, (const fp8_t*)w_fp8, w_stride_h,
                        scale, scale_offset, scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales, (int)heads);

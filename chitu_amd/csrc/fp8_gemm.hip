@@ -18,6 +18,13 @@
 // kernel): deterministic, no atomics.
 #include "common.h"
 #include "gemm_common.h"
+// Profiling aid, compile-time only: a probe build (hipcc -DCHITU_GEMM_PHASE_MASK=<bits>) drops parts of fp8_gemm_kernel
+// (1: activation loads, 2: MFMAs, 4: activation-scale loads, 8: weight loads) to price them; such a build computes
+// garbage and is never shipped.  16: address the activations as if they were laid out tile-major ([K/16][16 tokens][16 B],
+// scales [K/128][16 tokens]) -- timing only.
+#ifndef CHITU_GEMM_PHASE_MASK
+#define CHITU_GEMM_PHASE_MASK 0
+#endif
 
 namespace chitu {
 
@@ -67,28 +74,48 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
         const int m = min(m_base + mt * 16 + j, M - 1);
         xp[mt] = X + (size_t)m * K + g * 16;
         xsp[mt] = XS + (size_t)m * KB;
+        if (CHITU_GEMM_PHASE_MASK & 16) {
+            xp[mt] = X + (size_t)(g * 16 + (m & 15)) * 16;
+            xsp[mt] = XS + (m & 15);
+        }
     }
 
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    constexpr int dbg = CHITU_GEMM_PHASE_MASK;  // 0 in every shipped build (see the macro)
     auto load = [&](GemmStage<MT>& st, int kb) {
         const int off = kb << 7;
-        st.w.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + off));
-        st.w.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + off));
+        if (!(dbg & 8)) {
+            st.w.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp0 + off));
+            st.w.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp1 + off));
+        } else {
+            st.w.w[0] = st.w.w[1] = i32x4{kb, lane, 3, 4};
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            st.x[mt][0] = *reinterpret_cast<const i32x4*>(xp[mt] + off);
-            st.x[mt][1] = *reinterpret_cast<const i32x4*>(xp[mt] + off + 64);
-            st.xs[mt] = xsp[mt][kb];
+            if (dbg & 16) {  // chunk c = kb*8 + g (+4): 16 tokens x 16 B = 256 B per chunk
+                st.x[mt][0] = *reinterpret_cast<const i32x4*>(xp[mt] + (size_t)kb * 2048);
+                st.x[mt][1] = *reinterpret_cast<const i32x4*>(xp[mt] + (size_t)kb * 2048 + 1024);
+            } else if (!(dbg & 1)) {
+                st.x[mt][0] = *reinterpret_cast<const i32x4*>(xp[mt] + off);
+                st.x[mt][1] = *reinterpret_cast<const i32x4*>(xp[mt] + off + 64);
+            } else {
+                st.x[mt][0] = st.x[mt][1] = i32x4{kb, lane, 1, 2};
+            }
+            st.xs[mt] = (dbg & 4) ? 1.0f : (dbg & 16) ? xsp[mt][kb * 16] : xsp[mt][kb];
         }
         st.ws = wsp[kb];
     };
     auto compute = [&](const GemmStage<MT>& st) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const f32x4 blk = w8a8_block_dot(st.w, st.x[mt][0], st.x[mt][1]);
+            f32x4 blk;
+            if (!(dbg & 2)) blk = w8a8_block_dot(st.w, st.x[mt][0], st.x[mt][1]);
+            else
+                blk = f32x4{__int_as_float(st.w.w[0][0] ^ st.x[mt][0][0]), __int_as_float(st.w.w[0][1] ^ st.x[mt][1][1]),
+                            __int_as_float(st.w.w[1][2] ^ st.x[mt][0][2]), __int_as_float(st.w.w[1][3] ^ st.x[mt][1][3])};
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mt][r] += (blk[r] * st.xs[mt]) * st.ws;
         }

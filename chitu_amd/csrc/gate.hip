@@ -243,6 +243,7 @@ struct RouteAlign {
     int32_t* cumsum;
     const int32_t* expert_map;
     unsigned int* ticket;
+    int small;                // 1: the one-workgroup launch sorts with moe_align_small_* (set by the launcher, never by callers)
 };
 
 // Called by EVERY thread of every routing workgroup after its ids are written.  The hand-off is the
@@ -586,6 +587,15 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     int* align_lds = dyn_lds + nwaves * E + 2 * ((M * out_stride + 1) & ~1);
     const int lane = threadIdx.x & 63, t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the wave's token: wave-uniform
     CHITU_PROBE_MARK(0);
+    // The sort's order-free half rides in the routing (moe_align_device.h, moe_align_small_*): the token masks are zeroed
+    // and the sentinels written NOW, while the logits are on their way; every token wave ORs its bit into the masks of the
+    // experts it picks; after the routing barrier only one scan and the scatter are left.  (SMALL: launcher's choice.)
+    const bool small_sort = al.small != 0;
+    if (small_sort) {
+        moe_align_small_init(al.num_experts, (int64_t)M * out_stride, al.sorted_ids, al.sorted_cap, al.expert_ids, al.expert_cap,
+                             align_lds, (int)threadIdx.x, (int)blockDim.x);
+        __syncthreads();
+    }
     if (t < M) {  // wave-uniform
         // ---- logits of experts 4*lane .. 4*lane+3: all loads up front
         float lg[4];
@@ -682,11 +692,13 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
             out_w[(int64_t)t * out_stride + lane] = f32_to_bf16(w);
             out_ids[(int64_t)t * out_stride + lane] = we;
             ids_lds[t * out_stride + lane] = we;
+            if (small_sort) moe_align_small_mark(align_lds, we, t);
         }
         if (lane < extra_n && extra_id >= 0) {  // always-on (shared) experts appended as slots topk .. topk+extra_n-1
             out_ids[(int64_t)t * out_stride + topk + lane] = extra_id + lane;
             out_w[(int64_t)t * out_stride + topk + lane] = f32_to_bf16(extra_w);
             ids_lds[t * out_stride + topk + lane] = extra_id + lane;
+            if (small_sort) moe_align_small_mark(align_lds, extra_id + lane, t);
         }
     }
     CHITU_PROBE_MARK(2);
@@ -696,6 +708,12 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     // counts at s_barrier), so the sort's barriers and per-wave histograms span 5 waves instead of up to 16
     const int sort_waves = min((int)(blockDim.x >> 6), max((al.num_experts + 63) >> 6, (M * out_stride + 63) >> 6));
     if (t >= sort_waves) return;
+    if (small_sort) {
+        moe_align_small_tail(ids_lds, M * out_stride, out_stride, al.num_experts, al.block_size, al.sorted_ids, al.sorted_cap,
+                             al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, al.expert_map, align_lds, sort_waves * 64);
+        CHITU_PROBE_MARK(4);
+        return;
+    }
     moe_align_workgroup<int64_t>(ids_lds, (int64_t)M * out_stride, al.num_experts, al.block_size, al.sorted_ids,
                                  al.sorted_cap, al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, 1,
                                  al.expert_map, align_lds, sort_waves * 64);
@@ -790,11 +808,15 @@ static int gate_route_launch(const void* logits, int32_t num_partials, int64_t t
         const size_t wg_lds = sizeof(int) * ((size_t)(wg_threads / 64) * 256 + ids_ints +
                                              moe_align_lds_ints(al.num_experts, wg_threads));
         CHITU_REQUIRE(wg_threads <= 1024 && wg_lds <= 64 * 1024);
+        // ids distinct within a token (top-k of distinct routed experts + always-on ids past them): the sort's order-free
+        // half rides in the routing (moe_align_small_*); option 15 = 0 keeps the general sort (equivalence tests, A/B)
+        RouteAlign alw = al;
+        alw.small = (extra_expert_id < 0 || extra_expert_id >= num_experts) && debug_option(kOptGateSmallSort) != 0 ? 1 : 0;
 #define LAUNCHW(GSV)                                                                                          \
     hipLaunchKernelGGL(gate_route_align_wg_kernel<GSV>, dim3(1), dim3(wg_threads), wg_lds, st, logits,         \
                        (int)num_partials, (int)tokens, (const bf16_t*)bias_bf16, (int)n_groups, (int)topk_groups, \
                        (int)topk, route_scale, (bf16_t*)out_weights_bf16, out_ids, (int)out_stride,           \
-                       (int)extra_expert_id, extra_weight, (int)extra_count, al)
+                       (int)extra_expert_id, extra_weight, (int)extra_count, alw)
         if (gs == 32) LAUNCHW(32);
         else LAUNCHW(0);
 #undef LAUNCHW
@@ -857,7 +879,7 @@ extern "C" int chitu_hip_gate_route_align(const void* logits, int32_t num_partia
     // the sort runs over out_ids as a dense [tokens * out_stride] array: every column must be written
     CHITU_REQUIRE(out_stride == topk + (extra_expert_id >= 0 ? extra_count : 0));
     chitu::RouteAlign al{align_num_experts, align_block_size, sorted_token_ids, sorted_cap, expert_ids, expert_ids_cap,
-                         num_tokens_post_pad, cumsum, expert_map, ticket};
+                         num_tokens_post_pad, cumsum, expert_map, ticket, 0};
     return gate_route_launch(logits, num_partials, tokens, num_experts, bias_bf16, n_groups, topk_groups, topk,
                              score_func, route_scale, out_weights_bf16, out_ids, out_stride, extra_expert_id,
                              extra_weight, extra_count, al, stream);

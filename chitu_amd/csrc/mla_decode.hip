@@ -12,7 +12,7 @@
 //
 // Design.  One workgroup (4 waves) = 16 heads x one KV split of one sequence.  Per 64-token
 // tile: coalesced 16-B global loads of the 64 x 576 bf16 rows, register-staged one tile ahead,
-// into LDS (row stride padded to 1168 B for the ds_read_b128 K fragments); QK^T: each wave owns
+// into LDS (row stride padded to 1184 B for the ds_read_b128 K fragments); QK^T: each wave owns
 // 16 tokens, 18 x v_mfma_f32_16x16x32_bf16 with Q (A operand) read from its own LDS copy;
 // online softmax in fp32 with 16-lane shuffles + a 4-wave LDS exchange; P -> bf16 -> LDS;
 // PV: each wave owns 128 latent columns, V^T fragments come straight from the row-major tile
@@ -32,7 +32,9 @@ constexpr int kC = 512;        // kv_lora_rank (latent / V width)
 constexpr int kR = 64;         // qk_rope_head_dim
 constexpr int kD = kC + kR;    // cached row width (576)
 constexpr int kTile = 64;      // KV tokens per tile
-constexpr int kRowB = 1168;    // LDS row stride in bytes (1152 + 16 pad)
+constexpr int kRowB = 1184;    // LDS row stride in bytes (1152 + 32 pad): 296 dwords = 40 mod 64 banks, which makes the 16 rows of a
+                               // ds_read_b128 lane group land on 16 distinct 16-B slots (1168 left them 2-way conflicted: 34 % of the
+                               // LDS cycles, r02 PMC); the transpose reads of PV stay 2-way at any 16-B-aligned stride
 constexpr int kPStride = 72;   // P row stride in bf16 elements (64 + 8 pad)
 constexpr int kMaxTilesLds = 512;  // page ids cached in LDS per split (32k tokens)
 
@@ -46,12 +48,12 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     const bf16_t* __restrict__ q_nope, int64_t qn_sb, int64_t qn_sh, const bf16_t* __restrict__ q_pe,
     int64_t qp_sb, int64_t qp_sh, const bf16_t* __restrict__ cache, int64_t num_pages, int page_size,
     const int32_t* __restrict__ block_table, int table_stride, const int32_t* __restrict__ seqlens,
-    float scale, float* __restrict__ part_o, float* __restrict__ part_lse, bf16_t* __restrict__ out,
+    float scale, bf16_t* __restrict__ part_o, float* __restrict__ part_lse, bf16_t* __restrict__ out,
     int H, int num_splits) {
     constexpr int dbg = CHITU_MLA_PHASE_MASK;  // 0 in every shipped build (see the macro)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* kv_lds = smem;                                   // [64][1168]
-    uint8_t* q_lds = smem + kTile * kRowB;                    // [16][1168]
+    uint8_t* kv_lds = smem;                                   // [64][kRowB]
+    uint8_t* q_lds = smem + kTile * kRowB;                    // [16][kRowB]
     bf16_t* p_lds = reinterpret_cast<bf16_t*>(q_lds + 16 * kRowB);  // [16][72]
     float* red_max = reinterpret_cast<float*>(q_lds + 16 * kRowB + 16 * kPStride * 2);  // [4][16]
     float* red_sum = red_max + 64;                                                      // [4][16]
@@ -243,37 +245,40 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         }
         return;
     }
-    // split partials: transposed through LDS (the KV tile is dead) so every thread stores 16-B
-    // pieces of whole rows instead of 32 scattered dwords
+    // split partials: transposed through LDS (the KV tile is dead) so every thread stores 16-B pieces of whole rows
+    // instead of scattered elements.  Partials leave as BF16 (the normalised o of a split is an attention output:
+    // the merge's convex combination keeps the 2^-9 rounding below the final output's own) + the fp32 LSE: half the
+    // bytes of the write here and of the read-back in the merge -- 4.2 MB instead of 8.4 per bs-16 launch, which at one
+    // tile per workgroup were 45 % of the KV bytes.
     __syncthreads();
-    float* o_lds = reinterpret_cast<float*>(kv_lds);  // [16][512] f32 = 32 KB
+    bf16_t* o_lds = reinterpret_cast<bf16_t*>(kv_lds);  // [16][512] bf16 = 16 KB
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float inv = empty ? 0.f : 1.0f / l_run[r];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o_lds[(g * 4 + r) * kC + wave * 128 + c * 16 + j] = o[c][r] * inv;
+        for (int c = 0; c < 8; ++c) o_lds[(g * 4 + r) * kC + wave * 128 + c * 16 + j] = f32_to_bf16(o[c][r] * inv);
         const int h = h0 + g * 4 + r;
         if (wave == 0 && j == 0 && h < H)
             part_lse[((int64_t)b * H + h) * num_splits + split] = empty ? -INFINITY : m_run[r] + __logf(l_run[r]);
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
         const int chunk = tid + i * 256;
-        const int hr = chunk >> 7, c4 = chunk & 127;
+        const int hr = chunk >> 6, c8 = chunk & 63;
         if (h0 + hr < H) {
-            // write-through (sc1): 8.4 MB of partials left DIRTY in the L2s would be flushed by the end-of-kernel
-            // release, in front of the launch that reads them back; streamed out here they overlap the other workgroups
-            const f32x4 v = *reinterpret_cast<const f32x4*>(o_lds + hr * kC + c4 * 4);
-            float* dst = part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c4 * 4;
+            // write-through (sc1): partials left DIRTY in the L2s would be flushed by the end-of-kernel release, in
+            // front of the launch that reads them back; streamed out here they overlap the other workgroups
+            const i32x4 v = *reinterpret_cast<const i32x4*>(o_lds + hr * kC + c8 * 8);
+            bf16_t* dst = part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c8 * 8;
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         }
     }
     CHITU_PROBE_MARK(13);
 }
 
-// Stage 2: out[b,h,:] = sum_s w_s * part_o[b,h,s,:] / sum_s w_s, w_s = exp(lse_s - max lse).
-__global__ __launch_bounds__(128) void mla_merge_kernel(const float* __restrict__ part_o,
+// Stage 2: out[b,h,:] = sum_s w_s * part_o[b,h,s,:] / sum_s w_s, w_s = exp(lse_s - max lse).  part_o bf16, sums fp32.
+__global__ __launch_bounds__(128) void mla_merge_kernel(const bf16_t* __restrict__ part_o,
                                                         const float* __restrict__ part_lse,
                                                         bf16_t* __restrict__ out, int num_splits) {
     const int64_t bh = blockIdx.x;
@@ -283,21 +288,25 @@ __global__ __launch_bounds__(128) void mla_merge_kernel(const float* __restrict_
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     float wsum = 0.f;
     for (int s0 = 0; s0 < num_splits; s0 += 8) {  // 8 partial rows in flight
-        f32x4 v[8];
+        i32x2 v[8];
         float w[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int s = s0 + i;
             const float l = s < num_splits ? lse[s] : -INFINITY;
             w[i] = l == -INFINITY ? 0.f : __expf(l - m);
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (w[i] != 0.f) v[i] = *reinterpret_cast<const f32x4*>(part_o + (bh * num_splits + s) * kC + threadIdx.x * 4);
+            v[i] = i32x2{0, 0};
+            if (w[i] != 0.f) v[i] = *reinterpret_cast<const i32x2*>(part_o + (bh * num_splits + s) * kC + threadIdx.x * 4);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             wsum += w[i];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc[k] += w[i] * v[i][k];
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t u = (uint32_t)v[i][k];
+                acc[2 * k] += w[i] * __uint_as_float(u << 16);
+                acc[2 * k + 1] += w[i] * __uint_as_float(u & 0xffff0000u);
+            }
         }
     }
     const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(128) void mla_merge_kernel(const float* __restrict_
 extern "C" int chitu_hip_mla_decode_workspace_bytes(int32_t batch, int32_t heads, int32_t num_splits,
                                                     int64_t* bytes) {
     if (!bytes || batch < 0 || heads < 1 || num_splits < 1) return CHITU_ERR_BAD_ARG;
-    *bytes = (int64_t)batch * heads * num_splits * (chitu::kC + 1) * 4;
+    *bytes = (int64_t)batch * heads * num_splits * (chitu::kC * 2 + 4);  // bf16 partial rows + fp32 LSE
     return CHITU_OK;
 }
 
@@ -334,13 +343,14 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
     // the kernel's split arithmetic is 32-bit: tiles the table can address x (splits + 1) must stay below 2^31
     CHITU_REQUIRE((int64_t)table_stride * (page_size / kTile) * (num_splits + 1) < (1ll << 31));
     if (batch == 0) return CHITU_OK;
-    float* part_o = nullptr;
+    bf16_t* part_o = nullptr;
     float* part_lse = nullptr;
     if (num_splits > 1) {
-        const int64_t need = (int64_t)batch * heads * num_splits * (kC + 1) * 4;
+        // workspace: bf16 partial rows [batch, heads, splits, 512] | fp32 LSE [batch, heads, splits]
+        const int64_t need = (int64_t)batch * heads * num_splits * (kC * 2 + 4);
         CHITU_REQUIRE(workspace && workspace_bytes >= need);
-        part_o = (float*)workspace;
-        part_lse = part_o + (int64_t)batch * heads * num_splits * kC;
+        part_o = (bf16_t*)workspace;
+        part_lse = (float*)(part_o + (int64_t)batch * heads * num_splits * kC);
     }
     const size_t lds = (kTile + 16) * kRowB + 16 * kPStride * 2 + 2 * 64 * sizeof(float) + kMaxTilesLds * sizeof(int);
     static bool attr_set = false;

@@ -18,7 +18,7 @@ namespace chitu {
 namespace pf {
 constexpr int kC = 512, kR = 64;
 constexpr int kTile = 64;
-constexpr int kRowB = 1168;   // LDS row stride in bytes (1152 + 16 pad)
+constexpr int kRowB = 1184;   // LDS row stride in bytes (1152 + 32 pad): conflict-free ds_read_b128 rows, see mla_decode.hip
 constexpr int kPStride = 72;  // P row stride in bf16 elements
 constexpr int kBQ = 4;        // query tokens per workgroup
 }  // namespace pf
@@ -30,8 +30,8 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_kernel(
     const int32_t* __restrict__ cu_seqlens, float scale, bf16_t* __restrict__ out, int H) {
     using namespace pf;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* kv_lds = smem;                                    // [64][1168]
-    uint8_t* q_lds = smem + kTile * kRowB;                     // [kBQ][16][1168]
+    uint8_t* kv_lds = smem;                                    // [64][kRowB]
+    uint8_t* q_lds = smem + kTile * kRowB;                     // [kBQ][16][kRowB]
     bf16_t* p_lds = reinterpret_cast<bf16_t*>(q_lds + kBQ * 16 * kRowB);  // [16][72]
     float* red_max = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(p_lds) + 16 * kPStride * 2);  // [4][16]
     float* red_sum = red_max + 64;                                                                      // [4][16]

@@ -22,6 +22,11 @@
 // fp32 over bf16 values.  No atomics anywhere: results are run-to-run identical.
 #include "common.h"
 #include "gemm_common.h"
+// Profiling aid, compile-time only (probe builds, never shipped): 1 = moe_gemm1_silu_kernel addresses the activations as
+// if they were laid out tile-major ([K/16][16 tokens][16 B], scales [K/128][16 tokens]; batches <= 16) -- timing only.
+#ifndef CHITU_MOE_PROBE_MASK
+#define CHITU_MOE_PROBE_MASK 0
+#endif
 
 namespace chitu {
 
@@ -169,6 +174,10 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_silu_kernel(
         const int token = (valid ? slot : min(slot0, numel - 1)) / topk;
         const fp8_t* xp = Xq + (size_t)token * K + g * 16;
         const float* xsp = Xs + (size_t)token * KB;
+        if (CHITU_MOE_PROBE_MASK & 1) {
+            xp = Xq + (size_t)(g * 16 + (token & 15)) * 16;
+            xsp = Xs + (token & 15);
+        }
         const fp8_t* Wb = W + (size_t)e * N * K;
         const fp8_t *gp0, *gp1, *up0, *up1;
         w8_lane_ptrs(Wb, n0, N, K, j, g, gp0, gp1);
@@ -182,9 +191,15 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_silu_kernel(
             st.wg.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(gp1 + off));
             st.wu.w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(up0 + off));
             st.wu.w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(up1 + off));
-            st.x[0] = *reinterpret_cast<const i32x4*>(xp + off);
-            st.x[1] = *reinterpret_cast<const i32x4*>(xp + off + 64);
-            st.xs = xsp[kb];
+            if (CHITU_MOE_PROBE_MASK & 1) {
+                st.x[0] = *reinterpret_cast<const i32x4*>(xp + (size_t)kb * 2048);
+                st.x[1] = *reinterpret_cast<const i32x4*>(xp + (size_t)kb * 2048 + 1024);
+                st.xs = xsp[kb * 16];
+            } else {
+                st.x[0] = *reinterpret_cast<const i32x4*>(xp + off);
+                st.x[1] = *reinterpret_cast<const i32x4*>(xp + off + 64);
+                st.xs = xsp[kb];
+            }
             st.wsg = wsgp[kb];
             st.wsu = wsup[kb];
         };

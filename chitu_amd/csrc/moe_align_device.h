@@ -127,4 +127,77 @@ __device__ __forceinline__ void moe_align_workgroup(
     }
 }
 
+// ---- the sort for ONE decode batch of <= 32 tokens whose ids are DISTINCT WITHIN A TOKEN (a router's top-k + always-on
+// slots), split in two so that its order-free half rides inside the routing itself (gate.hip):
+//   moe_align_small_mark:  tmask[e] |= 1 << token            (LDS atomic OR: exact and order-free)
+//   moe_align_small_tail:  count[e] = popcount(tmask[e]); segment starts by one scan; the slot of (token t, expert e)
+//                          is start[e] + popcount(tmask[e] & ((1 << t) - 1)) -- its rank among the tokens that chose e,
+//                          i.e. exactly the stable order of moe_align_workgroup (flat index = t * stride + k grows with t).
+// Bit-identical to moe_align_workgroup(fill = 1) on such ids, in 2 barriers instead of 7 and without the per-wave
+// histograms.  lds: tmask[E] | start[E] | wave_tot[nthreads / 64]; tmask zeroed and the sentinels written by the caller
+// (moe_align_small_init) before the marks.  `nthreads` threads (a multiple of 64, >= E and >= numel) call the tail.
+__host__ __device__ inline size_t moe_align_small_lds_ints(int E, int nthreads) { return (size_t)2 * E + nthreads / 64; }
+
+__device__ __forceinline__ void moe_align_small_init(int E, int64_t numel, int32_t* __restrict__ sorted_ids, int64_t sorted_cap,
+                                                     int32_t* __restrict__ expert_ids, int64_t expert_cap, int* lds,
+                                                     int tid, int nthreads) {
+    for (int i = tid; i < E; i += nthreads) lds[i] = 0;
+    for (int64_t i = tid; i < sorted_cap; i += nthreads) sorted_ids[i] = (int32_t)numel;  // the allocator's sentinels
+    for (int64_t i = tid; i < expert_cap; i += nthreads) expert_ids[i] = 0;                // (fused_moe.py:493-502)
+}
+
+__device__ __forceinline__ void moe_align_small_mark(int* lds, int e, int token) { atomicOr(&lds[e], 1 << token); }
+
+__device__ __forceinline__ void moe_align_small_tail(
+    const int64_t* __restrict__ ids_lds, int numel, int stride, int E, int block_size, int32_t* __restrict__ sorted_ids,
+    int64_t sorted_cap, int32_t* __restrict__ expert_ids, int64_t expert_cap, int32_t* __restrict__ num_post_pad,
+    int32_t* __restrict__ cumsum, const int32_t* __restrict__ expert_map, int* lds, const int nthreads) {
+    const int nwaves = nthreads >> 6;
+    int* tmask = lds;
+    int* start_l = lds + E;
+    int* wave_tot = lds + 2 * E;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int padded = 0;
+    if (tid < E) padded = ((__popc((unsigned)tmask[tid]) + block_size - 1) / block_size) * block_size;
+    int incl = padded;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wave_base = 0, total = 0;
+    for (int w = 0; w < nwaves; ++w) {
+        const int t = wave_tot[w];
+        if (w < wave) wave_base += t;
+        total += t;
+    }
+    incl += wave_base;
+    const int start = incl - padded;
+    if (tid < E) {
+        const int32_t own_id = expert_map ? expert_map[tid] : (int32_t)tid;
+        start_l[tid] = start;
+        cumsum[tid + 1] = incl;
+        for (int i = start; i < incl; i += block_size) {
+            const int b = i / block_size;
+            if (b < expert_cap) expert_ids[b] = own_id;
+        }
+        if (tid == E - 1) *num_post_pad = incl;
+    }
+    if (tid == 0) cumsum[0] = 0;
+    if (expert_map) {  // expert_ids = expert_map[expert_ids] over the WHOLE array: the tail holds expert_map[0]
+        const int32_t tail_id = expert_map[0];
+        for (int64_t b = total / block_size + tid; b < expert_cap; b += nthreads) expert_ids[b] = tail_id;
+    }
+    __syncthreads();
+    if (tid < numel) {
+        const int e = (int)ids_lds[tid];
+        const int t = tid / stride;
+        const int pos = start_l[e] + __popc((unsigned)tmask[e] & ((1u << t) - 1u));
+        if (pos < sorted_cap) sorted_ids[pos] = (int32_t)tid;
+    }
+}
+
 }  // namespace chitu

@@ -560,7 +560,7 @@ def mla_merge_absorb_uv_quant_fp8(partials, num_splits, batch, w, scale, scale_o
     assert w.element_size() == 1 and scale.dtype == torch.float32 and w.dim() == 3 and w.shape[1] == 128
     assert w.stride(2) == 1 and w.stride(1) == w.shape[2] and w.shape[2] == 512 and num_splits >= 2
     H = w.shape[0]
-    assert partials.numel() * partials.element_size() >= batch * H * num_splits * 513 * 4
+    assert partials.numel() * partials.element_size() >= batch * H * num_splits * (512 * 2 + 4)  # bf16 rows + fp32 LSE
     q = torch.empty(batch, H * 128, dtype=torch.float8_e4m3fn, device=w.device)
     s = torch.empty(batch, H, dtype=torch.float32, device=w.device)
     check(

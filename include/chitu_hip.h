@@ -291,7 +291,8 @@ int chitu_hip_embed_rope_gather(const int64_t* tokens, const void* embed_bf16, i
  * 6 ticket-based route + align (1), 7 radix-only sampler (1), 8 dense fp8 GEMM K-split waves, 9 its whole-K-in-flight
  * form for <= 8 blocks per wave (0 = off), 10 / 11 the same two for the bf16 GEMM, 12 K-split waves of the bf16 SwiGLU GEMM,
  * 13 the tiled (compute-shaped) form of the dense fp8 GEMM for M >= 128 (0 = keep streaming the weights per 64 rows),
- * 14 the same for the bf16 GEMM (0 = per 32 rows). */
+ * 14 the same for the bf16 GEMM (0 = per 32 rows), 15 the in-routing sort of the one-workgroup route + align launch (0 = the
+ * general sort after the routing barrier). */
 int chitu_hip_debug_option(int32_t option, int32_t value);
 
 /* ---- arithmetic self-test ----------------------------------------------------------------------
@@ -338,8 +339,8 @@ int chitu_hip_moe_i8_gemm2(const void* a_int8, const float* a_scale, const void*
  *   row appended this step -- append is chitu_hip_append_paged_kv); out [batch, heads, C] bf16.
  *   num_splits: KV splits per sequence (graph-static; any value >= 1 gives the same result up to
  *   fp32 rounding).  workspace: >= chitu_hip_mla_decode_workspace_bytes when num_splits > 1;
- *   it then holds part_o [batch, heads, num_splits, C] f32 followed by part_lse [batch, heads,
- *   num_splits] f32.  out_bf16 == NULL (num_splits > 1 only): skip the merge pass and leave the
+ *   it then holds part_o [batch, heads, num_splits, C] bf16 (each split's normalised output) followed by
+ *   part_lse [batch, heads, num_splits] f32.  out_bf16 == NULL (num_splits > 1 only): skip the merge pass and leave the
  *   partials for chitu_hip_mla_merge_absorb_uv_quant_fp8. */
 int chitu_hip_mla_decode_workspace_bytes(int32_t batch, int32_t heads, int32_t num_splits,
                                          int64_t* bytes);

@@ -147,3 +147,29 @@ def test_route_and_align_in_one_launch_equals_the_two_launches(cfg, M):
         graph.replay()
         torch.cuda.synchronize()
         same(out, run(x, False))
+
+
+@pytest.mark.parametrize("M", [1, 5, 16])
+def test_in_routing_sort_equals_general_sort(M):
+    """The one-workgroup route + align launch with the sort's order-free half inside the routing (token masks by LDS
+    atomic OR, one scan, ranks by popcount: moe_align_small_*) against the same launch with the general sort behind the
+    routing barrier (debug option gate_small_sort = 0): every output identical, R1 router with the shared slot and the
+    expert-parallel map."""
+    from chitu_amd import _lib, ops
+
+    E, K = 256, 1024
+    g = torch.Generator().manual_seed(77 + M)
+    w = (torch.randn(E, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
+    bias = (torch.randn(E, generator=g) * 0.01).to(torch.bfloat16).cuda()
+    emap = torch.full((E,), -1, dtype=torch.int32)
+    emap[64:96] = torch.arange(32, dtype=torch.int32)
+    for extra, em in ((1, None), (0, emap.cuda())):
+        kw = dict(extra_expert_id=E if extra else -1, extra_count=max(extra, 1))
+        for _ in range(3):
+            x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+            a = ops.gate_deepseek_v3(x, w, bias, 8, 4, 8, "sigmoid", 2.5, align=(E + extra, 16, em), **kw)
+            with _lib.debug_option("gate_small_sort", 0):
+                b = ops.gate_deepseek_v3(x, w, bias, 8, 4, 8, "sigmoid", 2.5, align=(E + extra, 16, em), **kw)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            for p, q in zip(a[2], b[2]):
+                assert torch.equal(p, q)

@@ -165,7 +165,7 @@ struct LayerPtrs {
     const i32x4* w1; const i32x4* w2; const i32x4* w3;  // this layer's weights
     const i32x4* x;        // stage 1's input (written before the launch)
     i32x4* o1; i32x4* o2; i32x4* o3;
-    unsigned* st;          // [0]: epoch, [16]: ticket, [32]: cnt1, [48]: cnt2
+    unsigned* st;          // words [0]: epoch, [16]: ticket, [32]: cnt1 (+ per-XCC leader / go words from +64), [512]: cnt2 (likewise)
     int* err; unsigned long long* mism;
     unsigned tag;          // layer tag folded into every output word (checked by the consumer)
 };
@@ -234,8 +234,11 @@ __global__ __launch_bounds__(kThreads) void stage_kernel(LayerPtrs p) {
     if (bad) atomicAdd(p.mism, (unsigned long long)bad);
 }
 
-// B1 / B2: one launch; PREFETCH = weights requested before the dependency wait
-template <bool PREFETCH>
+// B1 / B2: one launch; PREFETCH = weights requested before the dependency wait.
+// B3 (HIER): as B1, but only ONE consumer workgroup per XCC polls the fan-in counter (the first of its XCC to arrive:
+// CAS on a per-XCC "leader of this epoch" word); it then raises a per-XCC go word that the XCC's other consumers poll --
+// a line their own L2 serves, so 8 pollers instead of 256 load the fabric while the producers stream.
+template <bool PREFETCH, bool HIER>
 __global__ __launch_bounds__(kThreads) void fused_kernel(LayerPtrs p) {
     const int b = blockIdx.x;
     unsigned* st = p.st;
@@ -249,7 +252,25 @@ __global__ __launch_bounds__(kThreads) void fused_kernel(LayerPtrs p) {
     };
     auto await = [&](unsigned* cnt, unsigned n) -> bool {
         if (threadIdx.x == 0) {
-            ok_s = spin_ge(cnt, epoch * n, p.err);
+            if (HIER) {
+                const unsigned x = xcc_id();
+                unsigned* lead = cnt + 64 + 32 * x;  // 128-byte apart per XCC
+                unsigned* go = lead + 16;
+                const unsigned old = atomicCAS(lead, epoch - 1, epoch);
+                if (old == epoch - 1) {  // this XCC's poller
+                    ok_s = spin_ge(cnt, epoch * n, p.err);
+                    __hip_atomic_store(go, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    int ok = 1;
+                    for (int spins = 0; (int)(rlx_load(go) - epoch) < 0; ++spins) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (spins > 2000000) { *p.err = 2; ok = 0; break; }
+                    }
+                    ok_s = ok;
+                }
+            } else {
+                ok_s = spin_ge(cnt, epoch * n, p.err);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
@@ -273,12 +294,12 @@ __global__ __launch_bounds__(kThreads) void fused_kernel(LayerPtrs p) {
         bad = check_in<kS2.in16>(p.o1, kS1.wgs * kS1.out16, p.tag, kS1.out16);
         f = fold_w(w);
         store_out(p.o2, wg, kS2.out16, p.tag, f, true);
-        publish(st + 48);
+        publish(st + 512);
     } else {
         const int wg = b - kS1.wgs - kS2.wgs;
         i32x4 w[kS3.w16];
         if (PREFETCH) load_w(w, p.w3, wg);
-        if (!await(st + 48, kS2.wgs)) return;
+        if (!await(st + 512, kS2.wgs)) return;
         if (!PREFETCH) load_w(w, p.w3, wg);
         if (threadIdx.x < 256) {
             const i32x4 v = p.o2[((size_t)(wg % 24) * 8 * kS2.out16 + threadIdx.x) % (kS2.wgs * kS2.out16)];
@@ -303,7 +324,7 @@ int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     unsigned* state; int* err; unsigned long long* mism; uint32_t* buf; unsigned* n_xcc;
-    CK(hipMalloc(&state, 4096)); CK(hipMalloc(&err, 4)); CK(hipMalloc(&mism, 8)); CK(hipMalloc(&buf, 64 << 20)); CK(hipMalloc(&n_xcc, 64));
+    CK(hipMalloc(&state, 8192)); CK(hipMalloc(&err, 4)); CK(hipMalloc(&mism, 8)); CK(hipMalloc(&buf, 64 << 20)); CK(hipMalloc(&n_xcc, 64));
 
     // ---- part A
     const int rounds = 2000;
@@ -315,7 +336,7 @@ int main() {
         printf("census G=%d: workgroups per XCC = %u %u %u %u %u %u %u %u\n", G, h_n[0], h_n[1], h_n[2], h_n[3], h_n[4], h_n[5], h_n[6], h_n[7]);
         for (int kind : {1, 2}) {
             for (int words : {0, 256, 4096}) {
-                CK(hipMemsetAsync(state, 0, 4096, st)); CK(hipMemsetAsync(err, 0, 4, st)); CK(hipMemsetAsync(mism, 0, 8, st));
+                CK(hipMemsetAsync(state, 0, 8192, st)); CK(hipMemsetAsync(err, 0, 4, st)); CK(hipMemsetAsync(mism, 0, 8, st));
                 CK(hipEventRecord(e0, st));
                 if (kind == 1) hipLaunchKernelGGL(barrier_kernel<1>, dim3(G), dim3(256), 0, st, state, n_xcc, active, rounds, buf, words, err, mism);
                 else hipLaunchKernelGGL(barrier_kernel<2>, dim3(G), dim3(256), 0, st, state, n_xcc, active, rounds, buf, words, err, mism);
@@ -329,7 +350,7 @@ int main() {
         }
     }
     for (int G : {128, 256, 512}) {
-        CK(hipMemsetAsync(state, 0, 4096, st)); CK(hipMemsetAsync(err, 0, 4, st)); CK(hipMemsetAsync(mism, 0, 8, st));
+        CK(hipMemsetAsync(state, 0, 8192, st)); CK(hipMemsetAsync(err, 0, 4, st)); CK(hipMemsetAsync(mism, 0, 8, st));
         CK(hipEventRecord(e0, st));
         hipLaunchKernelGGL(flag_kernel, dim3(G), dim3(256), 0, st, state, rounds, buf, err, mism);
         CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
@@ -349,8 +370,8 @@ int main() {
     CK(hipMalloc(&o1, (size_t)kS1.wgs * kS1.out16 * 16)); CK(hipMalloc(&o2, (size_t)kS2.wgs * kS2.out16 * 16)); CK(hipMalloc(&o3, (size_t)kS3.wgs * kS3.out16 * 16));
     printf("part B: %d layers, %.1f MB of weights per layer (%.2f GB in all), stage grids %d / %d / %d x %d threads\n", layers,
            per_layer * 16 / 1e6, per_layer * layers * 16 / 1e9, kS1.wgs, kS2.wgs, kS3.wgs, kThreads);
-    for (int variant = 0; variant < 3; ++variant) {
-        CK(hipMemsetAsync(state, 0, 4096, st)); CK(hipMemsetAsync(err, 0, 4, st)); CK(hipMemsetAsync(mism, 0, 8, st));
+    for (int variant = 0; variant < 4; ++variant) {
+        CK(hipMemsetAsync(state, 0, 8192, st)); CK(hipMemsetAsync(err, 0, 4, st)); CK(hipMemsetAsync(mism, 0, 8, st));
         hipGraph_t graph; hipGraphExec_t exec;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
         for (int l = 0; l < layers; ++l) {
@@ -362,9 +383,11 @@ int main() {
                 hipLaunchKernelGGL(stage_kernel<2>, dim3(kS2.wgs), dim3(kThreads), 0, st, p);
                 hipLaunchKernelGGL(stage_kernel<3>, dim3(kS3.wgs), dim3(kThreads), 0, st, p);
             } else if (variant == 1) {
-                hipLaunchKernelGGL(fused_kernel<true>, dim3(kS1.wgs + kS2.wgs + kS3.wgs), dim3(kThreads), 0, st, p);
+                hipLaunchKernelGGL((fused_kernel<true, false>), dim3(kS1.wgs + kS2.wgs + kS3.wgs), dim3(kThreads), 0, st, p);
+            } else if (variant == 2) {
+                hipLaunchKernelGGL((fused_kernel<false, false>), dim3(kS1.wgs + kS2.wgs + kS3.wgs), dim3(kThreads), 0, st, p);
             } else {
-                hipLaunchKernelGGL(fused_kernel<false>, dim3(kS1.wgs + kS2.wgs + kS3.wgs), dim3(kThreads), 0, st, p);
+                hipLaunchKernelGGL((fused_kernel<true, true>), dim3(kS1.wgs + kS2.wgs + kS3.wgs), dim3(kThreads), 0, st, p);
             }
         }
         CK(hipStreamEndCapture(st, &graph)); CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -379,7 +402,7 @@ int main() {
         int herr; unsigned long long hm; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hm, mism, 8, hipMemcpyDeviceToHost));
         printf("B%d %-62s: %.2f us per layer (best %.2f)  timeout=%d mismatches=%llu\n", variant,
                variant == 0 ? "three graph-captured launches per layer" : variant == 1 ? "ONE launch, weights prefetched before the dependency wait"
-                                                                                       : "ONE launch, weights requested after the wait",
+               : variant == 2 ? "ONE launch, weights requested after the wait" : "ONE launch, prefetch, one poller per XCC + XCC-local go word",
                sum / reps * 1e3 / layers, best * 1e3 / layers, herr, hm);
         CK(hipGraphExecDestroy(exec)); CK(hipGraphDestroy(graph));
     }
