@@ -122,22 +122,21 @@ def enable_collectives(world, max_bs, vocab_local):
 
 
 @torch.inference_mode()  # like the decode step: the capture touches state created under inference mode
-def time_collectives(bs, dim, vocab_local, iters=200):
-    """GPU time of one fused all-reduce launch and one logits all-gather at this batch size: `iters` launches
-    of each captured in a hipGraph, timed with events on the replay stream (every rank runs them)."""
+def time_collectives(bs, dim, vocab_local, iters=200, batches=(1, 16, 32)):
+    """GPU time per launch (`iters` launches captured in a hipGraph, events on the replay stream; every rank runs them) of
+    the step's collectives ALONE, per transport, so that an N > 1 line can be read: the fused [all-reduce + residual add +
+    RMSNorm + fp8 quant] launch on the xGMI kernels in its one-shot and two-shot form, the same launch WITHOUT the
+    collective (chitu_hip_rmsnorm: what a one-rank step pays at that place), the logits all-gather, and the library's
+    (RCCL's) all-reduce / all-gather of the same tensors, eager.  `allreduce_add_norm_quant_us` / `logits_all_gather_us`
+    are at the bench's batch size on the form the step uses."""
+    from chitu_amd import ops
     from chitu_amd import tensor_parallel as tp
 
     comm = tp.xgmi_comm()
-    if comm is None:
-        return None
     gen = torch.Generator(device="cuda").manual_seed(3)
-    part = torch.randn(bs, dim, device="cuda", generator=gen).to(torch.bfloat16)
-    x = torch.randn(bs, dim, device="cuda", generator=gen).to(torch.bfloat16)
     w = torch.ones(dim, device="cuda", dtype=torch.bfloat16)
-    y = torch.randn(bs, vocab_local, device="cuda", generator=gen).to(torch.bfloat16)
-    out = {}
-    for name, fn in (("allreduce_add_norm_quant_us", lambda: comm.allreduce_rmsnorm(part, x, w, 1e-6, out_bf16=False, quant="act")),
-                     ("logits_all_gather_us", lambda: comm.all_gather_last_dim(y, torch.float32))):
+
+    def graph_us(fn):
         fn()
         torch.cuda.synchronize()
         dist.barrier()
@@ -153,8 +152,51 @@ def time_collectives(bs, dim, vocab_local, iters=200):
         g.replay()
         e1.record()
         torch.cuda.synchronize()
-        out[name] = round(e0.elapsed_time(e1) * 1e3 / iters, 2)
         del g
+        return round(e0.elapsed_time(e1) * 1e3 / iters, 2)
+
+    def eager_us(fn, n=50):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) * 1e3 / n, 2)
+
+    out, table = {}, {}
+    for b in sorted(set(batches) | {bs}):
+        part = torch.randn(b, dim, device="cuda", generator=gen).to(torch.bfloat16)
+        x = torch.randn(b, dim, device="cuda", generator=gen).to(torch.bfloat16)
+        y = torch.randn(b, vocab_local, device="cuda", generator=gen).to(torch.bfloat16)
+        row = {"message_KB_per_rank": round(b * dim * 2 / 1024, 1),
+               "norm_quant_without_collective_us": graph_us(lambda: ops.rms_norm(x, w, 1e-6, out_bf16=False, quant="act", add=part))}
+        if comm is not None:
+            default = comm.two_shot_bytes
+            comm.set_two_shot(1 << 60)
+            row["xgmi_one_shot_fused_us"] = graph_us(lambda: comm.allreduce_rmsnorm(part, x, w, 1e-6, out_bf16=False, quant="act"))
+            if (dim // 8) % comm.world == 0:
+                comm.set_two_shot(0)
+                row["xgmi_two_shot_fused_us"] = graph_us(lambda: comm.allreduce_rmsnorm(part, x, w, 1e-6, out_bf16=False, quant="act"))
+            comm.set_two_shot(default)
+            row["xgmi_form_in_step"] = "two-shot" if comm.uses_two_shot(b, dim) else "one-shot"
+            if comm.gather_fits(b, vocab_local):
+                row["xgmi_logits_all_gather_us"] = graph_us(lambda: comm.all_gather_last_dim(y, torch.float32))
+        if dist.get_backend() == "nccl":  # the library's own collectives on the same tensors (eager: not captured here)
+            t = part.clone()
+            row["library_all_reduce_us"] = eager_us(lambda: dist.all_reduce(t))
+            gathered = torch.empty(dist.get_world_size() * b, vocab_local, device="cuda", dtype=torch.bfloat16)
+            row["library_all_gather_us"] = eager_us(lambda: dist.all_gather_into_tensor(gathered, y))
+        table[f"bs{b}"] = row
+    mine = table[f"bs{bs}"]
+    if comm is not None:
+        out["allreduce_add_norm_quant_us"] = mine["xgmi_two_shot_fused_us" if mine["xgmi_form_in_step"] == "two-shot" else "xgmi_one_shot_fused_us"]
+        out["logits_all_gather_us"] = mine.get("xgmi_logits_all_gather_us")
+    out["per_transport"] = table
     return out
 
 
@@ -706,8 +748,8 @@ def main():
                 "fused": "every per-layer all-reduce runs inside the launch that also does the top-k sum, the residual "
                          "add, the RMSNorm and the fp8 quant" if transport.startswith("xgmi") else "no"}
         timing = time_collectives(a.bs, margs.dim, model.vocab_local)
-        if timing:
-            coll.update(timing)
+        coll.update(timing)
+        if timing.get("allreduce_add_norm_quant_us") and timing.get("logits_all_gather_us"):
             coll["collective_ms_per_step_est"] = round(
                 ((n_coll - 1) * timing["allreduce_add_norm_quant_us"] + timing["logits_all_gather_us"]) * 1e-3, 3)
         from chitu_amd import tensor_parallel as tp
@@ -768,7 +810,11 @@ def main():
         res.update(extra)
         if a.opt:
             res["launch_variant_overrides"] = a.opt
-        if coll and coll.get("xgmi_error_word"):
+        if dinfo["ranks_seen"] != a.gpus:
+            # the library's own all-reduce of ones must have seen every rank the line claims
+            res["invalid"] = f"--gpus {a.gpus} but the process group's all-reduce saw {dinfo['ranks_seen']} rank(s): the line is void"
+            res["value"] = None
+        elif coll and coll.get("xgmi_error_word"):
             res["invalid"] = "an xGMI collective timed out (error word != 0): the step's results and timings are void"
         elif a.layers != 61 or a.router_std is not None or dinfo["shared_device"]:
             res["invalid"] = ("debug run: " + ", ".join(

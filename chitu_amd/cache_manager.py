@@ -3,10 +3,11 @@
 Mirrors chitu/cache_manager.py:12-225 (PagedKVCacheManager): same methods, same buffers
 (`curr_seq_lens_gpu_{excl,incl}_this_decode`, `gpu_block_table_buffer`, `paged_kv_cache` /
 `paged_k_cache`+`paged_v_cache`).  Differences, all host-side: the free list is a deque instead
-of `list(set)[0]` (the reference's own TODO, :69), per-step H2D traffic is three small
-copies instead of one per request, and no Timers (their cuda syncs, global_vars.py:132,140,
-would serialise the decode loop).  Device memory layout is unchanged, so the HIP kernels see
-exactly the reference's cache.
+of `list(set)[0]` (the reference's own TODO, :69), per-step H2D traffic is ONE small asynchronous copy from
+pinned memory (the two length vectors; the block table travels only on the steps that change it) instead of
+one blocking copy per request, and no Timers (their cuda syncs, global_vars.py:132,140, would serialise the
+decode loop) -- so the host can prepare step t + 1 while the GPU runs step t.  Device memory layout is unchanged,
+so the HIP kernels see exactly the reference's cache.
 """
 
 from collections import deque
@@ -17,6 +18,7 @@ import torch
 logger = getLogger(__name__)
 _BLOCK_SIZE = 512
 _MAX_SEQ_LEN = 2048
+_STAGE_RING = 4
 
 
 class PagedKVCacheManager:
@@ -57,16 +59,25 @@ class PagedKVCacheManager:
         self.seq_lens = {}
         self.block_table = {}  # req_id -> [block ids]
         self.curr_seq_lens = []
-        self.curr_seq_lens_gpu_excl_this_decode = torch.zeros(num_hot_req, dtype=torch.int32, device=self.device)
-        self.curr_seq_lens_gpu_incl_this_decode = torch.zeros(num_hot_req, dtype=torch.int32, device=self.device)
+        # excl / incl live in one device allocation so that one copy refreshes both (same names and shapes as the reference's)
+        self._lens_dev = torch.zeros(2, num_hot_req, dtype=torch.int32, device=self.device)
+        self.curr_seq_lens_gpu_excl_this_decode = self._lens_dev[0]
+        self.curr_seq_lens_gpu_incl_this_decode = self._lens_dev[1]
         self.gpu_block_table_buffer = torch.zeros(
             (num_hot_req, self.max_blocks_per_req), dtype=torch.int32, device=self.device
         )
-        # Pageable host staging: copy_() from pageable memory returns only after the runtime has staged
-        # the bytes, so these buffers can be rewritten for the next step right away.  (That copy waits for
-        # the stream, as the reference's per-request copies do: the host is never ahead of the GPU here.)
-        self._host_lens = torch.zeros(2, num_hot_req, dtype=torch.int32)
-        self._host_table = torch.zeros((num_hot_req, self.max_blocks_per_req), dtype=torch.int32)
+        # Host staging: a small RING of pinned buffers + copy_(non_blocking=True).  A pageable copy_() returns only after
+        # the runtime has staged the bytes, which waits for the stream -- the host then never runs ahead of the GPU.
+        # From pinned memory the copy is just enqueued; a slot is rewritten _STAGE_RING steps later, after the event
+        # recorded behind its copy has completed (it has, long since, unless the host is that far ahead).
+        self._pinned = self.device.type == "cuda"
+        self._host_lens = torch.zeros(_STAGE_RING, 2, num_hot_req, dtype=torch.int32, pin_memory=self._pinned)
+        self._host_table = torch.zeros((_STAGE_RING, num_hot_req, self.max_blocks_per_req), dtype=torch.int32,
+                                       pin_memory=self._pinned)
+        self._lens_np, self._table_np = self._host_lens.numpy(), self._host_table.numpy()
+        self._stage_events = {"lens": [None] * _STAGE_RING, "table": [None] * _STAGE_RING}
+        self._stage_next = {"lens": 0, "table": 0}
+        self._table_rows = None  # request ids whose rows the device table currently holds, in order (None = stale)
         self.free_blocks = deque(range(self.num_blocks))
         if self.kv_shape_per_sample is not None:
             self.paged_kv_cache = torch.zeros(
@@ -97,6 +108,7 @@ class PagedKVCacheManager:
                 n_prepared = (varlen.cpu_lens[idx] + self.block_size - 1) // self.block_size
                 self.seq_lens[req_id] = varlen.cpu_lens[idx]
                 self.block_table[req_id] = [self.get_free_block() for _ in range(n_prepared)]
+                self._table_rows = None
                 n_tok = varlen.cpu_prefix_lens[idx + 1] - varlen.cpu_prefix_lens[idx]
                 t = torch.arange(n_tok, dtype=torch.int64)
                 blocks = torch.tensor(self.block_table[req_id], dtype=torch.int64)
@@ -119,19 +131,37 @@ class PagedKVCacheManager:
         self.seq_lens[req_id] = length
         n = (length + self.block_size - 1) // self.block_size
         self.block_table[req_id] = [self.get_free_block() for _ in range(n)]
+        self._table_rows = None
 
     def finalize_cache_all_prefill(self, req_ids, varlen):
         self.curr_varlens = None
         self.curr_req_ids = None
 
+    def _stage_slot(self, kind):
+        """Next pinned slot of a ring; waits for the copy that last read it (a no-op unless the host is a ring ahead)."""
+        slot = self._stage_next[kind]
+        self._stage_next[kind] = (slot + 1) % _STAGE_RING
+        ev = self._stage_events[kind][slot]
+        if ev is not None:
+            ev.synchronize()
+        return slot
+
+    def _stage_done(self, kind, slot):
+        if self._pinned:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._stage_events[kind][slot] = ev
+
     def prepare_cache_decode(self, req_ids):
         n = len(req_ids)
         seq_lens = [self.seq_lens[r] for r in req_ids]
         self.curr_seq_lens = seq_lens
-        self._host_lens[0, :n] = torch.tensor(seq_lens, dtype=torch.int32)
-        self._host_lens[1, :n] = self._host_lens[0, :n] + 1
-        self.curr_seq_lens_gpu_excl_this_decode[:n].copy_(self._host_lens[0, :n])
-        self.curr_seq_lens_gpu_incl_this_decode[:n].copy_(self._host_lens[1, :n])
+        slot = self._stage_slot("lens")
+        h = self._lens_np[slot]
+        h[0, :n] = seq_lens
+        h[1, :n] = h[0, :n] + 1
+        self._lens_dev.copy_(self._host_lens[slot], non_blocking=True)  # both vectors, one enqueued copy
+        self._stage_done("lens", slot)
 
     def get_free_block(self):
         if not self.free_blocks:
@@ -159,19 +189,29 @@ class PagedKVCacheManager:
         for block in self.block_table[req_id]:
             self.free_blocks.append(block)
         del self.block_table[req_id]
+        self._table_rows = None
 
     def prepare_block_table_for_decode(self, req_ids):
         """Make room for the token this decode step appends, then refresh the device table
-        (chitu/cache_manager.py:196-209).  Page allocation stays on the host, outside the graph."""
+        (chitu/cache_manager.py:196-209).  Page allocation stays on the host, outside the graph.  The table is copied
+        only on the steps that change it (a request crossed a page boundary, or the batch's rows changed): in a
+        steady decode that is one step in `block_size`."""
         n = len(req_ids)
+        changed = self._table_rows is None or self._table_rows != list(req_ids)
         for req_id in req_ids:
             if self.seq_lens[req_id] % self.block_size == 0:
                 self.block_table[req_id].append(self.get_free_block())
-        self._host_table[:n].zero_()
-        for idx, req_id in enumerate(req_ids):
-            ids = self.block_table[req_id]
-            self._host_table[idx, : len(ids)] = torch.tensor(ids, dtype=torch.int32)
-        self.gpu_block_table_buffer[:n].copy_(self._host_table[:n])
+                changed = True
+        if changed:
+            slot = self._stage_slot("table")
+            h = self._table_np[slot]
+            h[:n] = 0
+            for idx, req_id in enumerate(req_ids):
+                ids = self.block_table[req_id]
+                h[idx, : len(ids)] = ids
+            self.gpu_block_table_buffer[:n].copy_(self._host_table[slot, :n], non_blocking=True)
+            self._stage_done("table", slot)
+            self._table_rows = list(req_ids)
         self.gpu_block_table = self.gpu_block_table_buffer[:n]
 
     def finalize_cache_single_decode(self, req_ids):

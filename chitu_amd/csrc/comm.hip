@@ -22,7 +22,10 @@
 // loads and reduces in RANK ORDER in fp32 with one rounding: every rank computes bit-identical results,
 // whatever the arrival order.  xGMI is point-to-point, a push is one hop, and the messages of a decode
 // step are 14 KB (bs 1) to 458 KB (bs 32) per rank: one-shot (every rank sends its whole row block to
-// all peers) beats a two-hop reduce-scatter + all-gather until the per-link bytes dominate the extra hop.
+// all peers) beats a two-hop reduce-scatter + all-gather until the per-link bytes dominate the extra hop; from
+// `two_shot_bytes` (256 KB per rank by default) on, the SAME launch runs the two-shot form: a row's chunks are dealt to
+// the ranks in slices, hop 1 sends each chunk to its owner only, the owner reduces in rank order and hop 2 sends the
+// reduced chunk to everybody -- 2/world of the bytes per link, one more flag hop, bit-identical results.
 //
 // Replay safety.  Kernel arguments are frozen in a hipGraph, so the call counter lives in device memory:
 // epoch (local, ordinary memory) counts calls -- per ROW for the all-reduce (a row's data slot has a fixed address),
@@ -53,7 +56,8 @@ struct CommPeers {
 struct CommGeom {
     int rank, world, max_rows, max_dim, max_blocks;
     int64_t flags_ar, flags_ag, data_ar, data_ag, ag_bytes;
-    uint32_t data_ar_bytes, data_ag_bytes;  // whole regions (buffer descriptors)
+    int64_t flags_ar2, data_ar2;            // second hop of the two-shot all-reduce: flags[src][row], data[parity][row][max_dim]
+    uint32_t data_ar_bytes, data_ag_bytes, data_ar2_bytes;  // whole regions (buffer descriptors)
     uint64_t timeout_ticks;
     uint32_t* host_err;  // pinned host word (device-visible): set together with the device error word, so the host can
                          // notice a timed-out collective between two steps WITHOUT synchronising the stream
@@ -63,6 +67,7 @@ struct Comm {
     CommGeom g;
     CommPeers peers;
     bool ipc_opened[kCommMaxRanks];
+    int64_t two_shot_bytes;  // all-reduces of at least this many bytes per rank take the two-shot form (host-side choice)
     uint32_t* state;  // device, ordinary memory: epoch_ar[max_rows] | epoch_ag (word 0: the all-gather CALL counter) [max_blocks] | err[4]
     int64_t total;
 };
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
     CommPeers peers, CommGeom g, uint32_t* state, const bf16_t* part, int64_t part_stride, int terms,
     int64_t term_stride, const bf16_t* x, int64_t x_stride, bf16_t* sum_out, int64_t sum_stride,
     const bf16_t* __restrict__ w, bf16_t* y, int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs, int dim,
-    float eps, float qeps, int phase) {
+    float eps, float qeps, int phase, int two_shot) {
     __shared__ float red[kCommThreads / 64];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n_chunks = dim >> 3;
@@ -154,24 +159,28 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
 
     const i32x4 mine = terms == 1 ? traw[0] : sum_terms_bf16x8<kCommMaxTerms>(traw, terms);
 
-    // push this rank's row into its slot of every peer
     const uint32_t slot_off = (uint32_t)(((((int64_t)parity * kCommMaxRanks + g.rank) * g.max_rows + row) * g.max_dim + c * 8) * 2);
-    if (phase != 2) {
+    i32x4 sraw;  // the all-reduced chunk (one rounding)
+    auto reduce_rank_order = [&](const i32x4 (&theirs)[kCommMaxRanks]) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < kCommMaxRanks; ++p) {
-            if (p < g.world && p != g.rank && act) {
-                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[p] + g.data_ar, 0, g.data_ar_bytes, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(mine, rsrc, slot_off, 0, kCommAux);
+        for (int s = 0; s < kCommMaxRanks; ++s) {
+            if (s < g.world) {
+                const i32x4 t = (s == g.rank) ? mine : theirs[s];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t u = (uint32_t)t[i];
+                    a[2 * i] += __uint_as_float(u << 16);
+                    a[2 * i + 1] += __uint_as_float(u & 0xffff0000u);
+                }
             }
         }
-        signal_peers(peers, g, g.flags_ar, g.max_rows, row, epoch);
-        if (phase == 1) return;
-    }
-    await_peers(peers, g, g.flags_ar, g.max_rows, row, epoch, err);
-
-    // reduce in rank order
-    i32x4 theirs[kCommMaxRanks];
-    {
+        i32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = (int)f32x2_to_bf16x2(a[2 * i], a[2 * i + 1]);
+        return r;
+    };
+    auto load_contributions = [&](i32x4 (&theirs)[kCommMaxRanks]) {
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[g.rank] + g.data_ar, 0, g.data_ar_bytes, 0x00020000);
 #pragma unroll
         for (int s = 0; s < kCommMaxRanks; ++s) {
@@ -179,23 +188,69 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
             const uint32_t off = (uint32_t)(((((int64_t)parity * kCommMaxRanks + src) * g.max_rows + row) * g.max_dim + c * 8) * 2);
             theirs[s] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, kCommAux);
         }
-    }
-    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    };
+    if (!two_shot) {
+        // ---- ONE-SHOT: push this rank's whole row into its slot of every peer, wait, reduce everything locally
+        if (phase != 2) {
 #pragma unroll
-    for (int s = 0; s < kCommMaxRanks; ++s) {
-        if (s < g.world) {
-            const i32x4 t = (s == g.rank) ? mine : theirs[s];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t u = (uint32_t)t[i];
-                a[2 * i] += __uint_as_float(u << 16);
-                a[2 * i + 1] += __uint_as_float(u & 0xffff0000u);
+            for (int p = 0; p < kCommMaxRanks; ++p) {
+                if (p < g.world && p != g.rank && act) {
+                    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[p] + g.data_ar, 0, g.data_ar_bytes, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(mine, rsrc, slot_off, 0, kCommAux);
+                }
             }
+            signal_peers(peers, g, g.flags_ar, g.max_rows, row, epoch);
+            if (phase == 1) return;
+        }
+        await_peers(peers, g, g.flags_ar, g.max_rows, row, epoch, err);
+        i32x4 theirs[kCommMaxRanks];
+        load_contributions(theirs);
+        sraw = reduce_rank_order(theirs);
+    } else {
+        // ---- TWO-SHOT (reduce-scatter + all-gather inside the launch): the row's chunks are dealt to the ranks in
+        // `world` contiguous slices; hop 1 sends every chunk only to the rank that owns its slice, the owner reduces it
+        // in rank order (the SAME arithmetic as the one-shot form: results are bit-identical) and hop 2 sends the
+        // reduced chunk to everybody.  Per link 2 * bytes / world instead of bytes: for messages whose transfer time,
+        // not the flag hop, is what a collective costs.  phase 1 = hop 1 only, 3 = wait + reduce + hop 2 only,
+        // 2 = wait + assemble + finish (split phases: all ranks on one stream in the tests).
+        const int cps = n_chunks / g.world;  // chunks per slice (the launcher checked divisibility)
+        const int owner = min(c / cps, g.world - 1);
+        const bool own = act && owner == g.rank;
+        const uint32_t off2 = (uint32_t)((((int64_t)parity * g.max_rows + row) * g.max_dim + c * 8) * 2);
+        if (phase == 0 || phase == 1) {
+            if (act && owner != g.rank) {
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[owner] + g.data_ar, 0, g.data_ar_bytes, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(mine, rsrc, slot_off, 0, kCommAux);
+            }
+            signal_peers(peers, g, g.flags_ar, g.max_rows, row, epoch);
+            if (phase == 1) return;
+        }
+        i32x4 reduced = {0, 0, 0, 0};
+        if (phase == 0 || phase == 3) {
+            await_peers(peers, g, g.flags_ar, g.max_rows, row, epoch, err);
+            if (own) {
+                i32x4 theirs[kCommMaxRanks];
+                load_contributions(theirs);
+                reduced = reduce_rank_order(theirs);
+#pragma unroll
+                for (int p = 0; p < kCommMaxRanks; ++p) {
+                    // (the split-phase form also parks the owner's copy in its own buffer: registers do not survive a launch)
+                    if (p < g.world && (p != g.rank || phase == 3)) {
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[p] + g.data_ar2, 0, g.data_ar2_bytes, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b128(reduced, rsrc, off2, 0, kCommAux);
+                    }
+                }
+            }
+            signal_peers(peers, g, g.flags_ar2, g.max_rows, row, epoch);
+            if (phase == 3) return;
+        }
+        await_peers(peers, g, g.flags_ar2, g.max_rows, row, epoch, err);
+        {
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(peers.buf[g.rank] + g.data_ar2, 0, g.data_ar2_bytes, 0x00020000);
+            const i32x4 got = __builtin_amdgcn_raw_buffer_load_b128(rsrc, act ? off2 : 0u, 0, kCommAux);
+            sraw = (own && phase == 0) ? reduced : got;
         }
     }
-    i32x4 sraw;  // the all-reduce's rounding
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sraw[i] = (int)f32x2_to_bf16x2(a[2 * i], a[2 * i + 1]);
     float v[8];
     if (x) add_bf16x8(xraw, sraw, v, sraw);
     else unpack_bf16x8(sraw, v);
@@ -303,6 +358,7 @@ extern "C" int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_ro
     g.ag_bytes = align_up(gather_bytes, 256);
     g.max_blocks = (int)(g.ag_bytes / (kCommThreads * 16)) + max_rows + 2;  // a row's last chunk may be partial; >= 2 state words
     const int64_t ar = (int64_t)2 * kCommMaxRanks * max_rows * max_dim * 2, ag = (int64_t)2 * kCommMaxRanks * g.ag_bytes;
+    const int64_t ar2 = (int64_t)2 * max_rows * max_dim * 2;
     if (ar >= (1ll << 32) || ag >= (1ll << 32)) {
         delete cm;
         return CHITU_ERR_UNSUPPORTED;
@@ -311,8 +367,11 @@ extern "C" int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_ro
     g.flags_ag = align_up(g.flags_ar + (int64_t)kCommMaxRanks * max_rows * 4, 256);
     g.data_ar = align_up(g.flags_ag + (int64_t)kCommMaxRanks * g.max_blocks * 4, 4096);
     g.data_ag = align_up(g.data_ar + ar, 4096);
-    g.data_ar_bytes = (uint32_t)ar, g.data_ag_bytes = (uint32_t)ag;
-    cm->total = align_up(g.data_ag + ag, 4096);
+    g.data_ar_bytes = (uint32_t)ar, g.data_ag_bytes = (uint32_t)ag, g.data_ar2_bytes = (uint32_t)ar2;
+    g.flags_ar2 = align_up(g.data_ag + ag, 4096);
+    g.data_ar2 = align_up(g.flags_ar2 + (int64_t)kCommMaxRanks * max_rows * 4, 4096);
+    cm->total = align_up(g.data_ar2 + ar2, 4096);
+    cm->two_shot_bytes = 256 << 10;
     g.timeout_ticks = (uint64_t)timeout_ms * 100000ull;  // wall_clock64: 100 MHz
     for (int i = 0; i < kCommMaxRanks; ++i) cm->peers.buf[i] = nullptr, cm->ipc_opened[i] = false;
     void* p = nullptr;
@@ -383,6 +442,14 @@ extern "C" int chitu_hip_comm_status(void* comm, uint32_t* err_out) {
     return e == hipSuccess ? CHITU_OK : (int)e;
 }
 
+// All-reduces of at least `min_bytes` per rank (rows * dim * 2) take the two-shot form from now on (0 = always, a huge value
+// = never; default 256 KB).  Host-side and graph-static: call it before capturing, with the same value on every rank.
+extern "C" int chitu_hip_comm_set_two_shot(void* comm, int64_t min_bytes) {
+    CHITU_REQUIRE(comm && min_bytes >= 0);
+    ((Comm*)comm)->two_shot_bytes = min_bytes;
+    return CHITU_OK;
+}
+
 // Non-blocking: the pinned host copy of the error word (set by the kernel that timed out, visible as soon as that
 // store has crossed the bus).  No stream is synchronised; 0 only means "nothing reported yet".
 extern "C" int chitu_hip_comm_poll_error(void* comm, uint32_t* err_out) {
@@ -417,9 +484,13 @@ extern "C" int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf1
                                                 const void* weight_bf16, void* y_bf16, int64_t y_row_stride,
                                                 int64_t rows, int32_t dim, float eps, void* q_fp8, float* q_scales,
                                                 int32_t quant_mode, float quant_eps, int32_t phase, void* stream) {
-    CHITU_REQUIRE(comm && part_bf16 && rows >= 0 && dim >= 8 && dim % 8 == 0 && phase >= 0 && phase <= 2);
+    CHITU_REQUIRE(comm && part_bf16 && rows >= 0 && dim >= 8 && dim % 8 == 0 && phase >= 0 && phase <= 3);
     Comm* cm = (Comm*)comm;
     CHITU_REQUIRE(comm_ready(cm));
+    // two-shot (reduce-scatter + all-gather in the launch) from `two_shot_bytes` per rank on, when the row's 16-byte chunks
+    // deal evenly to the ranks; bit-identical to the one-shot form, so the choice is pure speed (chitu_hip_comm_set_two_shot)
+    const int two_shot = cm->g.world >= 2 && (dim / 8) % cm->g.world == 0 && rows * (int64_t)dim * 2 >= cm->two_shot_bytes ? 1 : 0;
+    CHITU_REQUIRE(phase != 3 || two_shot);
     if (rows > cm->g.max_rows || dim > cm->g.max_dim) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(terms >= 1 && part_row_stride % 8 == 0 && (terms == 1 || term_stride % 8 == 0));
     if (terms > kCommMaxTerms) return CHITU_ERR_UNSUPPORTED;
@@ -443,7 +514,7 @@ extern "C" int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf1
                        cm->g, cm->state, (const bf16_t*)part_bf16, part_row_stride, (int)terms, term_stride,        \
                        (const bf16_t*)x_bf16, x_row_stride, (bf16_t*)sum_out_bf16, sum_row_stride,                  \
                        (const bf16_t*)weight_bf16, (bf16_t*)y_bf16, y_row_stride, (fp8_t*)q_fp8, q_scales, (int)dim, \
-                       eps, quant_eps, (int)phase)
+                       eps, quant_eps, (int)phase, two_shot)
     if (quant_mode == 0) LAUNCH(0);
     else if (quant_mode == 1) LAUNCH(1);
     else LAUNCH(2);

@@ -465,7 +465,7 @@ def _route_ticket(device) -> torch.Tensor:
     """The zero-initialised word chitu_hip_gate_route_align's workgroups count themselves on (reset by
     the kernel).  Created on the first eager call per device -- before any graph capture (decode() warms up
     eagerly) -- and kept for the life of the process, so captured launches keep a valid address."""
-    key = torch.device(device).index or 0
+    key = (torch.device(device).index or 0, workspace._namespace)  # launches that share a ticket must not overlap
     t = _route_tickets.get(key)
     if t is None:
         if torch.cuda.is_current_stream_capturing():

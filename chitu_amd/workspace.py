@@ -9,10 +9,19 @@ import torch
 
 _ws = {}
 _retired = []  # outgrown buffers stay alive: hipGraphs captured earlier still launch on their addresses
+_namespace = None
+
+
+def set_namespace(ns):
+    """Scratch is per (device, tag) -- one decode engine per process and device, the normal deployment.  Several engines
+    driven from ONE process on one device at the same time (the tests' rank-instances on separate streams) each select
+    their own namespace before they launch or capture, so that their launches never share scratch."""
+    global _namespace
+    _namespace = ns
 
 
 def get(nbytes: int, device, tag: str = "default") -> torch.Tensor:
-    key = (torch.device(device).index or 0, tag)
+    key = (torch.device(device).index or 0, tag, _namespace)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None and torch.cuda.is_current_stream_capturing():

@@ -31,6 +31,7 @@ class XgmiComm:
         check(_lib.lib().chitu_hip_comm_create(i32(rank), i32(world), i32(max_rows), i32(max_dim), i64(gather_bytes),
                                                i32(timeout_ms), ctypes.byref(h)), "comm_create")
         self._h = h
+        self.two_shot_bytes = 256 << 10  # the library's default (chitu_hip_comm_set_two_shot)
 
     # ------------------------------------------------------------------ wiring
     def ipc_handle(self) -> bytes:
@@ -105,6 +106,16 @@ class XgmiComm:
         err = ctypes.c_uint32()
         check(_lib.lib().chitu_hip_comm_status(self._h, ctypes.byref(err)), "comm_status")
         return err.value
+
+    def set_two_shot(self, min_bytes: int):
+        """All-reduces of at least `min_bytes` per rank use the two-shot (reduce-scatter + all-gather) form from now on:
+        2 / world of the bytes per link, one more flag hop, bit-identical results.  0 = always; default 256 KB."""
+        check(_lib.lib().chitu_hip_comm_set_two_shot(self._h, i64(min_bytes)), "comm_set_two_shot")
+        self.two_shot_bytes = int(min_bytes)
+
+    def uses_two_shot(self, rows: int, dim: int) -> bool:
+        """The library's choice for an all-reduce of [rows, dim] bf16 (mirrors chitu_hip_comm_allreduce_rmsnorm)."""
+        return self.world >= 2 and (dim // 8) % self.world == 0 and rows * dim * 2 >= self.two_shot_bytes
 
     def poll_error(self) -> int:
         """Non-blocking: the host-visible copy of the error word (0 = nothing reported so far).  Cheap enough to

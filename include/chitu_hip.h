@@ -613,6 +613,11 @@ int chitu_hip_comm_local_ptr(void* comm, void** ptr_out);
 int chitu_hip_comm_set_peer(void* comm, int32_t peer, void* ptr);
 int chitu_hip_comm_status(void* comm, uint32_t* err_out);
 int chitu_hip_comm_poll_error(void* comm, uint32_t* err_out);
+/* All-reduces of >= min_bytes per rank take the two-shot form (reduce-scatter + all-gather inside the same launch: 2/world
+ * of the bytes per xGMI link, one more flag hop; bit-identical to the one-shot form).  Default 256 KB; same value on every
+ * rank; host-side, set before capture.  With it, phase 3 = "wait for hop 1, reduce my slice, send hop 2" of a split launch
+ * (1 = hop 1, 3, 2 = wait for hop 2 + finish). */
+int chitu_hip_comm_set_two_shot(void* comm, int64_t min_bytes);
 int chitu_hip_comm_destroy(void* comm);
 int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf16, int64_t part_row_stride,
                                      int32_t terms, int64_t term_stride, const void* x_bf16,

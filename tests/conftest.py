@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# before HIP initialises: more hardware queues for the process's streams (test_gpu_xgmi.py runs several ranks of one
+# process on their own streams, and kernels that wait for each other must not share a queue); the default is 4
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -10,7 +10,7 @@ import torch
 from oracle import deepseek as ods
 from tests.test_gpu_deepseek import cfg_of, tiny_args, v2lite_like_args
 from tests.test_tp_gloo import _shard_ep
-from tests.util import max_rel_to_peak
+from tests.util import assert_close, max_rel_to_peak
 
 pytestmark = pytest.mark.gpu
 
@@ -70,12 +70,12 @@ def test_expert_parallel_ranks_match_the_oracle_and_sum_to_the_full_layer(make_a
         assert torch.equal(y, y2)  # deterministic
         p = {k: v.detach().cpu() for k, v in m.named_parameters()}
         y_ref, _ = ods.moe_layer_ep(p, "", hn_cpu, cfg, m.expert_map.cpu(), routing=routing)
-        assert max_rel_to_peak(y.cpu(), y_ref) < 1e-2, r
+        assert_close(y.cpu(), y_ref, 1e-2, atol_frac=1.0, what=r)  # a rank's partial sum: few terms, near-zero elements carry their neighbours' rounding
         hit_any_remote |= bool((m.expert_map.cpu()[routing[1]] < 0).any())
         total += y.float().cpu()
     assert hit_any_remote
     # the all-reduce's arithmetic (bf16 partial sums per rank) vs the unsharded fused layer
-    assert max_rel_to_peak(total.to(torch.bfloat16), y_full.to(torch.bfloat16)) < 2e-2
+    assert_close(total.to(torch.bfloat16), y_full.to(torch.bfloat16), 2e-2)
 
 
 def test_expert_parallel_rank_decode_step_graph_equals_eager():

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import fp8 as ofp8
-from tests.util import bf16, bits16, bits8, fp8, golden, max_rel_to_peak
+from tests.util import assert_close, bf16, bits16, bits8, fp8, golden, max_rel_to_peak
 
 pytestmark = pytest.mark.gpu
 
@@ -96,9 +96,9 @@ def test_fp8_gemm_fixture():
         torch.set_default_dtype(torch.float32)
     assert c.dtype == torch.bfloat16 and tuple(c.shape) == (5, 384)
     # fixture was truncated to bf16 by the interpreter: allow one bf16 ulp per element
-    assert max_rel_to_peak(c, bf16(g["c"])) < 8e-3
+    assert_close(c, bf16(g["c"]), 8e-3)
     exact = ofp8.fp8_gemm_deepseek_v3(fp8(g["xq"]), torch.from_numpy(g["xs"]), fp8(g["w"]), torch.from_numpy(g["ws"]), torch.float32)
-    assert max_rel_to_peak(c, exact) < 4e-3
+    assert_close(c, exact, 4e-3)
 
 
 R1_SHAPES = [(2112, 7168), (3072, 1536), (7168, 2048), (512, 7168), (7168, 256), (4608, 7168), (7168, 2304)]
@@ -122,8 +122,8 @@ def test_fp8_gemm_vs_oracle(M, N, K):
     finally:
         torch.set_default_dtype(torch.float32)
     assert tuple(c.shape) == (M, N)
-    assert max_rel_to_peak(c, ref) < 5e-3  # bf16 output rounding only
-    assert max_rel_to_peak(c, ref) < REL_TOL
+    assert_close(c, ref, 5e-3)# bf16 output rounding only
+    assert_close(c, ref, REL_TOL)
     # deterministic (no atomics in the split-K path)
     torch.set_default_dtype(torch.bfloat16)
     try:
@@ -147,7 +147,7 @@ def test_soft_fp8_gemm_vs_oracle(M, N, K):
         c = ops.soft_fp8_gemm_deepseek_v3(x.cuda(), w.cuda(), ws.cuda())
     finally:
         torch.set_default_dtype(torch.float32)
-    assert max_rel_to_peak(c, ref) < 5e-3
+    assert_close(c, ref, 5e-3)
 
 
 def test_linearity_property_full_size():
@@ -221,7 +221,7 @@ def test_fp8_gemm_split_k_partial_planes(M, N, K, S):
     total = parts[0].clone()
     for s in range(1, S):
         total += parts[s]
-    assert max_rel_to_peak(total.to(torch.bfloat16), ref) < 5e-3
+    assert_close(total.to(torch.bfloat16), ref, 5e-3)
     # each plane is a partial contraction over a contiguous K range: plane s == the GEMM on that range alone
     KB = K // 128
     T = S * (8 if KB >= 8 * S else 4 if KB >= 4 * S else 2 if KB >= 2 * S else 1)
@@ -229,7 +229,7 @@ def test_fp8_gemm_split_k_partial_planes(M, N, K, S):
         k0, k1 = (KB * (s * (T // S)) // T) * 128, (KB * ((s + 1) * (T // S)) // T) * 128
         ref_s = ofp8.fp8_gemm_deepseek_v3(xq[:, k0:k1].contiguous(), xs[:, k0 // 128:k1 // 128].contiguous(),
                                           w[:, k0:k1].contiguous(), ws[:, k0 // 128:k1 // 128].contiguous(), torch.float32)
-        assert max_rel_to_peak(parts[s], ref_s) < 1e-4, s
+        assert_close(parts[s], ref_s, 1e-4, what=s)
     assert torch.equal(parts, ops.fp8_gemm_partials_deepseek_v3(xq.cuda(), xs.cuda(), w.cuda(), ws.cuda(), S))
 
 
@@ -251,10 +251,10 @@ def test_fp8_gemm_tiled_prefill_form_vs_streaming_form_and_oracle(M, N, K):
     with _lib.debug_option("fp8_gemm_tiled", 0):
         streamed = ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.float32)
     assert tuple(tiled.shape) == (M, N) and torch.isfinite(tiled).all()
-    assert max_rel_to_peak(tiled, streamed) < 1e-5
+    assert_close(tiled, streamed, 1e-5)
     assert torch.equal(tiled, ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.float32))
     b16 = ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.bfloat16)
-    assert max_rel_to_peak(b16, streamed) < 5e-3
+    assert_close(b16, streamed, 5e-3)
     if M * N * K <= 2e8:
         ref = ofp8.fp8_gemm_deepseek_v3(xq.cpu(), xs.cpu(), w.cpu(), ws.cpu(), torch.float32)
-        assert max_rel_to_peak(b16, ref) < 5e-3
+        assert_close(b16, ref, 5e-3)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import mla as omla
-from tests.util import bf16, golden, max_rel_to_peak
+from tests.util import assert_close, bf16, golden, max_rel_to_peak
 
 pytestmark = pytest.mark.gpu
 
@@ -28,8 +28,8 @@ def test_reference_kernel_fixture(splits):
         num_splits=splits,
     )
     ref = torch.from_numpy(g["out"])  # reference Triton kernels, fp32 interpreter run
-    assert max_rel_to_peak(out, ref) < REL_TOL
-    assert max_rel_to_peak(out, ref) < 6e-3
+    assert_close(out, ref, REL_TOL)
+    assert_close(out, ref, 6e-3)
 
 
 def make_case(bs, H, lens, pages, page=64, seed=0):
@@ -102,7 +102,7 @@ def test_long_contexts_vs_oracle(lens):
     wd = ofp8.weight_dequant_deepseek_v3(w.view(H * 256, 512), sc).view(H, 256, 512)[:, 128:]
     proj = torch.einsum("bhc,hdc->bhd", ref.float(), wd.float()).to(torch.bfloat16).reshape(bs, H * 128)
     got = (q.float().view(bs, H, 128) * s_.view(bs, H, 1)).reshape(bs, H * 128)
-    assert max_rel_to_peak(got, proj) < 4e-2  # one fp8 quantisation step (2^-4 relative) on top of the attention bar
+    assert_close(got, proj, 4e-2)# one fp8 quantisation step (2^-4 relative) on top of the attention bar
 
 
 def test_garbage_beyond_seqlen_is_ignored_and_zero_length():
@@ -114,7 +114,7 @@ def test_garbage_beyond_seqlen_is_ignored_and_zero_length():
     poisoned[table[1, 2].item(), 2:] = float("inf")   # after token 130 of seq 1
     out = backend().mla_decode(q_nope.cuda(), q_pe.cuda(), poisoned.cuda(), sl.cuda(), table.cuda(), 0.1352)
     assert torch.isfinite(out.float()).all()
-    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close(out, ref, REL_TOL)
     sl0 = torch.tensor([0, 130], dtype=torch.int32)
     out0 = backend().mla_decode(q_nope.cuda(), q_pe.cuda(), cache.cuda(), sl0.cuda(), table.cuda(), 0.1352, num_splits=2)
     assert (out0[0] == 0).all()
@@ -130,7 +130,7 @@ def test_softmax_rescale_branch_is_exercised():
     ref = omla.mla_decode(q_nope, q_pe, cache, table, sl, 0.1352)
     for splits in (1, 2, 5):
         out = backend().mla_decode(q_nope.cuda(), q_pe.cuda(), cache.cuda(), sl.cuda(), table.cuda(), 0.1352, num_splits=splits)
-        assert max_rel_to_peak(out, ref) < REL_TOL
+        assert_close(out, ref, REL_TOL)
 
 
 def test_mla_attn_with_kvcache_appends_then_attends():
@@ -151,7 +151,7 @@ def test_mla_attn_with_kvcache_appends_then_attends():
     )
     assert tuple(out.shape) == (bs, 1, H, 512)
     assert torch.equal(cache_d.cpu(), cache_ref)  # append is an exact copy
-    assert max_rel_to_peak(out.view(bs, H, 512), ref) < REL_TOL
+    assert_close(out.view(bs, H, 512), ref, REL_TOL)
 
 
 def test_cache_manager_drives_the_kernel():
@@ -189,7 +189,7 @@ def test_cache_manager_drives_the_kernel():
             ref, new_layer = omla.mla_attn_with_kvcache(q_nope, q_pe, shadow[layer], kv, excl.cpu(), incl.cpu(),
                                                         table.cpu(), 0.1352)
             shadow[layer] = new_layer
-            assert max_rel_to_peak(out.view(2, 16, 512), ref) < REL_TOL
+            assert_close(out.view(2, 16, 512), ref, REL_TOL)
         cm.finalize_cache_single_decode(reqs)
     assert len(cm.block_table["a"]) == 2  # crossed a page boundary at step 1
     n_free = len(cm.free_blocks)
@@ -209,7 +209,7 @@ def test_prefill_varlen_matches_reference_fixture_and_oracle():
     out = be.attn_varlen_func(c["q"].cuda(), kv, kv[..., :512].contiguous(), c["cu"].cuda(), c["cu"].cuda(), max(c["seqs"]),
                               max(c["seqs"]), causal=True, softmax_scale=c["scale"])
     assert tuple(out.shape) == (sum(c["seqs"]), 16, 512)
-    assert max_rel_to_peak(out.cpu()[c["rows"]], c["out"]) < REL_TOL
+    assert_close(out.cpu()[c["rows"]], c["out"], REL_TOL)
 
     g = torch.Generator().manual_seed(12)
     seqs = [3, 200, 1, 64, 129]
@@ -220,7 +220,7 @@ def test_prefill_varlen_matches_reference_fixture_and_oracle():
     out = be.attn_varlen_func(q.cuda(), kv.cuda(), kv[..., :512].contiguous().cuda(), cu.cuda(), cu.cuda(), max(seqs), max(seqs),
                               causal=True, softmax_scale=0.1352).cpu()
     ref = omla.mla_prefill(q, kv[:, 0], cu, 0.1352)
-    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close(out, ref, REL_TOL)
     # last token of each sequence == decode over that sequence's pages
     for s0, s1 in zip(cu[:-1].tolist(), cu[1:].tolist()):
         n = s1 - s0
@@ -230,7 +230,7 @@ def test_prefill_varlen_matches_reference_fixture_and_oracle():
         o = be.mla_decode(q[s1 - 1 : s1, :, :512].contiguous().cuda(), q[s1 - 1 : s1, :, 512:].contiguous().cuda(), cache.cuda(),
                           torch.tensor([n], dtype=torch.int32).cuda(), torch.arange(pages, dtype=torch.int32).view(1, -1).cuda(),
                           0.1352, num_splits=1)
-        assert max_rel_to_peak(o.cpu(), out[s1 - 1 : s1]) < 2e-3
+        assert_close(o.cpu(), out[s1 - 1 : s1], 2e-3)
 
 
 def test_prefill_kernel_equals_per_token_decode_composition(monkeypatch):
@@ -253,4 +253,4 @@ def test_prefill_kernel_equals_per_token_decode_composition(monkeypatch):
                                              softmax_scale=0.1352)
         assert torch.equal(outs["kernel"], outs["compose"]), (H, seqs)
         ref = omla.mla_prefill(q.cpu(), kv.cpu()[:, 0], cu.cpu(), 0.1352)
-        assert max_rel_to_peak(outs["kernel"].cpu(), ref) < REL_TOL
+        assert_close(outs["kernel"].cpu(), ref, REL_TOL)

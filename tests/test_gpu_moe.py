@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import moe as omoe
-from tests.util import assert_close_elementwise, bf16, fp8, golden, max_rel_to_peak
+from tests.util import assert_close, assert_close_elementwise, bf16, fp8, golden, max_rel_to_peak
 
 pytestmark = pytest.mark.gpu
 
@@ -44,10 +44,10 @@ def test_reference_fixture_inputs():
             torch.from_numpy(g["ids"]), bf16(g["wts"]))
     out = run_hip(*args)
     ref = omoe.fused_experts_fp8(args[0], args[1], args[2], args[6], args[5], args[3], args[4])
-    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close(out, ref, REL_TOL)
     # the interpreter-generated fixture itself carries ~10% of cast-defect noise (see
     # tests/test_oracle_golden.py); it must still be the same function
-    assert max_rel_to_peak(out, bf16(g["out"])) < 0.2
+    assert_close(out, bf16(g["out"]), 0.2)
 
 
 @pytest.mark.parametrize(
@@ -105,7 +105,7 @@ def test_bf16_experts_vs_oracle(M, E, topk, K, I):
     wts = torch.rand(M, topk, generator=g).to(torch.bfloat16)
     out = run_hip_bf16_act(x, w1, w2, ids, wts)
     ref = omoe.fused_experts_bf16(x, w1, w2, wts, ids)
-    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close(out, ref, REL_TOL)
     assert_close_elementwise(out, ref, what="bf16 experts")
     assert torch.equal(out, run_hip_bf16_act(x, w1, w2, ids, wts))  # deterministic
 
@@ -121,7 +121,7 @@ def test_soft_fp8_experts_vs_oracle_and_vs_dequantised_bf16(M, E, topk, K, I):
     x, w1, w2, w1s, w2s, ids, wts = make_case(M, E, topk, K, I, seed=M * 1000 + E + 9)
     out = run_hip_bf16_act(x, w1, w2, ids, wts, w1s, w2s)
     ref = omoe.fused_experts_soft_fp8(x, w1, w2, wts, ids, w1s, w2s)
-    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close(out, ref, REL_TOL)
     assert_close_elementwise(out, ref, what="soft-fp8 experts")
     torch.set_default_dtype(torch.bfloat16)  # the dequant's output dtype is torch's default, as in the reference (ops.py:413)
     try:
@@ -130,7 +130,7 @@ def test_soft_fp8_experts_vs_oracle_and_vs_dequantised_bf16(M, E, topk, K, I):
     finally:
         torch.set_default_dtype(torch.float32)
     via_bf16 = run_hip_bf16_act(x, w1d.cpu(), w2d.cpu(), ids, wts)
-    assert max_rel_to_peak(out, via_bf16) < 4e-3  # one bf16 flip of an intermediate at most
+    assert_close(out, via_bf16, 4e-3)# one bf16 flip of an intermediate at most
 
 
 def test_bf16_act_modes_expert_map_and_unreduced_output():
@@ -140,7 +140,7 @@ def test_bf16_act_modes_expert_map_and_unreduced_output():
     out = run_hip_bf16_act(x, w1[:4].contiguous(), w2[:4].contiguous(), ids, wts, w1s[:4].contiguous(), w2s[:4].contiguous(),
                            expert_map=emap.cuda(), global_num_experts=8)
     ref = omoe.fused_experts_soft_fp8(x, w1, w2, wts_masked, ids, w1s, w2s)
-    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close(out, ref, REL_TOL)
     un = run_hip_bf16_act(x, w1, w2, ids, wts, w1s, w2s, reduce_topk=False)
     assert tuple(un.shape) == (6, 2, 256)
     assert torch.equal(un.float().sum(1).to(torch.bfloat16), run_hip_bf16_act(x, w1, w2, ids, wts, w1s, w2s))
@@ -160,7 +160,7 @@ def test_inplace_fp32_weights_and_determinism():
         assert torch.equal(run_hip(*args), a)  # no atomics => bit-reproducible
     x, w1, w2, w1s, w2s, ids, wts = args
     ref = omoe.fused_experts_fp8(x, w1, w2, wts, ids, w1s, w2s)
-    assert max_rel_to_peak(a, ref) < REL_TOL
+    assert_close(a, ref, REL_TOL)
 
 
 def test_expert_map_masks_remote_experts():
@@ -172,7 +172,7 @@ def test_expert_map_masks_remote_experts():
     # oracle: zero the routed weight of remote experts
     wts_masked = torch.where(ids < 4, wts.float(), torch.zeros(())).to(wts.dtype)
     ref = omoe.fused_experts_fp8(x, w1, w2, wts_masked, ids, w1s, w2s)
-    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close(out, ref, REL_TOL)
 
 
 def test_linearity_in_routed_weight_full_r1_shape():
@@ -207,7 +207,7 @@ def test_two_launch_expert_path_is_bit_identical_to_three_launch(M, E, topk, K, 
     monkeypatch.setenv("CHITU_MOE_FUSE_SILU", "1")
     a = run_hip(*args)
     monkeypatch.setenv("CHITU_MOE_FUSE_SILU", "0")
-    assert max_rel_to_peak(a, run_hip(*args)) < 4e-3
+    assert_close(a, run_hip(*args), 4e-3)
 
 
 @pytest.mark.parametrize("M,E,topk,K,I", [(128, 32, 8, 7168, 256), (300, 16, 4, 512, 128), (1000, 64, 6, 2048, 384),
@@ -233,7 +233,8 @@ def test_prefill_tiled_expert_path_vs_decode_kernels_and_oracle(M, E, topk, K, I
         ref = omoe.fused_experts_fp8(x, w1, w2, wts, ids, w1s, w2s)
         # hundreds of rows: the largest single deviation (one h value on an fp8 rounding boundary, SiLU by expf vs
         # torch.exp) grows with the element count and is shared with the decode kernels; the mean stays put
-        assert max_rel_to_peak(tiled, ref) < 2e-2 and max_rel_to_peak(streamed, ref) < 2e-2
+        assert_close(tiled, ref, 2e-2)
+        assert max_rel_to_peak(streamed, ref) < 2e-2
         assert ((tiled.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item() < 5e-3
 
 
@@ -245,4 +246,4 @@ def test_prefill_tiled_expert_path_with_expert_map():
                   ids, wts, expert_map=emap.cuda(), global_num_experts=8)
     wts_masked = torch.where(ids < 4, wts.float(), torch.zeros(())).to(wts.dtype)
     ref = omoe.fused_experts_fp8(x, w1, w2, wts_masked, ids, w1s, w2s)
-    assert max_rel_to_peak(out, ref) < REL_TOL
+    assert_close(out, ref, REL_TOL, atol_frac=1.0)  # 64-slot tiles: near-zero outputs carry their tile's rounding

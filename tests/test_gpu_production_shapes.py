@@ -8,9 +8,10 @@ kernel, the K-split dense GEMMs, 1024-context MLA splits).
   * config 4: one Mixtral-8x7B layer (dim 4096, 32 / 8 heads, 8 experts of width 14336, INT8 W8A8 experts).
 Each HIP layer (chitu_amd.deepseek_v3 / chitu_amd.mixtral) against the CPU oracle (oracle.deepseek.block /
 oracle.llama.block + oracle.mixtral.sparse_moe) on identical inputs and the HIP layer's own routing decisions
-(the router itself is compared separately: same experts except bf16 near-ties).  Bar: <= 2e-2 of the output's
-peak for a whole layer (a chain of ~8 fp8 GEMMs / attention, each <= 1e-2: BASELINE.json north_star), the
-appended KV row <= 1e-2.
+(the router itself is compared separately: same experts except bf16 near-ties).  Bar: <= 1e-2 of the output's
+peak for a whole DeepSeek layer (BASELINE.json north_star's own figure, held per LAYER here although a layer chains ~8
+fp8 GEMMs and the attention; measured 4-6e-3) and the appended KV row; the Mixtral INT8 layer keeps 2e-2 (per-token int8
+activations: one quantisation step is 2^-7 of the row's peak, twice in a layer; measured 9.6e-3).
 """
 
 import pytest
@@ -18,7 +19,7 @@ import torch
 
 from oracle import deepseek as ods
 from tests.test_gpu_deepseek import cfg_of
-from tests.util import max_rel_to_peak
+from tests.util import assert_close, max_rel_to_peak
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +38,7 @@ def _build_deepseek(args, max_reqs, max_seq, heads):
     return model, cache
 
 
-def _deepseek_layers_vs_oracle(args, heads, batches, ctx, bar=2e-2):
+def _deepseek_layers_vs_oracle(args, heads, batches, ctx, bar=1e-2):
     model, cache = _build_deepseek(args, max(batches), ctx + 64, heads)
     cfg = cfg_of(args)
     cfg["H"] = heads  # local heads of this rank
@@ -78,7 +79,7 @@ def _deepseek_layers_vs_oracle(args, heads, batches, ctx, bar=2e-2):
                 layer.ffn.gate.forward = orig
             rt = (routing["w"], routing["i"]) if layer.is_moe else None
             y_ref, new_cache, _ = ods.block(params, i, x, cos, sin, shadow[i], table, lens_excl, cfg, layer.is_moe, rt)
-            assert max_rel_to_peak(cache.paged_kv_cache[i].cpu(), new_cache) < 1e-2, (bs, i, "appended KV row")
+            assert_close(cache.paged_kv_cache[i].cpu(), new_cache, 1e-2, what=(bs, i, "appended KV row"))
             err = max_rel_to_peak(y, y_ref)
             worst[(bs, i)] = err
             assert err < bar, (bs, i, err)

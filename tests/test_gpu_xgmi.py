@@ -93,16 +93,61 @@ def _check(res, exp, what):
 
 
 # ------------------------------------------------------------------ two ranks, one process
+_RANK_STREAMS = []
+
+
+def _rank_streams(n):
+    """The streams the in-process ranks launch on: created ONCE per process and reused by every test.  Kernels of
+    different ranks wait for each other, so their streams must sit on different hardware queues; HIP deals a process's
+    streams onto a handful of queues (GPU_MAX_HW_QUEUES; tests/conftest.py asks for 8), and two fresh streams can land
+    on one queue -- the waiting kernel then sits in front of the one it waits for until its timeout.  So every stream is
+    ADMITTED by a rendezvous: a tiny all-reduce among the streams chosen so far plus the candidate, with a short timeout;
+    a candidate that cannot run beside the others is dropped.  Skips the test when the process cannot get n such streams."""
+    from chitu_amd.xgmi import XgmiComm
+
+    tries = 0
+    while len(_RANK_STREAMS) < n and tries < 16:
+        tries += 1
+        cand = _RANK_STREAMS + [torch.cuda.Stream()]
+        if len(cand) == 1:
+            _RANK_STREAMS.append(cand[0])
+            continue
+        world = len(cand)
+        comms = [XgmiComm(r, world, max_rows=1, max_dim=64, timeout_ms=200) for r in range(world)]
+        XgmiComm.connect_local(comms)
+        part = torch.ones(1, 64, dtype=torch.bfloat16, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(2):
+            for r in range(world):
+                with torch.cuda.stream(cand[r]):
+                    comms[r].allreduce_rmsnorm(part)
+        torch.cuda.synchronize()
+        ok = all(c.status() == 0 for c in comms)
+        for c in comms:
+            c.close()
+        if ok:
+            _RANK_STREAMS.append(cand[-1])
+    if len(_RANK_STREAMS) < n:
+        pytest.skip(f"this process got only {len(_RANK_STREAMS)} streams that run side by side (hardware queues); {n} needed")
+    return _RANK_STREAMS[:n]
+
+
 def _local_pair(**kw):
     from chitu_amd.xgmi import XgmiComm
 
     comms = [XgmiComm(r, 2, timeout_ms=3000, **kw) for r in range(2)]
     XgmiComm.connect_local(comms)
-    return comms, [torch.cuda.Stream() for _ in range(2)]
+    return comms, _rank_streams(2)
 
 
-def test_two_ranks_one_process_every_fusion_is_bit_exact():
+@pytest.mark.parametrize("two_shot", [None, 0], ids=["auto256k", "two_shot"])
+def test_two_ranks_one_process_every_fusion_is_bit_exact(two_shot):
+    """Two ranks on two streams really waiting for each other inside ONE launch each -- in the two-shot form through
+    both hops (slice to its owner, reduced slice back)."""
     comms, streams = _local_pair(max_rows=32, max_dim=8192)
+    if two_shot is not None:
+        for c in comms:
+            c.set_two_shot(two_shot)
     torch.cuda.synchronize()
     for salt in range(3):  # the same slots again: epochs / parity advance
         for case in CASES:
@@ -119,29 +164,47 @@ def test_two_ranks_one_process_every_fusion_is_bit_exact():
         c.close()
 
 
-def _local_world(world, **kw):
+def _local_world(world, two_shot=None, **kw):
     from chitu_amd.xgmi import XgmiComm
 
     comms = [XgmiComm(r, world, timeout_ms=3000, **kw) for r in range(world)]
     XgmiComm.connect_local(comms)
+    if two_shot is not None:  # bytes per rank from which the all-reduce takes its two-shot form (0 = always)
+        for c in comms:
+            c.set_two_shot(two_shot)
     return comms
 
 
+def _split_allreduce(comms, ins, quant=None, **kw):
+    """One all-reduce of every rank on ONE stream: all ranks contribute (phase 1), [two-shot: all ranks reduce their
+    slice and send it on, phase 3,] all ranks complete (phase 2).  ins[r] = (part, x, w)."""
+    world = len(comms)
+    part = ins[0][0]
+    rows, dim = part.shape[0], part.shape[-1]
+    outs = [comms[r].allreduce_rmsnorm(*ins[r], 1e-6, quant=quant, phase=1, **kw) for r in range(world)]
+    if comms[0].uses_two_shot(rows, dim):
+        for r in range(world):
+            comms[r].allreduce_rmsnorm(*ins[r], 1e-6, quant=quant, phase=3, into=outs[r], **kw)
+    return [comms[r].allreduce_rmsnorm(*ins[r], 1e-6, quant=quant, phase=2, into=outs[r], **kw) for r in range(world)]
+
+
+@pytest.mark.parametrize("two_shot", [None, 0, 1 << 40], ids=["auto256k", "two_shot", "one_shot"])
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_split_phase_every_fusion_any_world_size(world):
+def test_split_phase_every_fusion_any_world_size(world, two_shot):
     """All `world` ranks on ONE stream through the split-phase form -- every rank contributes (phase 1: push + flags),
     then every rank completes (phase 2: wait, rank-order reduce, norm, quant): no kernel ever waits for a later one,
     so slot addressing, flags, epochs / parity and the reduction order are checked for 2, 4 and 8 ranks without
-    depending on how one GPU co-schedules spinning kernels.  Three rounds over the same slots."""
-    comms = _local_world(world, max_rows=32, max_dim=8192)
+    depending on how one GPU co-schedules spinning kernels.  Three rounds over the same slots.  In the one-shot form,
+    the two-shot form (reduce-scatter + all-gather inside the launch; three split phases) and the library's own choice
+    by message size -- all three must give the oracle's bits."""
+    comms = _local_world(world, two_shot=two_shot, max_rows=32, max_dim=8192)
     for salt in range(3):
         for case in CASES:
             ins = []
             for r in range(world):
                 part, x, w = _inputs(case, r, salt)
                 ins.append((part.cuda(), x.cuda() if x is not None else None, w.cuda() if w is not None else None))
-            outs = [comms[r].allreduce_rmsnorm(*ins[r], 1e-6, quant=case[5], phase=1) for r in range(world)]
-            res = [comms[r].allreduce_rmsnorm(*ins[r], 1e-6, quant=case[5], phase=2, into=outs[r]) for r in range(world)]
+            res = _split_allreduce(comms, ins, case[5])
             torch.cuda.synchronize()
             assert [c.status() for c in comms] == [0] * world, case
             exp = _expected(case, world, salt)
@@ -154,20 +217,20 @@ def test_split_phase_every_fusion_any_world_size(world):
         c.close()
 
 
+@pytest.mark.parametrize("two_shot", [None, 0], ids=["auto256k", "two_shot"])
 @pytest.mark.parametrize("world", [4, 8])
-def test_split_phase_chain_in_place_and_all_gather(world):
+def test_split_phase_chain_in_place_and_all_gather(world, two_shot):
     """A chain of dependent collectives (fused all-reduce -> in-place plain all-reduce of its output -> all-gather of a
     slice, bf16 and fp32), split-phase on one stream, repeated: what a decode step strings together."""
-    comms = _local_world(world, max_rows=16, max_dim=7168, gather_bytes=16 * 16160 * 2)
+    comms = _local_world(world, two_shot=two_shot, max_rows=16, max_dim=7168, gather_bytes=16 * 16160 * 2)
     case = (16, 7168, 9, True, True, "group")
     for salt in range(4):
         ins = [[v.cuda() for v in _inputs(case, r, salt)] for r in range(world)]
-        o1 = [comms[r].allreduce_rmsnorm(*ins[r], 1e-6, quant="group", phase=1) for r in range(world)]
-        o1 = [comms[r].allreduce_rmsnorm(*ins[r], 1e-6, quant="group", phase=2, into=o1[r]) for r in range(world)]
+        o1 = _split_allreduce(comms, ins, "group")
         ts = [o1[r][1].clone() for r in range(world)]
-        for ph in (1, 2):
+        for ph in (1, 3, 2) if comms[0].uses_two_shot(16, 7168) else (1, 2):
             for r in range(world):
-                comms[r].allreduce_rmsnorm(ts[r], out=ts[r], phase=ph, into=ts[r] if ph == 2 else None)
+                comms[r].allreduce_rmsnorm(ts[r], out=ts[r], phase=ph, into=ts[r] if ph != 1 else None)
         ys = [(ts[r][:, :4096] * (r + 1)).contiguous() for r in range(world)]  # rank-distinct slices
         for dt in (torch.bfloat16, torch.float32):
             g = [comms[r].all_gather_last_dim(ys[r], dt, phase=1) for r in range(world)]
@@ -323,12 +386,15 @@ def _collectives_worker(rank, world):
 
     assert tp.enable_xgmi(max_rows=32, max_dim=8192, gather_bytes=16 * 16160 * 2, timeout_ms=8000), "xGMI setup / self-test failed"
     comm = tp.xgmi_comm()
-    for salt in range(2):
+    for salt in range(4):
+        # salts 2, 3: every all-reduce in its two-shot form (both hops between real processes); set on every rank
+        comm.set_two_shot(0 if salt >= 2 else 256 << 10)
         results = [_run_case(comm, case, rank, salt) for case in CASES]  # back to back: ranks run ahead of each other
         torch.cuda.synchronize()
         assert comm.status() == 0, salt
         for case, res in zip(CASES, results):
             _check(res, _expected(case, world, salt), (case, salt, rank))
+    comm.set_two_shot(256 << 10)
     # tensor_parallel's seam: all_reduce in place, all_gather with the fp32 cast folded in
     for rows, cols in ((16, 16160), (1, 16160), (3, 64)):
         ys = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(5 + r + rows)) * 3).to(torch.bfloat16) for r in range(world)]
@@ -507,3 +573,124 @@ def _mixtral_worker(rank, world):
 
 def test_mixtral_int8_tp2_one_graph_on_xgmi_equals_eager_on_library():
     _spawn(_mixtral_worker, 2, timeout=240)
+
+
+def test_mixtral_int8_tp4_one_graph_per_rank_on_four_streams():
+    """BASELINE config 4 at its stated degree (TP = 4) on the in-graph collectives, on ONE GPU: four rank-instances of a
+    tiny INT8 Mixtral in one process, each with its own stream, KV cache, scratch namespace and XgmiComm (wired by raw
+    pointers).  Every rank's decode step is captured as ONE hipGraph; the four graphs are replayed on their four streams
+    and really wait for each other inside the collective launches (every all-reduce folded into the norm that consumes it,
+    the vocabulary all-gather at the end).  Checked: graph replay == eager launches bit for bit over several steps, every
+    rank holds the same logits, no timeout.  (Four PROCESSES on one GPU are at the mercy of its time slicing, see
+    tools/xgmi_world8.py; four streams of one process run side by side.)"""
+    from chitu_amd import tensor_parallel as tp
+    from chitu_amd import workspace
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.mixtral import MixtralArgs, MixtralDecoder, init_synthetic_
+
+    world, bs = 4, 3
+    args = MixtralArgs(dim=128 * 2 * world, n_layers=2, n_heads=2 * world, n_kv_heads=world, vocab_size=1024,
+                       ffn_dim=128 * world, num_local_experts=4, num_experts_per_tok=2)
+    comms = _local_world(world, max_rows=16, max_dim=args.dim, gather_bytes=16 * args.vocab_size * 2)
+    streams = _rank_streams(world)
+    saved = (tp.get_tp_size, tp.get_tp_rank, tp._xgmi)
+
+    def as_rank(r):
+        tp.get_tp_size, tp.get_tp_rank, tp._xgmi = (lambda: world), (lambda: r), comms[r]
+        workspace.set_namespace(("tp4", r))
+
+    try:
+        caches, models = [], []
+        for r in range(world):
+            as_rank(r)
+            cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=4, block_size=256, max_seq_len=512, device="cuda",
+                                        n_local_kv_heads=args.n_kv_heads // world, head_dim=args.head_dim, dtype=torch.bfloat16)
+            model = MixtralDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads // world, max_seq_len=512),
+                                   max_position_embeddings=512, device="cuda")
+            init_synthetic_(model, seed=300 + r)
+            # replicated tensors must really be replicated: router, norms (embedding / head are vocabulary shards)
+            if r > 0:
+                for (n0, p0), (_, p) in zip(models[0].named_parameters(), model.named_parameters()):
+                    if n0.endswith("ffn.gate") or n0.endswith("norm"):
+                        p.data.copy_(p0.data)
+            caches.append(cache), models.append(model)
+        starts = (250, 3, 300)
+
+        def fresh(tag):
+            reqs = [f"{tag}{i}" for i in range(bs)]
+            for r in range(world):
+                g = torch.Generator().manual_seed(7 + r)
+                for q, n in zip(reqs, starts):
+                    caches[r].register_sequence(q, n)
+                    for blk in caches[r].block_table[q]:
+                        caches[r].paged_k_cache[:, blk] = (torch.randn(args.n_layers, 256, 1, 128, generator=g) * 0.5).to(torch.bfloat16).cuda()
+                        caches[r].paged_v_cache[:, blk] = (torch.randn(args.n_layers, 256, 1, 128, generator=g) * 0.5).to(torch.bfloat16).cuda()
+            return reqs
+
+        def prepare(reqs):
+            for r in range(world):
+                caches[r].prepare_cache_decode(reqs)
+                caches[r].prepare_block_table_for_decode(reqs)
+
+        def finish(reqs):
+            for r in range(world):
+                caches[r].finalize_cache_single_decode(reqs)
+
+        steps = 4
+        # ---- eager: every rank's launches enqueued on its own stream, no host sync in between
+        reqs = fresh("e")
+        toks = torch.tensor([5, 17, 900], dtype=torch.int64, device="cuda")
+        eager, fed = [], []
+        torch.cuda.synchronize()
+        for _ in range(steps):
+            prepare(reqs)
+            torch.cuda.synchronize()
+            outs = []
+            for r in range(world):
+                as_rank(r)
+                with torch.cuda.stream(streams[r]), torch.inference_mode():
+                    outs.append(models[r].decode_eager(toks))
+            torch.cuda.synchronize()
+            assert [c.status() for c in comms] == [0] * world
+            finish(reqs)
+            for r in range(1, world):
+                assert torch.equal(outs[0], outs[r])  # replicated sampling relies on it
+            assert torch.isfinite(outs[0]).all()
+            eager.append(outs[0].clone())
+            fed.append(toks.clone())
+            toks = outs[0].argmax(-1)
+        for q in reqs:
+            for r in range(world):
+                caches[r].finalize_cache_all_decode(q)
+        # ---- one graph per rank, captured once, replayed on the four streams
+        reqs = fresh("g")
+        static_tok = [torch.zeros(bs, dtype=torch.int64, device="cuda") for _ in range(world)]
+        static_out, graphs_ = [None] * world, [None] * world
+        prepare(reqs)
+        torch.cuda.synchronize()
+        for r in range(world):
+            as_rank(r)
+            static_tok[r].copy_(fed[0])
+            graphs_[r] = torch.cuda.CUDAGraph()
+            with torch.inference_mode(), torch.cuda.graph(graphs_[r], stream=streams[r]):
+                static_out[r] = models[r].decode_eager(static_tok[r])
+        for step in range(steps):
+            if step:
+                prepare(reqs)
+            for r in range(world):
+                static_tok[r].copy_(fed[step])
+            torch.cuda.synchronize()
+            for r in range(world):
+                with torch.cuda.stream(streams[r]):
+                    graphs_[r].replay()
+            torch.cuda.synchronize()
+            assert [c.status() for c in comms] == [0] * world, step
+            finish(reqs)
+            for r in range(world):
+                assert torch.equal(static_out[r], eager[step]), (step, r)
+    finally:
+        tp.get_tp_size, tp.get_tp_rank, tp._xgmi = saved
+        workspace.set_namespace(None)
+        for c in comms:
+            c.close()

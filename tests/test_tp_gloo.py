@@ -367,7 +367,7 @@ def test_llama_wiring_reproduces_the_reference_cpu_run(world):
     _run(_llama_tp, world)
 
 
-def _mixtral_tp(rank, world):
+def _mixtral_tp(rank, world, heads=4, kv_heads=2, ffn_dim=256, tag="mx"):
     """BASELINE config 4's parallelism at test size: chitu_amd/mixtral.py under tensor parallelism -- attention heads
     and every expert's width split over the ranks (w13 rows per gate / up half, w2 columns; per-channel scales follow
     their channels, w2's stay whole), router replicated, two all-reduces per layer -- two decode steps."""
@@ -377,8 +377,8 @@ def _mixtral_tp(rank, world):
     from tests import cpu_ops_shim
 
     cpu_ops_shim.install_llama(setattr)
-    args = MixtralArgs(dim=512, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=512, ffn_dim=256, num_local_experts=4,
-                       num_experts_per_tok=2)
+    args = MixtralArgs(dim=128 * heads, n_layers=2, n_heads=heads, n_kv_heads=kv_heads, vocab_size=512, ffn_dim=ffn_dim,
+                       num_local_experts=4, num_experts_per_tok=2)
     hq, hkv, hd = args.n_heads, args.n_kv_heads, args.head_dim
     cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=2, block_size=64, max_seq_len=128, device="cpu",
                                 n_local_kv_heads=hkv // world, head_dim=hd, dtype=torch.bfloat16)
@@ -446,7 +446,19 @@ def _mixtral_tp(rank, world):
         dist.broadcast(ref, 0)
         assert torch.equal(ref, t)
     if rank == 0:
-        torch.save({"logits": outs}, os.environ["TP_OUT"] + f".mx{world}")
+        torch.save({"logits": outs}, os.environ["TP_OUT"] + f".{tag}{world}")
+
+
+def test_mixtral_int8_decode_step_tp4_matches_tp1(tmp_path):
+    """BASELINE config 4 at its stated degree: "Mixtral-8x7B W8A8 ... TP=4".  World-size-4 gloo run of the Mixtral INT8
+    step (8 query / 4 kv heads, expert width 512: every rank keeps whole 128-column int8 blocks) against TP = 1."""
+    base = str(tmp_path / "mx4")
+    os.environ["TP_OUT"] = base
+    _run(_mixtral_tp, 1, 8, 4, 512, "q")
+    _run(_mixtral_tp, 4, 8, 4, 512, "q")
+    l1, l4 = torch.load(base + ".q1")["logits"], torch.load(base + ".q4")["logits"]
+    err = ((l1[0] - l4[0]).abs().max() / l1[0].abs().max()).item()
+    assert err < 5e-2, err  # per-rank int8 quantisation of the experts' hidden activations (see the TP = 2 test)
 
 
 def test_mixtral_int8_decode_step_tp2_matches_tp1(tmp_path):

@@ -56,6 +56,21 @@ def assert_close_elementwise(a, b, rtol=1e-2, atol_peak=2e-3, what=""):
                              f"worst: got {a.flatten()[i].item()}, want {b.flatten()[i].item()}, peak {b.abs().max().item()}")
 
 
+def assert_close(a, b, peak_tol, rtol=1e-2, atol_frac=None, what=""):
+    """The two bars together: max|a - b| < peak_tol * max|b| (BASELINE's "1e-2 rel" in the peak norm) AND, for every
+    element, |a - b| <= rtol * |b| + atol_frac * peak_tol * max|b| -- 1 % of the element's own value plus half of the
+    peak bar as the absolute floor wherever the bar is the north_star's (peak_tol <= 1e-2: op-level comparisons against
+    the oracle).  Looser bars are model-level comparisons (a tiny random model amplifies one flipped bf16 per layer) or
+    fixtures carrying the Triton interpreter's cast defects: there the element-wise form adds nothing to the peak bar.
+    Returns the peak-normalised error."""
+    if atol_frac is None:
+        atol_frac = 0.5 if peak_tol <= 1e-2 else 1.0
+    err = max_rel_to_peak(a, b)
+    assert err < peak_tol, (what, err)
+    assert_close_elementwise(a, b, rtol=rtol, atol_peak=peak_tol * atol_frac, what=what)
+    return err
+
+
 def pattern_cache(pages, page, dim):
     p = torch.arange(pages).view(-1, 1, 1)
     s = torch.arange(page).view(1, -1, 1)
