@@ -34,7 +34,8 @@ def _build_deepseek(args, max_reqs, max_seq, heads):
     model = DeepSeekV3Decoder(args, cache, HipAttnBackend(local_n_heads=heads, max_seq_len=max_seq),
                               max_position_embeddings=4097, device="cuda")
     init_synthetic_(model, seed=11)
-    cache.paged_kv_cache.normal_(0, 0.5)
+    cache.paged_kv_cache.normal_(0, 0.5, generator=torch.Generator(device="cuda").manual_seed(12))  # seeded: the layer's router
+    # is compared on the oracle's own activations, and an unseeded cache made a near-tie flip (a different expert) a matter of luck
     return model, cache
 
 
@@ -135,8 +136,10 @@ def test_mixtral_8x7b_layer_int8():
     model = MixtralDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=ctx + 256),
                            max_position_embeddings=ctx + 256, device="cuda")
     init_synthetic_(model, seed=4)
-    cache.paged_k_cache.normal_(0, 0.5)
-    cache.paged_v_cache.normal_(0, 0.5)
+    kv_gen = torch.Generator(device="cuda").manual_seed(13)  # seeded (see _build_deepseek): one run of this test in three
+    # landed on a router near-tie with unseeded caches (0.30 instead of 0.007)
+    cache.paged_k_cache.normal_(0, 0.5, generator=kv_gen)
+    cache.paged_v_cache.normal_(0, 0.5, generator=kv_gen)
     params = {k: v.detach().cpu() for k, v in model.named_parameters()}
     for bs in (1, 16):
         reqs = [f"m{bs}_{i}" for i in range(bs)]
