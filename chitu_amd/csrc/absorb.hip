@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
 __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
     const bf16_t* __restrict__ part_o, const float* __restrict__ part_lse, int S, const fp8_t* __restrict__ W,
     int64_t w_sh, const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sk,
-    fp8_t* __restrict__ q, float* __restrict__ qs, int H) {
+    fp8_t* __restrict__ q, float* __restrict__ qs, int H, int tile_major) {
     constexpr int K = 512, KC = 8;
     __shared__ __attribute__((aligned(16))) bf16_t xs[K];
     __shared__ float red[8];
@@ -268,8 +268,15 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
     CHITU_PROBE_MARK(4);
     if (j != 0) return;
     const uint32_t packed = f32x2_to_fp8x2(t[0], t[1]) | (f32x2_to_fp8x2(t[2], t[3]) << 16);
-    *reinterpret_cast<uint32_t*>(q + bh * 128 + wave * 16 + g * 4) = packed;
-    if (wave == 0 && g == 0) qs[bh] = sc;
+    if (tile_major) {  // row b of a [batch, H * 128] matrix, tile-major (gemm_common.h): 16-B chunk index h * 8 + wave
+        const int64_t tile = b >> 4;
+        const int m = b & 15;
+        *reinterpret_cast<uint32_t*>(q + ((tile * (H * 8) + h * 8 + wave) * 16 + m) * 16 + g * 4) = packed;
+        if (wave == 0 && g == 0) qs[(tile * H + h) * 16 + m] = sc;
+    } else {
+        *reinterpret_cast<uint32_t*>(q + bh * 128 + wave * 16 + g * 4) = packed;
+        if (wave == 0 && g == 0) qs[bh] = sc;
+    }
 }
 
 }  // namespace chitu
@@ -348,12 +355,10 @@ extern "C" int chitu_hip_absorb_bmm_rope_fp8(const void* x_bf16, int64_t x_strid
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, int32_t num_splits,
-                                                       const void* w_fp8, int64_t w_stride_h,
-                                                       const float* scale, int64_t scale_offset,
-                                                       int64_t scale_stride_h, int64_t scale_stride_k,
-                                                       void* q_fp8, float* q_scales, int32_t batch,
-                                                       int32_t heads, int32_t K, void* stream) {
+static int launch_merge_uv_quant(const void* workspace, int32_t num_splits, const void* w_fp8, int64_t w_stride_h,
+                                 const float* scale, int64_t scale_offset, int64_t scale_stride_h, int64_t scale_stride_k,
+                                 void* q_fp8, float* q_scales, int32_t batch, int32_t heads, int32_t K, int tile_major,
+                                 void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(workspace && w_fp8 && scale && q_fp8 && q_scales);
     CHITU_REQUIRE(batch >= 0 && heads >= 1 && num_splits >= 2 && num_splits <= 256 && w_stride_h % 16 == 0);
@@ -363,8 +368,30 @@ extern "C" int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, in
     const float* part_lse = (const float*)(part_o + (int64_t)batch * heads * num_splits * 512);
     hipLaunchKernelGGL(mla_merge_uv_quant_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(512), 0,
                        (hipStream_t)stream, part_o, part_lse, (int)num_splits, (const fp8_t*)w_fp8, w_stride_h,
-                       scale, scale_offset, scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales, (int)heads);
+                       scale, scale_offset, scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales, (int)heads, tile_major);
     CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, int32_t num_splits,
+                                                       const void* w_fp8, int64_t w_stride_h,
+                                                       const float* scale, int64_t scale_offset,
+                                                       int64_t scale_stride_h, int64_t scale_stride_k,
+                                                       void* q_fp8, float* q_scales, int32_t batch,
+                                                       int32_t heads, int32_t K, void* stream) {
+    return launch_merge_uv_quant(workspace, num_splits, w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
+                                 scale_stride_k, q_fp8, q_scales, batch, heads, K, 0, stream);
+}
+
+// The same with the fp8 output TILE-MAJOR (see chitu_hip_fp8_gemm_blockscale_tm): q_fp8 [ceil(batch/16)*16, heads*128]
+// bytes, q_scales [ceil(batch/16), heads, 16].
+extern "C" int chitu_hip_mla_merge_absorb_uv_quant_fp8_tm(const void* workspace, int32_t num_splits,
+                                                          const void* w_fp8, int64_t w_stride_h,
+                                                          const float* scale, int64_t scale_offset,
+                                                          int64_t scale_stride_h, int64_t scale_stride_k,
+                                                          void* q_fp8, float* q_scales, int32_t batch,
+                                                          int32_t heads, int32_t K, void* stream) {
+    return launch_merge_uv_quant(workspace, num_splits, w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
+                                 scale_stride_k, q_fp8, q_scales, batch, heads, K, 1, stream);
 }
 
 CHITU_PROBE_READER(absorb)

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
     CommPeers peers, CommGeom g, uint32_t* state, const bf16_t* part, int64_t part_stride, int terms,
     int64_t term_stride, const bf16_t* x, int64_t x_stride, bf16_t* sum_out, int64_t sum_stride,
     const bf16_t* __restrict__ w, bf16_t* y, int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs, int dim,
-    float eps, float qeps, int phase, int two_shot) {
+    float eps, float qeps, int phase, int two_shot, int tile_major) {
     __shared__ float red[kCommThreads / 64];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n_chunks = dim >> 3;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kCommThreads) void allreduce_rmsnorm_kernel(
     if (act && sum_out) *reinterpret_cast<i32x4*>(sum_out + (int64_t)row * sum_stride + tid * 8) = sraw;
     if (tid == 0) epoch_ar[row] = epoch;
     if (!w) return;  // uniform
-    rmsnorm_wide_finish<QMODE>(v, act, row, wraw, y, y_stride, q, qs, dim, eps, qeps, red);
+    rmsnorm_wide_finish<QMODE>(v, act, row, wraw, y, y_stride, q, qs, dim, eps, qeps, red, tile_major);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -497,6 +497,9 @@ extern "C" int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf1
     CHITU_REQUIRE(!x_bf16 || x_row_stride % 8 == 0);
     CHITU_REQUIRE(!sum_out_bf16 || sum_row_stride % 8 == 0);
     CHITU_REQUIRE(sum_out_bf16 || weight_bf16);
+    const int tile_major = (quant_mode & 4) ? 1 : 0;  // quant_mode + 4: tile-major codes and scales, as chitu_hip_rmsnorm
+    quant_mode &= 3;
+    CHITU_REQUIRE(!tile_major || quant_mode != 0);
     if (weight_bf16) {
         CHITU_REQUIRE(y_bf16 || quant_mode != 0);
         CHITU_REQUIRE(!y_bf16 || y_row_stride % 8 == 0);
@@ -514,7 +517,7 @@ extern "C" int chitu_hip_comm_allreduce_rmsnorm(void* comm, const void* part_bf1
                        cm->g, cm->state, (const bf16_t*)part_bf16, part_row_stride, (int)terms, term_stride,        \
                        (const bf16_t*)x_bf16, x_row_stride, (bf16_t*)sum_out_bf16, sum_row_stride,                  \
                        (const bf16_t*)weight_bf16, (bf16_t*)y_bf16, y_row_stride, (fp8_t*)q_fp8, q_scales, (int)dim, \
-                       eps, quant_eps, (int)phase, two_shot)
+                       eps, quant_eps, (int)phase, two_shot, tile_major)
     if (quant_mode == 0) LAUNCH(0);
     else if (quant_mode == 1) LAUNCH(1);
     else LAUNCH(2);

@@ -46,7 +46,12 @@ struct GemmStage {
 };
 
 // ---------------------------------------------------------------- W8A8 block-scaled
-template <int MT, int WK, bool DEEP = false>
+// TM: the activations are TILE-MAJOR -- X[tile = m / 16][K / 16][m % 16][16 B], XS[tile][K / 128][m % 16] -- the layout the
+// fused step's quantising kernels write for batches up to 64 (chitu_hip_rmsnorm quant_mode + 4, ..._uv_quant_fp8_tm).  A
+// 16-lane group (one k chunk, 16 tokens) then reads 256 CONTIGUOUS bytes instead of 16 B from each of 16 rows, and a
+// block's 16 scales one 64-B segment instead of 16 scattered dwords: the activation loads of this kernel were 2.9 of its
+// 9.9 us at bs 16 (profiles/r03_phase_masks.txt); same arithmetic, bit-identical results.
+template <int MT, int WK, bool DEEP = false, bool TM = false>
 __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
     const fp8_t* __restrict__ X, const float* __restrict__ XS, const fp8_t* __restrict__ W,
     const float* __restrict__ WS, void* __restrict__ out, int out_dt, float* __restrict__ partial,
@@ -74,7 +79,10 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
         const int m = min(m_base + mt * 16 + j, M - 1);
         xp[mt] = X + (size_t)m * K + g * 16;
         xsp[mt] = XS + (size_t)m * KB;
-        if (CHITU_GEMM_PHASE_MASK & 16) {
+        if (TM) {
+            xp[mt] = X + (size_t)(m >> 4) * 16 * K + (size_t)(g * 16 + (m & 15)) * 16;
+            xsp[mt] = XS + (size_t)(m >> 4) * KB * 16 + (m & 15);
+        } else if (CHITU_GEMM_PHASE_MASK & 16) {
             xp[mt] = X + (size_t)(g * 16 + (m & 15)) * 16;
             xsp[mt] = XS + (m & 15);
         }
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            if (dbg & 16) {  // chunk c = kb*8 + g (+4): 16 tokens x 16 B = 256 B per chunk
+            if (TM || (dbg & 16)) {  // chunk c = kb*8 + g (+4): 16 tokens x 16 B = 256 B per chunk
                 st.x[mt][0] = *reinterpret_cast<const i32x4*>(xp[mt] + (size_t)kb * 2048);
                 st.x[mt][1] = *reinterpret_cast<const i32x4*>(xp[mt] + (size_t)kb * 2048 + 1024);
             } else if (!(dbg & 1)) {
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(64 * WK) void fp8_gemm_kernel(
             } else {
                 st.x[mt][0] = st.x[mt][1] = i32x4{kb, lane, 1, 2};
             }
-            st.xs[mt] = (dbg & 4) ? 1.0f : (dbg & 16) ? xsp[mt][kb * 16] : xsp[mt][kb];
+            st.xs[mt] = (dbg & 4) ? 1.0f : (TM || (dbg & 16)) ? xsp[mt][kb * 16] : xsp[mt][kb];
         }
         st.ws = wsp[kb];
     };
@@ -261,12 +269,43 @@ static SplitPlan plan_split(int N, int K) {
         case 4: hipLaunchKernelGGL((KERNEL<MT, 4>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
         default: hipLaunchKernelGGL((KERNEL<MT, 8>), grid, dim3(512), 0, st, __VA_ARGS__); break; \
     }
+// the same for tile-major activations (fp8_gemm_kernel<MT, WK, DEEP, TM = true>)
+#define DISPATCH_WK_TM(MT, ...)                                                                                   \
+    switch (plan.WK) {                                                                                            \
+        case 1: hipLaunchKernelGGL((fp8_gemm_kernel<MT, 1, false, true>), grid, dim3(64), 0, st, __VA_ARGS__); break;   \
+        case 2: hipLaunchKernelGGL((fp8_gemm_kernel<MT, 2, false, true>), grid, dim3(128), 0, st, __VA_ARGS__); break;  \
+        case 4: hipLaunchKernelGGL((fp8_gemm_kernel<MT, 4, false, true>), grid, dim3(256), 0, st, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((fp8_gemm_kernel<MT, 8, false, true>), grid, dim3(512), 0, st, __VA_ARGS__); break; \
+    }
+
+static int fp8_gemm_blockscale_launch(const void* a_fp8, const float* a_scale, const void* b_fp8, const float* b_scale,
+                                      void* out, int out_dtype, int64_t M, int64_t N, int64_t K, void* workspace,
+                                      int64_t workspace_bytes, bool tile_major, void* stream);
 
 extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_scale,
                                              const void* b_fp8, const float* b_scale, void* out,
                                              int out_dtype, int64_t M, int64_t N, int64_t K,
                                              void* workspace, int64_t workspace_bytes,
                                              void* stream) {
+    return fp8_gemm_blockscale_launch(a_fp8, a_scale, b_fp8, b_scale, out, out_dtype, M, N, K, workspace, workspace_bytes,
+                                      false, stream);
+}
+
+// The same GEMM on TILE-MAJOR activations (decode-sized M only): a_fp8 [ceil(M/16)][K/16][16][16 B], a_scale
+// [ceil(M/16)][K/128][16] -- the layout chitu_hip_rmsnorm(quant_mode + 4) and ..._uv_quant_fp8_tm write.  Bit-identical output.
+extern "C" int chitu_hip_fp8_gemm_blockscale_tm(const void* a_fp8, const float* a_scale,
+                                                const void* b_fp8, const float* b_scale, void* out,
+                                                int out_dtype, int64_t M, int64_t N, int64_t K,
+                                                void* workspace, int64_t workspace_bytes,
+                                                void* stream) {
+    if (M >= chitu::kTiledMinRows) return CHITU_ERR_UNSUPPORTED;
+    return fp8_gemm_blockscale_launch(a_fp8, a_scale, b_fp8, b_scale, out, out_dtype, M, N, K, workspace, workspace_bytes,
+                                      true, stream);
+}
+
+static int fp8_gemm_blockscale_launch(const void* a_fp8, const float* a_scale, const void* b_fp8, const float* b_scale,
+                                      void* out, int out_dtype, int64_t M, int64_t N, int64_t K, void* workspace,
+                                      int64_t workspace_bytes, bool tile_major, void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(a_fp8 && a_scale && b_fp8 && b_scale && out);
     CHITU_REQUIRE(M >= 0 && N >= 1 && K >= 128 && N < (1 << 30) && K < (1 << 30));
@@ -274,7 +313,7 @@ extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_s
     if (K % 128 != 0) return CHITU_ERR_UNSUPPORTED;  // act_quant's contract, ops.py:345-348
     if (M == 0) return CHITU_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (M >= kTiledMinRows && debug_option(kOptFp8GemmTiled) != 0) {
+    if (!tile_major && M >= kTiledMinRows && debug_option(kOptFp8GemmTiled) != 0) {
         // prefill-sized M: a GEMM, not a weight stream (fp8_gemm_tiled.hip)
         launch_fp8_gemm_tiled((const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, out, out_dtype, M, N, K, st);
         CHITU_RETURN_LAUNCH_STATUS();
@@ -288,6 +327,25 @@ extern "C" int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_s
     for (int64_t mb = 0; mb < M; mb += 64) {
         const int rem = (int)(M - mb);
         const int mbase = (int)mb;
+        if (tile_major) {
+            if (rem <= 16) {
+                const int per_wave = (int)(K / 128) / (plan.WK * plan.S);
+                if (plan.WK == 8 && per_wave > 4 && per_wave <= 8 && debug_option(kOptFp8GemmDeep) != 0)
+                    hipLaunchKernelGGL((fp8_gemm_kernel<1, 8, true, true>), grid, dim3(512), 0, st, (const fp8_t*)a_fp8, a_scale,
+                                       (const fp8_t*)b_fp8, b_scale, out, out_dtype, partial, (int)M, (int)N, (int)K,
+                                       plan.S, mbase);
+                else
+                    DISPATCH_WK_TM(1, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, out, out_dtype, partial,
+                                   (int)M, (int)N, (int)K, plan.S, mbase)
+            } else if (rem <= 32) {
+                DISPATCH_WK_TM(2, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, out, out_dtype, partial,
+                               (int)M, (int)N, (int)K, plan.S, mbase)
+            } else {
+                DISPATCH_WK_TM(4, (const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, out, out_dtype, partial,
+                               (int)M, (int)N, (int)K, plan.S, mbase)
+            }
+            continue;
+        }
         if (rem <= 16) {
             const int per_wave = (int)(K / 128) / (plan.WK * plan.S);
             if (plan.WK == 8 && per_wave > 4 && per_wave <= 8 && debug_option(kOptFp8GemmDeep) != 0)

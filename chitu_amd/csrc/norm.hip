@@ -34,7 +34,7 @@ template <int QMODE, int MAXT>
 __global__ __launch_bounds__(kNormWideThreads) void rmsnorm_add_kernel(
     const bf16_t* x, int64_t x_stride, const bf16_t* add, int64_t add_stride, int terms, int64_t term_stride,
     bf16_t* sum_out, int64_t sum_stride, const bf16_t* __restrict__ w, bf16_t* y, int64_t y_stride,
-    fp8_t* __restrict__ q, float* __restrict__ qs, int dim, float eps, float qeps) {
+    fp8_t* __restrict__ q, float* __restrict__ qs, int dim, float eps, float qeps, int tile_major) {
     __shared__ float red[kNormWideThreads / 64];
     if (QMODE == 2 && MAXT == 1) CHITU_PROBE_MARK(0);
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(kNormWideThreads) void rmsnorm_add_kernel(
         if (v[0] == 1.2345e30f) CHITU_PROBE_MARK(9);
         CHITU_PROBE_MARK(1);  // inputs arrived, residual added
     }
-    rmsnorm_wide_finish<QMODE>(v, act, row, wraw, y, y_stride, q, qs, dim, eps, qeps, red);
+    rmsnorm_wide_finish<QMODE>(v, act, row, wraw, y, y_stride, q, qs, dim, eps, qeps, red, tile_major);
     if (QMODE == 2 && MAXT == 1) CHITU_PROBE_MARK(2);
 }
 
@@ -74,11 +74,15 @@ extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const
     if (dim % 8 != 0 || dim > kNormThreads * 8 * kNormMaxChunks || dim > kNormWideThreads * 8) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(x_row_stride % 8 == 0 && (!y_bf16 || y_row_stride % 8 == 0));
     CHITU_REQUIRE((!add_bf16 || add_row_stride % 8 == 0) && (!sum_out_bf16 || (add_bf16 && sum_row_stride % 8 == 0)));
+    // quant_mode + 4: the same codes and scales written TILE-MAJOR (see the header); only with a residual add (wide form)
+    const int tile_major = (quant_mode & 4) ? 1 : 0;
+    quant_mode &= 3;
     if (quant_mode != 0) {
         CHITU_REQUIRE(q_fp8 && q_scales);
         if (dim % 128 != 0) return CHITU_ERR_UNSUPPORTED;
         CHITU_REQUIRE(quant_mode == 1 || quant_mode == 2);
     }
+    CHITU_REQUIRE(!tile_major || (quant_mode != 0 && add_bf16));
     CHITU_REQUIRE(add_terms >= 1 && (add_terms == 1 || (add_bf16 && add_term_stride % 8 == 0)));
     if (add_terms > kNormMaxTerms) return CHITU_ERR_UNSUPPORTED;
     if (rows == 0) return CHITU_OK;
@@ -89,7 +93,7 @@ extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const
                        (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)add_bf16, add_row_stride,       \
                        (int)add_terms, add_term_stride, (bf16_t*)sum_out_bf16, sum_row_stride,             \
                        (const bf16_t*)weight_bf16, (bf16_t*)y_bf16, y_row_stride, (fp8_t*)q_fp8, q_scales, \
-                       (int)dim, eps, quant_eps)
+                       (int)dim, eps, quant_eps, tile_major)
         if (add_terms == 1) {
             if (quant_mode == 0) LAUNCHA(0, 1);
             else if (quant_mode == 1) LAUNCHA(1, 1);

@@ -158,10 +158,12 @@ __device__ __forceinline__ i32x4 sum_terms_bf16x8(const i32x4 (&t)[MAXT], int te
 // v[8]: this thread's chunk `tid` of the (already residual-added, bf16-valued) row; act: chunk inside the row.
 // Mean square over the row (per-thread sequential, wave butterfly, the 16 wave sums in order), y = (v * rr) * w
 // with one rounding, optional fp8 quantisation of the rounded y (16 lanes = one 128-wide group).
+// tile_major: the fp8 output in the layout the small-batch GEMMs read with fully coalesced loads (gemm_common.h,
+// "tile-major activations"): q[tile = row / 16][dim / 16][row % 16][16 B], qs[tile][dim / 128][row % 16].
 template <int QMODE>
 __device__ __forceinline__ void rmsnorm_wide_finish(const float (&v)[8], bool act, int row, const i32x4& wraw, bf16_t* y,
                                                     int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs,
-                                                    int dim, float eps, float qeps, float* red) {
+                                                    int dim, float eps, float qeps, float* red, int tile_major = 0) {
     const int tid = threadIdx.x;
     float ss = 0.f;
     if (act) {
@@ -197,8 +199,15 @@ __device__ __forceinline__ void rmsnorm_wide_finish(const float (&v)[8], bool ac
         const float sc = amax / 448.0f;
         const i32x2 packed = quant8_fp8<QMODE == 2>(o, act ? sc : 1.0f);
         if (act) {
-            *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + tid * 8) = packed;
-            if ((tid & 15) == 0) qs[(int64_t)row * (dim >> 7) + (tid >> 4)] = sc;
+            if (tile_major) {
+                const int64_t tile = row >> 4;
+                const int m = row & 15;
+                *reinterpret_cast<i32x2*>(q + ((tile * (dim >> 4) + (tid >> 1)) * 16 + m) * 16 + (tid & 1) * 8) = packed;
+                if ((tid & 15) == 0) qs[(tile * (dim >> 7) + (tid >> 4)) * 16 + m] = sc;
+            } else {
+                *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + tid * 8) = packed;
+                if ((tid & 15) == 0) qs[(int64_t)row * (dim >> 7) + (tid >> 4)] = sc;
+            }
         }
     }
 }

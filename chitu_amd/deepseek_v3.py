@@ -130,6 +130,12 @@ def linear_deepseek_v3(x, weight, weight_scale=None, bias=None, x_quant=None):
     if weight.element_size() > 1:
         return F.linear(x, weight, bias)
     assert weight_scale is not None
+    if x_quant is not None and isinstance(x_quant[0], ops.TiledQuant):
+        # the fused step's tile-major activations (ops.TiledQuant): same GEMM, coalesced activation loads
+        y = ops.fp8_gemm_deepseek_v3(x_quant[0], None, weight, weight_scale, out_dtype=torch.bfloat16)
+        if bias is not None:
+            y += bias
+        return y
     if x_quant is None:
         shape = x.shape
         xq, xs = ops.act_quant_deepseek_v3(x.reshape(-1, shape[-1]).contiguous(), BLOCK)
@@ -245,13 +251,15 @@ class AttentionDeepSeekV3(torch.nn.Module):
         MLA decode, [split merge + W_UV absorb + quant], wo GEMM.  (7 with batches above 16: the q_norm / kv
         launch and the wq_b GEMM apart.)"""
         H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
-        bs = x_quant[0].shape[0]
+        bs = x_quant[0].rows if isinstance(x_quant[0], ops.TiledQuant) else x_quant[0].shape[0]
         cache = self.cache
         kv_cache = cache.get_paged_kv_cache(self.layer_id)
         nblk = C // BLOCK
         if self.q_lora_rank > 0:
             # wqkv_a: [bs, q_lora + C + R] (optionally as split-K planes, see _wqkv_a_splits)
             splits = _wqkv_a_splits(bs, self.wqkv_a.out_features, self.wqkv_a.in_features)
+            if isinstance(x_quant[0], ops.TiledQuant):
+                splits = 1
             if splits > 1:
                 q_a_kv = ops.fp8_gemm_partials_deepseek_v3(x_quant[0], x_quant[1], self.wqkv_a.weight, self.wqkv_a.scale, splits)
             else:
@@ -289,7 +297,8 @@ class AttentionDeepSeekV3(torch.nn.Module):
         # out = o . W_UV^T  (einsum "bshc,hdc->bshd", :697) + the act-quant of wo's input
         w_uv = self.wkv_b.weight.view(H, self.qk_nope_head_dim + self.v_head_dim, C)[:, self.qk_nope_head_dim :]
         if isinstance(o, tuple):
-            oq, os_ = ops.mla_merge_absorb_uv_quant_fp8(o[0], o[1], bs, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1)
+            oq, os_ = ops.mla_merge_absorb_uv_quant_fp8(o[0], o[1], bs, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1,
+                                                        tile_major=ops.tile_major_ok(bs))
         else:
             oq, os_ = ops.absorb_uv_quant_fp8(o, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1)
         return self.wo(None, x_quant=(oq, os_))
@@ -472,7 +481,10 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
         :1107-1113).  With tensor parallelism the sublayer outputs are partials: `tp.defer_all_reduce` hands
         their all-reduce to that same norm launch when the in-graph xGMI collectives are on (then a layer has
         no stand-alone collective at all), and performs it through the library otherwise."""
-        x, _, xq, xs = add_norm(x, pending, self.attn_norm, out_bf16=False, quant="act")
+        # decode: the fp8 form of the normed row goes to wqkv_a only -> tile-major (ops.TiledQuant), wherever a residual
+        # is folded in (every layer but the first)
+        tm = varlens is None and pending is not None and ops.tile_major_ok(x.shape[0])
+        x, _, xq, xs = add_norm(x, pending, self.attn_norm, out_bf16=False, quant="act", tile_major=tm)
         if varlens is None:
             a = tp.defer_all_reduce(self.attn.decode_forward_paged((xq, xs), cos, sin))
         else:
@@ -485,15 +497,16 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
                      and self.ffn.moe_world_size == 1 and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")
             f = self.ffn(hn, (hq, hs), defer_sum=defer)
         else:
-            x, _, hq, hs = add_norm(x, a, self.ffn_norm, out_bf16=False, quant="act")
+            x, _, hq, hs = add_norm(x, a, self.ffn_norm, out_bf16=False, quant="act",
+                                    tile_major=varlens is None and ops.tile_major_ok(x.shape[0]))
             f = self.ffn((hq, hs))
         return x, tp.defer_all_reduce(f)
 
 
-def add_norm(x, pending, norm, out_bf16=True, quant=None):
+def add_norm(x, pending, norm, out_bf16=True, quant=None, tile_major=False):
     """tensor_parallel.add_norm on an RMSNormW module: residual add (+ the all-reduce of a deferred partial) + norm
-    [+ fp8 quant] in one launch; returns (x_new, y, q, s)."""
-    return tp.add_norm(x, pending, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant)
+    [+ fp8 quant] in one launch; returns (x_new, y, q, s) (q an ops.TiledQuant and s None under tile_major)."""
+    return tp.add_norm(x, pending, norm.weight, norm.eps, out_bf16=out_bf16, quant=quant, tile_major=tile_major)
 
 
 class DeepSeekV3Decoder(torch.nn.Module):

@@ -4,6 +4,7 @@ Reference (read-only): chitu/ops.py:51-511.  Each function below calls one C-ABI
 point of libchitu_hip.so on torch's current stream.  There is no Triton and no fallback.
 """
 
+import os as _os
 from typing import Tuple
 
 import torch
@@ -23,6 +24,40 @@ __all__ = [
 ]
 
 _GEMM_WS_BYTES = 64 << 20
+_TILE_MAJOR_MAX_ROWS = 64
+_TILE_MAJOR = _os.environ.get("CHITU_TILE_MAJOR", "1") != "0"  # read once: A/B timing and the equivalence test flip it
+
+
+class TiledQuant:
+    """fp8 activations in the TILE-MAJOR layout of the fused decode step: q bytes [ceil(rows/16)][K/16][16 rows][16 B],
+    scales [ceil(rows/16)][K/128][16 rows] -- what a small-batch GEMM reads with fully coalesced loads (a 16-lane group =
+    256 contiguous bytes; row-major it is 16 B from each of 16 rows).  Written by rms_norm(add=, quant=, tile_major=True)
+    and mla_merge_absorb_uv_quant_fp8(tile_major=True), read by fp8_gemm_deepseek_v3(TiledQuant, ...).  Internal to the
+    fused step: the drop-in op surface keeps the reference's row-major [rows, K] / [rows, K/128] pair."""
+
+    __slots__ = ("q", "s", "rows", "cols")
+
+    def __init__(self, q, s, rows, cols):
+        self.q, self.s, self.rows, self.cols = q, s, rows, cols
+
+    def to_row_major(self):
+        """(q [rows, K] fp8, s [rows, K/128] f32): the same codes and scales in the reference's layout (tests)."""
+        t = (self.rows + 15) // 16
+        q = self.q.view(torch.uint8).view(t, self.cols // 16, 16, 16).permute(0, 2, 1, 3).reshape(t * 16, self.cols)
+        s = self.s.view(t, self.cols // 128, 16).permute(0, 2, 1).reshape(t * 16, self.cols // 128)
+        return q[: self.rows].contiguous().view(torch.float8_e4m3fn), s[: self.rows].contiguous()
+
+
+def tile_major_ok(rows: int) -> bool:
+    """Do the fused step's quantising launches write their fp8 output tile-major for a batch of `rows`?  (Decode-sized
+    batches only: from _TILE_MAJOR_MAX_ROWS on the GEMMs are tiled for compute and read row-major.)"""
+    return _TILE_MAJOR and 0 < rows <= _TILE_MAJOR_MAX_ROWS
+
+
+def _tiled_buffers(rows, cols, device):
+    t = (rows + 15) // 16
+    return (torch.empty(t * 16, cols, dtype=torch.float8_e4m3fn, device=device),
+            torch.empty(t, cols // 128, 16, dtype=torch.float32, device=device))
 
 
 def act_quant_deepseek_v3(x: torch.Tensor, block_size: int = 128) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -85,7 +120,22 @@ def weight_dequant_soft_fp8_deepseek_v3(x: torch.Tensor, s: torch.Tensor, block_
 
 def fp8_gemm_deepseek_v3(a: torch.Tensor, a_s: torch.Tensor, b: torch.Tensor, b_s: torch.Tensor, out_dtype=None):
     """c = sum_kb (a_kb . b_kb^T) * a_s[:, kb] * b_s[n//128, kb]   (chitu/ops.py:453-483).
-    Output dtype = torch.get_default_dtype() like the reference (:474), unless out_dtype is given."""
+    Output dtype = torch.get_default_dtype() like the reference (:474), unless out_dtype is given.
+    a may be a TiledQuant (then a_s is ignored): the same GEMM reading tile-major activations, bit-identical."""
+    if isinstance(a, TiledQuant):
+        assert b.is_contiguous() and b_s.is_contiguous() and b.element_size() == 1 and b_s.dtype == torch.float32
+        require_cuda(a.q, a.s, b, b_s)
+        assert a.cols == b.size(-1)
+        c = torch.empty(a.rows, b.size(0), dtype=out_dtype or torch.get_default_dtype(), device=b.device)
+        ws = workspace.get(_GEMM_WS_BYTES, b.device, "gemm")
+        check(
+            _lib.lib().chitu_hip_fp8_gemm_blockscale_tm(
+                ptr(a.q), ptr(a.s), ptr(b), ptr(b_s), ptr(c), float_dtype_code(c.dtype), i64(a.rows), i64(b.size(0)),
+                i64(a.cols), ptr(ws), i64(ws.numel()), stream_ptr(),
+            ),
+            "fp8_gemm_deepseek_v3 (tile-major activations)",
+        )
+        return c
     assert a.is_contiguous() and b.is_contiguous(), "Input tensors must be contiguous"
     assert a_s.is_contiguous() and b_s.is_contiguous(), "Scaling factor tensors must be contiguous"
     require_cuda(a, a_s, b, b_s)
@@ -224,7 +274,7 @@ def apply_rotary_pos_emb(q, k, cos, sin, rotary_type="hf-llama"):
 
 
 def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16: bool = True, quant: str = None,
-             add: torch.Tensor = None):
+             add: torch.Tensor = None, tile_major: bool = False):
     """RMSNorm (chitu/models/model.py:29-78), optionally fused with the FP8 quantisation that the
     next fp8 linear would run on its output (model_deepseek_v3.py:98-100).
 
@@ -236,6 +286,8 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
     MoE's top-k sum (fused_experts(reduce_topk=False)) folded into this launch.
     Returns y, or (y, q, s) when quant is set (y is None if out_bf16=False); with `add`, x_new is
     prepended: (x_new, y) / (x_new, y, q, s).
+    tile_major (needs add and quant): q is a TiledQuant and s is None -- the same codes and scales in the layout
+    the small-batch GEMM reads coalesced (fp8_gemm_deepseek_v3(TiledQuant, ...)).
     """
     require_cuda(x, weight)
     assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
@@ -264,8 +316,13 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
     mode = 0
     if quant is not None:
         mode = {"act": 1, "group": 2}[quant]
-        q = torch.empty(rows, dim, dtype=torch.float8_e4m3fn, device=x.device)
-        s = torch.empty(rows, dim // 128, dtype=torch.float32, device=x.device)
+        if tile_major:
+            assert add is not None and x.dim() == 2, "tile-major output: the residual-add (wide row) form on [rows, dim]"
+            mode += 4
+            q, s = _tiled_buffers(rows, dim, x.device)
+        else:
+            q = torch.empty(rows, dim, dtype=torch.float8_e4m3fn, device=x.device)
+            s = torch.empty(rows, dim // 128, dtype=torch.float32, device=x.device)
     check(
         _lib.lib().chitu_hip_rmsnorm(
             ptr(x2), i64(x2.stride(0)), ptr(a2), i64(a2.stride(0) if a2 is not None else 0), i32(terms), i64(term_stride),
@@ -277,7 +334,10 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
     )
     if y is not None:
         y = y.view(*x.shape[:-1], dim)
-    res = (y,) if quant is None else (y, q.view(*x.shape[:-1], dim), s.view(*x.shape[:-1], dim // 128))
+    if quant is not None and tile_major:
+        res = (y, TiledQuant(q, s, rows, dim), None)
+    else:
+        res = (y,) if quant is None else (y, q.view(*x.shape[:-1], dim), s.view(*x.shape[:-1], dim // 128))
     if add is not None:
         res = (sum_out.view(x.shape),) + res
     return res[0] if len(res) == 1 else res
@@ -552,7 +612,8 @@ def mla_kv_prep(kv_in, q_pe, cos, sin, kv_norm_weight, eps, kv_cache, page_table
     )
 
 
-def mla_merge_absorb_uv_quant_fp8(partials, num_splits, batch, w, scale, scale_offset, scale_stride_h, scale_stride_k):
+def mla_merge_absorb_uv_quant_fp8(partials, num_splits, batch, w, scale, scale_offset, scale_stride_h, scale_stride_k,
+                                  tile_major: bool = False):
     """Split-KV merge of the MLA partials + absorb_uv_quant_fp8 in one launch (one workgroup per
     (head, token), meant for decode batches up to a few dozen tokens).  partials: the workspace
     returned by HipAttnBackend.mla_decode(return_partials=True)."""
@@ -561,16 +622,19 @@ def mla_merge_absorb_uv_quant_fp8(partials, num_splits, batch, w, scale, scale_o
     assert w.stride(2) == 1 and w.stride(1) == w.shape[2] and w.shape[2] == 512 and num_splits >= 2
     H = w.shape[0]
     assert partials.numel() * partials.element_size() >= batch * H * num_splits * (512 * 2 + 4)  # bf16 rows + fp32 LSE
-    q = torch.empty(batch, H * 128, dtype=torch.float8_e4m3fn, device=w.device)
-    s = torch.empty(batch, H, dtype=torch.float32, device=w.device)
+    if tile_major:  # (TiledQuant, None): the fp8 row of every token tile-major, for fp8_gemm_deepseek_v3(TiledQuant, ...)
+        q, s = _tiled_buffers(batch, H * 128, w.device)
+        fn = _lib.lib().chitu_hip_mla_merge_absorb_uv_quant_fp8_tm
+    else:
+        q = torch.empty(batch, H * 128, dtype=torch.float8_e4m3fn, device=w.device)
+        s = torch.empty(batch, H, dtype=torch.float32, device=w.device)
+        fn = _lib.lib().chitu_hip_mla_merge_absorb_uv_quant_fp8
     check(
-        _lib.lib().chitu_hip_mla_merge_absorb_uv_quant_fp8(
-            ptr(partials), i32(num_splits), ptr(w), i64(w.stride(0)), ptr(scale), i64(scale_offset),
-            i64(scale_stride_h), i64(scale_stride_k), ptr(q), ptr(s), i32(batch), i32(H), i32(512), stream_ptr(),
-        ),
+        fn(ptr(partials), i32(num_splits), ptr(w), i64(w.stride(0)), ptr(scale), i64(scale_offset),
+           i64(scale_stride_h), i64(scale_stride_k), ptr(q), ptr(s), i32(batch), i32(H), i32(512), stream_ptr()),
         "mla_merge_absorb_uv_quant_fp8",
     )
-    return q, s
+    return (TiledQuant(q, s, batch, H * 128), None) if tile_major else (q, s)
 
 
 def embed_rope_gather(tokens, embed_weight, vocab_start, positions=None, cos_table=None, sin_table=None):

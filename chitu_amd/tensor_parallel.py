@@ -221,18 +221,21 @@ def defer_all_reduce(t: torch.Tensor):
     return all_reduce(t)
 
 
-def add_norm(x, pending, weight, eps, out_bf16=True, quant=None):
+def add_norm(x, pending, weight, eps, out_bf16=True, quant=None, tile_major=False):
     """(x_new, y, q, s) with x_new = x + pending and y / (q, s) = RMSNorm(x_new) [fp8-quantised]; entries not asked
     for are None.  pending: None | a tensor ([rows, dim], or [rows, terms, dim]: terms summed first) | a
     PendingAllReduce (this rank's partial: all-reduced over xGMI inside the same launch).  The one place where a
-    residual add, its norm and -- under tensor parallelism -- the all-reduce in front of them meet."""
+    residual add, its norm and -- under tensor parallelism -- the all-reduce in front of them meet.
+    tile_major: q comes back as an ops.TiledQuant (s None) wherever a residual is folded in (the wide row form)."""
     from . import ops
 
     if isinstance(pending, PendingAllReduce):
-        res = _xgmi.allreduce_rmsnorm(pending.part, x, weight, eps, out_bf16=out_bf16, quant=quant)
-    elif pending is None:
+        res = _xgmi.allreduce_rmsnorm(pending.part, x, weight, eps, out_bf16=out_bf16, quant=quant, tile_major=tile_major)
+    elif pending is None:  # (no residual yet: the narrow row form, row-major output whatever tile_major asks for)
         r = ops.rms_norm(x, weight, eps, out_bf16=out_bf16, quant=quant)
         res = (x,) + (r if isinstance(r, tuple) else (r,))
+    elif tile_major:
+        res = ops.rms_norm(x, weight, eps, out_bf16=out_bf16, quant=quant, add=pending, tile_major=True)
     else:
         res = ops.rms_norm(x, weight, eps, out_bf16=out_bf16, quant=quant, add=pending)
     return tuple(res) + (None,) * (4 - len(res))

@@ -135,7 +135,7 @@ class XgmiComm:
 
     def allreduce_rmsnorm(self, part: torch.Tensor, x: Optional[torch.Tensor] = None, weight: Optional[torch.Tensor] = None,
                           eps: float = 1e-6, out_bf16: bool = True, quant: Optional[str] = None, out: Optional[torch.Tensor] = None,
-                          phase: int = 0, into=None):
+                          phase: int = 0, into=None, tile_major: bool = False):
         """part: this rank's partial, [rows, dim] or [rows, terms, dim] (terms summed first, chitu_hip_moe_sum's
         rounding).  Returns what ops.rms_norm(x, weight, eps, out_bf16, quant, add=<all-reduced part>) returns:
         (x_new, y[, q, s]) -- with x None, x_new is the all-reduced tensor itself; with weight None only
@@ -164,18 +164,28 @@ class XgmiComm:
             if out_bf16 and y is None:
                 y = torch.empty(rows, dim, dtype=torch.bfloat16, device=part.device)
             if quant is not None and q is None:
-                q = torch.empty(rows, dim, dtype=torch.float8_e4m3fn, device=part.device)
-                s = torch.empty(rows, dim // 128, dtype=torch.float32, device=part.device)
+                if tile_major:  # ops.TiledQuant layout (see chitu_hip_fp8_gemm_blockscale_tm)
+                    from .ops import _tiled_buffers
+
+                    q, s = _tiled_buffers(rows, dim, part.device)
+                else:
+                    q = torch.empty(rows, dim, dtype=torch.float8_e4m3fn, device=part.device)
+                    s = torch.empty(rows, dim // 128, dtype=torch.float32, device=part.device)
         else:
             assert quant is None
         check(
             _lib.lib().chitu_hip_comm_allreduce_rmsnorm(
                 self._h, ptr(part), i64(part_stride), i32(terms), i64(term_stride), ptr(x),
                 i64(x.stride(0) if x is not None else 0), ptr(sum_out), i64(sum_out.stride(0)), ptr(weight), ptr(y), i64(dim),
-                i64(rows), i32(dim), f32(eps), ptr(q), ptr(s), i32(_QUANT_MODE[quant]), f32(1e-10), i32(phase), stream_ptr()),
+                i64(rows), i32(dim), f32(eps), ptr(q), ptr(s), i32(_QUANT_MODE[quant] + (4 if tile_major and quant else 0)),
+                f32(1e-10), i32(phase), stream_ptr()),
             "comm_allreduce_rmsnorm")
         if weight is None:
             return sum_out
+        if quant is not None and tile_major:
+            from .ops import TiledQuant
+
+            return (sum_out, y, TiledQuant(q, s, rows, dim), None)
         return (sum_out, y) if quant is None else (sum_out, y, q, s)
 
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:

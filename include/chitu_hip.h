@@ -86,6 +86,18 @@ int chitu_hip_fp8_gemm_blockscale(const void* a_fp8, const float* a_scale, const
                                   const float* b_scale, void* out, int out_dtype, int64_t M,
                                   int64_t N, int64_t K, void* workspace,
                                   int64_t workspace_bytes, void* stream);
+/* The same GEMM on TILE-MAJOR activations, the layout the fused decode step keeps its fp8 activations in between two of
+ * its own launches (never across the drop-in op surface, which stays row-major like the reference's):
+ *   a_fp8   [ceil(M/16)][K/16][16 rows][16 B]   -- the 16 tokens of a tile side by side for every 16-byte k chunk
+ *   a_scale [ceil(M/16)][K/128][16 rows] f32
+ * so that a 16-lane group of the MFMA B-operand load (one k chunk, 16 tokens) reads 256 contiguous bytes instead of 16 B
+ * from each of 16 rows, and a block's 16 scales one 64-B segment (the activation loads were 2.9 of the 9.9 us of the wqkv_a
+ * launch at bs 16).  Written by chitu_hip_rmsnorm / chitu_hip_comm_allreduce_rmsnorm with quant_mode + 4 and by
+ * chitu_hip_mla_merge_absorb_uv_quant_fp8_tm.  M < 128; same arithmetic, bit-identical output. */
+int chitu_hip_fp8_gemm_blockscale_tm(const void* a_fp8, const float* a_scale, const void* b_fp8,
+                                     const float* b_scale, void* out, int out_dtype, int64_t M,
+                                     int64_t N, int64_t K, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
 /* The same contraction with the K range cut over num_splits (2..16) workgroups per output tile and the fp32 partial
  * planes as the OUTPUT: partials [num_splits, M, N], plane s = the contribution of its K blocks, no reduce launch.
  * For the dense GEMMs whose N cannot fill 256 CUs on its own (wqkv_a: 2112 rows = 132 tiles); the consumer sums
@@ -368,6 +380,13 @@ int chitu_hip_mla_prefill(const void* q_bf16, int64_t q_stride_t, int64_t q_stri
  * points as chitu_hip_mla_decode's merge pass followed by chitu_hip_absorb_uv_quant_fp8.
  * workspace: as left by chitu_hip_mla_decode(out_bf16 = NULL) with the same batch/heads/num_splits
  * (>= 2); weight/scale arguments as chitu_hip_absorb_uv_quant_fp8; K must be 512. */
+/* ..._tm: the same launch writing q / scales TILE-MAJOR (see chitu_hip_fp8_gemm_blockscale_tm): q_fp8 holds
+ * ceil(batch/16)*16 rows of heads*128 bytes, q_scales [ceil(batch/16), heads, 16]. */
+int chitu_hip_mla_merge_absorb_uv_quant_fp8_tm(const void* workspace, int32_t num_splits,
+                                               const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                               int64_t scale_offset, int64_t scale_stride_h,
+                                               int64_t scale_stride_k, void* q_fp8, float* q_scales,
+                                               int32_t batch, int32_t heads, int32_t K, void* stream);
 int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, int32_t num_splits,
                                             const void* w_fp8, int64_t w_stride_h, const float* scale,
                                             int64_t scale_offset, int64_t scale_stride_h,
@@ -379,6 +398,8 @@ int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, int32_t num_s
  * when quant_mode != 0, also the act-quant launch of the fp8 linear that consumes it
  * (chitu/models/model_deepseek_v3.py:98-100).  quant_mode 1 = act_quant_deepseek_v3 rule,
  * 2 = per_token_group_quant_fp8 rule (eps = quant_eps); the codes are those of the bf16-rounded y.
+ * quant_mode + 4 (5, 6; only with add_bf16): the same codes and scales written TILE-MAJOR for
+ * chitu_hip_fp8_gemm_blockscale_tm -- q_fp8 ceil(rows/16)*16*dim bytes, q_scales ceil(rows/16)*(dim/128)*16 floats.
  *   add_bf16 (optional): residual branch folded in first, x <- bf16(x + add) -- the reference's
  *   `x = x + attn(...)` / `x = x + ffn(...)` (model_deepseek_v3.py:1107-1113); sum_out receives it.
  *   add_terms > 1 (<= 16): the residual of row r is first formed as bf16(sum_k float(add[r*add_row_stride +

@@ -237,11 +237,16 @@ def install_llama(monkeypatch_setattr):
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)  # Mixtral's INT8 experts ride on the Llama wiring
 
 
+def tile_major_ok(rows):
+    """The CPU shim keeps the reference's row-major (q, s) pairs: tile-major is a device-side layout."""
+    return False
+
+
 def install(monkeypatch_setattr):
     """monkeypatch_setattr(obj, name, value) -- e.g. pytest's monkeypatch.setattr or plain setattr."""
     from chitu_amd import fused_moe, ops
 
-    for name in ("rms_norm", "act_quant_deepseek_v3", "fp8_gemm_deepseek_v3", "mla_kv_prep", "absorb_bmm_fp8",
+    for name in ("tile_major_ok", "rms_norm", "act_quant_deepseek_v3", "fp8_gemm_deepseek_v3", "mla_kv_prep", "absorb_bmm_fp8",
                  "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear", "mla_qkv_post", "mla_q_proj", "mla_q_proj_fits", "absorb_bmm_rope_fp8",
                  "embed_rope_gather"):
         monkeypatch_setattr(ops, name, globals()[name])

@@ -717,3 +717,43 @@ def test_large_batch_matches_small_batches():
         idx = list(range(s0, s0 + 7))
         part = step(small, idx, use_graph=False)
         assert_close(part, full[idx], 4e-2, what=s0)
+
+
+@pytest.mark.parametrize("make_args", [tiny_args, v2lite_like_args], ids=["v3_like", "v2lite_like"])
+def test_tile_major_activations_leave_the_decode_step_bit_identical(make_args, monkeypatch):
+    """The fused step keeps the fp8 activations of wqkv_a / wo / the dense MLP tile-major between its own launches
+    (ops.TiledQuant).  Same codes, same scales, same GEMM arithmetic: the logits and the KV rows of several decode steps
+    are bit-identical with the layout switched off (ops._TILE_MAJOR = False)."""
+    from chitu_amd import ops
+
+    args = make_args()
+    model, cache = build(args, max_reqs=4, max_seq=512)
+
+    def run(tag, flag):
+        monkeypatch.setattr(ops, "_TILE_MAJOR", flag)
+        reqs = [f"{tag}{i}" for i in range(3)]
+        g = torch.Generator().manual_seed(5)
+        for r, n in zip(reqs, (60, 3, 127)):
+            cache.register_sequence(r, n)
+            rows = (torch.randn(args.n_layers, 256, 576, generator=g) * 0.5).to(torch.bfloat16).cuda()
+            for p, blk in enumerate(cache.block_table[r]):
+                cache.paged_kv_cache[:, blk] = rows[:, p * 64 : (p + 1) * 64]
+        toks = torch.tensor([5, 17, 900], dtype=torch.int64, device="cuda")
+        out = []
+        for _ in range(6):
+            cache.prepare_cache_decode(reqs)
+            cache.prepare_block_table_for_decode(reqs)
+            logits = model.decode(toks, use_graph=False).clone()
+            cache.finalize_cache_single_decode(reqs)
+            out.append(logits)
+            toks = logits.argmax(-1)
+        kv = [torch.cat([cache.paged_kv_cache[:, b] for b in cache.block_table[r]], dim=1)[:, : cache.seq_lens[r]].clone() for r in reqs]
+        for r in reqs:
+            cache.finalize_cache_all_decode(r)
+        return out, kv
+
+    (la, ka), (lb, kb) = run("t", True), run("r", False)
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b)
+    for a, b in zip(ka, kb):
+        assert torch.equal(a, b)

@@ -258,3 +258,34 @@ def test_fp8_gemm_tiled_prefill_form_vs_streaming_form_and_oracle(M, N, K):
     if M * N * K <= 2e8:
         ref = ofp8.fp8_gemm_deepseek_v3(xq.cpu(), xs.cpu(), w.cpu(), ws.cpu(), torch.float32)
         assert_close(b16, ref, 5e-3)
+
+
+# ---------------------------------------------------------------- tile-major activations (the fused step's internal layout)
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("N,K", [(2112, 7168), (7168, 2048), (3072, 1536), (200, 512)])
+def test_tile_major_activations_are_the_same_gemm_bit_for_bit(M, N, K):
+    """ops.TiledQuant: the fp8 activations laid out [tile][K/16][16 rows][16 B] (+ scales [tile][K/128][16]) as the
+    fused decode step keeps them between the norm / W_UV launches and the GEMMs that read them.  Only the addresses
+    change: (1) rms_norm(add=, quant=, tile_major=True) writes the SAME codes and scales as the row-major form, permuted;
+    (2) the GEMM on them returns the SAME bits as the row-major GEMM -- every K-split variant, ragged M and N."""
+    from chitu_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    add = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    wn = (1 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.5).to(torch.float8_e4m3fn).cuda()
+    ws = (torch.rand((N + 127) // 128, K // 128, generator=g) * 0.02 + 0.01).cuda()
+    for quant in ("act", "group"):
+        x1, y1, q1, s1 = ops.rms_norm(x, wn, 1e-6, quant=quant, add=add)
+        x2, y2, tq, none = ops.rms_norm(x, wn, 1e-6, quant=quant, add=add, tile_major=True)
+        assert none is None and isinstance(tq, ops.TiledQuant) and torch.equal(x1, x2) and torch.equal(y1, y2)
+        q2, s2 = tq.to_row_major()
+        assert torch.equal(q1.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(s1, s2)
+        ref = ops.fp8_gemm_deepseek_v3(q1, s1, w, ws, out_dtype=torch.bfloat16)
+        out = ops.fp8_gemm_deepseek_v3(tq, None, w, ws, out_dtype=torch.bfloat16)
+        assert torch.equal(out, ref)
+        for wk in (1, 2, 4, 8):
+            with _lib.debug_option("fp8_gemm_wk", wk):
+                assert torch.equal(ops.fp8_gemm_deepseek_v3(tq, None, w, ws, out_dtype=torch.float32),
+                                   ops.fp8_gemm_deepseek_v3(q1, s1, w, ws, out_dtype=torch.float32)), wk

@@ -254,3 +254,25 @@ def test_prefill_kernel_equals_per_token_decode_composition(monkeypatch):
         assert torch.equal(outs["kernel"], outs["compose"]), (H, seqs)
         ref = omla.mla_prefill(q.cpu(), kv.cpu()[:, 0], cu.cpu(), 0.1352)
         assert_close(outs["kernel"].cpu(), ref, REL_TOL)
+
+
+def test_merge_uv_quant_tile_major_is_the_same_output_permuted():
+    """mla_merge_absorb_uv_quant_fp8(tile_major=True): the fp8 rows of wo's input in ops.TiledQuant layout -- the same
+    codes and scales as the row-major launch."""
+    from chitu_amd import ops
+
+    for bs, lens in ((1, [700]), (5, [64, 1, 300, 129, 1024]), (17, [200] * 17)):
+        H = 16
+        pages = sum((l + 63) // 64 for l in lens) + 2
+        q_nope, q_pe, cache, table, sl = make_case(bs, H, lens, pages, seed=bs)
+        be = backend(H)
+        dev = [t.cuda() for t in (q_nope, q_pe, cache, sl, table)]
+        part = be.mla_decode(dev[0], dev[1], dev[2], dev[3], dev[4], 0.1352, return_partials=True, num_splits=4)
+        g = torch.Generator().manual_seed(3)
+        w = (torch.randn(H, 256, 512, generator=g) * 0.5).to(torch.float8_e4m3fn).cuda()
+        sc = (torch.rand(H * 2, 4, generator=g) * 0.02 + 0.01).cuda()
+        q, s_ = ops.mla_merge_absorb_uv_quant_fp8(part[0], part[1], bs, w[:, 128:], sc, 4, 8, 1)
+        tq, none = ops.mla_merge_absorb_uv_quant_fp8(part[0], part[1], bs, w[:, 128:], sc, 4, 8, 1, tile_major=True)
+        assert none is None
+        q2, s2 = tq.to_row_major()
+        assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(s_, s2)
