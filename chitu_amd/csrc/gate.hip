@@ -720,6 +720,105 @@ __global__ __launch_bounds__(1024) void gate_route_align_wg_kernel(
     CHITU_PROBE_MARK(4);
 }
 
+// ---------------------------------------------------------------- routing + align, one workgroup, softmax routers
+// The same one-workgroup form for the softmax routers with at most 64 experts (DeepSeek-V2-Lite: 64 experts, top-6, two
+// always-on slots; Mixtral: 8 experts, top-2, renormalised): a wave per token, ONE expert per lane, fp32 scores.
+// gate_route_kernel<0>'s arithmetic exactly -- logits summed over the split-K planes in plane order and rounded to bf16,
+// softmax in fp32 with the wave's butterfly sum, selection by (score descending, index ascending), weights =
+// softmax scores [/ their sum in rank order] * route_scale -- so ids, weights and the align outputs are bit-identical
+// to the separate launches (one workgroup per token + ticket + sort by the last one: 12 us at bs 16 on the V2-Lite
+// step, most of it the ticket's release / acquire pair and a two-wave sort).
+__device__ __forceinline__ uint32_t ordered_u32(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return b ^ ((b & 0x80000000u) ? 0xffffffffu : 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void gate_route_align_wg_softmax_kernel(
+    const void* __restrict__ logits, int S, int M, int E, const bf16_t* __restrict__ bias, int topk, float route_scale,
+    bf16_t* __restrict__ out_w, int64_t* __restrict__ out_ids, int out_stride, int extra_id, float extra_w, int extra_n,
+    int renorm, RouteAlign al) {
+    extern __shared__ __attribute__((aligned(16))) int dyn_lds[];
+    int64_t* ids_lds = reinterpret_cast<int64_t*>(dyn_lds);                  // [M * out_stride]
+    int* align_lds = dyn_lds + 2 * ((M * out_stride + 1) & ~1);
+    const int lane = threadIdx.x & 63, t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // the wave's token
+    const bool small_sort = al.small != 0;
+    if (small_sort) {
+        moe_align_small_init(al.num_experts, (int64_t)M * out_stride, al.sorted_ids, al.sorted_cap, al.expert_ids, al.expert_cap,
+                             align_lds, (int)threadIdx.x, (int)blockDim.x);
+        __syncthreads();
+    }
+    if (t < M) {  // wave-uniform
+        const bool act = lane < E;
+        const int ec = act ? lane : E - 1;
+        float logit;
+        if (S == 0) {
+            logit = bf16_to_f32(((const bf16_t*)logits)[(int64_t)t * E + ec]);
+        } else {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = ((const float*)logits)[((int64_t)min(i, S - 1) * M + t) * E + ec];
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) a += i < S ? v[i] : 0.f;  // plane order, as gate_route_kernel
+            logit = bf16r(a);
+        }
+        const float bv = bias ? bf16_to_f32(bias[ec]) : 0.f;
+        if (!act) logit = -INFINITY;
+        const float m = wave_reduce_max(logit);
+        const float ex = act ? expf(logit - m) : 0.f;
+        const float sum = wave_reduce_sum(ex);
+        const float orig = ex / sum;  // softmax(dim=-1, dtype=float32)
+        const float sel = bias ? orig + bv : orig;
+        uint32_t key = act ? ordered_u32(sel) : 0u;
+        // ---- top-k: round r's winner (greatest score, lowest index among equals) becomes slot r, kept by lane r
+        int my_e = 0;
+        float my_w = 0.f;
+        for (int r = 0; r < topk; ++r) {
+            const uint32_t mk = wave_max_u32_uniform(key);
+            const unsigned long long hit = __ballot(act && key == mk);
+            const int win = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(orig), win));
+            if (lane == r) {
+                my_e = win;
+                my_w = w;
+            }
+            if (lane == win) key = 0u;  // below every real key: ordered_u32 of a finite or infinite float is never 0
+        }
+        float w = my_w;
+        if (renorm) {  // Mixtral: weights /= weights.sum() in fp32, rank order
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < topk) s2 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), i));
+            w = w / s2;
+        }
+        w = w * route_scale;  // fp32, then type_as(x)
+        if (lane < topk) {
+            out_w[(int64_t)t * out_stride + lane] = f32_to_bf16(w);
+            out_ids[(int64_t)t * out_stride + lane] = my_e;
+            ids_lds[t * out_stride + lane] = my_e;
+            if (small_sort) moe_align_small_mark(align_lds, my_e, t);
+        }
+        if (lane < extra_n && extra_id >= 0) {
+            out_ids[(int64_t)t * out_stride + topk + lane] = extra_id + lane;
+            out_w[(int64_t)t * out_stride + topk + lane] = f32_to_bf16(extra_w);
+            ids_lds[t * out_stride + topk + lane] = extra_id + lane;
+            if (small_sort) moe_align_small_mark(align_lds, extra_id + lane, t);
+        }
+    }
+    __syncthreads();
+    const int sort_waves = min((int)(blockDim.x >> 6), max((al.num_experts + 63) >> 6, (M * out_stride + 63) >> 6));
+    if (t >= sort_waves) return;
+    if (small_sort) {
+        moe_align_small_tail(ids_lds, M * out_stride, out_stride, al.num_experts, al.block_size, al.sorted_ids, al.sorted_cap,
+                             al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, al.expert_map, align_lds, sort_waves * 64);
+        return;
+    }
+    moe_align_workgroup<int64_t>(ids_lds, (int64_t)M * out_stride, al.num_experts, al.block_size, al.sorted_ids,
+                                 al.sorted_cap, al.expert_ids, al.expert_cap, al.num_post_pad, al.cumsum, 1,
+                                 al.expert_map, align_lds, sort_waves * 64);
+}
+
 }  // namespace chitu
 
 extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void* out, int out_dtype,
@@ -820,6 +919,22 @@ static int gate_route_launch(const void* logits, int32_t num_partials, int64_t t
         if (gs == 32) LAUNCHW(32);
         else LAUNCHW(0);
 #undef LAUNCHW
+        CHITU_RETURN_LAUNCH_STATUS();
+    }
+    if (!fast && al.num_experts > 0 && num_experts <= 64 && (score_func == 0 || score_func == 2) && n_groups <= 1 &&
+        tokens <= 16 && num_partials <= 16 && topk <= 16 && extra_count <= 32 && debug_option(kOptGateTicket) <= 0 &&
+        debug_option(kOptGateGeneric) <= 0) {
+        // softmax routers with <= 64 experts (V2-Lite, Mixtral), decode batches: one workgroup, a wave per token, then the sort
+        const int wg_threads = 64 * max((int)tokens, (max(num_experts, al.num_experts) + 63) / 64);
+        const size_t ids_ints = 2 * (((size_t)tokens * out_stride + 1) & ~(size_t)1);
+        const size_t wg_lds = sizeof(int) * (ids_ints + moe_align_lds_ints(al.num_experts, wg_threads));
+        CHITU_REQUIRE(wg_threads <= 1024 && wg_lds <= 64 * 1024);
+        RouteAlign alw = al;
+        alw.small = (extra_expert_id < 0 || extra_expert_id >= num_experts) && debug_option(kOptGateSmallSort) != 0 ? 1 : 0;
+        hipLaunchKernelGGL(gate_route_align_wg_softmax_kernel, dim3(1), dim3(wg_threads), wg_lds, st, logits, (int)num_partials,
+                           (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16, (int)topk, route_scale,
+                           (bf16_t*)out_weights_bf16, out_ids, (int)out_stride, (int)extra_expert_id, extra_weight,
+                           (int)extra_count, score_func == 2 ? 1 : 0, alw);
         CHITU_RETURN_LAUNCH_STATUS();
     }
     if (fast) {

@@ -369,9 +369,15 @@ def fused_experts_impl(
             ),
             "moe gemm2 (tiled)",
         )
-    elif I % 128 == 0 and I <= 512 and os.environ.get("CHITU_MOE_FUSE_SILU", "1") != "0":
+    elif (I % 128 == 0 and I <= int(os.environ.get("CHITU_MOE_TWO_LAUNCH_MAX_I", "512"))
+          and os.environ.get("CHITU_MOE_FUSE_SILU", "1") != "0"):
         # two launches: GEMM1 with SiLU-and-mul in its epilogue (gate and up tile of the same columns
-        # in one wave), GEMM2 with the fp8 re-quantisation of h in its prologue
+        # in one wave), GEMM2 with the fp8 re-quantisation of h in its prologue.  Experts wider than 512 have the
+        # same two launches in the library (up to 2048) but take the three-launch form by default: measured on
+        # MI355X at V2-Lite's 1408-wide experts, bs 16, GEMM2-with-prologue 39.0 us against SiLU + quant 4.95 us +
+        # generic GEMM2 27.2 us (profiles/r03_v2lite_wide_experts.txt) -- every workgroup of an m-block repeats the
+        # quantisation of its 16 x I activations before its first MFMA, which a 512-wide expert hides and a 1408-wide
+        # one does not.  CHITU_MOE_TWO_LAUNCH_MAX_I=2048 selects the two-launch form for them.
         check(
             lib.chitu_hip_moe_gemm1_silu_fp8(
                 a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("c1"),

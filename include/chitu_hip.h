@@ -173,7 +173,11 @@ int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, const void*
  * gemm1_silu: a wave owns the gate tile and the up tile of the same 16 columns of W1 [E, 2I, K] and
  *   writes h[slot, :] = bf16(bf16(silu(bf16(gate))) * bf16(up)) as bf16 [numel, I]; inter_size % 16 == 0.
  * gemm2_quant: per_token_group_quant_fp8 (eps rule, 128-wide groups) of h in the prologue, then gemm2.
- *   inter_size % 128 == 0 and <= 512 (CHITU_ERR_UNSUPPORTED otherwise: use the three-launch form). */
+ *   inter_size % 128 == 0 and <= 2048 (CHITU_ERR_UNSUPPORTED otherwise: use the three-launch form); above 512 the
+ *   quantised activations stay in LDS instead of registers (moe_gemm2_qw_kernel: DeepSeek-V2-Lite's 1408-wide experts,
+ *   an expert-parallel rank's 2048-wide ones) -- measured slower there than silu_mul_quant + gemm2 (39 us against
+ *   4.95 + 27.2 us at V2-Lite's shapes, bs 16), so chitu_amd.fused_moe takes the three-launch form above 512 unless
+ *   CHITU_MOE_TWO_LAUNCH_MAX_I raises the limit. */
 int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
                                  const float* w1_scale, const int32_t* sorted_token_ids,
                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad,

@@ -57,8 +57,11 @@ def test_reference_fixture_inputs():
         (16, 32, 8, 7168, 256),   # bs=16 (several tokens per expert)
         (33, 16, 4, 512, 128),    # > one 16-slot tile per expert
         (5, 8, 2, 256, 128),      # fixture shape
-        (7, 8, 3, 384, 640),      # I/128 = 5 -> generic GEMM2 path
+        (7, 8, 3, 384, 640),      # I/128 = 5 -> the wide two-launch form (quantised activations in LDS)
         (4, 64, 6, 2048, 384),    # V2-Lite-like: 64 experts, top-6
+        (16, 64, 8, 2048, 1408),  # DeepSeek-V2-Lite's expert width (11 K blocks), 6 routed + 2 shared slots
+        (5, 8, 2, 512, 2048),     # an expert-parallel rank's full-width R1 experts
+        (40, 4, 2, 256, 1024),    # several 16-slot tiles per expert, 4 tiles per wave
     ],
 )
 def test_vs_oracle(M, E, topk, K, I):
@@ -182,6 +185,29 @@ def test_linearity_in_routed_weight_full_r1_shape():
     a = run_hip(x, w1, w2, w1s, w2s, ids, wts)
     b = run_hip(x, w1, w2, w1s, w2s, ids, (wts.float() * 2).to(wts.dtype))
     assert torch.equal(b.float(), a.float() * 2)
+
+
+@pytest.mark.parametrize("M,E,topk,K,I", [(16, 64, 8, 2048, 1408), (5, 8, 2, 512, 2048), (3, 8, 2, 256, 640)])
+def test_wide_two_launch_expert_path_vs_three_launch(M, E, topk, K, I, monkeypatch):
+    """Experts wider than 512 (V2-Lite, expert-parallel ranks): GEMM1 + SiLU-and-mul, then GEMM2 with the requantisation
+    in its prologue and the codes in LDS, against GEMM1, SiLU + quant, generic GEMM2.  Same h, same codes, same scales;
+    only GEMM2's K order differs (the generic kernel may split K over waves), so equal up to the last bf16 bit."""
+    args = make_case(M, E, topk, K, I, seed=M + I)
+    monkeypatch.setenv("CHITU_MOE_TWO_LAUNCH_MAX_I", "2048")  # opt-in for wide experts (fused_moe.py: slower at 1408)
+    two = run_hip(*args)
+    monkeypatch.setenv("CHITU_MOE_FUSE_SILU", "0")
+    three = run_hip(*args)
+    assert_close(two, three, 4e-3)
+    assert (two != three).float().mean() < 0.02
+    x, w1, w2, w1s, w2s, ids, wts = args
+    emap = torch.full((E,), -1, dtype=torch.int32)
+    emap[: E // 2] = torch.arange(E // 2, dtype=torch.int32)
+    monkeypatch.delenv("CHITU_MOE_FUSE_SILU")
+    h = E // 2
+    mapped = run_hip(x, w1[:h].contiguous(), w2[:h].contiguous(), w1s[:h].contiguous(), w2s[:h].contiguous(), ids, wts,
+                     expert_map=emap.cuda(), global_num_experts=E)
+    ref = omoe.fused_experts_fp8(x, w1, w2, torch.where(ids < h, wts.float(), torch.zeros(())).to(wts.dtype), ids, w1s, w2s)
+    assert_close(mapped, ref, REL_TOL, atol_frac=1.0)
 
 
 @pytest.mark.parametrize("M,E,topk,K,I", [(1, 32, 8, 7168, 256), (16, 32, 8, 7168, 256), (33, 16, 4, 512, 128), (4, 64, 6, 2048, 384),

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Derived per-kernel metrics from the counter passes of tools/pmc_passes.sh:
-    python tools/pmc_report.py <pmc_dir> > profiles/r02_pmc_step.json
+    CHITU_GIT_HEAD=<sha> python tools/pmc_report.py <pmc_dir> > profiles/r03_pmc_step.json
 Per kernel (averages over its dispatches in an EAGER decode step, bs 16, ctx 1024):
   hbm_read_MB   = FETCH_SIZE [KB] * 1024 * 2   (gfx950: the counter tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM)
   hbm_write_MB  = WRITE_SIZE [KB] * 1024       (uncalibrated on gfx950: an indication only)
@@ -66,5 +66,13 @@ for k in sorted(fetch):
         if "hbm_read_MB" in r:
             r["read_TBs"] = round(r["hbm_read_MB"] / dur[name], 3)
     res[k] = r
+# identity of the code the counters were taken on: the git head handed in by the caller (the GPU box has no .git:
+# CHITU_GIT_HEAD=$(git rev-parse --short HEAD) in the gpurun command line) and digests of the kernel sources as found
+# next to this script -- bench.py withholds a kernel's counters when its source has changed since
+import hashlib
+
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "chitu_amd", "csrc")
+digests = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest() for f in sorted(glob.glob(os.path.join(csrc, "*.hip")))}
 print(json.dumps({"source": "rocprofv3 --kernel-trace --pmc <group>, one pass per group (tools/pmc_passes.sh), eager decode step "
-                            "of 8 R1 TP=8-rank layers, bs 16, ctx 1024", "kernels": res}, indent=1))
+                            "of 8 R1 TP=8-rank layers, bs 16, ctx 1024", "git_head": os.environ.get("CHITU_GIT_HEAD"),
+                  "source_sha256": digests, "kernels": res}, indent=1))
