@@ -13,8 +13,24 @@
 // One wave per (16 output columns, head, 16 tokens); weights are the MFMA A operand so a lane
 // ends with 4 consecutive output columns of one token.
 #include "common.h"
+#include "mla_kv_row.h"
 
 namespace chitu {
+
+// Optional rider of the W_UK absorb launch (q_lora_rank == 0 models: there is no wq_b launch to carry it): the
+// [kv_norm(kv_c) | rope(k_pe)] row of every token of the batch, appended to its page.  kv_in == nullptr: absent.
+struct AbsorbKvRow {
+    const bf16_t* kv_in;
+    int64_t kv_stride;
+    const bf16_t* norm_w;
+    float eps;
+    bf16_t* cache;
+    int64_t num_pages;
+    int page_size;
+    const int32_t* table;
+    int pages_per_seq;
+    const int32_t* old_lens;
+};
 
 __device__ __forceinline__ s16x8 dequant8_bf16(uint32_t w0, uint32_t w1, float s) {
     s16x8 r;
@@ -29,16 +45,24 @@ __device__ __forceinline__ s16x8 dequant8_bf16(uint32_t w0, uint32_t w1, float s
     return r;
 }
 
-// grid (N/16 [+1], H, ceil(batch/16)); block 64.  The optional extra block column (rope != null)
+// grid (N/16 [+1 [+1]], H, ceil(batch/16)); block 64.  The optional extra block column (rope != null)
 // rotates q_pe[b, h, :64] in place for the tile's 16 tokens (the q half of mla_kv_prep_kernel,
 // same arithmetic): it needs wq_b's output just like the absorb itself, so it rides in this launch.
+// A second extra column (kv.kv_in != null) writes the tile's KV rows (the other half of mla_kv_prep_kernel),
+// block h taking tokens h, h + H, ... of the tile.
 __global__ __launch_bounds__(64) void absorb_bmm_kernel(
     const bf16_t* __restrict__ x, int64_t x_sb, int64_t x_sh, const fp8_t* __restrict__ W, int64_t w_sh,
     const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sn, int64_t s_sk,
     bf16_t* __restrict__ out, int64_t o_sb, int64_t o_sh, int batch, int N, int K, bf16_t* __restrict__ q_pe,
-    int64_t p_sb, int64_t p_sh, const float* __restrict__ cos, const float* __restrict__ sin) {
+    int64_t p_sb, int64_t p_sh, const float* __restrict__ cos, const float* __restrict__ sin, AbsorbKvRow kv) {
     const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16, h = blockIdx.y, m0 = blockIdx.z * 16;
+    if (n0 >= N + 16) {
+        for (int b = m0 + h; b < min(m0 + 16, batch); b += gridDim.y)
+            mla_kv_row_one_wave(b, kv.kv_in + (int64_t)b * kv.kv_stride, kv.norm_w, kv.eps, cos, sin, kv.cache, kv.num_pages,
+                                kv.page_size, kv.table, kv.pages_per_seq, kv.old_lens);
+        return;
+    }
     if (n0 >= N) {
 #pragma clang fp contract(off)
         for (int idx = lane; idx < 16 * 32; idx += 64) {
@@ -284,12 +308,13 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
 static int launch_absorb_bmm(const void* x, int64_t x_sb, int64_t x_sh, const void* w, int64_t w_sh, const float* scale,
                              int64_t s_off, int64_t s_sh, int64_t s_sn, int64_t s_sk, void* out, int64_t o_sb,
                              int64_t o_sh, int batch, int heads, int N, int K, void* q_pe, int64_t p_sb, int64_t p_sh,
-                             const float* cos, const float* sin, void* stream) {
+                             const float* cos, const float* sin, void* stream, const chitu::AbsorbKvRow* kv = nullptr) {
     using namespace chitu;
-    const dim3 grid((unsigned)((N + 15) / 16 + (q_pe ? 1 : 0)), (unsigned)heads, (unsigned)((batch + 15) / 16));
+    // the riders' columns are found by n0 >= N (+ 16): N itself a multiple of 16 when they are present
+    const dim3 grid((unsigned)((N + 15) / 16 + (q_pe ? 1 : 0) + (kv ? 1 : 0)), (unsigned)heads, (unsigned)((batch + 15) / 16));
     hipLaunchKernelGGL(absorb_bmm_kernel, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, x_sb, x_sh,
                        (const fp8_t*)w, w_sh, scale, s_off, s_sh, s_sn, s_sk, (bf16_t*)out, o_sb, o_sh, batch, N, K,
-                       (bf16_t*)q_pe, p_sb, p_sh, cos, sin);
+                       (bf16_t*)q_pe, p_sb, p_sh, cos, sin, kv ? *kv : AbsorbKvRow{});
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
@@ -353,6 +378,34 @@ extern "C" int chitu_hip_absorb_bmm_rope_fp8(const void* x_bf16, int64_t x_strid
                              scale_stride_n, scale_stride_k, out_bf16, out_stride_b, out_stride_h, batch, heads, N, K,
                              q_pe_bf16, q_pe_stride_b, q_pe_stride_h, cos, sin, stream);
     CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_absorb_bmm_rope_kv_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
+                                                const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                                int64_t scale_offset, int64_t scale_stride_h,
+                                                int64_t scale_stride_n, int64_t scale_stride_k, void* out_bf16,
+                                                int64_t out_stride_b, int64_t out_stride_h, int32_t batch,
+                                                int32_t heads, int32_t N, int32_t K, void* q_pe_bf16,
+                                                int64_t q_pe_stride_b, int64_t q_pe_stride_h, const float* cos,
+                                                const float* sin, int32_t rope_dim, const void* kv_in_bf16,
+                                                int64_t kv_row_stride, const void* kv_norm_weight_bf16, float eps,
+                                                void* kv_cache, int64_t num_pages, int32_t page_size,
+                                                const int32_t* page_table, int32_t pages_per_seq,
+                                                const int32_t* old_seq_lens, int32_t kv_lora_rank, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && w_fp8 && scale && out_bf16 && q_pe_bf16 && cos && sin);
+    CHITU_REQUIRE(kv_in_bf16 && kv_norm_weight_bf16 && kv_cache && page_table && old_seq_lens);
+    CHITU_REQUIRE(batch >= 0 && heads >= 1 && N >= 1 && K >= 64 && w_stride_h % 16 == 0);
+    CHITU_REQUIRE(num_pages >= 1 && page_size >= 1 && pages_per_seq >= 1);
+    if (K % 64 != 0 || rope_dim != 64 || kv_lora_rank != 512 || N % 16 != 0) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(x_stride_b % 8 == 0 && x_stride_h % 8 == 0 && out_stride_b % 4 == 0 && out_stride_h % 4 == 0);
+    CHITU_REQUIRE(q_pe_stride_b % 2 == 0 && q_pe_stride_h % 2 == 0 && kv_row_stride % 8 == 0);
+    if (batch == 0) return CHITU_OK;
+    const AbsorbKvRow kv{(const bf16_t*)kv_in_bf16, kv_row_stride, (const bf16_t*)kv_norm_weight_bf16, eps,
+                         (bf16_t*)kv_cache, num_pages, (int)page_size, page_table, (int)pages_per_seq, old_seq_lens};
+    return launch_absorb_bmm(x_bf16, x_stride_b, x_stride_h, w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
+                             scale_stride_n, scale_stride_k, out_bf16, out_stride_b, out_stride_h, batch, heads, N, K,
+                             q_pe_bf16, q_pe_stride_b, q_pe_stride_h, cos, sin, stream, &kv);
 }
 
 static int launch_merge_uv_quant(const void* workspace, int32_t num_splits, const void* w_fp8, int64_t w_stride_h,

@@ -150,18 +150,27 @@ struct MoeStage2 {
     float xs, wsg, wsu;
 };
 
-template <int WK, int D>
-__global__ __launch_bounds__(64 * WK) void moe_gemm1_silu_kernel(
+// Q (needs WK == 1): the workgroup is 8 waves owning the 8 tiles of ONE 128-wide group of h, and the epilogue is
+// per_token_group_quant_fp8 of that group (moe_silu_quant_kernel's arithmetic: the group maximum goes through LDS) --
+// h leaves as e4m3 codes [numel, I] + scales [numel, I/128], the generic GEMM2's input, and no quantisation launch
+// or bf16 h round trip remains.  grid (I/128, max_mblocks); block 512.
+template <int WK, int D, bool Q = false>
+__global__ __launch_bounds__(Q ? 512 : 64 * WK) void moe_gemm1_silu_kernel(
     const fp8_t* __restrict__ Xq, const float* __restrict__ Xs, const fp8_t* __restrict__ W,
     const float* __restrict__ Ws, const int32_t* __restrict__ sorted_ids,
     const int32_t* __restrict__ expert_ids, const int32_t* __restrict__ num_post_pad,
-    bf16_t* __restrict__ out, int numel, int topk, int I, int K) {
+    bf16_t* __restrict__ out, int numel, int topk, int I, int K, fp8_t* __restrict__ hq = nullptr,
+    float* __restrict__ hs = nullptr, float eps = 0.f) {
+    static_assert(!Q || WK == 1, "the quantising epilogue owns whole K");
     __shared__ float red[WK > 1 ? WK * 512 : 1];
+    __shared__ float qmax[Q ? 8 * 16 : 1];
     const int mb = blockIdx.y;
     if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
+    const int lane = threadIdx.x & 63;
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: SGPR index math
+    const int wave = Q ? 0 : wave_id;                                       // position in the K split
     const int j = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = (Q ? blockIdx.x * 8 + wave_id : blockIdx.x) * 16;
     const int N = 2 * I;
     const int KB = K >> 7;
     const int slot = sorted_ids[mb * 16 + j];
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_silu_kernel(
             }
         }
     }
-    if (!valid) return;
+    if (!Q && !valid) return;
     f32x4 h;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -252,7 +261,29 @@ __global__ __launch_bounds__(64 * WK) void moe_gemm1_silu_kernel(
         const float sl = round_bf16(gv / (1.0f + expf(-gv)));
         h[r] = round_bf16(sl * uv);
     }
-    moe_store_tile(out + (size_t)slot * I, n0, g, I, h, 1.0f);
+    if (!Q) {
+        moe_store_tile(out + (size_t)slot * I, n0, g, I, h, 1.0f);
+        return;
+    }
+    // the lane's 4 values are columns n0 + {2g, 2g+1, 8+2g, 8+2g+1} of row j: the row's maximum over the tile, then
+    // over the group's 8 tiles
+    float amax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(h[0]), __builtin_fabsf(h[1])),
+                                 __builtin_fmaxf(__builtin_fabsf(h[2]), __builtin_fabsf(h[3])));
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
+    if (g == 0) qmax[wave_id * 16 + j] = amax;
+    __syncthreads();
+    amax = qmax[j];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) amax = __builtin_fmaxf(amax, qmax[w * 16 + j]);
+    const float sc = __builtin_fmaxf(amax, eps) / 448.0f;
+    const float v[8] = {h[0], h[1], h[2], h[3], 0.f, 0.f, 0.f, 0.f};
+    const uint32_t codes = (uint32_t)quant8_fp8<true>(v, sc)[0];
+    if (!valid) return;
+    fp8_t* qrow = hq + (size_t)slot * I + n0 + 2 * g;
+    *reinterpret_cast<uint16_t*>(qrow) = (uint16_t)(codes & 0xffffu);
+    *reinterpret_cast<uint16_t*>(qrow + 8) = (uint16_t)(codes >> 16);
+    if (wave_id == 0 && g == 0) hs[(size_t)slot * (I >> 7) + blockIdx.x] = sc;
 }
 
 // ---------------------------------------------------------------- SiLU-and-mul + fp8 requant
@@ -853,6 +884,33 @@ extern "C" int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_sc
     else if (WK == 2) { if (D == 4) LAUNCH1S(2, 4); else LAUNCH1S(2, 3); }
     else { if (D == 4) LAUNCH1S(1, 4); else LAUNCH1S(1, 3); }
 #undef LAUNCH1S
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_moe_gemm1_silu_quant_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
+                                                  const float* w1_scale, const int32_t* sorted_token_ids,
+                                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                                                  void* h_fp8, float* h_scales, int64_t numel, int32_t topk,
+                                                  int64_t inter_size, int64_t K, int64_t max_mblocks, float eps,
+                                                  void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(a_fp8 && a_scale && w1_fp8 && w1_scale && sorted_token_ids && expert_ids);
+    CHITU_REQUIRE(num_tokens_post_pad && h_fp8 && h_scales);
+    CHITU_REQUIRE(numel >= 0 && topk >= 1 && inter_size >= 128 && K >= 128 && max_mblocks >= 0);
+    if (K % 128 != 0 || inter_size % 128 != 0) return CHITU_ERR_UNSUPPORTED;
+    if (numel == 0 || max_mblocks == 0) return CHITU_OK;
+    int D = 3;
+    debug_override(kOptMoeGemm1D, D);
+    const dim3 grid((unsigned)(inter_size / 128), (unsigned)max_mblocks);
+#define LAUNCH1Q(DV)                                                                                              \
+    hipLaunchKernelGGL((moe_gemm1_silu_kernel<1, DV, true>), grid, dim3(512), 0, (hipStream_t)stream,              \
+                       (const fp8_t*)a_fp8, a_scale, (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids, \
+                       num_tokens_post_pad, (bf16_t*)nullptr, (int)numel, (int)topk, (int)inter_size, (int)K,     \
+                       (fp8_t*)h_fp8, h_scales, eps)
+    if (D == 4) LAUNCH1Q(4);
+    else if (D == 2) LAUNCH1Q(2);
+    else LAUNCH1Q(3);
+#undef LAUNCH1Q
     CHITU_RETURN_LAUNCH_STATUS();
 }
 

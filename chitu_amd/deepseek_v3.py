@@ -287,9 +287,10 @@ class AttentionDeepSeekV3(torch.nn.Module):
             nq = H * self.qk_head_dim
             q = q_kv[:, :nq].view(bs, H, self.qk_head_dim)
             q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
-            ops.mla_kv_prep(q_kv[:, nq:], q_pe, cos, sin, self.kv_norm.weight, self.kv_norm.eps, kv_cache,
-                            cache.get_gpu_block_table(), cache.get_gpu_seq_lens_excl_this_decode())
-            q_abs = ops.absorb_bmm_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0)
+            # ONE launch: W_UK absorb, RoPE(q_pe) in place, and this token's [kv_norm(kv_c) | rope(k_pe)] row into its page
+            q_abs = ops.absorb_bmm_rope_kv_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0, q_pe, cos, sin,
+                                               q_kv[:, nq:], self.kv_norm.weight, self.kv_norm.eps, kv_cache,
+                                               cache.get_gpu_block_table(), cache.get_gpu_seq_lens_excl_this_decode())
         # small batches: the split-KV merge runs inside the W_UV projection kernel
         fuse_merge = bs <= 32 and C == 512
         o = self.attn_backend.mla_decode(q_abs, q_pe, kv_cache, cache.get_gpu_seq_lens_incl_this_decode(),

@@ -750,6 +750,36 @@ def absorb_bmm_rope_fp8(x, w, scale, scale_offset, scale_stride_h, scale_stride_
     return out
 
 
+def absorb_bmm_rope_kv_fp8(x, w, scale, scale_offset, scale_stride_h, scale_stride_n, scale_stride_k, q_pe, cos, sin,
+                           kv_in, kv_norm_weight, eps, kv_cache, page_table, old_seq_lens):
+    """absorb_bmm_rope_fp8 + the KV half of mla_kv_prep (kv_norm, RoPE(k_pe), page append of kv_in [bs, 576]) in the
+    same launch: the decode path of models without a q low-rank projection (DeepSeek-V2-Lite), where no wq_b launch
+    exists to carry the KV row."""
+    require_cuda(x, w, scale, q_pe, cos, sin, kv_in, kv_norm_weight, kv_cache, page_table, old_seq_lens)
+    assert x.dtype == torch.bfloat16 and w.element_size() == 1 and scale.dtype == torch.float32
+    assert x.dim() == 3 and w.dim() == 3 and x.stride(-1) == 1 and w.stride(2) == 1 and w.stride(1) == w.shape[2]
+    assert q_pe.dtype == torch.bfloat16 and q_pe.shape[-1] == 64 and q_pe.stride(-1) == 1
+    assert cos.dtype == torch.float32 and cos.is_contiguous() and sin.is_contiguous()
+    assert kv_in.dtype == torch.bfloat16 and kv_cache.dtype == torch.bfloat16 and kv_in.shape[-1] == 576 and kv_in.stride(-1) == 1
+    assert kv_cache.is_contiguous() and kv_cache.shape[-1] == 576 and page_table.is_contiguous()
+    B, H, K = x.shape
+    N = w.shape[1]
+    assert kv_in.shape[0] == B and N % 16 == 0
+    out = torch.empty(B, H, N, dtype=torch.bfloat16, device=x.device)
+    check(
+        _lib.lib().chitu_hip_absorb_bmm_rope_kv_fp8(
+            ptr(x), i64(x.stride(0)), i64(x.stride(1)), ptr(w), i64(w.stride(0)), ptr(scale), i64(scale_offset),
+            i64(scale_stride_h), i64(scale_stride_n), i64(scale_stride_k), ptr(out), i64(out.stride(0)),
+            i64(out.stride(1)), i32(B), i32(H), i32(N), i32(K), ptr(q_pe), i64(q_pe.stride(0)), i64(q_pe.stride(1)),
+            ptr(cos), ptr(sin), i32(64), ptr(kv_in), i64(kv_in.stride(0)), ptr(kv_norm_weight), f32(eps), ptr(kv_cache),
+            i64(kv_cache.shape[0]), i32(kv_cache.shape[1]), ptr(page_table), i32(page_table.shape[1]), ptr(old_seq_lens),
+            i32(512), stream_ptr(),
+        ),
+        "absorb_bmm_rope_kv_fp8",
+    )
+    return out
+
+
 def absorb_uv_quant_fp8(x, w, scale, scale_offset, scale_stride_h, scale_stride_k):
     """absorb_bmm_fp8 for the W_UV half (N = 128) + act_quant of its bf16 result: returns
     (q [B, H*128] e4m3fn, s [B, H] f32), the input of the wo fp8 GEMM."""

@@ -183,6 +183,19 @@ int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_scale, const 
                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
                                  void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size, int64_t K,
                                  int64_t max_mblocks, void* stream);
+
+/* gemm1_silu with per_token_group_quant_fp8 (eps rule, 128-wide groups) of h in the epilogue as well: h leaves as
+ * e4m3 codes h_fp8 [numel, I] and scales h_scales [numel, I/128] -- exactly what chitu_hip_moe_silu_mul_quant_fp8 writes
+ * after chitu_hip_moe_gemm1_fp8 (bit for bit) and what chitu_hip_moe_gemm2_fp8 reads.  A workgroup owns the 8 tiles
+ * of one 128-wide group, each wave the whole K (no K split: meant for grids that fill the chip without one, the wide
+ * experts of DeepSeek-V2-Lite / expert-parallel ranks at batch >= 4).  inter_size % 128 == 0, K % 128 == 0.
+ * Measured on MI355X (V2-Lite shapes, bs 16): 64.5 us against 50.7 + 4.95 us for the two separate launches -- the
+ * 8-wave workgroups halve the resident waves per CU -- so chitu_amd.fused_moe uses it only under CHITU_MOE_GEMM1_QUANT=1. */
+int chitu_hip_moe_gemm1_silu_quant_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
+                                       const float* w1_scale, const int32_t* sorted_token_ids,
+                                       const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
+                                       void* h_fp8, float* h_scales, int64_t numel, int32_t topk,
+                                       int64_t inter_size, int64_t K, int64_t max_mblocks, float eps, void* stream);
 /* The same two grouped GEMMs tiled for PREFILL-sized batches (64 sorted slots x 128 weight rows per workgroup through
  * LDS, fused_moe.py:62-307 with its BLOCK_SIZE_M = 64): sorted_token_ids / expert_ids / num_tokens_post_pad must come from
  * chitu_hip_moe_align_block_size with block_size 64; max_mblocks <= 65535.
@@ -441,6 +454,24 @@ int chitu_hip_absorb_bmm_rope_fp8(const void* x_bf16, int64_t x_stride_b, int64_
                                   int64_t out_stride_h, int32_t batch, int32_t heads, int32_t N, int32_t K,
                                   void* q_pe_bf16, int64_t q_pe_stride_b, int64_t q_pe_stride_h,
                                   const float* cos, const float* sin, int32_t rope_dim, void* stream);
+
+/* chitu_hip_absorb_bmm_rope_fp8 plus, still in the same launch, the KV half of chitu_hip_mla_kv_prep: kv_norm(kv_c),
+ * RoPE(k_pe) and the page append of every token's kv_in row [kv_c (512) | k_pe (64)] (row stride kv_row_stride
+ * elements, a multiple of 8).  The decode path of models WITHOUT a q low-rank projection (DeepSeek-V2-Lite,
+ * q_lora_rank == 0; the reference asserts q_lora_rank > 0, model_deepseek_v3.py:477): their q, kv_c and k_pe all come
+ * out of one merged GEMM, so everything that consumes its output fits one launch.  N % 16 == 0, kv_lora_rank == 512,
+ * rope_dim == 64 (CHITU_ERR_UNSUPPORTED otherwise).  Same arithmetic as the two separate entries, bit for bit. */
+int chitu_hip_absorb_bmm_rope_kv_fp8(const void* x_bf16, int64_t x_stride_b, int64_t x_stride_h,
+                                     const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                     int64_t scale_offset, int64_t scale_stride_h, int64_t scale_stride_n,
+                                     int64_t scale_stride_k, void* out_bf16, int64_t out_stride_b,
+                                     int64_t out_stride_h, int32_t batch, int32_t heads, int32_t N, int32_t K,
+                                     void* q_pe_bf16, int64_t q_pe_stride_b, int64_t q_pe_stride_h,
+                                     const float* cos, const float* sin, int32_t rope_dim, const void* kv_in_bf16,
+                                     int64_t kv_row_stride, const void* kv_norm_weight_bf16, float eps,
+                                     void* kv_cache, int64_t num_pages, int32_t page_size,
+                                     const int32_t* page_table, int32_t pages_per_seq,
+                                     const int32_t* old_seq_lens, int32_t kv_lora_rank, void* stream);
 
 /* ---- skinny bf16 GEMM (router scores, LM head) ---------------------------------------------
  * Replaces the F.linear calls on bf16 weights on the decode path: gate scores

@@ -74,6 +74,12 @@ def absorb_bmm_rope_fp8(x, w, scale, scale_offset, sh, sn, sk, q_pe, cos, sin):
     return absorb_bmm_fp8(x, w, scale, scale_offset, sh, sn, sk)
 
 
+def absorb_bmm_rope_kv_fp8(x, w, scale, scale_offset, sh, sn, sk, q_pe, cos, sin, kv_in, kv_norm_weight, eps, kv_cache,
+                           page_table, old_seq_lens):
+    mla_kv_prep(kv_in, q_pe, cos, sin, kv_norm_weight, eps, kv_cache, page_table, old_seq_lens)
+    return absorb_bmm_fp8(x, w, scale, scale_offset, sh, sn, sk)
+
+
 def _dequant_heads(w, scale, off, sh, sn, sk):
     H, N, K = w.shape
     out = torch.empty(H, N, K, dtype=torch.bfloat16)
@@ -248,6 +254,7 @@ def install(monkeypatch_setattr):
 
     for name in ("tile_major_ok", "rms_norm", "act_quant_deepseek_v3", "fp8_gemm_deepseek_v3", "mla_kv_prep", "absorb_bmm_fp8",
                  "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear", "mla_qkv_post", "mla_q_proj", "mla_q_proj_fits", "absorb_bmm_rope_fp8",
+                 "absorb_bmm_rope_kv_fp8",
                  "embed_rope_gather"):
         monkeypatch_setattr(ops, name, globals()[name])
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)

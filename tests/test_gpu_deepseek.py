@@ -403,6 +403,37 @@ def test_qkv_post_and_absorb_rope_equal_the_separate_launches(bs):
     assert torch.equal(q2, q1) and torch.equal(ab, abs_ref)
 
 
+@pytest.mark.parametrize("bs,H", [(1, 16), (5, 16), (16, 16), (21, 4), (33, 2)])
+def test_absorb_rope_kv_equals_the_separate_launches(bs, H):
+    """absorb_bmm_rope_kv_fp8 (DeepSeek-V2-Lite's decode: no q low-rank path) == mla_kv_prep + absorb_bmm_fp8, bit for
+    bit: cache pages (rows of other tokens untouched), rotated q_pe, absorbed q_nope; also with fewer heads than the
+    16 tokens of a tile (a rider block then writes several rows)."""
+    from chitu_amd import ops
+
+    g = torch.Generator().manual_seed(150 + bs + H)
+    C = 512
+    q_kv = torch.randn(bs, H * 192 + 576, generator=g).to(torch.bfloat16).cuda()
+    cos, sin = torch.randn(bs, 32, generator=g).cuda(), torch.randn(bs, 32, generator=g).cuda()
+    wn = (torch.rand(512, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    pages = 2 * bs + 2
+    cache = torch.randn(pages, 64, 576, generator=g).to(torch.bfloat16).cuda()
+    table = torch.stack([torch.randperm(pages, generator=g)[:2] for _ in range(bs)]).to(torch.int32).cuda()
+    lens = torch.tensor([(37 * i + (63 if i % 2 else 64)) % 128 for i in range(bs)], dtype=torch.int32).cuda()
+    w_uk_t = (torch.randn(H, C, 128, generator=g) * 0.5).to(torch.float8_e4m3fn).cuda()
+    sc = (torch.rand(H * 2, C // 128, generator=g) * 0.02 + 0.01).cuda()
+    nq = H * 192
+    qkv1, cache1 = q_kv.clone(), cache.clone()
+    q1 = qkv1[:, :nq].view(bs, H, 192)
+    ops.mla_kv_prep(qkv1[:, nq:], q1[..., 128:], cos, sin, wn, 1e-6, cache1, table, lens)
+    abs_ref = ops.absorb_bmm_fp8(q1[..., :128], w_uk_t, sc, 0, 8, 1, 0)
+    qkv2, cache2 = q_kv.clone(), cache.clone()
+    q2 = qkv2[:, :nq].view(bs, H, 192)
+    ab = ops.absorb_bmm_rope_kv_fp8(q2[..., :128], w_uk_t, sc, 0, 8, 1, 0, q2[..., 128:], cos, sin, qkv2[:, nq:], wn, 1e-6,
+                                    cache2, table, lens)
+    assert torch.equal(cache2, cache1) and not torch.equal(cache2, cache)
+    assert torch.equal(qkv2, qkv1) and torch.equal(ab, abs_ref)
+
+
 @pytest.mark.parametrize("bs,S", [(1, 2), (16, 2), (5, 3)])
 def test_qkv_post_reads_split_k_planes_like_the_rounded_sum(bs, S):
     """mla_qkv_post(fp32 planes [S, bs, 2112]) == mla_qkv_post(bf16(plane 0 + plane 1 + ...)), bit for bit: the

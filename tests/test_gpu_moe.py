@@ -210,6 +210,28 @@ def test_wide_two_launch_expert_path_vs_three_launch(M, E, topk, K, I, monkeypat
     assert_close(mapped, ref, REL_TOL, atol_frac=1.0)
 
 
+@pytest.mark.parametrize("M,E,topk,K,I", [(16, 64, 8, 2048, 1408), (64, 8, 2, 512, 2048), (40, 32, 6, 1024, 640)])
+def test_wide_experts_gemm1_with_silu_and_quant_epilogue_is_bit_identical_to_three_launches(M, E, topk, K, I, monkeypatch):
+    """Wide experts with enough m-blocks: gemm1_silu_quant + gemm2 == gemm1 + silu_mul_quant + gemm2, every bit (same
+    K order once GEMM1's K split is pinned to one wave, same h, same group maxima, same codes), expert_map too."""
+    from chitu_amd._lib import debug_option
+
+    numel = M * topk
+    assert 2 * (I // 16) * min(numel, (numel + E * 15 + 15) // 16) > 3200  # fused_moe's own condition for the fused form
+    args = make_case(M, E, topk, K, I, seed=300 + M)
+    emap = torch.arange(E, dtype=torch.int32)
+    emap[E // 2:] = -1
+    outs = {}
+    with debug_option("moe_gemm1_wk", 1):
+        for fuse in ("1", "0"):  # opt-in (fused_moe.py: measured slower than the three launches on MI355X)
+            monkeypatch.setenv("CHITU_MOE_GEMM1_QUANT", fuse)
+            outs[fuse] = (run_hip(*args), run_hip(*args, expert_map=emap.cuda(), global_num_experts=E))
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    monkeypatch.setenv("CHITU_MOE_GEMM1_QUANT", "1")
+    x, w1, w2, w1s, w2s, ids, wts = args
+    assert_close(run_hip(*args), omoe.fused_experts_fp8(x, w1, w2, wts, ids, w1s, w2s), REL_TOL)
+
+
 @pytest.mark.parametrize("M,E,topk,K,I", [(1, 32, 8, 7168, 256), (16, 32, 8, 7168, 256), (33, 16, 4, 512, 128), (4, 64, 6, 2048, 384),
                                           (3, 8, 2, 256, 512), (70, 8, 4, 1024, 256)])
 def test_two_launch_expert_path_is_bit_identical_to_three_launch(M, E, topk, K, I, monkeypatch):
