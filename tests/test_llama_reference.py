@@ -29,6 +29,17 @@ def _check(logits, g, n_prompt, what):
     return err, int(agree.sum())
 
 
+def _forced_launch_variants(_lib):
+    """Launch-variant overrides (chitu_hip_debug_option) still in force: name -> value; {} when every one is at -1."""
+    import ctypes
+
+    try:
+        arr = (ctypes.c_int * len(_lib.DEBUG_OPTIONS)).in_dll(_lib.lib(), "_ZN5chitu15g_debug_optionsE")
+        return {k: arr[i] for k, i in _lib.DEBUG_OPTIONS.items() if arr[i] != -1}
+    except Exception as e:  # the symbol is an implementation detail: a diagnostic must not turn into the failure
+        return repr(e)
+
+
 def test_oracle_llama_reproduces_the_reference_cpu_run():
     g, cfg, p = ref_llama_fixture()
     prompt, toks = g["prompt"].tolist(), g["tokens"].tolist()
@@ -54,38 +65,64 @@ def test_hip_llama_reproduces_the_reference_cpu_run():
     ffn = p["layers.0.ffn.w2"].shape[1]
     args = LlamaArgs(dim=cfg["dim"], n_layers=cfg["n_layers"], n_heads=cfg["n_heads"], n_kv_heads=cfg["n_kv_heads"],
                      vocab_size=cfg["vocab_size"], ffn_dim=ffn, norm_eps=cfg["norm_eps"], rope_theta=cfg["rope_theta"])
-    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=1, block_size=256, max_seq_len=512, device="cuda",
-                                n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
-    model = LlamaDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=512),
-                         max_position_embeddings=512, device="cuda")
-    params = dict(model.named_parameters())
-    assert set(params) == set(p)
-    for k, t in p.items():
-        assert params[k].shape == t.shape, k
-        params[k].data.copy_(t)
-    def run(req, use_graph):
-        rows = [model.prefill([prompt], [req]).float().cpu()]
-        tok = torch.tensor([toks[0]], dtype=torch.int64, device="cuda")
-        for step in range(64):
-            cache.prepare_cache_decode([req])
-            cache.prepare_block_table_for_decode([req])
-            if step in (0, 1, 63):  # the device-side step state the kernels will read == the host's bookkeeping
-                n_pages = len(cache.block_table[req])
-                assert cache.get_gpu_block_table()[0, :n_pages].tolist() == list(cache.block_table[req]), (req, step, "block table")
-                assert cache.get_gpu_seq_lens_excl_this_decode().tolist() == [cache.seq_lens[req]], (req, step, "lens excl")
-                assert cache.get_gpu_seq_lens_incl_this_decode().tolist() == [cache.seq_lens[req] + 1], (req, step, "lens incl")
-            rows.append(model.decode(tok, use_graph=use_graph).float().cpu())
-            cache.finalize_cache_single_decode([req])
-            tok = torch.tensor([toks[step + 1]], dtype=torch.int64, device="cuda")
-        cache.finalize_cache_all_decode(req)
-        return rows
 
-    rows = run("r", True)
-    rows_eager = run("e", False)  # the same steps as eager launches: tells a replay problem from a kernel problem
+    def attempt(tag):
+        """A fresh cache + model; the 65 logits rows of the graph run and of the same steps as eager launches."""
+        cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=1, block_size=256, max_seq_len=512, device="cuda",
+                                    n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
+        model = LlamaDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=512),
+                             max_position_embeddings=512, device="cuda")
+        params = dict(model.named_parameters())
+        assert set(params) == set(p)
+        for k, t in p.items():
+            assert params[k].shape == t.shape, k
+            params[k].data.copy_(t)
+
+        def run(req, use_graph):
+            rows = [model.prefill([prompt], [req]).float().cpu()]
+            tok = torch.tensor([toks[0]], dtype=torch.int64, device="cuda")
+            for step in range(64):
+                cache.prepare_cache_decode([req])
+                cache.prepare_block_table_for_decode([req])
+                if step in (0, 1, 63):  # the device-side step state the kernels will read == the host's bookkeeping
+                    n_pages = len(cache.block_table[req])
+                    assert cache.get_gpu_block_table()[0, :n_pages].tolist() == list(cache.block_table[req]), (req, step, "block table")
+                    assert cache.get_gpu_seq_lens_excl_this_decode().tolist() == [cache.seq_lens[req]], (req, step, "lens excl")
+                    assert cache.get_gpu_seq_lens_incl_this_decode().tolist() == [cache.seq_lens[req] + 1], (req, step, "lens incl")
+                rows.append(model.decode(tok, use_graph=use_graph).float().cpu())
+                cache.finalize_cache_single_decode([req])
+                tok = torch.tensor([toks[step + 1]], dtype=torch.int64, device="cuda")
+            cache.finalize_cache_all_decode(req)
+            return rows
+
+        return run(tag + "g", True), run(tag + "e", False)  # eager too: tells a replay problem from a kernel problem
+
+    def verdict(rows):
+        logits = torch.cat([torch.zeros(len(prompt) - 1, rows[0].shape[-1])] + rows)
+        try:
+            return _check(logits, g, len(prompt), "hip"), None
+        except AssertionError as e:
+            return None, e
+
+    rows, rows_eager = attempt("a")
     same = sum(int(torch.equal(a, b)) for a, b in zip(rows, rows_eager))
     print("graph replay rows identical to eager launches:", same, "/ 65")
-    assert same == 65, ("graph replay != eager launches", same,
-                        [i for i, (a, b) in enumerate(zip(rows, rows_eager)) if not torch.equal(a, b)][:8])
-    logits = torch.cat([torch.zeros(len(prompt) - 1, rows[0].shape[-1])] + rows)
-    err, agree = _check(logits, g, len(prompt), "hip")
-    print("HIP vs reference Llama: rel err", err, "greedy agreement", agree, "/ 65")
+    ok, err = verdict(rows)
+    if err is not None or same != 65:
+        # seen twice in four runs of the WHOLE gpu suite and never alone: say as much as one failing run can --
+        # is the eager run right, does a second, fresh instance in the same process get it right, what process-wide
+        # state is set
+        from chitu_amd import _lib, ops, workspace
+        from chitu_amd import tensor_parallel as tp
+
+        ok_eager, err_eager = verdict(rows_eager)
+        rows2, rows2_eager = attempt("b")
+        ok2, err2 = verdict(rows2)
+        ok2_eager, _ = verdict(rows2_eager)
+        state = {"xgmi": tp.xgmi_comm() is not None, "tp_size": tp.get_tp_size(), "workspace_namespace": workspace._namespace,
+                 "debug_options_set": _forced_launch_variants(_lib),
+                 "tile_major": getattr(ops, "_TILE_MAJOR", None), "mem_allocated_GB": round(torch.cuda.memory_allocated() / 2**30, 2),
+                 "mem_reserved_GB": round(torch.cuda.memory_reserved() / 2**30, 2)}
+        raise AssertionError(("graph rows == eager rows", same, "graph run", err, "eager run ok", ok_eager, str(err_eager)[:300],
+                              "second fresh instance: graph ok", ok2, str(err2)[:300], "eager ok", ok2_eager, state))
+    print("HIP vs reference Llama: rel err", ok[0], "greedy agreement", ok[1], "/ 65")

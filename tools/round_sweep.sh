@@ -1,19 +1,26 @@
 #!/bin/bash
-# One gpurun call that refreshes every trace DESIGN.md section 5 quotes, on the current code:
-#   /usr/local/graft/bin/gpurun --timeout 600 -- 'tools/round_sweep.sh r03'
-# Writes gpurun_out/<tag>/: bench line, step breakdowns (bs 16 / 1) + whole-process kernel traces, Llama bs-1 trace,
-# prefill timings + trace, bs sweep.  ~4 GPU-minutes.  Copy what is to be judged into profiles/.
+# One gpurun call that refreshes every trace and counter DESIGN.md section 5 quotes, on the current code:
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- "tools/round_sweep.sh r03_sweep $(git rev-parse --short HEAD)"
+# (the GPU box has no .git: the head the numbers belong to is handed in and stamped into the PMC record).
+# Writes gpurun_out/<tag>/: the bench line, step breakdowns (bs 16 / 1 / 32) + whole-process kernel traces, the PMC
+# passes (tools/pmc_passes.sh -> pmc_step.json, what bench.py reads as profiles/r03_pmc_step.json), Llama bs-1 trace,
+# prefill timings + trace, bs sweep.  ~8 GPU-minutes.  Copy what is to be judged into profiles/.
 tag=${1:-sweep}
+head=${2:-unknown}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
+echo "$head" > $out/git_head.txt
 cd /tmp && export TMPDIR=/tmp
 python $GRAFT_REPO_ROOT/bench.py > $out/bench.json 2> $out/bench_err.txt
-for bs in 16 1; do
+for bs in 16 1 32; do
   rm -rf /tmp/pb$bs
   rocprofv3 --kernel-trace --stats -d /tmp/pb$bs -o t -- python $GRAFT_REPO_ROOT/bench.py --bs $bs --steps 8 --warmup 2 --no-bs1 --no-llama --no-cpu-baseline > /tmp/pb$bs.log 2>&1
   python $GRAFT_REPO_ROOT/tools/step_breakdown.py /tmp/pb$bs/t_results.db 8 > $out/step_breakdown_bs$bs.txt
   python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pb$bs/t_results.db > $out/kerneltrace_bs$bs.txt
 done
+bash $GRAFT_REPO_ROOT/tools/pmc_passes.sh $out/pmc > $out/pmc_passes.log 2>&1
+CHITU_GIT_HEAD=$head python $GRAFT_REPO_ROOT/tools/pmc_report.py $out/pmc > $out/pmc_step.json 2>> $out/pmc_passes.log
+cd /tmp
 rm -rf /tmp/pl; rocprofv3 --kernel-trace --stats -d /tmp/pl -o t -- python $GRAFT_REPO_ROOT/tools/llama_ab.py --bs 1 --reps 1 --steps 20 > $out/llama_ab.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pl/t_results.db --last-fraction 0.45 > $out/kerneltrace_llama_bs1.txt
 rm -rf /tmp/pp; rocprofv3 --kernel-trace --stats -d /tmp/pp -o t -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py 8 > $out/prefill.txt 2>&1
