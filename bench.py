@@ -427,6 +427,43 @@ def roofline_dominant_kernel(model, routing, margs, bs, iters=3):
     torch.cuda.synchronize()
     per_launch = sorted(a.elapsed_time(b) / len(plans) for a, b in reps)
     avg_ms = sum(per_launch) / len(per_launch)
+    # (1b) the same launches with a near-idle gap after each (a chain of 32 one-workgroup elementwise kernels, ~70 us: what
+    # the rest of a layer lasts in the step), minus a graph of the gaps alone: separates "58 launches streaming 22 GB without a pause"
+    # (HBM refresh / power management under an uninterrupted stream) from the kernel's own duration.  In the step the
+    # kernel trace shows the in-step figure; this leg reproduces it without a profiler.
+    spaced_ms = None
+    try:
+        tick = torch.zeros(64, device="cuda")
+
+        def gap():
+            for _ in range(32):
+                tick.add_(1.0)
+
+        gap()
+        torch.cuda.synchronize()
+        g_gap, g_spaced = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_gap):
+            for _ in plans:
+                gap()
+        with torch.cuda.graph(g_spaced):
+            for m, pl in zip(moe_layers, plans):
+                launch(m, pl)
+                gap()
+        both = []
+        for g in (g_gap, g_spaced, g_gap, g_spaced, g_gap, g_spaced):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            both.append((e0, e1))
+        torch.cuda.synchronize()
+        t = [a.elapsed_time(b) for a, b in both]
+        gap_ms, with_ms = min(t[0::2]), min(t[1::2])
+        spaced_ms = (with_ms - gap_ms) / len(plans)
+        gap_us = gap_ms / len(plans) * 1e3
+    except Exception as e:
+        print(f"[bench] spaced-launch leg skipped: {e!r}", file=sys.stderr)
+        gap_us = None
     # (2) for comparison, an event pair around every single eager launch: the interval then also holds the two
     # event packets and the launch itself (~4 us), which the step's graph does not pay
     times = []
@@ -477,6 +514,9 @@ def roofline_dominant_kernel(model, routing, margs, bs, iters=3):
         "avg_launch_us": round(avg_ms * 1e3, 2),
         "timing": f"HIP events around {iters} replays of one hipGraph holding the {len(plans)} launches back to back (the step's own form); "
                   "avg_launch_us = replay time / launches",
+        "spaced_launch_us": None if spaced_ms is None else round(spaced_ms * 1e3, 2),
+        "spaced_note": None if spaced_ms is None else f"the same graph with a {gap_us:.0f} us idle gap after every launch, minus a graph of the gaps "
+                       "alone: the launch as the step sees it (other kernels between two of them) rather than 58 of them streaming without a pause",
         "event_pair_avg_launch_us": round(pair_avg_ms * 1e3, 2), "event_pair_median_launch_us": round(ms[len(ms) // 2] * 1e3, 2),
         "algorithmic_bytes_per_launch": int(alg), "distinct_experts": round(distinct, 2),
         "distinct_experts_min_max": [min(pl[3] for pl in plans), max(pl[3] for pl in plans)],
