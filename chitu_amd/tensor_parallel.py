@@ -82,7 +82,7 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
     """Switch the TP group's decode-sized collectives to the in-graph xGMI kernels: every rank creates its
     buffer, the IPC handles travel over the process group, and (selftest) one all-reduce and one all-gather are
     checked against the library's on every rank.  Collective over the TP group, in STAGES (create, map, all-reduce
-    self-test, all-gather self-test): every rank takes part in every collective of a stage whatever happened to it
+    self-test in the one-shot and the two-shot form, all-gather self-test): every rank takes part in every collective of a stage whatever happened to it
     locally, the ranks agree on the stage's verdict (MIN over the group), and only a unanimous success moves on --
     so a failure on some ranks (IPC refused on one GPU, a mismatch on one rank) can never leave the others inside a
     collective nobody else enters.  On any failure the library path stays in place on EVERY rank and False is returned."""
@@ -126,6 +126,30 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
                 ok, why = False, repr(e)
             if not unanimous(ok):
                 return give_up(comm, why)
+        # stage 3b: the two-shot form (reduce-scatter + all-gather inside the launch, the form of >= 256 KB messages) on the
+        # same check, twice (both data-slot parities).  A timeout leaves the sticky error word set: give up as above.  A
+        # group on which only its VALUES are wrong keeps the xGMI collectives in the one-shot form for every size.
+        if (dim // 8) % world == 0:
+            default_threshold, values_ok = comm.two_shot_bytes, True
+            comm.set_two_shot(0)
+            for _ in range(2):
+                part = torch.randn(min(max_rows, 4), dim, device="cuda", generator=gen).to(torch.bfloat16)
+                want = part.float().to(lib_dev)
+                dist.all_reduce(want, group=group)
+                alive, same, why = True, True, ""
+                try:
+                    got = comm.allreduce_rmsnorm(part).float().to(lib_dev)
+                    alive = comm.status() == 0
+                    same = alive and torch.allclose(got, want, rtol=2e-2, atol=2e-2)
+                    why = "" if alive else "two-shot all-reduce self-test timeout"
+                except Exception as e:  # noqa: BLE001
+                    alive, same, why = False, False, repr(e)
+                if not unanimous(alive):
+                    return give_up(comm, why)
+                values_ok = unanimous(same) and values_ok
+            comm.set_two_shot(default_threshold if values_ok else 1 << 62)
+            if not values_ok:
+                print(f"[chitu_amd] rank {rank}: two-shot all-reduce self-test mismatch; keeping the one-shot form for every size", flush=True)
         if gather_bytes >= 2 * 32 * 2:  # stage 4
             y = torch.randn(2, 32, device="cuda", generator=gen).to(torch.bfloat16)
             ref = [torch.empty(2, 32, dtype=torch.float32, device=lib_dev) for _ in range(world)]
