@@ -55,7 +55,10 @@ __global__ __launch_bounds__(64 * kQProjWaves) void mla_q_proj_kernel(
     // rows padded to 36 floats: row j starts at bank (36 j) % 64 -- 16 distinct multiples of 4, so the 16-byte reads of the
     // 16 rows (and the scalar writes) spread over all 64 banks; unpadded (32 floats) they met on two bank groups (PMC:
     // 85 % of this kernel's LDS cycles were conflicts, profiles/r03_pmc_step.json)
-    __shared__ __attribute__((aligned(16))) float ssq[MT][16][WK * 4 + 4];
+#ifndef CHITU_QPROJ_SSQ_PAD
+#define CHITU_QPROJ_SSQ_PAD 4
+#endif
+    __shared__ __attribute__((aligned(16))) float ssq[MT][16][WK * 4 + CHITU_QPROJ_SSQ_PAD];
     if ((int)blockIdx.x < kv_blocks) {  // the first workgroups: one token's KV row each (waves 0 and 1)
         const int b = blockIdx.x;
         QPROJ_MARK(10, 0);
