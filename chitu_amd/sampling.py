@@ -33,9 +33,13 @@ __all__ = [
 ]
 
 
-def _rows(t: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+def _rows(t: torch.Tensor, writable: bool = False) -> Tuple[torch.Tensor, int, int]:
+    """[rows, vocab] with a unit stride along the vocabulary.  Read-only consumers take a dense copy of a strided input
+    (e.g. the permuted view a library all-gather hands back); in-place ones refuse it."""
     assert t.dim() >= 1
-    t2 = t.view(-1, t.shape[-1])
+    if t.stride(-1) != 1 and not writable:
+        t = t.contiguous()
+    t2 = t.reshape(-1, t.shape[-1]) if not writable else t.view(-1, t.shape[-1])
     assert t2.stride(-1) == 1, "the vocabulary axis must be contiguous"
     return t2, t2.shape[0], t2.shape[1]
 
@@ -46,7 +50,7 @@ def apply_frequency_penalty(logits: torch.Tensor, responses: Sequence[Sequence[i
     (executor.py:89-102).  Rows with penalty <= 0 or an empty response are untouched."""
     require_cuda(logits)
     assert logits.dtype == torch.float32, "fp32 logits (model.py:475 casts them)"
-    lg, rows, vocab = _rows(logits)
+    lg, rows, vocab = _rows(logits, writable=True)
     assert len(responses) == rows and len(frequency_penalties) == rows
     if not any(p > 0 and len(r) > 0 for p, r in zip(frequency_penalties, responses)):
         return logits
@@ -66,7 +70,7 @@ def apply_frequency_penalty_device(logits, tokens_i32, offsets_i32, penalties_f3
     """Same with the ragged response lists already on the device (graph-capturable): tokens_i32 flat,
     offsets_i32 [rows + 1], penalties_f32 [rows]."""
     require_cuda(logits, tokens_i32, offsets_i32, penalties_f32)
-    lg, rows, vocab = _rows(logits)
+    lg, rows, vocab = _rows(logits, writable=True)
     assert logits.dtype == torch.float32
     assert tokens_i32.dtype == torch.int32 and offsets_i32.dtype == torch.int32 and penalties_f32.dtype == torch.float32
     assert offsets_i32.numel() == rows + 1 and penalties_f32.numel() == rows

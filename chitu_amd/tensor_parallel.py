@@ -296,7 +296,12 @@ def all_gather_last_dim(y: torch.Tensor, out_dtype=None) -> torch.Tensor:
     else:
         run()
     out = gathered.permute(*range(1, y.dim()), 0)
-    return out if out_dtype is None else out.to(out_dtype)
+    # no cast: the reference's permuted view onto the gather's buffer (tensor_parallel.py:101-102).  With the cast (the
+    # logits' `.float()`): a DENSE result -- a cast keeps its input's strides unless told otherwise, and the sampler reads
+    # logits rows with a unit stride
+    if out_dtype is None or out_dtype == out.dtype:
+        return out
+    return out.to(out_dtype, memory_format=torch.contiguous_format)
 
 
 class _ShardedLinear(torch.nn.Module):

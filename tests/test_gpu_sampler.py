@@ -363,3 +363,21 @@ def test_generate_with_sampling_parameters():
     assert torch.equal(pen[2], greedy[2]) and torch.equal(pen[:, 0], greedy[:, 0])
     for r in (0, 1):  # a huge penalty forbids repeating any generated token
         assert len(set(pen[r].tolist())) == 6
+
+
+def test_read_only_launches_accept_a_strided_vocabulary_axis():
+    """The library all-gather hands back a permuted view (tensor_parallel.all_gather_last_dim without a cast): greedy and
+    sampling launches take a dense copy of it, the in-place penalty refuses it."""
+    from chitu_amd import sampling
+
+    g = torch.Generator().manual_seed(3)
+    dense = torch.randn(5, 1000, generator=g).cuda()
+    strided = dense.t().contiguous().t()  # same values, vocabulary stride 5
+    assert strided.stride(-1) != 1
+    assert torch.equal(sampling.argmax(strided), sampling.argmax(dense))
+    u = torch.rand(5, generator=g).cuda()
+    a = sampling.top_k_top_p_sampling_from_logits(strided, [0.8] * 5, [50] * 5, [0.9] * 5, uniforms=u)
+    b = sampling.top_k_top_p_sampling_from_logits(dense, [0.8] * 5, [50] * 5, [0.9] * 5, uniforms=u)
+    assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        sampling.apply_frequency_penalty(strided, [[1]] * 5, [0.5] * 5)

@@ -94,6 +94,10 @@ def _tp_layers(rank, world):
     y = torch.arange(6.0).view(2, 3) + 100 * rank
     gth = tp.all_gather_last_dim(y)
     assert gth.shape == (2, 3 * world) and torch.equal(gth[:, 3 * rank : 3 * rank + 3], y)
+    # with the logits' cast the result is DENSE (the sampler reads rows with a unit stride; bench.py --gpus N on the
+    # library path failed on the permuted view a plain .to() keeps)
+    g64 = tp.all_gather_last_dim(y, out_dtype=torch.float64)
+    assert g64.dtype == torch.float64 and g64.is_contiguous() and torch.equal(g64, gth.double())
 
 
 def test_tp_layers_world2():
