@@ -22,6 +22,9 @@
 
 namespace chitu {
 
+#ifndef CHITU_TILED_XCD
+#define CHITU_TILED_XCD 1  // 0: row-major tile order (A/B builds, tools/build_variant.sh)
+#endif
 constexpr int kTileN = 128, kTileM = 128, kTileK = 128;
 constexpr int kLdsRow = kTileK + 16;  // bytes per staged row
 
@@ -40,7 +43,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int wn = wave & 1, wm = wave >> 1;
+#if CHITU_TILED_XCD
+    int tile_m, tile_n;  // XCD-blocked order (gemm_common.h): workgroup-uniform, so is the early exit
+    if (!xcd_tile_of((int)blockIdx.x, (M + kTileM - 1) / kTileM, (N + kTileN - 1) / kTileN, tile_m, tile_n)) return;
+    const int n0 = tile_n * kTileN, m0 = tile_m * kTileM;
+#else
     const int n0 = blockIdx.x * kTileN, m0 = blockIdx.y * kTileM;
+#endif
     const int KB = K >> 7;
 
     // staging role: thread t moves 16 B of rows (t / 8) + 32 i at byte (t % 8) * 16, i < 4, of both tiles
@@ -158,7 +167,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // chitu_hip_fp8_gemm_blockscale's large-M form (declared in gemm_common.h, called from fp8_gemm.hip)
 void launch_fp8_gemm_tiled(const fp8_t* a, const float* a_s, const fp8_t* b, const float* b_s, void* out, int out_dt,
                            int64_t M, int64_t N, int64_t K, hipStream_t st) {
+#if CHITU_TILED_XCD
+    const XcdTiling t = xcd_tiling((int)((M + kTileM - 1) / kTileM), (int)((N + kTileN - 1) / kTileN));
+    const dim3 grid((unsigned)(8 * t.Mt * t.Nt));
+#else
     const dim3 grid((unsigned)((N + kTileN - 1) / kTileN), (unsigned)((M + kTileM - 1) / kTileM));
+#endif
     hipLaunchKernelGGL(fp8_gemm_tiled_kernel, grid, dim3(256), 0, st, a, a_s, b, b_s, out, out_dt, (int)M, (int)N, (int)K);
 }
 

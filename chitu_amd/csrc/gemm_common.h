@@ -192,4 +192,34 @@ void launch_bf16_gemm_tiled(const bf16_t* x, const bf16_t* w, void* out, int out
 // out[m][n] = sum_s partial[s][m][n] (s ascending), cast to out_dt.  Defined in fp8_gemm.hip.
 void launch_splitk_reduce(const float* partial, void* out, int out_dt, int S, int64_t MN, hipStream_t st);
 
+// ---------------------------------------------------------------- XCD-blocked tile order (prefill-shaped GEMMs)
+// Workgroup b of a launch runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md: used for speed only, never for
+// correctness), and every XCD has its own 4 MB L2.  A row-major walk over a (tiles_n x tiles_m) grid therefore gives each
+// XCD a stripe pattern that touches EVERY weight tile row and EVERY activation tile row: each L2 is filled with the
+// whole of both operands.  Here the 8 XCDs are laid out as an xm x xn grid of rectangles (the shape of 8 = xm * xn that
+// minimises tile rows per rectangle, Mt + Nt) and XCD k walks only its own rectangle: its L2 sees Mt + Nt operand
+// rows instead of tiles_m + tiles_n.  The launch has 8 * Mt * Nt workgroups; those whose tile falls outside the grid exit.
+struct XcdTiling {
+    int xm, xn, Mt, Nt;
+};
+
+__host__ __device__ inline XcdTiling xcd_tiling(int tiles_m, int tiles_n) {
+    XcdTiling best{1, 8, tiles_m, (tiles_n + 7) / 8};
+    int best_cost = best.Mt + best.Nt;
+    for (int xm = 2; xm <= 8; xm *= 2) {
+        const int xn = 8 / xm, Mt = (tiles_m + xm - 1) / xm, Nt = (tiles_n + xn - 1) / xn;
+        if (Mt + Nt < best_cost) best = XcdTiling{xm, xn, Mt, Nt}, best_cost = Mt + Nt;
+    }
+    return best;
+}
+
+// linear workgroup id -> (tile_m, tile_n); false = no tile (padding of the launch)
+__device__ __forceinline__ bool xcd_tile_of(int wg, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+    const XcdTiling t = xcd_tiling(tiles_m, tiles_n);
+    const int xcd = wg & 7, slot = wg >> 3;
+    tile_m = (xcd / t.xn) * t.Mt + slot / t.Nt;
+    tile_n = (xcd % t.xn) * t.Nt + slot % t.Nt;
+    return slot < t.Mt * t.Nt && tile_m < tiles_m && tile_n < tiles_n;
+}
+
 }  // namespace chitu
