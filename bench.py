@@ -23,6 +23,17 @@ model's weights, so N/8 of an 8-GPU node's tokens are attributed to them (weak s
 `node_tok_s` = bs*K/T is what an 8-GPU node emits at this per-rank step time; at N < 8 the collectives it
 would pay span only the live ranks (`collectives_in_step` is 0 at N=1), so only N=8 is the metric itself.
 
+`roofline` (dominant kernel, the routed experts' GEMM1 + SiLU): `achieved` = algorithmic bytes of one launch / its duration,
+measured live with HIP events around replays of one hipGraph holding every MoE layer's launch back to back
+(`avg_launch_us`); `spaced_launch_us` = the same launches with ~70 us of near-idle kernels between them (what the step
+looks like to this kernel; an uninterrupted 22 GB stream runs ~5 % slower); `traffic` / `mfma_util` from the committed PMC
+record profiles/r03_pmc_step.json, whose git head is echoed as `pmc_head` and which is withheld if csrc/moe.hip has changed
+since.  `collectives` (N > 1): transport, per-launch GPU time of the fused all-reduce and of the logits all-gather, and
+`per_transport`: the same norm + quant launch without a collective, with the xGMI all-reduce in its one-shot and its
+two-shot form, and the all-gather, at bs 1 / 16 / 32.  A line whose `ranks_seen_by_library` differs from --gpus, or whose
+xGMI error word is set, carries `invalid` (and no `value` in the first case).  `v2_lite`, `mixtral_8x7b_int8`, `llama3_8b`:
+BASELINE configs 3 / 4 / 2 as extra objects with their own step_algorithmic_GB and roofline_frac (N = 1 only).
+
 Prints ONE JSON line on rank 0.
 """
 
