@@ -29,6 +29,10 @@ __device__ __forceinline__ float moe_tiled_routed_weight(const void* topk_w, int
     return ((const float*)topk_w)[slot];
 }
 
+#ifndef CHITU_MOE_TILED_NREP
+#define CHITU_MOE_TILED_NREP 4  // 1: a workgroup per tile always (A/B builds, tools/build_variant.sh)
+#endif
+
 struct MoeTileRegs {
     i32x4 w[4], x[2];
     float xs[4];
@@ -39,7 +43,11 @@ struct MoeTileRegs {
 //   SILU: Nw = 2I rows per expert, blockIdx.x covers output columns [64 bx, 64 bx + 64); `out` = h [numel, I].
 //   else: Nw = N rows per expert, blockIdx.x covers rows [128 bx, +128); `out` = [numel, Nw] scaled by the routed weight.
 // row_div: activation row of slot s = s / row_div (topk for GEMM1: the token; 1 for GEMM2: the slot's own h row).
-template <bool SILU>
+// NREP (GEMM2 form only): consecutive 128-row weight tiles a workgroup walks with ONE pipeline -- (tile, K block) pairs are
+// one sequence of steps, the next step's operands are in flight while this one is multiplied, a tile's C is stored when its
+// last K block is done.  With K = 256 (two K blocks, R1 at TP=8) a workgroup per tile is all prologue and epilogue: its
+// dependent chain (padded count -> expert id -> slot ids -> rows -> LDS -> MFMA -> store) is paid once per NREP tiles.
+template <bool SILU, int NREP = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void moe_gemm_tiled_kernel(
     const fp8_t* __restrict__ Xq, const float* __restrict__ Xs, const fp8_t* __restrict__ W, const float* __restrict__ Ws,
     const int32_t* __restrict__ sorted_ids, const int32_t* __restrict__ expert_ids,
@@ -54,7 +62,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int j = lane & 15, g = lane >> 4;
     const int e = expert_ids[mb];
     const int I = Nw >> 1;
-    const int n0 = SILU ? blockIdx.x * 64 : blockIdx.x * 128;
+    static_assert(!SILU || NREP == 1, "the GEMM1 form keeps one tile per workgroup");
+    const int n0 = SILU ? blockIdx.x * 64 : blockIdx.x * 128 * NREP;
     const int KB = K >> 7;
 
     // this lane's output slots (token column j of each of the 4 slot tiles)
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) slot[mt] = sorted_ids[mb * kMoeTileM + mt * 16 + j];
     if (e < 0) {  // another rank's expert (expert parallelism): its slots are zero-filled, fused_moe.py:40-59
-        const int cols = SILU ? 64 : 128, ldo = SILU ? I : Nw;
+        const int cols = SILU ? 64 : 128 * NREP, ldo = SILU ? I : Nw;
         for (int idx = tid; idx < kMoeTileM * (cols / 8); idx += 256) {
             const int r = idx / (cols / 8), c = idx % (cols / 8);
             const int s = sorted_ids[mb * kMoeTileM + r];
@@ -94,16 +103,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* wsp0 = wsb + (size_t)(n0 >> 7) * KB;
     const float* wsp1 = SILU ? wsb + (size_t)((I + n0) >> 7) * KB : wsp0;
 
-    auto fetch = [&](MoeTileRegs& r, int kb) {
+    auto fetch = [&](MoeTileRegs& r, int kb, int rep = 0) {
         const int off = kb << 7;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r.w[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wg[i] + off));
+        for (int i = 0; i < 4; ++i) {
+            // tile `rep` of this workgroup: 128 rows further down (rows past the matrix re-read its last row, never stored)
+            const fp8_t* wp = NREP == 1 ? wg[i] : We + (size_t)min(n0 + rep * 128 + srow + 32 * i, Nw - 1) * K + scol;
+            r.w[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) r.x[i] = *reinterpret_cast<const i32x4*>(xg[i] + off);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) r.xs[mt] = xsp[mt][kb];
-        r.ws0 = wsp0[kb];
-        r.ws1 = wsp1[kb];
+        r.ws0 = wsp0[(size_t)rep * KB + kb];  // one 128-row tile = one row of block scales
+        r.ws1 = SILU ? wsp1[kb] : r.ws0;
     };
     auto stage = [&](const MoeTileRegs& r, int buf) {
 #pragma unroll
@@ -120,13 +133,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // C tile (nt, mt): lane holds weight rows 4g .. 4g+3 of the tile for slot column j
+    float rw[4] = {1.f, 1.f, 1.f, 1.f};
+    if (!SILU && topk_w) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            if (slot[mt] < numel) rw[mt] = moe_tiled_routed_weight(topk_w, w_dt, slot[mt]);
+    }
+    auto store_tile = [&](int nb) {  // nb = first weight row (GEMM2) / output column (GEMM1) of the finished tile
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int s = slot[mt];
+            if (s >= numel) continue;
+            if (SILU) {
+                const int n = nb + 16 * wave + 4 * g;  // output column of r = 0
+                uint16_t h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gv = round_bf16(acc[0][mt][r]), uv = round_bf16(acc[1][mt][r]);  // GEMM1's bf16 output (c1)
+                    const float sl = round_bf16(gv / (1.0f + expf(-gv)));
+                    h[r] = f32_to_bf16(sl * uv);
+                }
+                bf16_t* dst = out + (size_t)s * I + n;
+                if (n + 3 < I) {
+                    i32x2 o;
+                    o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
+                    o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                    *reinterpret_cast<i32x2*>(dst) = o;
+                } else {
+                    for (int r = 0; r < 4 && n + r < I; ++r) dst[r] = h[r];
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int n = nb + 32 * wave + 16 * nt + 4 * g;
+                    uint16_t h[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = f32_to_bf16(acc[nt][mt][r] * rw[mt]);
+                    bf16_t* dst = out + (size_t)s * Nw + n;
+                    if (n + 3 < Nw) {
+                        i32x2 o;
+                        o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
+                        o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
+                        *reinterpret_cast<i32x2*>(dst) = o;
+                    } else {
+                        for (int r = 0; r < 4 && n + r < Nw; ++r) dst[r] = h[r];
+                    }
+                }
+            }
+        }
+    };
+
+    // (tile, K block) steps: the next step's operands are fetched while this one is multiplied
+    const int reps = NREP == 1 ? 1 : min(NREP, (Nw - n0 + 127) >> 7);
+    const int steps = reps * KB;
     MoeTileRegs cur, nxt;
-    fetch(cur, 0);
+    fetch(cur, 0, 0);
     stage(cur, 0);
     __syncthreads();
-    for (int kb = 0; kb < KB; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < KB) fetch(nxt, kb + 1);
+    int rep = 0, kb = 0;
+    for (int t = 0; t < steps; ++t) {
+        const int buf = t & 1;
+        int nkb = kb + 1, nrep = rep;
+        if (nkb == KB) nkb = 0, nrep = rep + 1;
+        if (t + 1 < steps) fetch(nxt, nkb, nrep);
         i32x4 wa[2][2];
         {
             const uint8_t* w0 = &sW[buf][(wrow0 + j) * kMoeLdsRow + g * 16];
@@ -153,55 +223,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * wsc;
             }
         }
-        if (kb + 1 < KB) {
+        if (t + 1 < steps) {
             stage(nxt, buf ^ 1);
             cur = nxt;
         }
-        __syncthreads();
-    }
-
-    // C tile (nt, mt): lane holds weight rows 4g .. 4g+3 of the tile for slot column j
+        if (kb == KB - 1) {  // this tile's last K block: its C leaves now, under the next tile's loads
+            store_tile(n0 + rep * 128);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int s = slot[mt];
-        if (s >= numel) continue;
-        if (SILU) {
-            const int n = n0 + 16 * wave + 4 * g;  // output column of r = 0
-            uint16_t h[4];
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float gv = round_bf16(acc[0][mt][r]), uv = round_bf16(acc[1][mt][r]);  // GEMM1's bf16 output (c1)
-                const float sl = round_bf16(gv / (1.0f + expf(-gv)));
-                h[r] = f32_to_bf16(sl * uv);
-            }
-            bf16_t* dst = out + (size_t)s * I + n;
-            if (n + 3 < I) {
-                i32x2 o;
-                o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
-                o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                *reinterpret_cast<i32x2*>(dst) = o;
-            } else {
-                for (int r = 0; r < 4 && n + r < I; ++r) dst[r] = h[r];
-            }
-        } else {
-            const float rw = topk_w ? moe_tiled_routed_weight(topk_w, w_dt, s) : 1.0f;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = n0 + 32 * wave + 16 * nt + 4 * g;
-                uint16_t h[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = f32_to_bf16(acc[nt][mt][r] * rw);
-                bf16_t* dst = out + (size_t)s * Nw + n;
-                if (n + 3 < Nw) {
-                    i32x2 o;
-                    o[0] = (int)((uint32_t)h[0] | ((uint32_t)h[1] << 16));
-                    o[1] = (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16));
-                    *reinterpret_cast<i32x2*>(dst) = o;
-                } else {
-                    for (int r = 0; r < 4 && n + r < Nw; ++r) dst[r] = h[r];
-                }
-            }
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        __syncthreads();
+        kb = nkb, rep = nrep;
     }
 }
 
@@ -238,10 +272,16 @@ extern "C" int chitu_hip_moe_gemm2_fp8_tiled(const void* h_fp8, const float* h_s
     if (inter_size % 128 != 0 || N % 8 != 0 || N >= (1 << 30) || inter_size >= (1 << 30)) return CHITU_ERR_UNSUPPORTED;
     if (numel == 0 || max_mblocks == 0) return CHITU_OK;
     CHITU_REQUIRE(max_mblocks <= 65535);
-    const dim3 grid((unsigned)((N + 127) / 128), (unsigned)max_mblocks);
-    hipLaunchKernelGGL((moe_gemm_tiled_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, (const fp8_t*)h_fp8, h_scale,
-                       (const fp8_t*)w2_fp8, w2_scale, sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)out_bf16,
-                       mul_routed_weight ? topk_weights : (const void*)nullptr, (int)weights_dtype, (int)numel, 1, (int)N,
-                       (int)inter_size);
+    const int n_tiles = (int)((N + 127) / 128);
+#define LAUNCH2T(NREPV)                                                                                                  \
+    hipLaunchKernelGGL((moe_gemm_tiled_kernel<false, NREPV>), dim3((unsigned)((n_tiles + NREPV - 1) / NREPV), (unsigned)max_mblocks), \
+                       dim3(256), 0, (hipStream_t)stream, (const fp8_t*)h_fp8, h_scale, (const fp8_t*)w2_fp8, w2_scale,         \
+                       sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)out_bf16,                                    \
+                       mul_routed_weight ? topk_weights : (const void*)nullptr, (int)weights_dtype, (int)numel, 1, (int)N,      \
+                       (int)inter_size)
+    // few K blocks (R1 at TP=8: two): four tiles per workgroup through one pipeline; long K: a tile per workgroup
+    if (inter_size <= 512 && n_tiles >= 8 && CHITU_MOE_TILED_NREP > 1) LAUNCH2T(CHITU_MOE_TILED_NREP);
+    else LAUNCH2T(1);
+#undef LAUNCH2T
     CHITU_RETURN_LAUNCH_STATUS();
 }
