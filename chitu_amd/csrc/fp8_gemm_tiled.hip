@@ -177,3 +177,24 @@ void launch_fp8_gemm_tiled(const fp8_t* a, const float* a_s, const fp8_t* b, con
 }
 
 }  // namespace chitu
+
+// Host-only: the tile order fp8_gemm_tiled_kernel walks, for a CPU test of the map (every tile exactly once, each XCD's
+// workgroups inside one rectangle).  tile_of_wg: 2 x grid ints (tile_m, tile_n; -1, -1 for a padding workgroup).
+extern "C" int chitu_hip_selftest_xcd_tile_order(int32_t tiles_m, int32_t tiles_n, int32_t* grid_out, int32_t* tile_of_wg,
+                                                 int64_t capacity) {
+    using namespace chitu;
+    CHITU_REQUIRE(tiles_m >= 1 && tiles_n >= 1 && grid_out);
+    const XcdTiling t = xcd_tiling(tiles_m, tiles_n);
+    const int grid = 8 * t.Mt * t.Nt;
+    *grid_out = grid;
+    if (!tile_of_wg) return CHITU_OK;
+    CHITU_REQUIRE(capacity >= grid);
+    for (int wg = 0; wg < grid; ++wg) {
+        int tm = -1, tn = -1;
+        if (!xcd_tile_of(wg, tiles_m, tiles_n, tm, tn)) tm = tn = -1;
+        tile_of_wg[2 * wg] = tm;
+        tile_of_wg[2 * wg + 1] = tn;
+    }
+    return CHITU_OK;
+}
+

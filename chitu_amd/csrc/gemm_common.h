@@ -214,7 +214,7 @@ __host__ __device__ inline XcdTiling xcd_tiling(int tiles_m, int tiles_n) {
 }
 
 // linear workgroup id -> (tile_m, tile_n); false = no tile (padding of the launch)
-__device__ __forceinline__ bool xcd_tile_of(int wg, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
+__host__ __device__ inline bool xcd_tile_of(int wg, int tiles_m, int tiles_n, int& tile_m, int& tile_n) {
     const XcdTiling t = xcd_tiling(tiles_m, tiles_n);
     const int xcd = wg & 7, slot = wg >> 3;
     tile_m = (xcd / t.xn) * t.Mt + slot / t.Nt;

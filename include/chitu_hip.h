@@ -335,6 +335,13 @@ int chitu_hip_debug_option(int32_t option, int32_t value);
 int chitu_hip_selftest_arith(const float* num, const float* den, int64_t n, uint64_t* mismatches,
                              void* stream);
 
+/* Host-only (no launch): the XCD-blocked tile order of the prefill-shaped dense GEMM (csrc/gemm_common.h::xcd_tile_of:
+ * workgroup b runs on XCD b % 8, so each XCD is given one rectangle of a tiles_m x tiles_n grid).  *grid_out = workgroups
+ * launched (8 * Mt * Nt); tile_of_wg (may be NULL; capacity >= *grid_out pairs) receives (tile_m, tile_n) per workgroup,
+ * (-1, -1) for padding workgroups.  Exists so that the map can be tested without a GPU. */
+int chitu_hip_selftest_xcd_tile_order(int32_t tiles_m, int32_t tiles_n, int32_t* grid_out, int32_t* tile_of_wg,
+                                      int64_t capacity);
+
 /* ---- fused MoE with INT8 W8A8 experts (BASELINE config 4: Mixtral-8x7B W8A8) ----------------------
  * The reference has no int8-W8A8 fused path (Mixtral loops over experts, model_hf_mixtral.py:76-94, each
  * linear a W8A8Linear after simple_w8a8, quantize/w8a8.py:38-164); these run the same per-expert arithmetic

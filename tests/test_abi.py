@@ -90,3 +90,35 @@ def test_fused_launch_shape_limits_agree_between_python_and_c():
         rc = lib.chitu_hip_mla_q_proj(p, i64(ql + 576 + (8 - (ql + 576) % 8) % 8), i32(ql), p, f32(1e-6), p, p, p, i32(0), i64(3072),
                                       p, f32(1e-6), p, p, p, i64(4), i32(64), p, i32(2), p, i32(bs), i32(512), i32(64), None)
         assert rc == -2, (bs, ql, rc)
+
+
+def test_xcd_blocked_tile_order_covers_every_tile_once():
+    """The prefill GEMM's workgroup -> tile map (gemm_common.h::xcd_tile_of), through its host-side entry: every tile of the
+    grid exactly once, padding workgroups only beyond it, and the workgroups of one XCD (b % 8) inside ONE rectangle whose
+    half-perimeter is the smallest an 8-way split allows."""
+    import ctypes
+
+    import numpy as np
+
+    from chitu_amd import _lib
+
+    lib = _lib.lib()
+    for tiles_m, tiles_n in [(16, 17), (1, 1), (1, 56), (16, 24), (3, 5), (7, 129), (33, 2), (128, 4), (5, 8)]:
+        grid = ctypes.c_int32()
+        assert lib.chitu_hip_selftest_xcd_tile_order(tiles_m, tiles_n, ctypes.byref(grid), None, ctypes.c_int64(0)) == 0
+        n = grid.value
+        assert n >= tiles_m * tiles_n and n % 8 == 0
+        tiles = np.full((n, 2), -7, dtype=np.int32)
+        assert lib.chitu_hip_selftest_xcd_tile_order(tiles_m, tiles_n, ctypes.byref(grid),
+                                                     tiles.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n)) == 0
+        real = tiles[tiles[:, 0] >= 0]
+        assert len(real) == tiles_m * tiles_n and len({(a, b) for a, b in real.tolist()}) == tiles_m * tiles_n
+        assert real[:, 0].max() == tiles_m - 1 and real[:, 1].max() == tiles_n - 1
+        assert (tiles[tiles[:, 0] < 0] == -1).all()
+        best = min((tiles_m + xm - 1) // xm + (tiles_n + 8 // xm - 1) // (8 // xm) for xm in (1, 2, 4, 8))
+        for xcd in range(8):
+            mine = tiles[xcd::8]
+            mine = mine[mine[:, 0] >= 0]
+            if len(mine):
+                span = (mine[:, 0].max() - mine[:, 0].min() + 1) + (mine[:, 1].max() - mine[:, 1].min() + 1)
+                assert span <= best, (tiles_m, tiles_n, xcd, span, best)
