@@ -1,5 +1,6 @@
 """Checkpoint preprocessing for the DeepSeek-V3 / R1 decode path: Hugging Face names -> this
-package's module tree, tensor-parallel shards, merged / stacked FP8 tensors, per-rank preprocessed files.
+package's module tree, tensor-parallel shards, merged / stacked FP8 tensors, per-rank preprocessed files -- and, at the
+end of the file, the same for the Llama family (HF Llama / Mixtral files -> LlamaDecoder / MixtralDecoder: configs 1, 2, 4).
 
 Restates, as one table-driven pipeline, what the reference spreads over
   * chitu/backend.py:431-481        load_state_dict_deepseek_v3  (HF -> chitu names, MTP layer 61 dropped)
@@ -344,3 +345,164 @@ def save_preprocessed(model: torch.nn.Module, target_dir: str, rank: int = 0) ->
     fp = os.path.join(target_dir, f"model.rank{rank}.safetensors")
     save_file({k: v.detach().cpu().contiguous() for k, v in model.named_parameters()}, fp)
     return fp
+
+
+# ---------------------------------------------------------------- Llama family (BASELINE configs 1, 2 and 4)
+# The reference's HF-Llama / HF-Mixtral load path, restated like the DeepSeek one above:
+#   chitu/backend.py:374-380                    the "model." prefix of HF names is dropped
+#   chitu/models/model_hf_mixtral.py:171-178    Mixtral: block_sparse_moe -> mlp, w1 / w3 / w2 -> gate / up / down_proj
+#   chitu/models/model_hf_llama.py:595-600      tensor parallelism: files that ship qkv / gate_up MERGED are split first
+#   chitu/models/model.py:332-370               column-parallel tensors chunked along dim 0 (biases: last dim), row-parallel
+#                                               along dim 1 (biases on rank 0 only)
+#   chitu/models/model_hf_llama.py:506-566      q | k | v -> qkv_proj, gate | up -> gate_up_proj, per rank
+# `preprocess_hf_llama` returns tensors under the REFERENCE'S final per-rank names (pinned digest by digest against the
+# reference's own methods, tests/golden/gen_ckpt_llama.py); `to_llama_module_names` / `to_mixtral_module_names` map them
+# onto chitu_amd.llama.LlamaDecoder / chitu_amd.mixtral.MixtralDecoder.
+
+HF_LLAMA_COLUMN = ("qkv_proj", "q_proj", "k_proj", "v_proj", "gate_up_proj", "gate_proj", "up_proj", "lm_head", "embed_tokens")
+HF_LLAMA_ROW = ("down_proj", "o_proj")  # model_hf_llama.py:403-417; Mixtral adds its router "gate" (model_hf_mixtral.py:157-160)
+
+
+def strip_model_prefix(state: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    return {(k[len("model."):] if k.startswith("model.") else k): v for k, v in state.items()}
+
+
+def map_mixtral_names(state: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in state.items():
+        for a, b in ((".block_sparse_moe.", ".mlp."), (".w1.", ".gate_proj."), (".w3.", ".up_proj."), (".w2.", ".down_proj.")):
+            k = k.replace(a, b)
+        out[k] = v
+    return out
+
+
+def _split_merged(state: Mapping[str, torch.Tensor], merged: str, parts, sizes_of) -> Dict[str, torch.Tensor]:
+    """`<p>.merged.{weight,bias}` -> `<p>.part.{weight,bias}` for part in parts, split along dim 0 into sizes_of(tensor)."""
+    out = {}
+    for k, t in state.items():
+        head, _, kind = k.rpartition(".")
+        if head.endswith("." + merged) and kind in ("weight", "bias"):
+            prefix = head[: -len(merged)]
+            for part in parts:
+                if prefix + part + "." + kind in state:
+                    raise KeyError(f"{k}: {prefix + part}.{kind} is present as well")
+            for part, piece in zip(parts, t.split(sizes_of(t), dim=0)):
+                out[prefix + part + "." + kind] = piece
+        else:
+            out[k] = t
+    return out
+
+
+def split_merged_qkv(state, n_heads: int, n_kv_heads: int, head_dim: int):
+    """qkv_proj -> q_proj | k_proj | v_proj (model_hf_llama.py:428-481): needed before TP sharding, where every part is
+    cut by heads."""
+    sizes = [n_heads * head_dim, n_kv_heads * head_dim, n_kv_heads * head_dim]
+    return _split_merged(state, "qkv_proj", ("q_proj", "k_proj", "v_proj"), lambda t: sizes)
+
+
+def split_merged_gate_up(state):
+    """gate_up_proj -> gate_proj | up_proj, two equal halves (model_hf_llama.py:483-504)."""
+    return _split_merged(state, "gate_up_proj", ("gate_proj", "up_proj"), lambda t: [t.shape[0] // 2, t.shape[0] - t.shape[0] // 2])
+
+
+def _merge_group(state: Mapping[str, torch.Tensor], parts, merged: str) -> Dict[str, torch.Tensor]:
+    """`<p>.parts[0].<kind>` .. `<p>.parts[-1].<kind>` -> `<p>.merged.<kind>` = cat along dim 0 at the position of the
+    first part, for kind in weight / bias (model_hf_llama.py:506-566)."""
+    out = {}
+    for k, t in state.items():
+        head, _, kind = k.rpartition(".")
+        if kind in ("weight", "bias") and head.endswith("." + parts[0]):
+            prefix = head[: -len(parts[0])]
+            names = [prefix + p + "." + kind for p in parts]
+            for n in names[1:]:
+                if n not in state:
+                    raise KeyError(f"{k} has no partner {n}")
+            if prefix + merged + "." + kind in state:
+                raise KeyError(f"{prefix + merged}.{kind} already present")
+            out[prefix + merged + "." + kind] = torch.cat([state[n] for n in names], dim=0)
+        elif kind in ("weight", "bias") and any(head.endswith("." + p) for p in parts[1:]):
+            continue
+        else:
+            out[k] = t
+    return out
+
+
+def preprocess_hf_llama(state: Mapping[str, torch.Tensor], n_heads: int, n_kv_heads: Optional[int], dim: int, rank: int = 0,
+                        world: int = 1, mixtral: bool = False, router_row_parallel: bool = True) -> Dict[str, torch.Tensor]:
+    """HF names -> this TP rank's tensors under the reference's final names (qkv_proj / gate_up_proj merged per rank).
+    router_row_parallel: the reference shards Mixtral's router along its INPUT dimension and all-reduces the logits
+    (model_hf_mixtral.py:157-160); chitu_amd.mixtral keeps the [experts, dim] matrix whole on every rank (False)."""
+    n_kv = n_heads if n_kv_heads is None else n_kv_heads
+    st = strip_model_prefix(state)
+    if mixtral:
+        st = map_mixtral_names(st)
+    if world > 1:
+        st = split_merged_gate_up(split_merged_qkv(st, n_heads, n_kv, dim // n_heads))
+        row = HF_LLAMA_ROW + (("gate",) if mixtral and router_row_parallel else ())
+        st = chunk_for_tensor_parallel(st, rank, world, column=HF_LLAMA_COLUMN, row=row)
+    st = _merge_group(st, ("q_proj", "k_proj", "v_proj"), "qkv_proj")
+    return _merge_group(st, ("gate_proj", "up_proj"), "gate_up_proj")
+
+
+_LLAMA_MODULE_NAMES = (("embed_tokens.weight", "embed_weight"), ("lm_head.weight", "head_weight"), ("norm.weight", "norm"),
+                       (".input_layernorm.weight", ".attn_norm"), (".post_attention_layernorm.weight", ".ffn_norm"),
+                       (".self_attn.qkv_proj.weight", ".attn.wqkv"), (".self_attn.o_proj.weight", ".attn.wo"),
+                       (".mlp.gate_up_proj.weight", ".ffn.w13"), (".mlp.down_proj.weight", ".ffn.w2"), (".mlp.gate.weight", ".ffn.gate"))
+
+
+def _rename_llama(name: str) -> str:
+    for a, b in _LLAMA_MODULE_NAMES:
+        if name == a or (a.startswith(".") and name.endswith(a)):
+            return name[: len(name) - len(a)] + b
+    return name
+
+
+def to_llama_module_names(state: Mapping[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Reference names -> chitu_amd.llama.LlamaDecoder's parameters.  Biases (Qwen-style qkv bias) have no parameter there
+    and are refused rather than dropped."""
+    bias = [k for k in state if k.endswith(".bias")]
+    if bias:
+        raise NotImplementedError(f"LlamaDecoder has no bias parameters: {bias[:4]}")
+    return {_rename_llama(k): v for k, v in state.items()}
+
+
+def to_mixtral_module_names(state: Mapping[str, torch.Tensor], num_experts: int) -> Dict[str, torch.Tensor]:
+    """Reference names -> chitu_amd.mixtral.MixtralDecoder's parameters: attention / norms / router as for Llama; the
+    experts' bf16 gate_up / down matrices are quantised per output channel exactly as `simple_w8a8` does at load time
+    (quantize/quantizer.py:117-145 -> quantize/w8a8.py:29-35: chitu_amd.quantize.w8a8.quant_weight, bit-exact against the
+    reference's own function) and stacked [experts, ...] for the grouped int8 GEMMs."""
+    from .quantize.w8a8 import quant_weight
+
+    out, experts = {}, {}
+    for k, v in state.items():
+        m = re.match(r"(layers\.\d+)\.mlp\.experts\.(\d+)\.(gate_up_proj|down_proj)\.weight$", k)
+        if m:
+            experts.setdefault(m.group(1), {}).setdefault(m.group(3), {})[int(m.group(2))] = v
+        else:
+            out[_rename_llama(k)] = v
+    for layer, mats in experts.items():
+        for ref_name, mine in (("gate_up_proj", "w13"), ("down_proj", "w2")):
+            per = mats.get(ref_name, {})
+            if sorted(per) != list(range(num_experts)):
+                raise KeyError(f"{layer}: experts present for {ref_name}: {sorted(per)}, expected 0..{num_experts - 1}")
+            q = [quant_weight(per[e].to(torch.float16)) for e in range(num_experts)]  # the reference quantises its fp16 module weights
+            out[f"{layer}.ffn.{mine}"] = torch.stack([w for w, _ in q])
+            out[f"{layer}.ffn.{mine}_scale"] = torch.stack([s for _, s in q])
+    return out
+
+
+def load_checkpoint_hf_llama(model, path: str, rank: int = 0, world: int = 1) -> None:
+    """HF Llama-family directory -> a LlamaDecoder or MixtralDecoder built for this TP rank, one call."""
+    args = model.args
+    state = {}
+    for fp in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
+        from safetensors import safe_open
+
+        with safe_open(fp, framework="pt", device="cpu") as f:
+            for name in f.keys():
+                state[name] = f.get_tensor(name)
+    mixtral = hasattr(args, "num_local_experts")
+    st = preprocess_hf_llama(state, args.n_heads, args.n_kv_heads, args.dim, rank, world, mixtral=mixtral,
+                             router_row_parallel=False)
+    st = to_mixtral_module_names(st, args.num_local_experts) if mixtral else to_llama_module_names(st)
+    load_deepseek_v3(model, st)  # the generic strict, shape- and dtype-checked in-place copy

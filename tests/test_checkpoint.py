@@ -259,3 +259,107 @@ def test_transposed_w_uk_tracks_the_weights_and_keeps_its_buffer():
         m2 = DeepSeekV3Decoder(_args(1), None, None, max_position_embeddings=64, device="cpu")
         m2.layers[0].attn.wkv_b.weight.view(torch.uint8).fill_(3)
         assert int(m2.layers[0].attn.w_uk_transposed().view(torch.uint8).max()) == 3
+
+
+# ---------------------------------------------------------------- Llama family (BASELINE configs 1, 2, 4)
+def _llama_golden():
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ckpt_preprocess_llama.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("kind", ["llama", "merged", "mixtral"])
+@pytest.mark.parametrize("world", [1, 2])
+def test_hf_llama_family_shard_and_merge_bit_identical_to_the_reference(kind, world):
+    """strip "model." -> (Mixtral renames) -> split merged qkv / gate_up for TP -> TP chunk -> merge per rank: the same
+    ordered names, shapes, dtypes and bytes as the reference's own TransformerHFLlama / TransformerHFMixtral loader methods
+    (tests/golden/gen_ckpt_llama.py), files with separate projections, files that ship them merged (+ qkv bias), Mixtral."""
+    from tests.util import HF_LLAMA_TINY, tiny_hf_llama_checkpoint
+
+    c = HF_LLAMA_TINY
+    gold = _llama_golden()[kind][str(world)]
+    for rank in range(world):
+        st = ck.preprocess_hf_llama(tiny_hf_llama_checkpoint(kind), c["n_heads"], c["n_kv_heads"], c["dim"], rank, world,
+                                    mixtral=kind == "mixtral")
+        got = [[k] + tensor_digest(v) for k, v in st.items()]
+        assert [g[0] for g in got] == [g[0] for g in gold[rank]]
+        assert got == gold[rank]
+
+
+def test_hf_llama_loads_into_the_decoder_and_ranks_partition_it():
+    from chitu_amd.llama import LlamaArgs, LlamaDecoder
+    from tests.util import HF_LLAMA_TINY, tiny_hf_llama_checkpoint
+
+    c = dict(HF_LLAMA_TINY, dim=512)  # the decoders' attention kernels are built for head_dim 128
+    hf = tiny_hf_llama_checkpoint("llama", cfg=c)
+    args = LlamaArgs(dim=c["dim"], n_layers=c["n_layers"], n_heads=c["n_heads"], n_kv_heads=c["n_kv_heads"],
+                     vocab_size=c["vocab_size"], ffn_dim=c["ffn_dim"])
+    model = LlamaDecoder(args, None, None, max_position_embeddings=64, device="cpu")
+    st = ck.to_llama_module_names(ck.preprocess_hf_llama(hf, args.n_heads, args.n_kv_heads, args.dim))
+    ck.load_deepseek_v3(model, st)  # strict: every parameter named, nothing left over
+    p = dict(model.named_parameters())
+    a = "model.layers.1.self_attn."
+    assert torch.equal(p["layers.1.attn.wqkv"], torch.cat([hf[a + "q_proj.weight"], hf[a + "k_proj.weight"], hf[a + "v_proj.weight"]]))
+    assert torch.equal(p["layers.1.ffn.w13"], torch.cat([hf["model.layers.1.mlp.gate_proj.weight"], hf["model.layers.1.mlp.up_proj.weight"]]))
+    assert torch.equal(p["head_weight"], hf["lm_head.weight"]) and torch.equal(p["layers.0.attn_norm"], hf["model.layers.0.input_layernorm.weight"])
+    # two ranks: heads / FFN width / vocabulary split, every byte of the checkpoint on exactly one rank (norms on both)
+    r = [ck.to_llama_module_names(ck.preprocess_hf_llama(hf, args.n_heads, args.n_kv_heads, args.dim, rank, 2)) for rank in range(2)]
+    hd, hq, hkv = c["dim"] // c["n_heads"], c["n_heads"], c["n_kv_heads"]
+    q = torch.cat([r[0]["layers.0.attn.wqkv"][: hq // 2 * hd], r[1]["layers.0.attn.wqkv"][: hq // 2 * hd]])
+    assert torch.equal(q, hf["model.layers.0.self_attn.q_proj.weight"])
+    v = torch.cat([r[0]["layers.0.attn.wqkv"][-(hkv // 2) * hd:], r[1]["layers.0.attn.wqkv"][-(hkv // 2) * hd:]])
+    assert torch.equal(v, hf["model.layers.0.self_attn.v_proj.weight"])
+    assert torch.equal(torch.cat([r[0]["layers.0.attn.wo"], r[1]["layers.0.attn.wo"]], 1), hf["model.layers.0.self_attn.o_proj.weight"])
+    assert torch.equal(torch.cat([r[0]["layers.0.ffn.w2"], r[1]["layers.0.ffn.w2"]], 1), hf["model.layers.0.mlp.down_proj.weight"])
+    assert torch.equal(torch.cat([r[0]["embed_weight"], r[1]["embed_weight"]]), hf["model.embed_tokens.weight"])
+    with pytest.raises(NotImplementedError):  # a qkv bias has no parameter in LlamaDecoder: refused, not dropped
+        ck.to_llama_module_names(ck.preprocess_hf_llama(tiny_hf_llama_checkpoint("merged", cfg=c), hq, hkv, c["dim"]))
+    with pytest.raises(ValueError):  # 3 ranks do not divide 2 KV heads' rows evenly... nor the vocabulary: refused
+        ck.preprocess_hf_llama(hf, hq, hkv, c["dim"], 0, 3)
+
+
+def test_hf_mixtral_loads_with_int8_experts_quantised_like_simple_w8a8():
+    from chitu_amd.mixtral import MixtralArgs, MixtralDecoder
+    from chitu_amd.quantize.w8a8 import quant_weight
+    from tests.util import HF_LLAMA_TINY, tiny_hf_llama_checkpoint
+
+    c = dict(HF_LLAMA_TINY, dim=512)
+    hf = tiny_hf_llama_checkpoint("mixtral", cfg=c)
+    args = MixtralArgs(dim=c["dim"], n_layers=c["n_layers"], n_heads=c["n_heads"], n_kv_heads=c["n_kv_heads"], vocab_size=c["vocab_size"],
+                       ffn_dim=c["ffn_dim"], num_local_experts=c["num_local_experts"])
+    model = MixtralDecoder(args, None, None, max_position_embeddings=64, device="cpu")
+    st = ck.preprocess_hf_llama(hf, args.n_heads, args.n_kv_heads, args.dim, mixtral=True, router_row_parallel=False)
+    ck.load_deepseek_v3(model, ck.to_mixtral_module_names(st, args.num_local_experts))  # strict
+    p = dict(model.named_parameters())
+    m = "model.layers.1.block_sparse_moe."
+    assert torch.equal(p["layers.1.ffn.gate"], hf[m + "gate.weight"])
+    for e in (0, 3):
+        w13 = torch.cat([hf[m + f"experts.{e}.w1.weight"], hf[m + f"experts.{e}.w3.weight"]]).to(torch.float16)
+        q, s = quant_weight(w13)
+        assert torch.equal(p["layers.1.ffn.w13"][e], q) and torch.equal(p["layers.1.ffn.w13_scale"][e], s)
+        deq = p["layers.1.ffn.w2"][e].float() * p["layers.1.ffn.w2_scale"][e][:, None]
+        ref = hf[m + f"experts.{e}.w2.weight"].float()
+        assert (deq - ref).abs().max() <= 0.5 * p["layers.1.ffn.w2_scale"][e].max() * 1.001  # half an int8 step per channel
+    # TP = 2 keeps the router whole on both ranks here (the reference shards it along dim and all-reduces the logits)
+    r1 = ck.preprocess_hf_llama(hf, args.n_heads, args.n_kv_heads, args.dim, 1, 2, mixtral=True, router_row_parallel=False)
+    assert r1["layers.0.mlp.gate.weight"].shape == (c["num_local_experts"], c["dim"])
+    assert r1["layers.0.mlp.experts.2.gate_up_proj.weight"].shape == (c["ffn_dim"], c["dim"])  # 2 x ffn / 2 rows
+
+
+def test_hf_llama_directory_to_decoder_in_one_call(tmp_path):
+    from safetensors.torch import save_file
+
+    from chitu_amd.llama import LlamaArgs, LlamaDecoder
+    from tests.util import HF_LLAMA_TINY, tiny_hf_llama_checkpoint
+
+    c = dict(HF_LLAMA_TINY, dim=512)
+    hf = tiny_hf_llama_checkpoint("llama", cfg=c)
+    names = sorted(hf)
+    save_file({k: hf[k].contiguous() for k in names[: len(names) // 2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: hf[k].contiguous() for k in names[len(names) // 2:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    args = LlamaArgs(dim=c["dim"], n_layers=c["n_layers"], n_heads=c["n_heads"], n_kv_heads=c["n_kv_heads"],
+                     vocab_size=c["vocab_size"], ffn_dim=c["ffn_dim"])
+    model = LlamaDecoder(args, None, None, max_position_embeddings=64, device="cpu")
+    ck.load_checkpoint_hf_llama(model, str(tmp_path))
+    p = dict(model.named_parameters())
+    assert torch.equal(p["layers.0.attn.wo"], hf["model.layers.0.self_attn.o_proj.weight"])
+    assert torch.equal(p["embed_weight"], hf["model.embed_tokens.weight"]) and torch.equal(p["norm"], hf["model.norm.weight"])

@@ -227,6 +227,57 @@ def tiny_hf_checkpoint(cfg=CKPT_TINY, seed=77):
     return sd
 
 
+HF_LLAMA_TINY = dict(dim=64, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=32, ffn_dim=96, num_local_experts=4)
+
+
+def tiny_hf_llama_checkpoint(kind="llama", cfg=HF_LLAMA_TINY, seed=91):
+    """A Llama-family checkpoint under HUGGING FACE names (bf16), for the loaders of configs 1 / 2 / 4:
+      "llama":   separate q / k / v and gate / up projections (GQA), no biases -- Llama-2 / Llama-3;
+      "merged":  qkv_proj / gate_up_proj already merged, with a qkv bias -- the Phi-3 / GLM-style files the reference
+                 splits before tensor-parallel sharding (model_hf_llama.py:428-504);
+      "mixtral": block_sparse_moe.gate + experts.{e}.w1 / w3 / w2 (model_hf_mixtral.py:171-178).
+    Shared by tests/golden/gen_ckpt_llama.py (fed to the reference's loader methods) and tests/test_checkpoint.py."""
+    g = torch.Generator().manual_seed(seed + {"llama": 0, "merged": 1, "mixtral": 2}[kind])
+    c = cfg
+    hd = c["dim"] // c["n_heads"]
+    sd = {}
+
+    def bf(name, *shape):
+        sd[name] = (torch.randn(*shape, generator=g, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+
+    bf("model.embed_tokens.weight", c["vocab_size"], c["dim"])
+    for i in range(c["n_layers"]):
+        p = f"model.layers.{i}."
+        bf(p + "input_layernorm.weight", c["dim"])
+        bf(p + "post_attention_layernorm.weight", c["dim"])
+        a = p + "self_attn."
+        if kind == "merged":
+            bf(a + "qkv_proj.weight", (c["n_heads"] + 2 * c["n_kv_heads"]) * hd, c["dim"])
+            bf(a + "qkv_proj.bias", (c["n_heads"] + 2 * c["n_kv_heads"]) * hd)
+        else:
+            bf(a + "q_proj.weight", c["n_heads"] * hd, c["dim"])
+            bf(a + "k_proj.weight", c["n_kv_heads"] * hd, c["dim"])
+            bf(a + "v_proj.weight", c["n_kv_heads"] * hd, c["dim"])
+        bf(a + "o_proj.weight", c["dim"], c["n_heads"] * hd)
+        if kind == "mixtral":
+            m = p + "block_sparse_moe."
+            bf(m + "gate.weight", c["num_local_experts"], c["dim"])
+            for e in range(c["num_local_experts"]):
+                bf(m + f"experts.{e}.w1.weight", c["ffn_dim"], c["dim"])
+                bf(m + f"experts.{e}.w3.weight", c["ffn_dim"], c["dim"])
+                bf(m + f"experts.{e}.w2.weight", c["dim"], c["ffn_dim"])
+        elif kind == "merged":
+            bf(p + "mlp.gate_up_proj.weight", 2 * c["ffn_dim"], c["dim"])
+            bf(p + "mlp.down_proj.weight", c["dim"], c["ffn_dim"])
+        else:
+            bf(p + "mlp.gate_proj.weight", c["ffn_dim"], c["dim"])
+            bf(p + "mlp.up_proj.weight", c["ffn_dim"], c["dim"])
+            bf(p + "mlp.down_proj.weight", c["dim"], c["ffn_dim"])
+    bf("model.norm.weight", c["dim"])
+    bf("lm_head.weight", c["vocab_size"], c["dim"])
+    return sd
+
+
 def tensor_digest(t):
     import hashlib
 
