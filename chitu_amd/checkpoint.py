@@ -506,3 +506,32 @@ def load_checkpoint_hf_llama(model, path: str, rank: int = 0, world: int = 1) ->
                              router_row_parallel=False)
     st = to_mixtral_module_names(st, args.num_local_experts) if mixtral else to_llama_module_names(st)
     load_deepseek_v3(model, st)  # the generic strict, shape- and dtype-checked in-place copy
+
+
+# Meta-format Llama checkpoints (`consolidated.*.pth` names: tok_embeddings, attention.wq .. wo, feed_forward.w1 .. w3,
+# attention_norm / ffn_norm, output) -- what the reference's TransformerLlama loads (models/model_llama.py:86-99), the class
+# BASELINE config 1 runs.  Its column list spells the embedding "embed", which never matches "tok_embeddings"
+# (utils.py:34-39), so at TP > 1 the reference leaves the table whole while its VocabParallelEmbedding expects a shard; here
+# the table is sharded like every other vocabulary-parallel tensor.
+META_LLAMA_COLUMN = ("wq", "wk", "wv", "w1", "w3", "output", "tok_embeddings")
+META_LLAMA_ROW = ("wo", "w2")
+_META_LLAMA_MODULE_NAMES = (("tok_embeddings.weight", "embed_weight"), ("output.weight", "head_weight"), ("norm.weight", "norm"),
+                            (".attention_norm.weight", ".attn_norm"), (".ffn_norm.weight", ".ffn_norm"),
+                            (".attention.wqkv.weight", ".attn.wqkv"), (".attention.wo.weight", ".attn.wo"),
+                            (".feed_forward.w13.weight", ".ffn.w13"), (".feed_forward.w2.weight", ".ffn.w2"))
+
+
+def preprocess_meta_llama(state: Mapping[str, torch.Tensor], rank: int = 0, world: int = 1) -> Dict[str, torch.Tensor]:
+    """Meta names -> this TP rank's LlamaDecoder parameters: TP chunk (models/model.py:332-370), wq | wk | wv -> wqkv and
+    w1 | w3 -> w13 per rank, module names."""
+    st = chunk_for_tensor_parallel(state, rank, world, column=META_LLAMA_COLUMN, row=META_LLAMA_ROW)
+    st = _merge_group(st, ("wq", "wk", "wv"), "wqkv")
+    st = _merge_group(st, ("w1", "w3"), "w13")
+    out = {}
+    for k, v in st.items():
+        for a, b in _META_LLAMA_MODULE_NAMES:
+            if k == a or (a.startswith(".") and k.endswith(a)):
+                k = k[: len(k) - len(a)] + b
+                break
+        out[k] = v
+    return out

@@ -363,3 +363,31 @@ def test_hf_llama_directory_to_decoder_in_one_call(tmp_path):
     p = dict(model.named_parameters())
     assert torch.equal(p["layers.0.attn.wo"], hf["model.layers.0.self_attn.o_proj.weight"])
     assert torch.equal(p["embed_weight"], hf["model.embed_tokens.weight"]) and torch.equal(p["norm"], hf["model.norm.weight"])
+
+
+def test_meta_format_llama_names_and_shards():
+    """TransformerLlama's `consolidated.pth` names -> LlamaDecoder parameters (the map tests/util.ref_llama_fixture uses for
+    the reference-run comparisons), TP = 1 and 2."""
+    g = torch.Generator().manual_seed(5)
+    D, hq, hkv, hd, F, V = 256, 2, 1, 128, 96, 32
+    sd = {"tok_embeddings.weight": torch.randn(V, D, generator=g), "norm.weight": torch.randn(D, generator=g),
+          "output.weight": torch.randn(V, D, generator=g)}
+    for n, shape in (("attention.wq", (hq * hd, D)), ("attention.wk", (hkv * hd, D)), ("attention.wv", (hkv * hd, D)),
+                     ("attention.wo", (D, hq * hd)), ("feed_forward.w1", (F, D)), ("feed_forward.w3", (F, D)),
+                     ("feed_forward.w2", (D, F))):
+        sd[f"layers.0.{n}.weight"] = torch.randn(*shape, generator=g)
+    sd["layers.0.attention_norm.weight"] = torch.randn(D, generator=g)
+    sd["layers.0.ffn_norm.weight"] = torch.randn(D, generator=g)
+    p = ck.preprocess_meta_llama(sd)
+    assert sorted(p) == sorted(["embed_weight", "norm", "head_weight", "layers.0.attn.wqkv", "layers.0.attn.wo", "layers.0.ffn.w13",
+                                "layers.0.ffn.w2", "layers.0.attn_norm", "layers.0.ffn_norm"])
+    assert torch.equal(p["layers.0.attn.wqkv"], torch.cat([sd["layers.0.attention.wq.weight"], sd["layers.0.attention.wk.weight"],
+                                                          sd["layers.0.attention.wv.weight"]]))
+    assert torch.equal(p["layers.0.ffn.w13"], torch.cat([sd["layers.0.feed_forward.w1.weight"], sd["layers.0.feed_forward.w3.weight"]]))
+    sd["layers.0.attention.wk.weight"] = torch.randn(2 * hd, D, generator=g)  # two KV heads so that two ranks divide them
+    sd["layers.0.attention.wv.weight"] = torch.randn(2 * hd, D, generator=g)
+    r = [ck.preprocess_meta_llama(sd, rank, 2) for rank in range(2)]
+    assert r[0]["layers.0.attn.wqkv"].shape == ((hq + 4) // 2 * hd, D) and r[1]["embed_weight"].shape == (V // 2, D)
+    assert torch.equal(torch.cat([r[0]["layers.0.attn.wo"], r[1]["layers.0.attn.wo"]], 1), sd["layers.0.attention.wo.weight"])
+    assert torch.equal(r[1]["layers.0.attn.wqkv"][:hd], sd["layers.0.attention.wq.weight"][hd:])
+    assert torch.equal(r[0]["norm"], sd["norm.weight"]) and torch.equal(r[1]["norm"], sd["norm.weight"])

@@ -289,7 +289,8 @@ def tensor_digest(t):
 def ref_llama_fixture():
     """tests/golden/ref_llama.npz (tests/golden/gen_ref_llama.py: the reference's TransformerLlama, bs 1, prefill +
     64 greedy decode steps on CPU) plus the parameters, regenerated from the generator's seed in its sorted-name
-    order and mapped onto chitu_amd.llama / oracle.llama names (wq|wk|wv -> wqkv, w1|w3 -> w13)."""
+    order and mapped onto chitu_amd.llama / oracle.llama names (wq|wk|wv -> wqkv, w1|w3 -> w13) by the product loader
+    chitu_amd.checkpoint.preprocess_meta_llama -- so the reference-vs-HIP Llama tests also cover that loader."""
     import ast
 
     g = golden("ref_llama")
@@ -305,16 +306,9 @@ def ref_llama_fixture():
         else:
             t = (torch.randn(shape, generator=gen, dtype=torch.float32) * shape[-1] ** -0.5).to(torch.bfloat16)
         ref[name] = t
-    p = {"embed_weight": ref["tok_embeddings.weight"], "norm": ref["norm.weight"], "head_weight": ref["output.weight"]}
-    for i in range(cfg["n_layers"]):
-        a, f = f"layers.{i}.attention.", f"layers.{i}.feed_forward."
-        p[f"layers.{i}.attn.wqkv"] = torch.cat([ref[a + "wq.weight"], ref[a + "wk.weight"], ref[a + "wv.weight"]], 0)
-        p[f"layers.{i}.attn.wo"] = ref[a + "wo.weight"]
-        p[f"layers.{i}.ffn.w13"] = torch.cat([ref[f + "w1.weight"], ref[f + "w3.weight"]], 0)
-        p[f"layers.{i}.ffn.w2"] = ref[f + "w2.weight"]
-        p[f"layers.{i}.attn_norm"] = ref[f"layers.{i}.attention_norm.weight"]
-        p[f"layers.{i}.ffn_norm"] = ref[f"layers.{i}.ffn_norm.weight"]
-    return g, cfg, p
+    from chitu_amd.checkpoint import preprocess_meta_llama
+
+    return g, cfg, preprocess_meta_llama(ref)  # the product loader: Meta names -> LlamaDecoder parameters
 
 
 # ---------------------------------------------------------------- cache manager scenario
