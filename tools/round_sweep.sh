@@ -4,7 +4,7 @@
 # (the GPU box has no .git: the head the numbers belong to is handed in and stamped into the PMC record).
 # Writes gpurun_out/<tag>/: the bench line, step breakdowns (bs 16 / 1 / 32) + whole-process kernel traces, the PMC
 # passes (tools/pmc_passes.sh -> pmc_step.json, what bench.py reads as profiles/r03_pmc_step.json), Llama bs-1 trace,
-# prefill timings + trace, bs sweep.  ~8 GPU-minutes.  Copy what is to be judged into profiles/.
+# prefill timings + trace, bs sweep.  ~2 GPU-minutes of run time on a warm box (r03: 96-108 s).  Copy what is to be judged into profiles/.
 tag=${1:-sweep}
 head=${2:-unknown}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
