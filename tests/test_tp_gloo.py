@@ -1,4 +1,4 @@
-"""Multi-process (gloo, world_size 2, CPU) tests of the tensor-parallel path.
+"""Multi-process (gloo, world_size 2 and 4, CPU) tests of the tensor-parallel path.
 
 1. chitu_amd.tensor_parallel layers vs an unsharded reference (same checks the reference would need
    for chitu/tensor_parallel.py:42-208).
@@ -104,12 +104,13 @@ def test_tp_layers_world2():
     _run(_tp_layers, 2)
 
 
-def _tiny_args():
+def _tiny_args(wide=False):
+    """wide: FFN widths that still leave whole 128-blocks per rank at 4 ranks."""
     from chitu_amd.deepseek_v3 import DeepSeekV3Args
 
-    return DeepSeekV3Args(vocab_size=256, dim=256, inter_dim=512, moe_inter_dim=256, n_layers=2, n_dense_layers=1,
-                          n_heads=16, n_routed_experts=8, n_shared_experts=1, n_activated_experts=2, n_expert_groups=2,
-                          n_limited_groups=1, q_lora_rank=128, gate_bias=True)
+    return DeepSeekV3Args(vocab_size=256, dim=256, inter_dim=1024 if wide else 512, moe_inter_dim=512 if wide else 256, n_layers=2,
+                          n_dense_layers=1, n_heads=16, n_routed_experts=8, n_shared_experts=1, n_activated_experts=2,
+                          n_expert_groups=2, n_limited_groups=1, q_lora_rank=128, gate_bias=True)
 
 
 def _build_cpu_model(args, seed=0):
@@ -207,13 +208,13 @@ def _shard_ep(sd, args, rank, world):
     return out
 
 
-def _decode_tp(rank, world, expert_parallel=False):
+def _decode_tp(rank, world, expert_parallel=False, wide=False):
     import copy
 
     from tests import cpu_ops_shim
 
     cpu_ops_shim.install(setattr)
-    args = _tiny_args()
+    args = _tiny_args(wide)
     full = _full_state(args)
     a = copy.copy(args)
     a.shard_degree = None  # live TP group size
@@ -249,6 +250,21 @@ def _decode_tp(rank, world, expert_parallel=False):
         assert torch.equal(ref, t)
     if rank == 0:
         torch.save({"logits": outs}, os.environ["TP_OUT"] + (f".ep{world}" if expert_parallel else f".w{world}"))
+
+
+def test_decode_step_tp4_and_ep4_match_tp1(tmp_path):
+    """Four ranks: 4 of 16 heads, a quarter of every FFN width and of the vocabulary per rank (TP); 2 of 8 routed experts
+    at full width + a quarter of the shared expert per rank (EP).  Both against the same single-rank step."""
+    base = str(tmp_path / "tp")
+    os.environ["TP_OUT"] = base
+    _run(_decode_tp, 1, False, True)
+    _run(_decode_tp, 4, False, True)
+    _run(_decode_tp, 4, True, True)
+    l1 = torch.load(base + ".w1")["logits"]
+    for other in (".w4", ".ep4"):
+        for a, b in zip(l1, torch.load(base + other)["logits"]):
+            err = ((a - b).abs().max() / a.abs().max()).item()
+            assert err < 5e-2, (other, err)
 
 
 def test_decode_step_tp2_matches_tp1(tmp_path):
