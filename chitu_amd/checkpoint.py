@@ -491,16 +491,25 @@ def to_mixtral_module_names(state: Mapping[str, torch.Tensor], num_experts: int)
     return out
 
 
-def load_checkpoint_hf_llama(model, path: str, rank: int = 0, world: int = 1) -> None:
-    """HF Llama-family directory -> a LlamaDecoder or MixtralDecoder built for this TP rank, one call."""
+def load_checkpoint_hf_llama(model, path: str, rank: int = 0, world: int = 1, skip_preprocess: bool = False) -> None:
+    """HF Llama-family directory -> a LlamaDecoder or MixtralDecoder built for this TP rank, one call.  skip_preprocess: the
+    directory holds this rank's `model.rank{rank}.safetensors` written by `save_preprocessed` (script/preprocess_and_save.py's
+    flow, backend.py:415-428) -- already sharded, merged, quantised and under module names."""
+    from safetensors import safe_open
+
     args = model.args
     state = {}
-    for fp in sorted(glob.glob(os.path.join(path, "*.safetensors"))):
-        from safetensors import safe_open
-
+    pattern = f"model.rank{rank}.safetensors" if skip_preprocess else "*.safetensors"
+    files = sorted(glob.glob(os.path.join(path, pattern)))
+    if not files:
+        raise FileNotFoundError(f"no {pattern} under {path}")
+    for fp in files:
         with safe_open(fp, framework="pt", device="cpu") as f:
             for name in f.keys():
                 state[name] = f.get_tensor(name)
+    if skip_preprocess:
+        load_deepseek_v3(model, state)
+        return
     mixtral = hasattr(args, "num_local_experts")
     st = preprocess_hf_llama(state, args.n_heads, args.n_kv_heads, args.dim, rank, world, mixtral=mixtral,
                              router_row_parallel=False)

@@ -391,3 +391,28 @@ def test_meta_format_llama_names_and_shards():
     assert torch.equal(torch.cat([r[0]["layers.0.attn.wo"], r[1]["layers.0.attn.wo"]], 1), sd["layers.0.attention.wo.weight"])
     assert torch.equal(r[1]["layers.0.attn.wqkv"][:hd], sd["layers.0.attention.wq.weight"][hd:])
     assert torch.equal(r[0]["norm"], sd["norm.weight"]) and torch.equal(r[1]["norm"], sd["norm.weight"])
+
+
+def test_mixtral_preprocess_once_save_and_reload(tmp_path):
+    """script/preprocess_and_save.py's flow for the Llama family: HF files -> this rank's decoder (int8 experts) ->
+    model.rank0.safetensors -> a second decoder loaded with skip_preprocess holds the same bytes."""
+    from safetensors.torch import save_file
+
+    from chitu_amd.mixtral import MixtralArgs, MixtralDecoder
+    from tests.util import HF_LLAMA_TINY, tiny_hf_llama_checkpoint
+
+    c = dict(HF_LLAMA_TINY, dim=512)
+    hf = tiny_hf_llama_checkpoint("mixtral", cfg=c)
+    os.makedirs(tmp_path / "hf")
+    save_file({k: v.contiguous() for k, v in hf.items()}, str(tmp_path / "hf" / "model.safetensors"))
+    args = MixtralArgs(dim=c["dim"], n_layers=c["n_layers"], n_heads=c["n_heads"], n_kv_heads=c["n_kv_heads"], vocab_size=c["vocab_size"],
+                       ffn_dim=c["ffn_dim"], num_local_experts=c["num_local_experts"])
+    a = MixtralDecoder(args, None, None, max_position_embeddings=64, device="cpu")
+    ck.load_checkpoint_hf_llama(a, str(tmp_path / "hf"))
+    ck.save_preprocessed(a, str(tmp_path / "pre"), rank=0)
+    b = MixtralDecoder(args, None, None, max_position_embeddings=64, device="cpu")
+    ck.load_checkpoint_hf_llama(b, str(tmp_path / "pre"), skip_preprocess=True)
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p.view(torch.uint8), q.view(torch.uint8)), n
+    with pytest.raises(FileNotFoundError):
+        ck.load_checkpoint_hf_llama(b, str(tmp_path / "pre"), rank=1, skip_preprocess=True)
