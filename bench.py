@@ -327,6 +327,22 @@ def run_decode(model, cache, reqs, tokens, steps, world, use_graph, timed):
     return dt, tokens
 
 
+GRAPH_CHECKS = {}  # tag -> one replay of the timed graph == one eager step on the same state (bitwise), per measured loop
+
+
+def check_graph_against_eager(model, cache, reqs, tokens, use_graph, tag):
+    """The graph that was just timed, once more, against the eager launches of the same step on the same state (same
+    tokens, lengths, block table; the step's only side effect -- the KV row at position L -- is rewritten with the same
+    bytes).  Bitwise, on every rank; a line whose graph differs from its eager step is void (main())."""
+    if not use_graph:
+        return
+    cache.prepare_cache_decode(reqs)
+    cache.prepare_block_table_for_decode(reqs)
+    eager = model.decode(tokens, use_graph=False).clone()
+    replay = model.decode(tokens, use_graph=use_graph)
+    GRAPH_CHECKS[tag] = bool(torch.equal(eager, replay))
+
+
 def measure(model, cache, bs, ctx, steps, warmup, world, use_graph, tag):
     reqs = [f"{tag}{i}" for i in range(bs)]
     for r in reqs:
@@ -335,9 +351,20 @@ def measure(model, cache, bs, ctx, steps, warmup, world, use_graph, tag):
     tokens = torch.randint(100, 1000, (bs,), device="cuda", generator=gen)
     _, tokens = run_decode(model, cache, reqs, tokens, warmup, world, use_graph, timed=False)
     dt, tokens = run_decode(model, cache, reqs, tokens, steps, world, use_graph, timed=True)
+    check_graph_against_eager(model, cache, reqs, tokens, use_graph, tag)
     for r in reqs:
         cache.finalize_cache_all_decode(r)
     return dt
+
+
+def graph_report():
+    """What stands behind every graph this run timed: the replay checks above, and the capture-time checks of
+    chitu_amd.graphs.capture_verified (a capture whose first replay differs from the eager step is rejected and repeated;
+    any such event is listed)."""
+    from chitu_amd import graphs
+
+    return {"all_equal_eager": all(GRAPH_CHECKS.values()), "replay_vs_eager_after_timing": dict(GRAPH_CHECKS),
+            "captures_checked_at_capture": len(graphs.capture_log), "captures_rejected_and_repeated": graphs.unverified_or_retried()}
 
 
 def capture_step_routing(model, cache, bs, ctx):
@@ -896,12 +923,17 @@ def main():
             "step_hbm_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "step_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof, "cpu_baseline": cpu, "build_s": round(build_s, 1),
+            "graph_verified": graph_report(),
             "device_state_under_load": dev_state.summary(),
         }
         res.update(extra)
         if a.opt:
             res["launch_variant_overrides"] = a.opt
-        if dinfo["ranks_seen"] != a.gpus:
+        if use_graph and not res["graph_verified"]["all_equal_eager"]:
+            res["invalid"] = ("a timed hipGraph did not reproduce the eager launches of the same step (graph_verified): "
+                              "the line is void")
+            res["value"] = None
+        elif dinfo["ranks_seen"] != a.gpus:
             # the library's own all-reduce of ones must have seen every rank the line claims
             res["invalid"] = f"--gpus {a.gpus} but the process group's all-reduce saw {dinfo['ranks_seen']} rank(s): the line is void"
             res["value"] = None

@@ -38,6 +38,26 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+# Diagnostics (tests, chitu_amd.graphs.capture_verified in its diagnostic mode): while this is a list, every C-ABI call
+# is appended to it as (entry name, (argument values ...)) -- device pointers, sizes, the stream -- before it is made.
+call_log = None
+
+
+class _Recorder:
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+
+        def recorded(*args):
+            if call_log is not None:
+                call_log.append((name, tuple(getattr(a, "value", a) for a in args)))
+            return fn(*args)
+
+        return recorded
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
@@ -47,7 +67,7 @@ def lib() -> ctypes.CDLL:
                 "(or `make -C chitu_amd/csrc`). There is no CPU fallback."
             )
         _lib = ctypes.CDLL(LIB_PATH)
-    return _lib
+    return _lib if call_log is None else _Recorder(_lib)
 
 
 def ptr(t):

@@ -632,27 +632,18 @@ class DeepSeekV3Decoder(torch.nn.Module):
             return self.decode_eager(tokens)
         mode = graphs.graph_mode(use_graph)
         key = (bs, mode)
+        if bs not in self.static_tokens:
+            self.static_tokens[bs] = tokens.clone()
+        else:
+            self.static_tokens[bs].copy_(tokens)
         if key not in self.graphs:
-            if bs not in self.static_tokens:
-                self.static_tokens[bs] = tokens.clone()
-                # Warm-up replicates the graph's side effect (append at position L), which the captured
-                # run then overwrites with the same values.
-                sample = self.decode_eager(self.static_tokens[bs])
-                self.static_out[bs] = torch.zeros_like(sample)
-            torch.cuda.synchronize()
-            if mode == "full":
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.graph_pool):
-                    self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs]))
-                if self.graph_pool is None:
-                    self.graph_pool = g.pool()
-            else:
-                if self.graph_pool is None:
-                    self.graph_pool = torch.cuda.graph_pool_handle()
-                g = graphs.capture_piecewise(
-                    lambda: self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs])), self.graph_pool)
+            # Eager step on the static inputs (it replicates the graph's side effect, the append at position L, which the
+            # replays then overwrite with the same values), capture, ONE replay checked bit for bit against that eager
+            # step (graphs.capture_verified): a graph that does not reproduce the eager launches is never used.
+            g, self.graph_pool, self.static_out[bs] = graphs.capture_verified(
+                lambda: self.decode_eager(self.static_tokens[bs]), self.static_out.get(bs), mode, self.graph_pool,
+                what=f"DeepSeekV3Decoder decode step bs={bs}")
             self.graphs[key] = g
-        self.static_tokens[bs].copy_(tokens)
         self.graphs[key].replay()
         return self.static_out[bs]
 

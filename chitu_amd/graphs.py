@@ -9,6 +9,9 @@ depends on RCCL calls being capturable; it costs 2 x layers + 2 extra host calls
 bit-identical to eager.
 """
 
+import os
+import sys
+
 import torch
 
 from . import tensor_parallel as tp
@@ -83,3 +86,110 @@ def graph_mode(use_graph) -> str:
     if tp.get_tp_size() == 1 or tp.xgmi_comm() is not None:
         return "full"
     return "full" if os.environ.get("CHITU_TP_GRAPH", "piecewise") == "full" else "piecewise"
+
+
+# ---------------------------------------------------------------- a captured step is checked before it is trusted
+# Every capture of a decode step is followed by ONE replay on the very inputs the eager step in front of the capture
+# ran on (the static token / length / block-table buffers; the step's only side effect, the KV row at position L, is
+# rewritten with the same bytes), and the replayed logits must equal the eager ones bit for bit -- every launch of the
+# step is deterministic.  A graph that fails the check is never returned: the capture is repeated (a fresh graph object)
+# and a second failure raises.  Round 3's GPU suite saw a Llama decode graph whose 64 replays all differed from the
+# eager launches of the same model in the same process ("graph replay"); whatever produces such a
+# graph, it is caught here, at capture time, instead of in the tokens.
+capture_log = []      # one record per capture_verified call: {"what", "mode", "attempts", "mismatches": [...]}
+on_mismatch = None    # tests: callable(context dict) run in the failing state, before the capture is repeated
+_MAX_CAPTURE_ATTEMPTS = int(os.environ.get("CHITU_GRAPH_CAPTURE_ATTEMPTS", "3"))
+
+
+def _ranks_agree(ok: bool) -> bool:
+    """MIN of the ranks' verdicts over the TP group (every rank captures at the same step and must repeat or accept the
+    capture together: a verification replay contains the step's collectives)."""
+    import torch.distributed as dist
+
+    if tp.get_tp_size() <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return ok
+    group = tp.get_tp_group()
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    verdict = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+    return int(verdict.item()) == 1
+
+
+def _capture(step, mode, pool):
+    if mode == "full":
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool):
+            step()
+        return g, (g.pool() if pool is None else pool)
+    if pool is None:
+        pool = torch.cuda.graph_pool_handle()
+    return capture_piecewise(step, pool), pool
+
+
+def _describe_mismatch(got, want):
+    g, w = got.float(), want.float()
+    rows_same = int((got == want).all(-1).sum()) if got.dim() >= 2 else int(torch.equal(got, want))
+    return {"rows_equal": rows_same, "rows": int(got.shape[0]) if got.dim() >= 2 else 1,
+            "max_abs_diff": float((g - w).abs().max()), "peak": float(w.abs().max()),
+            "nan_in_replay": bool(torch.isnan(g).any()), "all_zero_replay": bool((g == 0).all())}
+
+
+def capture_verified(run_eager, static_out, mode, pool, what="decode step"):
+    """Capture `static_out.copy_(run_eager())` in graph mode `mode` ("full" | "piecewise") and return (graph, pool,
+    static_out) only once one replay has reproduced, bit for bit, the eager step run just before the capture on the
+    same static inputs.  `run_eager()` -> the step's output tensor (logits); static_out None = allocate it.  Raises
+    RuntimeError after _MAX_CAPTURE_ATTEMPTS captures that all fail the check."""
+    record = {"what": what, "mode": mode, "attempts": 0, "mismatches": []}
+    capture_log.append(record)
+    for attempt in range(_MAX_CAPTURE_ATTEMPTS):
+        record["attempts"] = attempt + 1
+        logs = None
+        if on_mismatch is not None:  # diagnostic mode: the launches of the eager step and of the capture, argument by argument
+            from . import _lib
+
+            logs, _lib.call_log = ([], []), None
+        try:
+            if logs is not None:
+                _lib.call_log = logs[0]
+            reference = run_eager().clone()  # also creates every workspace the step needs (workspace.get refuses under capture)
+            if static_out is None:
+                static_out = torch.zeros_like(reference)
+            torch.cuda.synchronize()
+            if logs is not None:
+                _lib.call_log = logs[1]
+            g, new_pool = _capture(lambda: static_out.copy_(run_eager()), mode, pool)
+        finally:
+            if logs is not None:
+                _lib.call_log = None
+        torch.cuda.synchronize()  # device-wide, every stream: nothing is in flight when the first replay starts
+        static_out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        ok = torch.equal(static_out, reference)
+        if _ranks_agree(ok):
+            return g, new_pool, static_out
+        if not ok:
+            info = _describe_mismatch(static_out, reference)
+            info["attempt"] = attempt
+            # does the same graph object give the same wrong answer again?  (a property of the graph vs a one-off)
+            again = static_out.clone()
+            g.replay()
+            torch.cuda.synchronize()
+            info["second_replay_equals_first"] = bool(torch.equal(static_out, again))
+            info["second_replay_equals_eager"] = bool(torch.equal(static_out, reference))
+            record["mismatches"].append(info)
+            print(f"[chitu_amd] hipGraph capture of {what} ({mode}) failed its replay check, attempt {attempt + 1}: {info}",
+                  file=sys.stderr, flush=True)
+            if on_mismatch is not None:
+                on_mismatch({"graph": g, "run_eager": run_eager, "static_out": static_out, "reference": reference,
+                             "mode": mode, "pool": new_pool, "info": info, "launch_logs": logs})
+        del g
+        # the rejected graph's pool is not reused: the next attempt allocates its intermediates elsewhere
+        pool = None
+    raise RuntimeError(f"hipGraph replay of {what} does not reproduce the eager step after {_MAX_CAPTURE_ATTEMPTS} captures; "
+                       f"refusing to decode through it: {record['mismatches']}")
+
+
+def unverified_or_retried():
+    """Captures of this process that needed more than one attempt (bench.py voids its line on any; tests assert [])."""
+    return [r for r in capture_log if r["attempts"] > 1 or r["mismatches"]]

@@ -277,25 +277,16 @@ class LlamaDecoder(torch.nn.Module):
             return self.decode_eager(tokens)
         mode = graphs.graph_mode(use_graph)
         key = (bs, mode)
+        if bs not in self.static_tokens:
+            self.static_tokens[bs] = tokens.clone()
+        else:
+            self.static_tokens[bs].copy_(tokens)
         if key not in self.graphs:
-            if bs not in self.static_tokens:
-                self.static_tokens[bs] = tokens.clone()
-                sample = self.decode_eager(self.static_tokens[bs])  # also re-writes this step's KV rows
-                self.static_out[bs] = torch.zeros_like(sample)
-            torch.cuda.synchronize()
-            step = lambda: self.static_out[bs].copy_(self.decode_eager(self.static_tokens[bs]))
-            if mode == "full":
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.graph_pool):
-                    step()
-                if self.graph_pool is None:
-                    self.graph_pool = g.pool()
-            else:
-                if self.graph_pool is None:
-                    self.graph_pool = torch.cuda.graph_pool_handle()
-                g = graphs.capture_piecewise(step, self.graph_pool)
+            # eager step on the static inputs (also re-writes this step's KV rows), capture, ONE checked replay
+            g, self.graph_pool, self.static_out[bs] = graphs.capture_verified(
+                lambda: self.decode_eager(self.static_tokens[bs]), self.static_out.get(bs), mode, self.graph_pool,
+                what=f"{type(self).__name__} decode step bs={bs}")
             self.graphs[key] = g
-        self.static_tokens[bs].copy_(tokens)
         self.graphs[key].replay()
         return self.static_out[bs]
 

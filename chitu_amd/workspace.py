@@ -24,10 +24,14 @@ def get(nbytes: int, device, tag: str = "default") -> torch.Tensor:
     key = (torch.device(device).index or 0, tag, _namespace)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
-        if buf is not None and torch.cuda.is_current_stream_capturing():
+        if torch.cuda.is_current_stream_capturing():
+            # a buffer created under capture would live in that graph's PRIVATE pool (and die with it, while this
+            # table and later graphs still hold its address); growth would change an address earlier launches of the
+            # same capture already recorded.  decode() runs one eager step before it captures, so neither happens on
+            # the product path -- refuse both instead of relying on that.
             raise RuntimeError(
-                f"workspace '{tag}' must grow ({buf.numel()} -> {nbytes} B) during graph capture; "
-                "run one eager step first"
+                f"workspace '{tag}' must be {'created' if buf is None else f'grown ({buf.numel()} -> {nbytes} B)'} "
+                "during graph capture; run one eager step first"
             )
         if buf is not None:
             _retired.append(buf)

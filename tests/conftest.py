@@ -24,3 +24,106 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---------------------------------------------------------------- hipGraph captures that failed their replay check
+# chitu_amd.graphs.capture_verified rejects a captured decode step whose first replay differs from the eager step and
+# captures again.  In the GPU suite every such event is examined IN THE FAILING STATE (round 3's GPUTEST saw a Llama
+# graph like that, only inside a whole-suite process) and listed at the end of the run, whether or not a test failed.
+def _graph_mismatch_probe(ctx):
+    """What can be learned from a rejected graph before it is destroyed; everything goes to stderr and into the
+    capture record (chitu_amd.graphs.capture_log)."""
+    import torch
+
+    from chitu_amd import graphs, workspace
+
+    g, static_out, reference, info = ctx["graph"], ctx["static_out"], ctx["reference"], ctx["info"]
+    out = {}
+
+    def replay_equals_eager():
+        static_out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        return bool(torch.equal(static_out, reference))
+
+    try:
+        # 1. is it something cached (L2 / memory-side cache / kernel-argument lines)?  stream 4 GB through the chip, replay
+        junk = torch.empty(1 << 30, dtype=torch.uint8, device="cuda")
+        for v in range(4):
+            junk.fill_(v)
+        torch.cuda.synchronize()
+        del junk
+        out["after_4GB_of_fills_replay_equals_eager"] = replay_equals_eager()
+        # 2. the eager step again, now: still the reference?  (the state the graph was captured in vs the kernels)
+        again = ctx["run_eager"]()
+        torch.cuda.synchronize()
+        out["eager_again_equals_reference"] = bool(torch.equal(again, reference))
+        out["replay_after_eager_again_equals_eager"] = replay_equals_eager()
+        # 3. launches of the eager step vs launches recorded by the capture: same entry points, same non-pointer
+        #    arguments, and every pointer that differs must lie in the capture's private pool
+        logs = ctx.get("launch_logs")
+        snap = torch.cuda.memory_snapshot()
+        private = [(s["address"], s["address"] + s["total_size"]) for s in snap if tuple(s.get("segment_pool_id", (0, 0))) != (0, 0)]
+        default = [(s["address"], s["address"] + s["total_size"]) for s in snap if tuple(s.get("segment_pool_id", (0, 0))) == (0, 0)]
+        overl = [(a, b) for a in private for b in default if a[0] < b[1] and b[0] < a[1]]
+        out["private_segments"], out["default_segments"], out["overlapping_segments"] = len(private), len(default), overl[:4]
+        ws = [(t.data_ptr(), t.data_ptr() + t.numel(), k) for k, t in workspace._ws.items()]
+        out["workspaces_in_private_pools"] = [str(k) for lo, hi, k in ws if any(a <= lo < b for a, b in private)]
+        if logs is not None:
+            e, c = logs
+            out["launches_eager"], out["launches_capture"] = len(e), len(c)
+            odd = []
+            for i, ((n1, a1), (n2, a2)) in enumerate(zip(e, c)):
+                if n1 != n2 or len(a1) != len(a2):
+                    odd.append((i, n1, n2, "different entry / arity"))
+                    continue
+                for j, (x, y) in enumerate(zip(a1[:-1], a2[:-1])):  # the last argument is the stream
+                    if x != y:
+                        in_private = isinstance(y, int) and any(lo <= y < hi for lo, hi in private)
+                        in_default = isinstance(x, int) and any(lo <= x < hi for lo, hi in default)
+                        if not (in_private and in_default):
+                            odd.append((i, n1, j, x, y, "differs, not (default pool -> private pool)"))
+            out["launch_argument_anomalies"] = odd[:12]
+        # 4. a second graph captured right now in a NEW pool: good?
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            static_out.copy_(ctx["run_eager"]())
+        torch.cuda.synchronize()
+        static_out.zero_()
+        g2.replay()
+        torch.cuda.synchronize()
+        out["fresh_capture_now_equals_eager"] = bool(torch.equal(static_out, reference))
+        out["rejected_graph_after_fresh_capture_equals_eager"] = replay_equals_eager()
+        del g2
+        out["mem_allocated_MB"] = round(torch.cuda.memory_allocated() / 2**20, 1)
+        out["mem_reserved_MB"] = round(torch.cuda.memory_reserved() / 2**20, 1)
+        out["graphs_captured_so_far"] = len(graphs.capture_log)
+    except Exception as exc:  # noqa: BLE001 -- a diagnostic must not become the failure
+        out["probe_error"] = repr(exc)
+    info["probe"] = out
+    print(f"[graph mismatch probe] {out}", file=sys.stderr, flush=True)
+
+
+def pytest_sessionstart(session):
+    import torch
+
+    if torch.cuda.is_available():
+        from chitu_amd import graphs
+
+        graphs.on_mismatch = _graph_mismatch_probe
+
+
+def pytest_terminal_summary(terminalreporter):
+    try:
+        from chitu_amd import graphs
+    except Exception:  # noqa: BLE001
+        return
+    terminalreporter.write_line(f"hipGraph captures checked by one replay against the eager step: {len(graphs.capture_log)}")
+    for r in graphs.unverified_or_retried():
+        terminalreporter.write_line(f"GRAPH CAPTURE REJECTED AND REPEATED: {r}")
+    out = os.path.join(ROOT, "gpurun_out")
+    if graphs.capture_log and os.path.isdir(out):
+        import json
+
+        with open(os.path.join(out, "graph_capture_log.json"), "w") as f:
+            json.dump({"captures": len(graphs.capture_log), "rejected": graphs.unverified_or_retried()}, f, default=str, indent=1)

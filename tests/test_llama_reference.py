@@ -56,6 +56,7 @@ def test_oracle_llama_reproduces_the_reference_cpu_run():
 def test_hip_llama_reproduces_the_reference_cpu_run():
     """Prefill of the prompt, then 64 hipGraph decode steps fed the reference's tokens: logits within 2e-2 of the
     reference's CPU run, identical greedy tokens wherever the reference's choice is not a near-tie."""
+    from chitu_amd import _lib, graphs
     from chitu_amd.attn_backend import HipAttnBackend
     from chitu_amd.cache_manager import PagedKVCacheManager
     from chitu_amd.llama import LlamaArgs, LlamaDecoder
@@ -107,22 +108,14 @@ def test_hip_llama_reproduces_the_reference_cpu_run():
     rows, rows_eager = attempt("a")
     same = sum(int(torch.equal(a, b)) for a, b in zip(rows, rows_eager))
     print("graph replay rows identical to eager launches:", same, "/ 65")
+    # Round 3's GPU suite saw all 64 replayed rows differ from the eager ones here (whole-suite process only; DESIGN
+    # section 4 "graph replay").  decode() now checks every captured step by one replay against the eager step before
+    # it uses the graph (chitu_amd.graphs.capture_verified, examined in the failing state by tests/conftest.py), so a
+    # difference here means a graph that passed its check at capture and went wrong later.
     ok, err = verdict(rows)
-    if err is not None or same != 65:
-        # seen twice in four runs of the WHOLE gpu suite and never alone: say as much as one failing run can --
-        # is the eager run right, does a second, fresh instance in the same process get it right, what process-wide
-        # state is set
-        from chitu_amd import _lib, ops, workspace
-        from chitu_amd import tensor_parallel as tp
-
-        ok_eager, err_eager = verdict(rows_eager)
-        rows2, rows2_eager = attempt("b")
-        ok2, err2 = verdict(rows2)
-        ok2_eager, _ = verdict(rows2_eager)
-        state = {"xgmi": tp.xgmi_comm() is not None, "tp_size": tp.get_tp_size(), "workspace_namespace": workspace._namespace,
-                 "debug_options_set": _forced_launch_variants(_lib),
-                 "tile_major": getattr(ops, "_TILE_MAJOR", None), "mem_allocated_GB": round(torch.cuda.memory_allocated() / 2**30, 2),
-                 "mem_reserved_GB": round(torch.cuda.memory_reserved() / 2**30, 2)}
-        raise AssertionError(("graph rows == eager rows", same, "graph run", err, "eager run ok", ok_eager, str(err_eager)[:300],
-                              "second fresh instance: graph ok", ok2, str(err2)[:300], "eager ok", ok2_eager, state))
+    ok_eager, err_eager = verdict(rows_eager)
+    assert same == 65 and err is None and err_eager is None, (
+        "graph rows == eager rows", same, "graph run", ok, str(err)[:300], "eager run", ok_eager, str(err_eager)[:300],
+        "captures rejected at their replay check:", graphs.unverified_or_retried(),
+        "forced launch variants:", _forced_launch_variants(_lib))
     print("HIP vs reference Llama: rel err", ok[0], "greedy agreement", ok[1], "/ 65")

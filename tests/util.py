@@ -386,3 +386,44 @@ def cache_manager_scenario(make_manager, make_varlens):
     for step in range(2):
         decode(["c", "a"], f"decode ca {step}")
     return obs
+
+
+# ---------------------------------------------------------------- reads of memory nobody wrote
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def poisoned_allocations():
+    """torch.empty / empty_like / Tensor.new_empty on the GPU return memory filled with 0xFF bytes (NaN as bf16 / fp32 /
+    e4m3fn, -1 as int32) and every workspace.get() re-fills its buffer: a launch that READS what no launch of the step
+    wrote reads NaN / -1, and the step's output changes.  (An `empty` buffer normally holds whatever its previous user
+    left -- usually the same step's own values of the previous iteration, which hides such a read.)"""
+    from chitu_amd import workspace
+
+    real_empty, real_like, real_new, real_ws = torch.empty, torch.empty_like, torch.Tensor.new_empty, workspace.get
+
+    def foul(t):
+        if isinstance(t, torch.Tensor) and t.is_cuda and t.numel():
+            if t.is_contiguous():
+                t.view(-1).view(torch.uint8).fill_(0xFF)
+            else:
+                t.fill_(float("nan") if t.is_floating_point() else -1)
+        return t
+
+    def empty(*a, **k):
+        return foul(real_empty(*a, **k))
+
+    def empty_like(*a, **k):
+        return foul(real_like(*a, **k))
+
+    def new_empty(self, *a, **k):
+        return foul(real_new(self, *a, **k))
+
+    def ws_get(nbytes, device, tag="default"):
+        return foul(real_ws(nbytes, device, tag))
+
+    torch.empty, torch.empty_like, torch.Tensor.new_empty, workspace.get = empty, empty_like, new_empty, ws_get
+    try:
+        yield
+    finally:
+        torch.empty, torch.empty_like, torch.Tensor.new_empty, workspace.get = real_empty, real_like, real_new, real_ws
