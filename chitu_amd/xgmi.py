@@ -20,6 +20,7 @@ from . import _lib
 from ._lib import check, f32, i32, i64, ptr, require_cuda, stream_ptr
 
 _QUANT_MODE = {None: 0, "act": 1, "group": 2}
+closed_buffers = []  # device addresses of the (uncached) exchange buffers this process has freed: diagnostics (tests/conftest.py)
 
 
 class XgmiComm:
@@ -126,6 +127,10 @@ class XgmiComm:
 
     def close(self):
         if self._h is not None:
+            try:
+                closed_buffers.append(self.local_ptr())
+            except Exception:  # noqa: BLE001 -- bookkeeping for diagnostics only
+                pass
             _lib.lib().chitu_hip_comm_destroy(self._h)
             self._h = None
 
