@@ -56,11 +56,22 @@ __device__ __forceinline__ void add_norm_issue(AddNormRegs<WK, MR>& r, const bf1
     }
 }
 
+// What else the prologue's owner workgroup (the one that writes the residual stream) can leave behind for launches that are
+// NOT this GEMM: the normalised rows (bf16) and / or their fp8 form -- quant_mode 1 = act_quant (no eps), 2 =
+// per_token_group_quant (eps, clamp): chitu_hip_rmsnorm's arithmetic on the rounded rows, 16 lanes = one 128-wide group.
+struct NormOut {
+    bf16_t* y;   // [M, K] or null
+    fp8_t* q;    // [M, K] codes or null
+    float* qs;   // [M, K / 128]
+    float qeps;
+    int qmode;   // 0 | 1 | 2
+};
+
 // x_new = bf16(x + add) (written to sum_out by the workgroup told to), y = bf16((x_new * rr) * w) -> ybuf [M][K].
 // nred: [kFusedNormMaxRows][16] floats.  Ends with a workgroup barrier: ybuf is readable.
-template <int WK, int MR>
+template <int WK, int MR, bool POUT = false>
 __device__ __forceinline__ void add_norm_finish(AddNormRegs<WK, MR>& r, bf16_t* sum_out, int64_t sum_stride, bool write_sum,
-                                                int M, int K, float eps, bf16_t* ybuf, float* nred) {
+                                                int M, int K, float eps, bf16_t* ybuf, float* nred, const NormOut* po = nullptr) {
     constexpr int T = AddNormRegs<WK, MR>::T, NCH = AddNormRegs<WK, MR>::NCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_chunks = K >> 3;
@@ -108,6 +119,34 @@ __device__ __forceinline__ void add_norm_finish(AddNormRegs<WK, MR>& r, bf16_t* 
                                                     (v[2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
                     }
                     *reinterpret_cast<i32x4*>(ybuf + (size_t)m * K + vt * 8) = o;
+                    if (POUT && write_sum && po->y) *reinterpret_cast<i32x4*>(po->y + (size_t)m * K + vt * 8) = o;
+                }
+                if (POUT && write_sum && po->qmode != 0) {  // workgroup-uniform; K % 128 == 0: a 16-lane group is all in or all out
+                    const bool act = vt < n_chunks;
+                    float ov[8];
+                    {
+                        float v[8];
+                        unpack_bf16x8(r.x[m][i], v);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t u = (uint32_t)r.w[i][k];
+                            const uint32_t h2 = f32x2_to_bf16x2((v[2 * k] * rr) * __uint_as_float(u << 16),
+                                                                (v[2 * k + 1] * rr) * __uint_as_float(u & 0xffff0000u));
+                            ov[2 * k] = act ? __uint_as_float(h2 << 16) : 0.f;
+                            ov[2 * k + 1] = act ? __uint_as_float(h2 & 0xffff0000u) : 0.f;
+                        }
+                    }
+                    float amax = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) amax = __builtin_fmaxf(amax, __builtin_fabsf(ov[k]));
+                    amax = row16_reduce_max(amax);
+                    if (po->qmode == 2) amax = __builtin_fmaxf(amax, po->qeps);
+                    const float sc = amax / 448.0f;
+                    const i32x2 packed = po->qmode == 2 ? quant8_fp8<true>(ov, act ? sc : 1.0f) : quant8_fp8<false>(ov, act ? sc : 1.0f);
+                    if (act) {
+                        *reinterpret_cast<i32x2*>(po->q + (size_t)m * K + vt * 8) = packed;
+                        if ((tid & 15) == 0) po->qs[(size_t)m * (K >> 7) + (vt >> 4)] = sc;
+                    }
                 }
             }
         }
@@ -134,11 +173,14 @@ struct QkvPostArgs {
 // ---------------------------------------------------------------- add + norm -> out = y . W^T
 // K loop, K split and accumulation order of bf16_gemm_kernel<1, WK> (gate.hip); D = ring depth (8: the wave's whole
 // K range in one round trip, the form chitu_hip_bf16_gemm picks for <= 8 blocks per wave).
-template <int WK, int D, int MR, bool QKV = false>
+// POUT: the owner workgroup also leaves the normalised rows / their fp8 form (NormOut).  S > 1 (grid.y): K cut over S
+// workgroups per tile, fp32 partial planes [S][M][N] for the consumer to sum in plane order (chitu_hip_bf16_gemm's
+// num_splits form: the router scores, summed by the routing launch) -- every workgroup redoes the prologue.
+template <int WK, int D, int MR, bool QKV = false, bool POUT = false>
 __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
     const bf16_t* x, int64_t x_stride, const bf16_t* add, int64_t add_stride, bf16_t* sum_out, int64_t sum_stride,
     const bf16_t* __restrict__ nw, float eps, const bf16_t* __restrict__ W, void* __restrict__ out, int out_dt, int M,
-    int N, int K, QkvPostArgs qa) {
+    int N, int K, QkvPostArgs qa, NormOut po = NormOut{}, float* __restrict__ partial = nullptr, int S = 1) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ float red[WK > 1 ? WK * 256 : 1];
     __shared__ float nred[kFusedNormMaxRows * 16];
@@ -147,7 +189,8 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
     const int j = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int KB = K >> 6;
-    const int kb0 = (int)((long)KB * wave / WK), kb1 = (int)((long)KB * (wave + 1) / WK);
+    const int T = S * WK, tw = (int)blockIdx.y * WK + wave;
+    const int kb0 = (int)((long)KB * tw / T), kb1 = (int)((long)KB * (tw + 1) / T);
     // QKV: the token's rotary factors and page row, requested first (their round trips hide behind everything else)
     float rc[2] = {1.f, 1.f}, rs[2] = {0.f, 0.f};
     int old_len = -1;
@@ -174,7 +217,7 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
             w1[d] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp1 + ((kb0 + d) << 6)));
         }
     }
-    add_norm_finish<WK, MR>(regs, sum_out, sum_stride, blockIdx.x == 0, M, K, eps, ybuf, nred);
+    add_norm_finish<WK, MR, POUT>(regs, sum_out, sum_stride, blockIdx.x == 0 && blockIdx.y == 0, M, K, eps, ybuf, nred, &po);
     // QKV: the page row's address -- old_len arrived with the prologue's loads; its dependent table load is issued here
     // so that the round trip runs under the K loop, not after it
     int64_t dst_row = -1;
@@ -214,7 +257,7 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
     }
     f32x4 acc[1] = {f32x4{e0[0] + o0[1], e0[2] + o0[3], e1[0] + o1[1], e1[2] + o1[3]}};
     if (!QKV) {
-        gemm_epilogue_v2<1, WK>(acc, red, out, out_dt, nullptr, M, N, 1, 0, n0);
+        gemm_epilogue_v2<1, WK>(acc, red, out, out_dt, partial, M, N, S, 0, n0);
         return;
     }
     // ---- QKV: K-split reduce in wave order (gemm_epilogue_v2's), then rotate / scatter
@@ -457,6 +500,51 @@ extern "C" int chitu_hip_bf16_gemm_add_norm_qkv_post(
         if (per_wave <= 8) LAUNCH(4, 8);
         else LAUNCH(4, 4);
     }
+#undef LAUNCH
+#undef LAUNCH_MR
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+// The router's score GEMM with ffn_norm in front of it (decode batches of <= 3 rows at dim 7168): x_new = x + add,
+// y = RMSNorm(x_new), partial planes [S][M][N] of y . W^T (geometry, K split and accumulation order of
+// chitu_hip_bf16_gemm(num_splits = S), so the planes are bit-identical to that launch fed chitu_hip_rmsnorm's y), and --
+// from the one workgroup that also writes x_new -- y itself and / or its fp8 form for the expert GEMMs (quant_mode 1 =
+// act_quant, 2 = per_token_group_quant with quant_eps; chitu_hip_rmsnorm's codes and scales).  Replaces the stand-alone
+// add + norm + quant launch in front of GateDeepSeekV3.forward (model_deepseek_v3.py:1107-1113, 810-820).
+extern "C" int chitu_hip_bf16_gemm_add_norm_splitk(
+    const void* x_bf16, int64_t x_row_stride, const void* add_bf16, int64_t add_row_stride, void* sum_out_bf16,
+    int64_t sum_row_stride, const void* norm_weight_bf16, float eps, const void* w_bf16, float* partials, int64_t M, int64_t N,
+    int64_t K, int32_t num_splits, void* y_out_bf16, void* q_out_fp8, float* q_scales, int32_t quant_mode, float quant_eps,
+    void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(x_bf16 && add_bf16 && sum_out_bf16 && norm_weight_bf16 && w_bf16 && partials);
+    CHITU_REQUIRE(M >= 0 && N >= 1 && N < (1 << 30) && K >= 64 && K < (1 << 30) && num_splits >= 2 && num_splits <= 64);
+    CHITU_REQUIRE(x_row_stride % 8 == 0 && add_row_stride % 8 == 0 && sum_row_stride % 8 == 0);
+    CHITU_REQUIRE(quant_mode >= 0 && quant_mode <= 2 && (quant_mode == 0 || (q_out_fp8 && q_scales)));
+    if (M == 0) return CHITU_OK;
+    if (!fused_norm_shape_ok(M, K) || (quant_mode != 0 && K % 128 != 0)) return CHITU_ERR_UNSUPPORTED;
+    const int KB = (int)(K / 64), tiles = (int)((N + 15) / 16), S = (int)num_splits;
+    if (S > KB) return CHITU_ERR_BAD_ARG;
+    int WK = 8;  // chitu_hip_bf16_gemm's choice for this shape and split (gate.hip), so the planes agree bit for bit
+    while (WK > 1 && (WK * S > KB || (int64_t)tiles * S * WK > 4096)) WK >>= 1;
+    if (WK < 4) return CHITU_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)M * K * 2;
+    hipStream_t st = (hipStream_t)stream;
+    const NormOut po{(bf16_t*)y_out_bf16, (fp8_t*)q_out_fp8, q_scales, quant_eps, (int)quant_mode};
+    const dim3 grid((unsigned)tiles, (unsigned)S);
+#define LAUNCH_MR(WKV, MRV)                                                                                              \
+    hipLaunchKernelGGL((bf16_gemm_add_norm_kernel<WKV, 4, MRV, false, true>), grid, dim3(64 * WKV), lds, st,             \
+                       (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)add_bf16, add_row_stride, (bf16_t*)sum_out_bf16, \
+                       sum_row_stride, (const bf16_t*)norm_weight_bf16, eps, (const bf16_t*)w_bf16, (void*)nullptr, 2,   \
+                       (int)M, (int)N, (int)K, QkvPostArgs{}, po, partials, S)
+#define LAUNCH(WKV)                        \
+    do {                                   \
+        if (M == 1) LAUNCH_MR(WKV, 1);     \
+        else if (M == 2) LAUNCH_MR(WKV, 2);\
+        else LAUNCH_MR(WKV, 4);            \
+    } while (0)
+    if (WK == 8) LAUNCH(8);
+    else LAUNCH(4);
 #undef LAUNCH
 #undef LAUNCH_MR
     CHITU_RETURN_LAUNCH_STATUS();

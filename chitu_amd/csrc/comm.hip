@@ -41,6 +41,9 @@
 #include "common.h"
 #include "norm_common.h"
 #include <string.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace chitu {
 
@@ -341,6 +344,47 @@ __global__ __launch_bounds__(kCommThreads) void allgather_kernel(CommPeers peers
 
 static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// ---- the exchange buffer's memory is UNCACHED, and uncached memory must not be recycled as ordinary memory -----------
+// Measured on MI355X / ROCm 7.2 (round 4, profiles/r04_graph_mismatch_probe_suite_run2.txt): device memory
+// that was allocated with hipDeviceMallocUncached, freed, and handed out again by hipMalloc as ordinary (cached) memory can
+// serve STALE L2 lines on one XCD -- lines left from the ordinary life the range had BEFORE it was uncached; neither the
+// uncached life nor the free evicts them, and a later reader on that XCD hits them (one eighth of a GEMM's workgroups read
+// an old activation row; a 64 MB fill, which evicts every L2, cures it for good).  So:
+//   * a buffer a Comm no longer needs is PARKED for the rest of the process and handed to the next Comm of that size
+//     (a process makes one Comm; the tests make a hundred) -- uncached memory never goes back to the allocator;
+//   * a FRESH uncached allocation is followed by one sweep of ordinary traffic larger than all L2s, so that no line of the
+//     range's earlier life is left to be hit through the uncached mapping's neighbours either.
+static std::mutex g_park_mutex;
+static std::vector<std::pair<void*, int64_t>> g_parked;  // (uncached buffer, bytes)
+
+static void* take_parked(int64_t bytes) {
+    std::lock_guard<std::mutex> lock(g_park_mutex);
+    for (size_t i = 0; i < g_parked.size(); ++i) {
+        if (g_parked[i].second == bytes) {
+            void* p = g_parked[i].first;
+            g_parked.erase(g_parked.begin() + (long)i);
+            return p;
+        }
+    }
+    return nullptr;
+}
+
+static void park(void* p, int64_t bytes) {
+    std::lock_guard<std::mutex> lock(g_park_mutex);
+    g_parked.emplace_back(p, bytes);
+}
+
+static hipError_t sweep_all_l2(void) {
+    constexpr size_t kSweepBytes = (size_t)256 << 20;  // 8 x the 8 x 4 MB of L2
+    void* t = nullptr;
+    hipError_t e = hipMalloc(&t, kSweepBytes);
+    if (e != hipSuccess) return e;
+    e = hipMemset(t, 0, kSweepBytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(t);
+    return e;
+}
+
 }  // namespace chitu
 
 using namespace chitu;
@@ -374,8 +418,12 @@ extern "C" int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_ro
     cm->two_shot_bytes = 256 << 10;
     g.timeout_ticks = (uint64_t)timeout_ms * 100000ull;  // wall_clock64: 100 MHz
     for (int i = 0; i < kCommMaxRanks; ++i) cm->peers.buf[i] = nullptr, cm->ipc_opened[i] = false;
-    void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, (size_t)cm->total, hipDeviceMallocUncached);
+    void* p = take_parked(cm->total);
+    hipError_t e = hipSuccess;
+    if (!p) {
+        e = hipExtMallocWithFlags(&p, (size_t)cm->total, hipDeviceMallocUncached);
+        if (e == hipSuccess) e = sweep_all_l2();
+    }
     if (e == hipSuccess) e = hipMemset(p, 0, (size_t)cm->total);
     const size_t state_bytes = ((size_t)max_rows + g.max_blocks + 4) * 4;
     if (e == hipSuccess) e = hipMalloc((void**)&cm->state, state_bytes);
@@ -384,7 +432,7 @@ extern "C" int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_ro
     if (e == hipSuccess) *g.host_err = 0;
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
-        if (p) (void)hipFree(p);
+        if (p) park(p, cm->total);
         if (cm->state) (void)hipFree(cm->state);
         if (g.host_err) (void)hipHostFree(g.host_err);
         delete cm;
@@ -465,7 +513,7 @@ extern "C" int chitu_hip_comm_destroy(void* comm) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < kCommMaxRanks; ++i)
         if (cm->ipc_opened[i]) (void)hipIpcCloseMemHandle(cm->peers.buf[i]);
-    (void)hipFree(cm->peers.buf[cm->g.rank]);
+    park(cm->peers.buf[cm->g.rank], cm->total);  // never back to the allocator: see "uncached memory must not be recycled"
     (void)hipFree(cm->state);
     (void)hipHostFree(cm->g.host_err);
     delete cm;

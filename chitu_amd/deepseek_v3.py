@@ -243,24 +243,35 @@ class AttentionDeepSeekV3(torch.nn.Module):
             self._w_uk_key = key
         return self._w_uk_t
 
-    def decode_forward_paged(self, x_quant, cos, sin):
+    def first_projection(self):
+        """The attention's first linear -- wqkv_a, or [wq | wkv_a] of a model without a q low-rank path."""
+        return self.wqkv_a if self.q_lora_rank > 0 else self.wq_kv_a
+
+    def decode_forward_paged(self, x_quant, cos, sin, first=None):
         """x_quant = fp8 (q, s) of attn_norm(x), [bs, dim].  Returns wo(attn) before the all-reduce.
+        first: the first projection's output [bs, N] bf16 when the launch in front already computed it
+        (ops.fp8_linear_add_norm: attn_norm as that GEMM's prologue); x_quant is then not read.
 
         6 launches (the reference's decode_forward_paged + _run_linear issue ~25): wqkv_a GEMM,
         [q_norm + quant -> wq_b GEMM | kv_norm + RoPE(k_pe) + page append], [W_UK absorb | RoPE(q_pe)],
         MLA decode, [split merge + W_UV absorb + quant], wo GEMM.  (7 with batches above 16: the q_norm / kv
         launch and the wq_b GEMM apart.)"""
         H, C, R = self.n_local_heads, self.kv_lora_rank, self.qk_rope_head_dim
-        bs = x_quant[0].rows if isinstance(x_quant[0], ops.TiledQuant) else x_quant[0].shape[0]
+        if first is not None:
+            bs = first.shape[0]
+        else:
+            bs = x_quant[0].rows if isinstance(x_quant[0], ops.TiledQuant) else x_quant[0].shape[0]
         cache = self.cache
         kv_cache = cache.get_paged_kv_cache(self.layer_id)
         nblk = C // BLOCK
         if self.q_lora_rank > 0:
             # wqkv_a: [bs, q_lora + C + R] (optionally as split-K planes, see _wqkv_a_splits)
             splits = _wqkv_a_splits(bs, self.wqkv_a.out_features, self.wqkv_a.in_features)
-            if isinstance(x_quant[0], ops.TiledQuant):
+            if first is not None or isinstance(x_quant[0], ops.TiledQuant):
                 splits = 1
-            if splits > 1:
+            if first is not None:
+                q_a_kv = first
+            elif splits > 1:
                 q_a_kv = ops.fp8_gemm_partials_deepseek_v3(x_quant[0], x_quant[1], self.wqkv_a.weight, self.wqkv_a.scale, splits)
             else:
                 q_a_kv = self.wqkv_a(None, x_quant=x_quant)
@@ -283,7 +294,7 @@ class AttentionDeepSeekV3(torch.nn.Module):
             # q_pe rotated in place by the same launch
             q_abs = ops.absorb_bmm_rope_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0, q_pe, cos, sin)
         else:
-            q_kv = self.wq_kv_a(None, x_quant=x_quant)  # [bs, H*192 + C + R]
+            q_kv = first if first is not None else self.wq_kv_a(None, x_quant=x_quant)  # [bs, H*192 + C + R]
             nq = H * self.qk_head_dim
             q = q_kv[:, :nq].view(bs, H, self.qk_head_dim)
             q_nope, q_pe = q[..., : self.qk_nope_head_dim], q[..., self.qk_nope_head_dim :]
@@ -373,12 +384,14 @@ class GateDeepSeekV3(torch.nn.Module):
         self.bias = (torch.nn.Parameter(torch.empty(args.n_routed_experts, dtype=torch.bfloat16, device=device), requires_grad=False)
                      if args.has_gate_bias() else None)
 
-    def forward(self, x, extra_expert_id: int = -1, extra_count: int = 1, align=None):
+    def forward(self, x, extra_expert_id: int = -1, extra_count: int = 1, align=None, logits_partials=None):
         """(weights [bs, topk(+extra)] bf16, indices int64).  Two HIP launches (ops.gate_deepseek_v3).
-        align=(num_experts, block, expert_map): also the moe_align triple, sorted inside the routing launch."""
+        align=(num_experts, block, expert_map): also the moe_align triple, sorted inside the routing launch.
+        logits_partials: the score GEMM's split-K planes when the launch in front already produced them
+        (ops.gate_scores_add_norm); x is then not read."""
         return ops.gate_deepseek_v3(x, self.weight, self.bias, self.n_groups, self.topk_groups, self.topk,
                                     self.score_func, self.route_scale, extra_expert_id=extra_expert_id,
-                                    extra_count=extra_count, align=align)
+                                    extra_count=extra_count, align=align, logits_partials=logits_partials)
 
 
 class MoEDeepSeekV3(torch.nn.Module):
@@ -419,8 +432,9 @@ class MoEDeepSeekV3(torch.nn.Module):
         self.w2_weight = torch.nn.Parameter(torch.empty(E, args.dim, self.inter, dtype=FP8, device=device), requires_grad=False)
         self.w2_scale = torch.nn.Parameter(torch.empty(E, args.dim // BLOCK, (self.inter + BLOCK - 1) // BLOCK, dtype=torch.float32, device=device), requires_grad=False)
 
-    def forward(self, x, x_quant, defer_sum: bool = False):
+    def forward(self, x, x_quant, defer_sum: bool = False, logits_partials=None):
         """x: ffn_norm output bf16 [bs, dim] (gate input); x_quant its fp8 (per-group) form.
+        logits_partials: the router's score planes if ffn_norm's launch computed them (then x is only the output buffer).
         defer_sum: return the un-summed [bs, topk + n_shared, dim] expert outputs; the next RMSNorm folds
         the top-k sum into its residual add (ops.rms_norm(add=<3-D>)).
 
@@ -434,7 +448,8 @@ class MoEDeepSeekV3(torch.nn.Module):
             return self.forward_expert_parallel(x, x_quant)
         # decode-sized batches: moe_align runs inside the routing launch (last workgroup sorts)
         align = (nr + ns, fused_moe._MOE_BLOCK_M, None) if _route_align_enabled(x.shape[0]) else None
-        routed = self.gate(x, extra_expert_id=nr, extra_count=ns, align=align) if ns >= 1 else self.gate(x, align=align)
+        routed = (self.gate(x, extra_expert_id=nr, extra_count=ns, align=align, logits_partials=logits_partials) if ns >= 1
+                  else self.gate(x, align=align, logits_partials=logits_partials))
         weights, indices = routed[0], routed[1]
         aligned = routed[2] if len(routed) > 2 else None
         return fused_moe.fused_experts(
@@ -485,12 +500,31 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
         # decode: the fp8 form of the normed row goes to wqkv_a only -> tile-major (ops.TiledQuant), wherever a residual
         # is folded in (every layer but the first)
         tm = varlens is None and pending is not None and ops.tile_major_ok(x.shape[0])
+        if varlens is None and _fuses_attn_norm_into_first_projection(x, pending, self.attn):
+            # batch 1: [the experts' top-k sum +] residual add + attn_norm + act_quant run as the prologue of the wqkv_a
+            # GEMM, redone by each of its workgroups -- one launch less per layer, bit-identical
+            proj = self.attn.first_projection()
+            x, first = ops.fp8_linear_add_norm(x, pending, self.attn_norm.weight, self.attn_norm.eps, proj.weight, proj.scale)
+            a = tp.defer_all_reduce(self.attn.decode_forward_paged(None, cos, sin, first=first))
+            return self.ffn_part(x, a, cos, sin, varlens)
         x, _, xq, xs = add_norm(x, pending, self.attn_norm, out_bf16=False, quant="act", tile_major=tm)
         if varlens is None:
             a = tp.defer_all_reduce(self.attn.decode_forward_paged((xq, xs), cos, sin))
         else:
             a = tp.defer_all_reduce(self.attn.prefill_forward((xq, xs), cos, sin, varlens))
-        if self.is_moe:
+        return self.ffn_part(x, a, cos, sin, varlens)
+
+    def ffn_part(self, x, a, cos, sin, varlens):
+        """The layer's second half: ffn_norm (+ the residual add of the attention output) and the MLP / MoE."""
+        if self.is_moe and varlens is None and _fuses_ffn_norm_into_router(x, a, self.ffn):
+            # small decode batches: ffn_norm (+ residual add + the experts' fp8 input) runs as the prologue of the router's
+            # score GEMM, redone by each of its workgroups -- one launch less per MoE layer, bit-identical
+            x, _, hq, hs, planes = ops.gate_scores_add_norm(x, a, self.ffn_norm.weight, self.ffn_norm.eps, self.ffn.gate.weight,
+                                                            quant="group")
+            defer = (tp.defers_topk_sum(x.shape[0], x.shape[1], self.ffn.gate.topk + self.ffn.n_shared)
+                     and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")
+            f = self.ffn(torch.empty_like(x), (hq, hs), defer_sum=defer, logits_partials=planes)
+        elif self.is_moe:
             x, hn, hq, hs = add_norm(x, a, self.ffn_norm, out_bf16=True, quant="group")
             # the experts' top-k sum moves into the next norm launch whenever nothing else needs the summed
             # tensor: always on one rank, and under TP when the all-reduce is that launch too
@@ -502,6 +536,35 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
                                     tile_major=varlens is None and ops.tile_major_ok(x.shape[0]))
             f = self.ffn((hq, hs))
         return x, tp.defer_all_reduce(f)
+
+
+# Decode batches up to this size run attn_norm as the prologue of the attention's first projection
+# (ops.fp8_linear_add_norm); 0 = off.
+FUSE_ATTN_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_ATTN_NORM_MAX_BS", "1"))
+
+
+def _fuses_attn_norm_into_first_projection(x, pending, attn) -> bool:
+    """pending: a plain [bs, dim] tensor or the experts' un-summed [bs, terms, dim] (not None: the first layer; not a partial
+    whose all-reduce the norm launch itself performs); a shape the fused launch takes; the split-K form of wqkv_a off."""
+    if not (isinstance(pending, torch.Tensor) and pending.dim() in (2, 3) and x.shape[0] <= FUSE_ATTN_NORM_MAX_BS):
+        return False
+    proj = attn.first_projection()
+    terms = pending.shape[1] if pending.dim() == 3 else 1
+    return (proj.weight.element_size() == 1 and os.environ.get("CHITU_WQKV_SPLIT", "0") != "1"
+            and ops.fp8_linear_add_norm_fits(x.shape[0], proj.out_features, proj.in_features, terms))
+
+
+# Decode batches up to this size run ffn_norm as the prologue of the router's score GEMM (ops.gate_scores_add_norm);
+# 0 = off.  The rows must fit the GEMM workgroups' LDS: 3 rows at dim 7168.
+FUSE_ROUTER_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_ROUTER_NORM_MAX_BS", "2"))
+
+
+def _fuses_ffn_norm_into_router(x, pending, ffn) -> bool:
+    """pending must be a plain [bs, dim] tensor (not a partial whose all-reduce the norm launch itself performs); one MoE
+    rank layout (expert parallel ranks quantise the shared slice's input differently); a shape the fused launch takes."""
+    return (isinstance(pending, torch.Tensor) and pending.dim() == 2 and x.shape[0] <= FUSE_ROUTER_NORM_MAX_BS
+            and ffn.moe_world_size == 1 and ffn.gate.weight.dtype == torch.bfloat16
+            and ops.gate_scores_add_norm_fits(x.shape[0], ffn.gate.weight.shape[0], x.shape[1]))
 
 
 def add_norm(x, pending, norm, out_bf16=True, quant=None, tile_major=False):

@@ -99,6 +99,7 @@ def graph_mode(use_graph) -> str:
 capture_log = []      # one record per capture_verified call: {"what", "mode", "attempts", "mismatches": [...]}
 on_mismatch = None    # tests: callable(context dict) run in the failing state, before the capture is repeated
 _MAX_CAPTURE_ATTEMPTS = int(os.environ.get("CHITU_GRAPH_CAPTURE_ATTEMPTS", "3"))
+_SWEEP_BEFORE_CAPTURE = os.environ.get("CHITU_GRAPH_SWEEP_L2", "1") != "0"  # 0: tests of the detection path itself
 
 
 def _ranks_agree(ok: bool) -> bool:
@@ -141,6 +142,12 @@ def capture_verified(run_eager, static_out, mode, pool, what="decode step"):
     RuntimeError after _MAX_CAPTURE_ATTEMPTS captures that all fail the check."""
     record = {"what": what, "mode": mode, "attempts": 0, "mismatches": []}
     capture_log.append(record)
+    # Prevention (the check below is the detection): a capture's private pool is served FRESH device memory, and fresh
+    # memory can carry stale L2 lines of its previous owner that survive the kernel-boundary invalidates (round 4: pages
+    # recycled from the uncached / IPC-shared exchange buffers of earlier xGMI communicators; one XCD read old rows).  256 MB
+    # of ordinary traffic evicts every L2 (8 x 4 MB); ~0.1 ms, once per captured batch size.
+    if _SWEEP_BEFORE_CAPTURE:
+        sweep_l2()
     for attempt in range(_MAX_CAPTURE_ATTEMPTS):
         record["attempts"] = attempt + 1
         logs = None
@@ -183,11 +190,24 @@ def capture_verified(run_eager, static_out, mode, pool, what="decode step"):
             if on_mismatch is not None:
                 on_mismatch({"graph": g, "run_eager": run_eager, "static_out": static_out, "reference": reference,
                              "mode": mode, "pool": new_pool, "info": info, "launch_logs": logs})
+            # Round 4's finding: such a replay read stale L2 lines on one XCD -- the capture's private pool had been served
+            # memory that was an uncached allocation earlier in the process.  The graph object itself was fine and a NEW
+            # capture read the same stale lines; ordinary traffic larger than all L2s cured both for good.  So before the
+            # capture is repeated every L2 is swept.
+            sweep_l2()
         del g
         # the rejected graph's pool is not reused: the next attempt allocates its intermediates elsewhere
         pool = None
     raise RuntimeError(f"hipGraph replay of {what} does not reproduce the eager step after {_MAX_CAPTURE_ATTEMPTS} captures; "
                        f"refusing to decode through it: {record['mismatches']}")
+
+
+def sweep_l2(nbytes: int = 256 << 20):
+    """Ordinary write traffic larger than every L2 of the device (8 x 4 MB): evicts whatever lines they hold."""
+    junk = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    junk.fill_(0)
+    torch.cuda.synchronize()
+    del junk
 
 
 def unverified_or_retried():

@@ -432,6 +432,94 @@ def bf16_add_norm_fits(M: int, N: int, K: int) -> bool:
     return wk >= 4
 
 
+def fp8_linear_add_norm_fits(M: int, N: int, K: int, terms: int = 1) -> bool:
+    """Shapes chitu_hip_fp8_gemm_add_norm takes (mirrors its launcher and fp8_gemm.hip::plan_split): one row (two without a
+    terms sum), K a multiple of 128 up to 8192, a GEMM that runs as one workgroup per 16 output rows with >= 4 waves."""
+    if not ((M == 1 or (M == 2 and terms == 1)) and K % 128 == 0 and 128 <= K <= 8192 and 1 <= terms <= 16):
+        return False
+    tiles, kb = (N + 15) // 16, K // 128
+    t = max(1, min(kb, (1536 + tiles - 1) // tiles))
+    wk = 1
+    while wk * 2 <= t and wk < 8:
+        wk *= 2
+    if tiles * wk < 256 and N * K >= (24 << 20):
+        return False
+    while wk > 1 and wk > kb:
+        wk >>= 1
+    return wk >= 4
+
+
+def fp8_linear_add_norm(x, add, norm_weight, eps, weight, weight_scale, out_dtype=torch.bfloat16):
+    """(x_new, fp8_linear(rms_norm(x_new))) with x_new = x + add [summed over its terms first], ONE launch: the residual
+    add, the experts' top-k sum, attn_norm, act_quant and the wqkv_a GEMM of a batch-1 decode step
+    (TransformerBlockDeepSeekV3.forward, model_deepseek_v3.py:1107-1113; linear_deepseek_v3 :98-100).  add [M, K] or
+    [M, terms, K].  Bit-identical to rms_norm(x, add=add, quant="act") + fp8_gemm_deepseek_v3."""
+    require_cuda(x, add, norm_weight, weight, weight_scale)
+    assert x.dtype == torch.bfloat16 and add.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    assert weight.element_size() == 1 and weight_scale.dtype == torch.float32 and weight.is_contiguous() and weight_scale.is_contiguous()
+    M, K = x.shape
+    N = weight.shape[0]
+    if add.dim() == 3:
+        assert add.shape[0] == M and add.shape[2] == K and add.is_contiguous()
+        terms, term_stride, add_stride = add.shape[1], K, add.shape[1] * K
+    else:
+        assert add.shape == x.shape and add.stride(1) == 1
+        terms, term_stride, add_stride = 1, 0, add.stride(0)
+    assert fp8_linear_add_norm_fits(M, N, K, terms)
+    x_new = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    check(
+        _lib.lib().chitu_hip_fp8_gemm_add_norm(
+            ptr(x), i64(x.stride(0)), ptr(add), i64(add_stride), i32(terms), i64(term_stride), ptr(x_new), i64(K),
+            ptr(norm_weight), f32(eps), ptr(weight), ptr(weight_scale), ptr(out), float_dtype_code(out.dtype), i64(M), i64(N),
+            i64(K), stream_ptr()),
+        "fp8_linear_add_norm",
+    )
+    return x_new, out
+
+
+def gate_scores_add_norm_fits(M: int, E: int, K: int) -> bool:
+    """Shapes chitu_hip_bf16_gemm_add_norm_splitk takes for the router scores: the rows must fit one workgroup's LDS beside
+    the GEMM (M * K * 2 <= 48 KB: 3 rows at dim 7168), the K range must split _GATE_SPLITS ways with >= 4 waves each."""
+    if not (1 <= M <= 4 and K % 128 == 0 and 512 <= K <= 8192 and M * K <= 24576 and K % (64 * _GATE_SPLITS) == 0):
+        return False
+    tiles, kb, wk = (E + 15) // 16, K // 64, 8
+    while wk > 1 and (wk * _GATE_SPLITS > kb or tiles * _GATE_SPLITS * wk > 4096):
+        wk >>= 1
+    return wk >= 4
+
+
+def gate_scores_add_norm(x, add, norm_weight, eps, gate_weight, quant="group", out_bf16=False):
+    """ffn_norm and the router's score GEMM in ONE launch (decode batches of 1-3 rows): x_new = x + add,
+    y = RMSNorm(x_new) * norm_weight, the fp32 split-K planes of y . gate_weight^T for gate_deepseek_v3(logits_partials=...),
+    and y's fp8 form for the expert GEMMs -- what rms_norm(x, add=add, quant=quant) followed by the score GEMM of
+    gate_deepseek_v3 return, bit for bit (TransformerBlockDeepSeekV3.forward + GateDeepSeekV3.forward,
+    model_deepseek_v3.py:1107-1113, 810-820).  Returns (x_new, y or None, q, s, partials [_GATE_SPLITS, M, E])."""
+    require_cuda(x, add, norm_weight, gate_weight)
+    assert x.dtype == torch.bfloat16 and add.dtype == torch.bfloat16 and gate_weight.dtype == torch.bfloat16
+    assert x.dim() == 2 and add.shape == x.shape and x.stride(1) == 1 and add.stride(1) == 1
+    assert gate_weight.is_contiguous() and norm_weight.is_contiguous()
+    M, K = x.shape
+    E = gate_weight.shape[0]
+    assert gate_weight.shape[1] == K and gate_scores_add_norm_fits(M, E, K)
+    x_new = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(M, K, dtype=torch.bfloat16, device=x.device) if out_bf16 else None
+    q = s = None
+    mode = {None: 0, "act": 1, "group": 2}[quant]
+    if mode:
+        q = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=x.device)
+        s = torch.empty(M, K // 128, dtype=torch.float32, device=x.device)
+    part = torch.empty(_GATE_SPLITS, M, E, dtype=torch.float32, device=x.device)
+    check(
+        _lib.lib().chitu_hip_bf16_gemm_add_norm_splitk(
+            ptr(x), i64(x.stride(0)), ptr(add), i64(add.stride(0)), ptr(x_new), i64(K), ptr(norm_weight), f32(eps),
+            ptr(gate_weight), ptr(part), i64(M), i64(E), i64(K), i32(_GATE_SPLITS), ptr(y), ptr(q), ptr(s), i32(mode),
+            f32(1e-10), stream_ptr()),
+        "gate_scores_add_norm",
+    )
+    return x_new, y, q, s, part
+
+
 def bf16_linear_add_norm(x, add, norm_weight, eps, weight, out_dtype=None):
     """(x_new, F.linear(rms_norm(x_new), weight)) with x_new = x + add, ONE launch (the add and the norm run as the
     GEMM's prologue in every workgroup; bit-identical to rms_norm(x, add=add) followed by bf16_linear).
@@ -535,7 +623,8 @@ def _route_ticket(device) -> torch.Tensor:
 
 
 def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale,
-                     extra_expert_id: int = -1, extra_weight: float = 1.0, extra_count: int = 1, align=None):
+                     extra_expert_id: int = -1, extra_weight: float = 1.0, extra_count: int = 1, align=None,
+                     logits_partials=None):
     """GateDeepSeekV3.forward (chitu/models/model_deepseek_v3.py:810-842) in two launches:
     split-K skinny GEMM for the scores, then one fused routing kernel.  Returns (weights bf16
     [M, topk(+1)], indices int64 [M, topk(+1)]); the optional extra slot routes every token to
@@ -545,17 +634,27 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
     returned ids inside the routing launch (chitu_hip_gate_route_align) and return a third value
     (sorted_token_ids, expert_ids, num_tokens_post_pad) -- what fused_moe.moe_align_block_size(ids.flatten(),
     block_size, num_experts, expert_map) returns, for fused_experts(aligned=...)."""
-    require_cuda(x, weight)
-    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous() and weight.is_contiguous()
-    M, K = x.shape
+    require_cuda(weight)
     E = weight.shape[0]
-    # decode: K cut over 16 workgroups per tile, the routing launch sums the fp32 planes; prefill-sized M: one tiled GEMM
-    splits = _GATE_SPLITS if K % (64 * _GATE_SPLITS) == 0 and M < 256 else 1
+    if logits_partials is not None:
+        # the score GEMM already ran (gate_scores_add_norm: ffn_norm + scores in one launch); x is not read
+        assert logits_partials.dtype == torch.float32 and logits_partials.dim() == 3 and logits_partials.is_contiguous()
+        assert logits_partials.shape[2] == E
+        M, dev = logits_partials.shape[1], logits_partials.device
+    else:
+        require_cuda(x)
+        assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous() and weight.is_contiguous()
+        M, K = x.shape
+        dev = x.device
+        # decode: K cut over 16 workgroups per tile, the routing launch sums the fp32 planes; prefill-sized M: one tiled GEMM
+        splits = _GATE_SPLITS if K % (64 * _GATE_SPLITS) == 0 and M < 256 else 1
     cols = topk + (extra_count if extra_expert_id >= 0 else 0)
-    w_out = torch.empty(M, cols, dtype=torch.bfloat16, device=x.device)
-    ids = torch.empty(M, cols, dtype=torch.int64, device=x.device)
+    w_out = torch.empty(M, cols, dtype=torch.bfloat16, device=dev)
+    ids = torch.empty(M, cols, dtype=torch.int64, device=dev)
     lib = _lib.lib()
-    if splits > 1:
+    if logits_partials is not None:
+        logits, nparts = logits_partials, logits_partials.shape[0]
+    elif splits > 1:
         part = torch.empty(splits, M, E, dtype=torch.float32, device=x.device)
         check(lib.chitu_hip_bf16_gemm(ptr(x), ptr(weight), ptr(None), i32(0), i64(M), i64(E), i64(K), i32(splits),
                                       ptr(part), stream_ptr()), "gate scores")
@@ -575,10 +674,10 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
     a_experts, a_block, a_map = align
     cap = M * cols + a_experts * (a_block - 1)
     nblk = (cap + a_block - 1) // a_block
-    sorted_ids = torch.empty(cap, dtype=torch.int32, device=x.device)
-    expert_ids = torch.empty(nblk, dtype=torch.int32, device=x.device)
-    npost = torch.empty(1, dtype=torch.int32, device=x.device)
-    cumsum = torch.empty(a_experts + 1, dtype=torch.int32, device=x.device)
+    sorted_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+    expert_ids = torch.empty(nblk, dtype=torch.int32, device=dev)
+    npost = torch.empty(1, dtype=torch.int32, device=dev)
+    cumsum = torch.empty(a_experts + 1, dtype=torch.int32, device=dev)
     if a_map is not None:
         assert a_map.dtype == torch.int32 and a_map.is_cuda and a_map.is_contiguous() and a_map.numel() >= a_experts
     check(
@@ -586,7 +685,7 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
                                        i32(topk), i32(sf), f32(route_scale), ptr(w_out), ptr(ids), i32(cols),
                                        i32(extra_expert_id), f32(extra_weight), i32(extra_count), i32(a_experts),
                                        i32(a_block), ptr(sorted_ids), i64(cap), ptr(expert_ids), i64(nblk), ptr(npost),
-                                       ptr(cumsum), ptr(a_map), ptr(_route_ticket(x.device)), stream_ptr()),
+                                       ptr(cumsum), ptr(a_map), ptr(_route_ticket(dev)), stream_ptr()),
         "gate_route_align",
     )
     return w_out, ids, (sorted_ids, expert_ids, npost)

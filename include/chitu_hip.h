@@ -262,6 +262,22 @@ int chitu_hip_gqa_qkv_post(void* qkv_bf16, int64_t row_stride, int32_t q_heads, 
 int chitu_hip_bf16_gemm_silu(const void* x_bf16, const void* w13_bf16, void* out_bf16, int64_t M, int64_t inter,
                              int64_t K, void* stream);
 
+/* ---- [top-k sum +] residual add + RMSNorm + act_quant as the prologue of the W8A8 GEMM that consumes it (batch 1-2) ----
+ * TransformerBlockDeepSeekV3.forward (model_deepseek_v3.py:1107-1113): x = x + ffn(...); attn(attn_norm(x)) with the first
+ * linear of the attention (wqkv_a; linear_deepseek_v3 :98-100 = act_quant_deepseek_v3 + fp8_gemm_deepseek_v3) in ONE launch:
+ *   a[m]       = add_terms == 1 ? add[m] : bf16(sum_k float(add[m, k, :]))   (the experts' top-k sum, fused_moe.py:1299-1305)
+ *   sum_out[m] = bf16(x[m] + a[m])                                          (the new residual stream)
+ *   y[m]       = bf16((sum_out[m] * rsqrt(mean(sum_out[m]^2) + eps)) * norm_weight);  (q, s) = act_quant(y, 128)
+ *   out        = fp8_gemm(q, s, w_fp8, w_scale)                              [M, N], out_dtype as chitu_hip_fp8_gemm_blockscale
+ * Bit-identical to chitu_hip_rmsnorm(add, add_terms, quant_mode = 1) followed by chitu_hip_fp8_gemm_blockscale (same
+ * summation orders, same K split).  M == 1 (any add_terms <= 16) or M == 2 with add_terms == 1; K % 128 == 0, K <= 8192; a
+ * shape whose GEMM runs as one workgroup per 16 output rows with 4 or 8 waves of K split (wqkv_a of R1 / V2-Lite, w1w3 of a
+ * dense layer); anything else: CHITU_ERR_UNSUPPORTED (use the two launches).  add row / term strides in elements. */
+int chitu_hip_fp8_gemm_add_norm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16, int64_t add_row_stride,
+                                int32_t add_terms, int64_t add_term_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                const void* norm_weight_bf16, float eps, const void* w_fp8, const float* w_scale, void* out,
+                                int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* stream);
+
 /* ---- residual add + RMSNorm as the prologue of the bf16 GEMM that consumes it (decode batches of 1-4 rows) -------
  * TransformerBlock (models/model.py:246-251): h = x + attention(attention_norm(x)); out = h + ffn(ffn_norm(h)) --
  * the add and the norm (RMSNorm.forward, models/model.py:29-78) in front of a layer's qkv projection and of its
@@ -277,6 +293,21 @@ int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_stride, const
                                  int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
                                  const void* norm_weight_bf16, float eps, const void* w_bf16, void* out,
                                  int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* stream);
+/* chitu_hip_bf16_gemm_add_norm with the K range cut over `num_splits` workgroups per tile (2..64), for a GEMM whose N is
+ * tiny -- the router scores of GateDeepSeekV3.forward (model_deepseek_v3.py:810-820: F.linear(ffn_norm(h), gate.weight),
+ * N = n_routed_experts) behind TransformerBlockDeepSeekV3's ffn_norm (:1107-1113): partials [num_splits, M, N] fp32 are
+ * left for the routing launch to sum in plane order (chitu_hip_gate_route / _align, num_partials = num_splits), and are
+ * bit-identical to chitu_hip_bf16_gemm(num_splits) fed chitu_hip_rmsnorm's output.  The workgroup that writes sum_out
+ * also writes, when asked, the normalised rows y_out [M, K] bf16 and / or their fp8 form q_out [M, K] + q_scales
+ * [M, K/128] (quant_mode 1 = act_quant_deepseek_v3, ops.py:330-353; 2 = per_token_group_quant_fp8 with quant_eps,
+ * fused_moe.py:613-714; 0 = none): chitu_hip_rmsnorm's codes and scales, for the expert GEMMs behind the router.
+ * Limits as chitu_hip_bf16_gemm_add_norm; K % 128 == 0 with a quant_mode. */
+int chitu_hip_bf16_gemm_add_norm_splitk(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
+                                        int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                        const void* norm_weight_bf16, float eps, const void* w_bf16, float* partials,
+                                        int64_t M, int64_t N, int64_t K, int32_t num_splits, void* y_out_bf16,
+                                        void* q_out_fp8, float* q_scales, int32_t quant_mode, float quant_eps,
+                                        void* stream);
 /* chitu_hip_bf16_gemm_add_norm for the merged q|k|v projection of a GQA / MHA layer with chitu_hip_gqa_qkv_post
  * (layout 0: interleaved rotary pairs) applied in the epilogue: qkv_out [M, (q_heads + 2*kv_heads) * head_dim] receives
  * the ROTATED q heads only; the rotated k heads and the v heads go straight into the token's page rows of k_cache /
