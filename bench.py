@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--router-std", type=float, default=None, help="debug only: synthetic router weight std (result flagged invalid)")
     ap.add_argument("--opt", type=str, default="", help="debug only: launch-variant overrides name=value,... (chitu_hip_debug_option; same results by construction, still reported in the line)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph-check", action="store_true", help="kernel-trace tools only: skip the replay-vs-eager check after each timed loop (its eager step would sit in the trace); the line is then flagged invalid")
     ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 and bs=32 measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -327,6 +328,7 @@ def run_decode(model, cache, reqs, tokens, steps, world, use_graph, timed):
     return dt, tokens
 
 
+NO_GRAPH_CHECK = False  # --no-graph-check (kernel-trace tools only: the check's eager step would sit in the trace)
 GRAPH_CHECKS = {}  # tag -> one replay of the timed graph == one eager step on the same state (bitwise), per measured loop
 
 
@@ -334,7 +336,7 @@ def check_graph_against_eager(model, cache, reqs, tokens, use_graph, tag):
     """The graph that was just timed, once more, against the eager launches of the same step on the same state (same
     tokens, lengths, block table; the step's only side effect -- the KV row at position L -- is rewritten with the same
     bytes).  Bitwise, on every rank; a line whose graph differs from its eager step is void (main())."""
-    if not use_graph:
+    if not use_graph or NO_GRAPH_CHECK:
         return
     cache.prepare_cache_decode(reqs)
     cache.prepare_block_table_for_decode(reqs)
@@ -363,7 +365,7 @@ def graph_report():
     any such event is listed)."""
     from chitu_amd import graphs
 
-    return {"all_equal_eager": all(GRAPH_CHECKS.values()), "replay_vs_eager_after_timing": dict(GRAPH_CHECKS),
+    return {"all_equal_eager": all(GRAPH_CHECKS.values()) if GRAPH_CHECKS else None, "replay_vs_eager_after_timing": dict(GRAPH_CHECKS),
             "captures_checked_at_capture": len(graphs.capture_log), "captures_rejected_and_repeated": graphs.unverified_or_retried()}
 
 
@@ -798,7 +800,9 @@ def mixtral_extra(steps, warmup, ctx):
 
 
 def main():
+    global NO_GRAPH_CHECK
     a = parse()
+    NO_GRAPH_CHECK = a.no_graph_check
     rank, world, local, dinfo = setup_dist(a.gpus)
     if a.opt:  # A/B of launch variants on one box (tools): identical results, different kernels
         from chitu_amd import _lib
@@ -929,9 +933,9 @@ def main():
         res.update(extra)
         if a.opt:
             res["launch_variant_overrides"] = a.opt
-        if use_graph and not res["graph_verified"]["all_equal_eager"]:
-            res["invalid"] = ("a timed hipGraph did not reproduce the eager launches of the same step (graph_verified): "
-                              "the line is void")
+        if use_graph and res["graph_verified"]["all_equal_eager"] is not True:
+            res["invalid"] = ("a timed hipGraph did not reproduce the eager launches of the same step, or was not checked "
+                              "(graph_verified): the line is void")
             res["value"] = None
         elif dinfo["ranks_seen"] != a.gpus:
             # the library's own all-reduce of ones must have seen every rank the line claims
