@@ -736,10 +736,11 @@ def v2_lite_extra(steps, warmup, ctx):
 
 
 def ep8_rank_extra(steps, warmup, ctx, moe_rank=0):
-    """Not part of the default run (tools/run_extra.py ep8): ONE rank of an expert-parallel R1 deployment
-     -- attention at 1/8 of the heads as in the TP=8 shard, routed experts
-    [32*moe_rank, 32*moe_rank + 32) at full width, 1/8 of the shared expert's width; same weight bytes
-    per rank as the TP shard.  The combine all-reduce is not paid on a lone GPU (as in the TP shard run)."""
+    """ONE rank of an expert-parallel R1 deployment (the reference only stubs it, fused_moe.py:163-179,
+    model_deepseek_v3.py:870-871, 1004) -- attention at 1/8 of the heads as in the TP=8 shard, routed experts
+    [32*moe_rank, 32*moe_rank + 32) at FULL width, 1/8 of the shared expert's width; the same weight bytes per rank as the
+    TP shard, and about the same bytes per step (the rank streams the local experts its tokens hit, whole).  The combine
+    all-reduce is not paid on a lone GPU (as in the TP shard run)."""
     from chitu_amd.attn_backend import HipAttnBackend
     from chitu_amd.cache_manager import PagedKVCacheManager
     from chitu_amd.deepseek_v3 import DeepSeekV3Args, DeepSeekV3Decoder, init_synthetic_
@@ -754,9 +755,23 @@ def ep8_rank_extra(steps, warmup, ctx, moe_rank=0):
     cache.paged_kv_cache.normal_(0, 0.5)
     out = {"model": f"DeepSeek-R1 FP8, one expert-parallel rank (ep=8, rank {moe_rank}: 32 routed experts at full "
                     "width + 1/8 shared width, attention 1/8 heads), hipGraph, synthetic weights"}
+    n_local = margs.n_routed_experts // SHARD
+    lo = moe_rank * n_local
+    d, t = margs.dim, SHARD
+    attn = (margs.q_lora_rank + margs.kv_lora_rank + margs.qk_rope_head_dim) * d \
+        + (margs.n_heads * 192 // t) * margs.q_lora_rank + (margs.n_heads * 256 // t) * margs.kv_lora_rank + d * (margs.n_heads * 128 // t)
+    n_moe = margs.n_layers - margs.n_dense_layers
     for bs in (1, 16):
         dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"e{bs}_")
-        out[f"bs{bs}"] = {"ms_per_step": round(dt / steps * 1e3, 4), "node_tok_s": round(bs * steps / dt, 1)}
+        routing = capture_step_routing(model, cache, bs, ctx)
+        # local routed experts a step streams (whole, 3 * 2048 * 7168 B each), measured on an eager step of this model
+        local = sum(int(r[(r >= lo) & (r < lo + n_local)].unique().numel()) for r in routing) / max(1, len(routing))
+        moe = margs.n_routed_experts * d * 2 + local * 3 * margs.moe_inter_dim * d + 3 * margs.moe_inter_dim * d // t
+        alg = margs.n_layers * attn + margs.n_dense_layers * 3 * margs.inter_dim * d // t + n_moe * moe \
+            + (margs.vocab_size // t) * d * 2 + margs.n_layers * bs * ctx * 576 * 2
+        out[f"bs{bs}"] = {"ms_per_step": round(dt / steps * 1e3, 4), "node_tok_s": round(bs * steps / dt, 1),
+                          "local_routed_experts_hit": round(local, 2), "step_algorithmic_GB": round(alg / 1e9, 3),
+                          "roofline_frac": round(alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
     del model, cache
     torch.cuda.empty_cache()
     return out
@@ -900,6 +915,7 @@ def main():
         extra["llama3_8b"] = llama3_8b_extra(a.steps, a.warmup, a.ctx)
         extra["v2_lite"] = v2_lite_extra(a.steps, a.warmup, a.ctx)
         extra["mixtral_8x7b_int8"] = mixtral_extra(a.steps, a.warmup, a.ctx)
+        extra["ep8_rank"] = ep8_rank_extra(a.steps, a.warmup, a.ctx)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         model = cache = None

@@ -160,7 +160,9 @@ class PagedKVCacheManager:
         h = self._lens_np[slot]
         h[0, :n] = seq_lens
         h[1, :n] = h[0, :n] + 1
-        self._lens_dev.copy_(self._host_lens[slot], non_blocking=True)  # both vectors, one enqueued copy
+        # both vectors, one enqueued copy of the live columns only (the tail keeps its old values: a ring slot's tail holds
+        # whatever step last used that slot)
+        self._lens_dev[:, :n].copy_(self._host_lens[slot][:, :n], non_blocking=True)
         self._stage_done("lens", slot)
 
     def get_free_block(self):

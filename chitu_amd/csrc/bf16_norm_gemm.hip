@@ -527,7 +527,7 @@ extern "C" int chitu_hip_bf16_gemm_add_norm_splitk(
     if (S > KB) return CHITU_ERR_BAD_ARG;
     int WK = 8;  // chitu_hip_bf16_gemm's choice for this shape and split (gate.hip), so the planes agree bit for bit
     while (WK > 1 && (WK * S > KB || (int64_t)tiles * S * WK > 4096)) WK >>= 1;
-    if (WK < 4) return CHITU_ERR_UNSUPPORTED;
+    if (WK < 2 || (WK == 2 && M > 2)) return CHITU_ERR_UNSUPPORTED;  // two waves: eight chunks per thread and row, two rows at most
     const size_t lds = (size_t)M * K * 2;
     hipStream_t st = (hipStream_t)stream;
     const NormOut po{(bf16_t*)y_out_bf16, (fp8_t*)q_out_fp8, q_scales, quant_eps, (int)quant_mode};
@@ -544,7 +544,9 @@ extern "C" int chitu_hip_bf16_gemm_add_norm_splitk(
         else LAUNCH_MR(WKV, 4);            \
     } while (0)
     if (WK == 8) LAUNCH(8);
-    else LAUNCH(4);
+    else if (WK == 4) LAUNCH(4);
+    else if (M == 1) LAUNCH_MR(2, 1);
+    else LAUNCH_MR(2, 2);
 #undef LAUNCH
 #undef LAUNCH_MR
     CHITU_RETURN_LAUNCH_STATUS();

@@ -910,7 +910,11 @@ static int gate_route_launch(const void* logits, int32_t num_partials, int64_t t
         // ids distinct within a token (top-k of distinct routed experts + always-on ids past them): the sort's order-free
         // half rides in the routing (moe_align_small_*); option 15 = 0 keeps the general sort (equivalence tests, A/B)
         RouteAlign alw = al;
-        alw.small = (extra_expert_id < 0 || extra_expert_id >= num_experts) && debug_option(kOptGateSmallSort) != 0 ? 1 : 0;
+        // (every id the kernel can emit must index the sort's tables: routed ids < num_experts <= al.num_experts, always-on
+        // ids inside [num_experts, al.num_experts) -- otherwise the general sort, which drops out-of-range ids, is used)
+        alw.small = (num_experts <= al.num_experts &&
+                     (extra_expert_id < 0 || (extra_expert_id >= num_experts && extra_expert_id + extra_count <= al.num_experts)) &&
+                     debug_option(kOptGateSmallSort) != 0) ? 1 : 0;
 #define LAUNCHW(GSV)                                                                                          \
     hipLaunchKernelGGL(gate_route_align_wg_kernel<GSV>, dim3(1), dim3(wg_threads), wg_lds, st, logits,         \
                        (int)num_partials, (int)tokens, (const bf16_t*)bias_bf16, (int)n_groups, (int)topk_groups, \
@@ -930,7 +934,11 @@ static int gate_route_launch(const void* logits, int32_t num_partials, int64_t t
         const size_t wg_lds = sizeof(int) * (ids_ints + moe_align_lds_ints(al.num_experts, wg_threads));
         CHITU_REQUIRE(wg_threads <= 1024 && wg_lds <= 64 * 1024);
         RouteAlign alw = al;
-        alw.small = (extra_expert_id < 0 || extra_expert_id >= num_experts) && debug_option(kOptGateSmallSort) != 0 ? 1 : 0;
+        // (every id the kernel can emit must index the sort's tables: routed ids < num_experts <= al.num_experts, always-on
+        // ids inside [num_experts, al.num_experts) -- otherwise the general sort, which drops out-of-range ids, is used)
+        alw.small = (num_experts <= al.num_experts &&
+                     (extra_expert_id < 0 || (extra_expert_id >= num_experts && extra_expert_id + extra_count <= al.num_experts)) &&
+                     debug_option(kOptGateSmallSort) != 0) ? 1 : 0;
         hipLaunchKernelGGL(gate_route_align_wg_softmax_kernel, dim3(1), dim3(wg_threads), wg_lds, st, logits, (int)num_partials,
                            (int)tokens, (int)num_experts, (const bf16_t*)bias_bf16, (int)topk, route_scale,
                            (bf16_t*)out_weights_bf16, out_ids, (int)out_stride, (int)extra_expert_id, extra_weight,

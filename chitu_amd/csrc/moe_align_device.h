@@ -146,6 +146,7 @@ __device__ __forceinline__ void moe_align_small_init(int E, int64_t numel, int32
     for (int64_t i = tid; i < expert_cap; i += nthreads) expert_ids[i] = 0;                // (fused_moe.py:493-502)
 }
 
+// (e is inside [0, E) by the launcher's choice of this sort -- gate.hip, `alw.small`; E is not known here)
 __device__ __forceinline__ void moe_align_small_mark(int* lds, int e, int token) { atomicOr(&lds[e], 1 << token); }
 
 __device__ __forceinline__ void moe_align_small_tail(
@@ -195,8 +196,10 @@ __device__ __forceinline__ void moe_align_small_tail(
     if (tid < numel) {
         const int e = (int)ids_lds[tid];
         const int t = tid / stride;
-        const int pos = start_l[e] + __popc((unsigned)tmask[e] & ((1u << t) - 1u));
-        if (pos < sorted_cap) sorted_ids[pos] = (int32_t)tid;
+        if (e >= 0 && e < E) {  // like the general sort: an id outside the table is dropped, never written through
+            const int pos = start_l[e] + __popc((unsigned)tmask[e] & ((1u << t) - 1u));
+            if (pos >= 0 && pos < sorted_cap) sorted_ids[pos] = (int32_t)tid;
+        }
     }
 }
 

@@ -539,7 +539,9 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
 
 
 # Decode batches up to this size run attn_norm as the prologue of the attention's first projection
-# (ops.fp8_linear_add_norm); 0 = off.
+# (ops.fp8_linear_add_norm); 0 = off.  Same-box A/B on the R1 step at bs 1: 4.587 -> 4.451 ms/step (the fused launch
+# lasts 10.2 us against 5.9 + 7.1 for the pair; profiles/r04_ab_norm_prologues.txt); a two-row batch only qualifies
+# behind a plain residual (no top-k terms) and is neutral.
 FUSE_ATTN_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_ATTN_NORM_MAX_BS", "1"))
 
 
@@ -554,9 +556,13 @@ def _fuses_attn_norm_into_first_projection(x, pending, attn) -> bool:
             and ops.fp8_linear_add_norm_fits(x.shape[0], proj.out_features, proj.in_features, terms))
 
 
-# Decode batches up to this size run ffn_norm as the prologue of the router's score GEMM (ops.gate_scores_add_norm);
-# 0 = off.  The rows must fit the GEMM workgroups' LDS: 3 rows at dim 7168.
-FUSE_ROUTER_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_ROUTER_NORM_MAX_BS", "2"))
+# Decode batches up to this size run ffn_norm as the prologue of the router's score GEMM (ops.gate_scores_add_norm).
+# Built, bit-identical, and measured SLOWER on the R1 step, so OFF by default (0): same-box A/B, bs 1 4.587 -> 4.668 ms/step
+# (4.451 -> 4.518 with the attn_norm fusion on), bs 2 5.14 -> 5.49 (profiles/r04_ab_norm_prologues.txt).  The score GEMM
+# runs 256 workgroups of 14 KB of weights each; the prologue makes every one of them read 43 KB of rows and norm weights
+# and redo the norm first -- the launch it removes (4.6 us) is cheaper than that.  wqkv_a's workgroups stream 114 KB
+# each: there the same trade wins (FUSE_ATTN_NORM_MAX_BS).  The rows must fit the GEMM workgroups' LDS: 3 at dim 7168.
+FUSE_ROUTER_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_ROUTER_NORM_MAX_BS", "0"))
 
 
 def _fuses_ffn_norm_into_router(x, pending, ffn) -> bool:
@@ -691,7 +697,7 @@ class DeepSeekV3Decoder(torch.nn.Module):
         tp.check_comm()  # a collective of an earlier step that timed out: raise instead of decoding garbage
         self.prepare_decoding_attn()
         bs = tokens.shape[0]
-        if not use_graph:
+        if not use_graph or tp.xgmi_split_phase():  # (split-phase collectives hold a host barrier: not capturable)
             return self.decode_eager(tokens)
         mode = graphs.graph_mode(use_graph)
         key = (bs, mode)

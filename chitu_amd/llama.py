@@ -273,7 +273,7 @@ class LlamaDecoder(torch.nn.Module):
         hipGraph pieces with the collectives between them (chitu_amd/graphs.py)."""
         tp.check_comm()  # a collective of an earlier step that timed out: raise instead of decoding garbage
         bs = tokens.shape[0]
-        if not use_graph:
+        if not use_graph or tp.xgmi_split_phase():  # (split-phase collectives hold a host barrier: not capturable)
             return self.decode_eager(tokens)
         mode = graphs.graph_mode(use_graph)
         key = (bs, mode)

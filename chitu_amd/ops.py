@@ -480,13 +480,14 @@ def fp8_linear_add_norm(x, add, norm_weight, eps, weight, weight_scale, out_dtyp
 
 def gate_scores_add_norm_fits(M: int, E: int, K: int) -> bool:
     """Shapes chitu_hip_bf16_gemm_add_norm_splitk takes for the router scores: the rows must fit one workgroup's LDS beside
-    the GEMM (M * K * 2 <= 48 KB: 3 rows at dim 7168), the K range must split _GATE_SPLITS ways with >= 4 waves each."""
+    the GEMM (M * K * 2 <= 48 KB: 3 rows at dim 7168), the K range must split _GATE_SPLITS ways with >= 4 waves each
+    (2 waves for at most two rows: V2-Lite's dim 2048)."""
     if not (1 <= M <= 4 and K % 128 == 0 and 512 <= K <= 8192 and M * K <= 24576 and K % (64 * _GATE_SPLITS) == 0):
         return False
     tiles, kb, wk = (E + 15) // 16, K // 64, 8
     while wk > 1 and (wk * _GATE_SPLITS > kb or tiles * _GATE_SPLITS * wk > 4096):
         wk >>= 1
-    return wk >= 4
+    return wk >= 4 or (wk == 2 and M <= 2)
 
 
 def gate_scores_add_norm(x, add, norm_weight, eps, gate_weight, quant="group", out_bf16=False):

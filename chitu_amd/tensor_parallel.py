@@ -27,6 +27,8 @@ __all__ = [
     "all_gather_last_dim",
 ]
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -103,13 +105,20 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
         if why:
             print(f"[chitu_amd] rank {rank}: xGMI collectives not enabled ({why}); using the library path", flush=True)
         if comm is not None:
-            comm.close()
+            try:
+                comm.close()
+            except Exception as e:  # noqa: BLE001 -- a failing clean-up must not take this rank out of the stages its peers still run
+                print(f"[chitu_amd] rank {rank}: closing the xGMI buffers failed ({e!r})", flush=True)
         return False
 
     try:  # stages 1 + 2 (create, map): from_group is collective-safe and raises on every rank or on none
         comm = XgmiComm.from_group(group, max_rows=max_rows, max_dim=max_dim, gather_bytes=gather_bytes, timeout_ms=timeout_ms)
-    except RuntimeError as e:
-        return give_up(None, str(e))
+    except Exception as e:  # noqa: BLE001 -- from_group raises only AFTER its agree() round, on every rank alike; whatever the type, the library path stays
+        return give_up(None, repr(e))
+    if os.environ.get("CHITU_XGMI_SPLIT_PHASE", "0") == "1":
+        # every collective as contribute -> host barrier over the group -> complete: no kernel waits for a peer (rank
+        # processes time-sliced on ONE GPU: tools/xgmi_world8.py, tests/test_gpu_xgmi.py); eager launches only
+        comm.split_phase_group = group
     if selftest:
         gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
         dim = min(max_dim, 1024)
@@ -191,6 +200,12 @@ def disable_xgmi():
 
 def xgmi_comm():
     return _xgmi
+
+
+def xgmi_split_phase() -> bool:
+    """The in-graph collectives are running in their split-phase test form (a host barrier inside every collective):
+    the decoders then launch eagerly -- such a step cannot be captured."""
+    return _xgmi is not None and _xgmi.split_phase_group is not None
 
 
 class PendingAllReduce:

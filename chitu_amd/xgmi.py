@@ -33,6 +33,11 @@ class XgmiComm:
                                                i32(timeout_ms), ctypes.byref(h)), "comm_create")
         self._h = h
         self.two_shot_bytes = 256 << 10  # the library's default (chitu_hip_comm_set_two_shot)
+        # Split-phase mode (tensor_parallel.enable_xgmi under CHITU_XGMI_SPLIT_PHASE=1): a process group over which every
+        # whole collective (phase 0) is run as contribute -> host barrier -> complete, so that no kernel ever waits for
+        # a peer -- the form in which 4 or 8 rank PROCESSES can share one time-sliced GPU (the single-GPU stand-in for a
+        # node: real handle exchange, peer mapping, slicing, epochs; eager launches only).  None = the product form.
+        self.split_phase_group = None
 
     # ------------------------------------------------------------------ wiring
     def ipc_handle(self) -> bytes:
@@ -125,6 +130,13 @@ class XgmiComm:
         check(_lib.lib().chitu_hip_comm_poll_error(self._h, ctypes.byref(err)), "comm_poll_error")
         return err.value
 
+    def _between_phases(self):
+        """Split-phase mode: this rank's contribution has left (stream drained), every rank's has (host barrier)."""
+        import torch.distributed as dist
+
+        torch.cuda.current_stream().synchronize()
+        dist.barrier(group=self.split_phase_group)
+
     def close(self):
         if self._h is not None:
             try:
@@ -147,6 +159,10 @@ class XgmiComm:
         x_new is returned (a plain all-reduce, `out` may alias `part` for the in-place form).
         phase: 0 = whole collective; 1 = contribute only (returns the output tensors, not yet valid); 2 = complete
         (pass the tuple phase 1 returned as `into`)."""
+        if phase == 0 and self.split_phase_group is not None:
+            first = self.allreduce_rmsnorm(part, x, weight, eps, out_bf16, quant, out, phase=1, tile_major=tile_major)
+            self._between_phases()
+            return self.allreduce_rmsnorm(part, x, weight, eps, out_bf16, quant, out, phase=2, into=first, tile_major=tile_major)
         require_cuda(part, x, weight)
         assert part.dtype == torch.bfloat16 and part.stride(-1) == 1
         dim = part.shape[-1]
@@ -161,6 +177,11 @@ class XgmiComm:
         y = q = s = None
         if into is not None:
             sum_out, y, q, s = (tuple(into) + (None,) * 4)[:4] if isinstance(into, tuple) else (into, None, None, None)
+            if q is not None and not isinstance(q, torch.Tensor):  # phase 1 handed back an ops.TiledQuant: its buffers
+                assert tile_major, "a tile-major result of phase 1 must be completed with tile_major=True"
+                q, s = q.q, q.s
+            else:
+                assert not (tile_major and q is not None), "phase 1 wrote row-major codes; complete it with tile_major=False"
         else:
             sum_out = out if out is not None else torch.empty(rows, dim, dtype=torch.bfloat16, device=part.device)
         assert sum_out.shape == (rows, dim) and sum_out.dtype == torch.bfloat16 and sum_out.stride(-1) == 1
@@ -205,6 +226,10 @@ class XgmiComm:
     def all_gather_last_dim(self, y: torch.Tensor, out_dtype=torch.bfloat16, phase: int = 0, into=None) -> torch.Tensor:
         """[rows, cols] bf16 per rank -> [rows, world * cols] (rank-major along the last dim) in bf16 or f32.
         phase / into: as allreduce_rmsnorm."""
+        if phase == 0 and self.split_phase_group is not None:
+            first = self.all_gather_last_dim(y, out_dtype, phase=1)
+            self._between_phases()
+            return self.all_gather_last_dim(y, out_dtype, phase=2, into=first)
         require_cuda(y)
         assert y.dim() == 2 and y.dtype == torch.bfloat16 and y.stride(-1) == 1
         rows, cols = y.shape

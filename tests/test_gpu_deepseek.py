@@ -792,7 +792,7 @@ def test_tile_major_activations_leave_the_decode_step_bit_identical(make_args, m
 
 # ---------------------------------------------------------------- ffn_norm as the prologue of the router's score GEMM
 @pytest.mark.parametrize("M", [1, 2, 3])
-@pytest.mark.parametrize("E,K", [(256, 7168), (64, 4096), (160, 6144)])
+@pytest.mark.parametrize("E,K", [(256, 7168), (64, 4096), (160, 6144), (64, 2048)])
 def test_ffn_norm_in_the_router_gemm_prologue_is_bit_identical(M, E, K):
     """ops.gate_scores_add_norm (ONE launch) against rms_norm(add=..., quant="group") followed by the score GEMM of
     gate_deepseek_v3: the residual stream, the fp8 codes and scales the experts read, the normalised rows and every fp32

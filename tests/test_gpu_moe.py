@@ -44,9 +44,20 @@ def test_reference_fixture_inputs():
             torch.from_numpy(g["ids"]), bf16(g["wts"]))
     out = run_hip(*args)
     ref = omoe.fused_experts_fp8(args[0], args[1], args[2], args[6], args[5], args[3], args[4])
-    assert_close(out, ref, REL_TOL)
-    # the interpreter-generated fixture itself carries ~10% of cast-defect noise (see
-    # tests/test_oracle_golden.py); it must still be the same function
+    assert_close(out, ref, REL_TOL)  # the bar: HIP vs the oracle with IEEE casts (what the reference computes on a GPU)
+    # The fixture was produced under the Triton INTERPRETER, whose fp8 / bf16 casts are defective (tests/test_oracle_golden.py):
+    # it differs from any correctly rounding implementation by ~10 % of its peak.  The loose bar below is therefore never
+    # the only link to the reference's own run -- the explaining link is asserted right here: the same oracle with the
+    # interpreter's two casts swapped in reproduces the fixture to 2e-3 on these very inputs (pins the ALGORITHM to the
+    # reference's run), and the oracle with IEEE casts is what HIP is held to above.
+    from oracle import fp8 as ofp8
+    from tests.test_oracle_golden import interpreter_casts
+
+    with pytest.MonkeyPatch.context() as mp:
+        interpreter_casts.__wrapped__(mp)
+        ref_interp = omoe.fused_experts_fp8(args[0], args[1], args[2], args[6], args[5], args[3], args[4])
+    assert ofp8.CAST["fp8"].__name__ != "to_fp8_interp"  # restored
+    assert max_rel_to_peak(ref_interp, bf16(g["out"])) < 2e-3, "the fixture is the oracle's algorithm under the interpreter's casts"
     assert_close(out, bf16(g["out"]), 0.2)
 
 
@@ -69,8 +80,7 @@ def test_vs_oracle(M, E, topk, K, I):
     out = run_hip(*args)
     x, w1, w2, w1s, w2s, ids, wts = args
     ref = omoe.fused_experts_fp8(x, w1, w2, wts, ids, w1s, w2s)
-    err = max_rel_to_peak(out, ref)
-    assert err < REL_TOL, err
+    assert_close(out, ref, REL_TOL, what=f"fused_experts fp8 {M, E, topk, K, I}")  # peak bar AND element-wise rtol 1e-2
     assert ((out.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item() < 5e-3
 
 

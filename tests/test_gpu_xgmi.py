@@ -506,6 +506,78 @@ def _decode_worker(rank, world):
     assert torch.equal(mine, ref)
 
 
+def _split_phase_worker(rank, world, r1_shapes=True):
+    """World-size readiness WITHOUT a second GPU (CHITU_XGMI_SPLIT_PHASE=1): `world` rank processes time-sliced on one GPU
+    run the product wiring -- IPC handle exchange, peer mapping, the staged unanimous() verdicts of enable_xgmi with its
+    self-tests, one-shot and two-shot slicing, epochs -- with every collective as contribute -> host barrier -> complete,
+    so no kernel ever waits for a peer.  Checked: every fusion of the all-reduce and the all-gather bit-exact against the
+    oracle's rank-order sum, and a decode step of a 2-layer model at DeepSeek-R1's per-rank shapes (TP = world; eager
+    launches, the step's 6 collectives on the xGMI kernels) giving bit-identical logits on every rank, three steps."""
+    os.environ["CHITU_XGMI_SPLIT_PHASE"] = "1"
+    import torch.distributed as dist
+
+    from chitu_amd import tensor_parallel as tp
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args, DeepSeekV3Decoder, init_synthetic_
+
+    if r1_shapes:
+        args = DeepSeekV3Args(n_layers=2, n_dense_layers=1)  # DeepSeek-R1's own shapes, sharded `world` ways
+    else:
+        args = DeepSeekV3Args(vocab_size=1024, dim=512, inter_dim=1024 * world, moe_inter_dim=256 * world, n_layers=2,
+                              n_dense_layers=1, n_heads=16 * world, n_routed_experts=16, n_shared_experts=1,
+                              n_activated_experts=4, n_expert_groups=4, n_limited_groups=2, q_lora_rank=256, gate_bias=True)
+    vocab_local = args.vocab_size // world
+    assert tp.enable_xgmi(max_rows=32, max_dim=8192, gather_bytes=16 * max(vocab_local, 16160) * 2, timeout_ms=4000), \
+        "xGMI setup / self-test failed in split-phase mode"
+    comm = tp.xgmi_comm()
+    assert tp.xgmi_split_phase() and comm.world == world
+    for salt, two_shot in ((0, 256 << 10), (1, 0)):  # salt 1: every all-reduce in its two-shot form
+        comm.set_two_shot(two_shot)
+        for case in CASES:
+            res = _run_case(comm, case, rank, salt)
+            torch.cuda.synchronize()
+            assert comm.status() == 0, (case, salt)
+            _check(res, _expected(case, world, salt), (case, salt, rank))
+    comm.set_two_shot(256 << 10)
+    for rows, cols in ((16, 16160), (3, 64)):
+        ys = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(5 + r + rows)) * 3).to(torch.bfloat16) for r in range(world)]
+        got = tp.all_gather_last_dim(ys[rank].cuda(), out_dtype=torch.float32)
+        assert torch.equal(got.cpu(), ocomm.all_gather_last_dim(ys, torch.float32))
+    # ---- the decode step
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=4, block_size=64, max_seq_len=256, device="cuda",
+                                kv_shape_per_sample=(576,), dtype=torch.bfloat16)
+    model = DeepSeekV3Decoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads // world, max_seq_len=256),
+                              max_position_embeddings=256, device="cuda")
+    init_synthetic_(model, seed=100 + rank)
+    reqs = ["s0", "s1", "s2"]
+    g = torch.Generator().manual_seed(99)
+    for r, n in zip(reqs, (60, 63, 127)):
+        cache.register_sequence(r, n)
+        rows = (torch.randn(args.n_layers, 256, 576, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        for p, blk in enumerate(cache.block_table[r]):
+            cache.paged_kv_cache[:, blk] = rows[:, p * 64 : (p + 1) * 64]
+    toks = torch.tensor([5, 17, 900], dtype=torch.int64, device="cuda")
+    for step in range(3):
+        cache.prepare_cache_decode(reqs)
+        cache.prepare_block_table_for_decode(reqs)
+        logits = model.decode(toks, use_graph=True)  # split-phase collectives: decode() launches eagerly
+        cache.finalize_cache_single_decode(reqs)
+        assert not model.graphs and torch.isfinite(logits).all() and logits.shape == (3, args.vocab_size)
+        mine = logits.cpu()
+        ref = mine.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(mine, ref), (step, "ranks disagree on the logits")
+        toks = logits.argmax(-1)
+    assert comm.status() == 0
+
+
+def test_four_rank_processes_split_phase_collectives_and_r1_shaped_step():
+    """World 4 as four PROCESSES on this one GPU, by construction instead of by the GPU's time slicing: the split-phase
+    form (see _split_phase_worker).  World 8: tools/xgmi_world8.py --split-phase 8 (profiles/r04_xgmi_world8_split_phase.txt)."""
+    _spawn(_split_phase_worker, 4, timeout=400)
+
+
 def test_tp_decode_step_one_graph_on_xgmi_equals_eager_on_library():
     """World 2 only: beyond two ranks the library's bf16 sum depends on its (unspecified) order, and this random
     tiny model amplifies one flipped bit per layer, so there is no tight bar to hold a run to."""
