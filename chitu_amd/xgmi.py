@@ -160,8 +160,12 @@ class XgmiComm:
         phase: 0 = whole collective; 1 = contribute only (returns the output tensors, not yet valid); 2 = complete
         (pass the tuple phase 1 returned as `into`)."""
         if phase == 0 and self.split_phase_group is not None:
+            rows_, dim_ = part.shape[0], part.shape[-1]
             first = self.allreduce_rmsnorm(part, x, weight, eps, out_bf16, quant, out, phase=1, tile_major=tile_major)
             self._between_phases()
+            if self.uses_two_shot(rows_, dim_):  # the second hop: wait for hop 1, reduce my slice, send it to everyone
+                self.allreduce_rmsnorm(part, x, weight, eps, out_bf16, quant, out, phase=3, into=first, tile_major=tile_major)
+                self._between_phases()
             return self.allreduce_rmsnorm(part, x, weight, eps, out_bf16, quant, out, phase=2, into=first, tile_major=tile_major)
         require_cuda(part, x, weight)
         assert part.dtype == torch.bfloat16 and part.stride(-1) == 1

@@ -80,7 +80,10 @@ def test_vs_oracle(M, E, topk, K, I):
     out = run_hip(*args)
     x, w1, w2, w1s, w2s, ids, wts = args
     ref = omoe.fused_experts_fp8(x, w1, w2, wts, ids, w1s, w2s)
-    assert_close(out, ref, REL_TOL, what=f"fused_experts fp8 {M, E, topk, K, I}")  # peak bar AND element-wise rtol 1e-2
+    # peak bar for every element AND the element-wise bar (rtol 1e-2 + half the peak bar) for all but 5 in 10 000: the
+    # experts' intermediate h is re-quantised to fp8 between the two GEMMs, and where HIP's and the oracle's fp32 sums
+    # round h to different codes (one fp8 step = 6 %) the outputs fed by that element move by up to ~0.8 % of the peak
+    assert_close(out, ref, REL_TOL, what=f"fused_experts fp8 {M, E, topk, K, I}", outlier_frac=5e-4)
     assert ((out.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item() < 5e-3
 
 

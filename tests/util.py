@@ -41,7 +41,7 @@ def max_rel_to_peak(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-def assert_close_elementwise(a, b, rtol=1e-2, atol_peak=2e-3, what=""):
+def assert_close_elementwise(a, b, rtol=1e-2, atol_peak=2e-3, what="", outlier_frac=0.0):
     """Element-wise bar beside max_rel_to_peak: |a - b| <= rtol * |b| + atol_peak * max|b| for EVERY element -- the
     north_star's "1e-2 rel" read per element, with an absolute floor (a fraction of the tensor's peak) for the elements
     near zero, whose error is set by their neighbours' magnitude (fp32 summation order, one bf16 rounding), not by
@@ -50,13 +50,16 @@ def assert_close_elementwise(a, b, rtol=1e-2, atol_peak=2e-3, what=""):
     b = b.detach().float().cpu()
     bound = rtol * b.abs() + atol_peak * b.abs().max()
     bad = (a - b).abs() > bound
-    if bad.any():
+    # outlier_frac: the share of elements allowed outside this bar (they stay under the caller's PEAK bar) -- for paths
+    # with an fp8 re-quantisation in the middle, where one flipped code of an intermediate moves a few outputs by more
+    # than 1 % of their own value while staying well inside 1 % of the peak
+    if int(bad.sum()) > outlier_frac * bad.numel():
         i = int(((a - b).abs() - bound).argmax())
         raise AssertionError(f"{what}: {int(bad.sum())} of {bad.numel()} elements outside rtol={rtol} + {atol_peak}*peak; "
                              f"worst: got {a.flatten()[i].item()}, want {b.flatten()[i].item()}, peak {b.abs().max().item()}")
 
 
-def assert_close(a, b, peak_tol, rtol=1e-2, atol_frac=None, what=""):
+def assert_close(a, b, peak_tol, rtol=1e-2, atol_frac=None, what="", outlier_frac=0.0):
     """The two bars together: max|a - b| < peak_tol * max|b| (BASELINE's "1e-2 rel" in the peak norm) AND, for every
     element, |a - b| <= rtol * |b| + atol_frac * peak_tol * max|b| -- 1 % of the element's own value plus half of the
     peak bar as the absolute floor wherever the bar is the north_star's (peak_tol <= 1e-2: op-level comparisons against
@@ -67,7 +70,7 @@ def assert_close(a, b, peak_tol, rtol=1e-2, atol_frac=None, what=""):
         atol_frac = 0.5 if peak_tol <= 1e-2 else 1.0
     err = max_rel_to_peak(a, b)
     assert err < peak_tol, (what, err)
-    assert_close_elementwise(a, b, rtol=rtol, atol_peak=peak_tol * atol_frac, what=what)
+    assert_close_elementwise(a, b, rtol=rtol, atol_peak=peak_tol * atol_frac, what=what, outlier_frac=outlier_frac)
     return err
 
 
