@@ -50,7 +50,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = "r03_pmc_step.json"  # tools/pmc_passes.sh + tools/pmc_report.py, stamped with git head + source digests
+PMC_FILE = "r04_pmc_step.json"  # tools/pmc_passes.sh + tools/pmc_report.py, stamped with git head + source digests
 
 
 def _sha256(path):
@@ -429,7 +429,7 @@ def roofline_dominant_kernel(model, routing, margs, bs, iters=3):
     expert ids that layer really routed in a decode step (capture_step_routing), captured into one hipGraph and
     replayed, i.e. the same launches in the same form as the timed step's graph."""
     from chitu_amd import _lib, fused_moe
-    from chitu_amd._lib import i32, i64, ptr, stream_ptr
+    from chitu_amd._lib import f32, i32, i64, ptr, stream_ptr
 
     lib = _lib.lib()
     moe_layers = [l.ffn for l in model.layers if l.is_moe]
