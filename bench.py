@@ -711,6 +711,11 @@ def cpu_baseline(margs, bs, ctx):
                                        f"{ref['host']['where']}: profiles/r02_ref_cpu_decode.json")
         if "llama2_7b_bf16_bs1" in ref:
             out["reference_config1_llama2_7b"] = ref["llama2_7b_bf16_bs1"]
+        # every `reference_*` field above is STATIC: read from a committed record, not timed in this run
+        out["reference_fields"] = {"static": True, "file": "profiles/r02_ref_cpu_decode.json",
+                                   "cores": ref.get("host", {}).get("cores"), "where": ref.get("host", {}).get("where"),
+                                   "why": "the reference tree exists in the build container only; the GPU box cannot import it, "
+                                          "so its CPU decode cannot be timed beside the port here"}
     except Exception:  # noqa: BLE001 -- the live port above is the baseline; the reference numbers are a committed record
         pass
     return out
