@@ -21,6 +21,12 @@ from .ops import append_to_paged_kv_cache
 __all__ = ["AttnBackend", "HipAttnBackend"]
 
 
+# Upper bound of the KV splits of the GQA decode launch (graph-static: sized from the page table's width, not from the
+# lengths).  32 by the sweep of round 4 (Llama-3-8B bs 1, ctx 1024: 64 -> 3.064, 32 -> 3.041, 16 -> 3.077, 8 -> 3.175 ms/step;
+# from bs 4 on the CU-count term decides; profiles/r04_gqa_split_sweep.txt); CHITU_GQA_MAX_SPLITS overrides it for sweeps.
+_GQA_MAX_SPLITS = int(os.environ.get("CHITU_GQA_MAX_SPLITS", "32"))
+
+
 class AttnBackend:
     """Interface (chitu/attn_backend.py:24-164)."""
 
@@ -328,7 +334,7 @@ class HipAttnBackend(AttnBackend):
             q3 = q3.contiguous()
         if num_splits is None:
             max_steps = max(1, int(block_table.shape[1]) * int(k_cache.shape[1]) // 16)
-            num_splits = max(1, min(max_steps, 64, (4 * _num_cus()) // max(1, bs * Hkv)))
+            num_splits = max(1, min(max_steps, _GQA_MAX_SPLITS, (4 * _num_cus()) // max(1, bs * Hkv)))
         out = torch.empty(bs, Hq, D, dtype=torch.bfloat16, device=q.device)
         need = bs * Hq * num_splits * (D + 1) * 4 if num_splits > 1 else 1
         ws = workspace.get(need, q.device, "gqa")

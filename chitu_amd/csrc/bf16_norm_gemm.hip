@@ -447,11 +447,18 @@ extern "C" int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_st
         else if (M == 2) LAUNCH_MR(WKV, DV, 2);  \
         else LAUNCH_MR(WKV, DV, 4);              \
     } while (0)
+    // Ring depth 8 = the wave's whole K range in one round trip: right for the launches that are latency-bound (<= 256
+    // workgroups: one per CU).  With MORE workgroups than CUs the 8-deep ring's ~160 VGPRs allow one 8-wave workgroup per
+    // CU only, the grid runs in two rounds and the second is half empty (Llama-3-8B's qkv projection, 384 workgroups:
+    // 15.5 us = 3.2 TB/s); the 4-deep ring (~98 VGPRs) keeps two workgroups per CU resident.  Same accumulation order either
+    // way.  Option 11 (bf16_gemm_deep): 0 = never 8 deep, 1 = always (A/B), -1 = this heuristic.
+    const int deep_opt = debug_option(kOptBf16GemmDeep);
+    const bool deep = per_wave <= 8 && (deep_opt < 0 ? tiles <= 256 : deep_opt != 0);
     if (WK == 8) {
-        if (per_wave <= 8) LAUNCH(8, 8);
+        if (deep) LAUNCH(8, 8);
         else LAUNCH(8, 4);
     } else {
-        if (per_wave <= 8) LAUNCH(4, 8);
+        if (deep) LAUNCH(4, 8);
         else LAUNCH(4, 4);
     }
 #undef LAUNCH
@@ -493,11 +500,18 @@ extern "C" int chitu_hip_bf16_gemm_add_norm_qkv_post(
         else if (M == 2) LAUNCH_MR(WKV, DV, 2);  \
         else LAUNCH_MR(WKV, DV, 4);              \
     } while (0)
+    // Ring depth 8 = the wave's whole K range in one round trip: right for the launches that are latency-bound (<= 256
+    // workgroups: one per CU).  With MORE workgroups than CUs the 8-deep ring's ~160 VGPRs allow one 8-wave workgroup per
+    // CU only, the grid runs in two rounds and the second is half empty (Llama-3-8B's qkv projection, 384 workgroups:
+    // 15.5 us = 3.2 TB/s); the 4-deep ring (~98 VGPRs) keeps two workgroups per CU resident.  Same accumulation order either
+    // way.  Option 11 (bf16_gemm_deep): 0 = never 8 deep, 1 = always (A/B), -1 = this heuristic.
+    const int deep_opt = debug_option(kOptBf16GemmDeep);
+    const bool deep = per_wave <= 8 && (deep_opt < 0 ? tiles <= 256 : deep_opt != 0);
     if (WK == 8) {
-        if (per_wave <= 8) LAUNCH(8, 8);
+        if (deep) LAUNCH(8, 8);
         else LAUNCH(8, 4);
     } else {
-        if (per_wave <= 8) LAUNCH(4, 8);
+        if (deep) LAUNCH(4, 8);
         else LAUNCH(4, 4);
     }
 #undef LAUNCH

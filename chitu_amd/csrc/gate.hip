@@ -860,7 +860,11 @@ extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void*
     for (int64_t mb = 0; mb < M; mb += 32) {
         const int mbase = (int)mb;
         if (M - mb <= 16) {
-            if (WK == 8 && per_wave > 4 && per_wave <= 8 && debug_option(kOptBf16GemmDeep) != 0)
+            // the 8-deep ring (the wave's whole K range in one round trip) for grids of at most one workgroup per CU: its
+            // register count admits one 8-wave workgroup per CU, so a larger grid would run in rounds (Llama-3-8B's qkv
+            // projection, 384 workgroups; see bf16_norm_gemm.hip).  Option 11: 0 never, 1 always, -1 this heuristic.
+            const int deep_opt = debug_option(kOptBf16GemmDeep);
+            if (WK == 8 && per_wave > 4 && per_wave <= 8 && (deep_opt < 0 ? (int64_t)tiles * S <= 256 : deep_opt != 0))
                 hipLaunchKernelGGL((bf16_gemm_kernel<1, 8, true>), grid, dim3(512), 0, st, (const bf16_t*)x_bf16,
                                    (const bf16_t*)w_bf16, out, out_dtype, partials, (int)M, (int)N, (int)K, S, mbase);
             else
