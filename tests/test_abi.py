@@ -92,6 +92,48 @@ def test_fused_launch_shape_limits_agree_between_python_and_c():
         assert rc == -2, (bs, ql, rc)
 
 
+def test_norm_prologue_launch_limits_agree_between_python_and_c():
+    """Round 4's fused launches: ops.fp8_linear_add_norm_fits (attn_norm in the first projection's prologue) and
+    ops.gate_scores_add_norm_fits (ffn_norm in the router GEMM's) against chitu_hip_fp8_gemm_add_norm /
+    chitu_hip_bf16_gemm_add_norm_splitk: an unfit shape is refused with CHITU_ERR_UNSUPPORTED on the host.  (A fit shape would
+    launch: those are the GPU tests' business.)"""
+    from chitu_amd import _lib, ops
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    buf = ctypes.create_string_buffer(64)
+    p = ctypes.c_void_p(ctypes.addressof(buf))
+    i32, i64, f32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    fit = unfit = 0
+    for M in (1, 2, 3):
+        for terms in (1, 2, 9, 16, 17):
+            for N, K in ((2112, 7168), (3648, 2048), (4608, 7168), (832, 512), (16, 7168), (256, 16384), (2112, 7232 - 64), (64, 128),
+                         (129280 // 8, 7168)):
+                if K % 128 != 0:
+                    continue
+                if ops.fp8_linear_add_norm_fits(M, N, K, terms):
+                    fit += 1
+                    continue
+                unfit += 1
+                rc = lib.chitu_hip_fp8_gemm_add_norm(p, i64(K), p, i64(K * terms), i32(terms), i64(K), p, i64(K), p, f32(1e-6), p, p, p,
+                                                     i32(0), i64(M), i64(N), i64(K), None)
+                assert rc == -2, (M, terms, N, K, rc)
+    assert fit >= 8 and unfit > 40
+    assert ops.fp8_linear_add_norm_fits(1, 2112, 7168, 9) and ops.fp8_linear_add_norm_fits(1, 3648, 2048, 8)  # R1, V2-Lite at batch 1
+    assert not ops.fp8_linear_add_norm_fits(2, 2112, 7168, 9) and ops.fp8_linear_add_norm_fits(2, 2112, 7168, 1)
+    unfit = 0
+    for M in (1, 2, 3, 4, 5):
+        for E, K in ((256, 7168), (64, 2048), (64, 4096), (256, 512), (8, 4096), (256, 8192 + 1024), (256, 7168 + 64)):
+            if ops.gate_scores_add_norm_fits(M, E, K):
+                continue
+            unfit += 1
+            rc = lib.chitu_hip_bf16_gemm_add_norm_splitk(p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, f32(1e-6), p, p,
+                                                         i64(M), i64(E), i64(K), i32(ops._GATE_SPLITS), p, p, p, i32(2), f32(1e-10), None)
+            assert rc in (-1, -2), (M, E, K, rc)  # (-1: more splits than K blocks -- refused as an argument error)
+    assert unfit >= 10 and ops.gate_scores_add_norm_fits(1, 256, 7168) and ops.gate_scores_add_norm_fits(2, 64, 2048)
+
+
 def test_xcd_blocked_tile_order_covers_every_tile_once():
     """The prefill GEMM's workgroup -> tile map (gemm_common.h::xcd_tile_of), through its host-side entry: every tile of the
     grid exactly once, padding workgroups only beyond it, and the workgroups of one XCD (b % 8) inside ONE rectangle whose
