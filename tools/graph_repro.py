@@ -12,7 +12,6 @@ Experiments, one process, all on the tiny reference-Llama fixture (tests/golden/
 """
 
 import argparse
-import contextlib
 import os
 import sys
 
@@ -25,7 +24,7 @@ from chitu_amd import ops, workspace  # noqa: E402
 from chitu_amd.attn_backend import HipAttnBackend  # noqa: E402
 from chitu_amd.cache_manager import PagedKVCacheManager  # noqa: E402
 from chitu_amd.llama import LlamaArgs, LlamaDecoder  # noqa: E402
-from tests.util import ref_llama_fixture  # noqa: E402
+from tests.util import poisoned_allocations, ref_llama_fixture  # noqa: E402
 
 G, CFG, P = ref_llama_fixture()
 PROMPT, TOKS = G["prompt"].tolist(), G["tokens"].tolist()
@@ -63,38 +62,7 @@ def ref_err(rows):
     return ((rows - ref).abs().amax(-1) / ref.abs().amax(-1)).max().item()
 
 
-# ---------------------------------------------------------------- E2: poisoned allocations
-@contextlib.contextmanager
-def poisoned_allocations():
-    """torch.empty / empty_like / Tensor.new_empty on the GPU return memory filled with 0xFF bytes, and every
-    workspace.get() re-fills its buffer: a launch that reads what no launch wrote reads NaN / -1."""
-    real_empty, real_like, real_new, real_ws = torch.empty, torch.empty_like, torch.Tensor.new_empty, workspace.get
-
-    def foul(t):
-        if isinstance(t, torch.Tensor) and t.is_cuda and t.numel():
-            if t.is_contiguous():
-                t.view(-1).view(torch.uint8).fill_(0xFF)
-            else:
-                t.fill_(float("nan") if t.is_floating_point() else -1)
-        return t
-
-    def empty(*a, **k):
-        return foul(real_empty(*a, **k))
-
-    def empty_like(*a, **k):
-        return foul(real_like(*a, **k))
-
-    def new_empty(self, *a, **k):
-        return foul(real_new(self, *a, **k))
-
-    def ws_get(nbytes, device, tag="default"):
-        return foul(real_ws(nbytes, device, tag))
-
-    torch.empty, torch.empty_like, torch.Tensor.new_empty, workspace.get = empty, empty_like, new_empty, ws_get
-    try:
-        yield
-    finally:
-        torch.empty, torch.empty_like, torch.Tensor.new_empty, workspace.get = real_empty, real_like, real_new, real_ws
+# ---------------------------------------------------------------- E2: poisoned allocations (tests/util.py)
 
 
 # ---------------------------------------------------------------- E3: dirty device memory
