@@ -491,3 +491,54 @@ def test_mixtral_int8_decode_step_tp2_matches_tp1(tmp_path):
     # (W8A8Linear under row parallelism), so TP = 2 differs from TP = 1 by int8 rounding, not bit for bit
     err = ((l1[0] - l2[0]).abs().max() / l1[0].abs().max()).item()
     assert err < 5e-2, err
+
+
+def _decode_bs1_fused_vs_unfused(rank, world):
+    """Host wiring of the batch-1 norm-prologue launch (deepseek_v3._fuses_attn_norm_into_first_projection ->
+    ops.fp8_linear_add_norm -> decode_forward_paged(first=...)) on the CPU shim, where the fused op IS the composition it
+    replaces: the step with the fusion must equal the step without it, behind a dense FFN and behind a MoE layer, and the KV
+    rows it appends must be the same.  (The un-summed top-k form of the pending tensor is a device-side optimisation the shim
+    does not model; tests/test_gpu_deepseek.py covers it.)"""
+    from chitu_amd import deepseek_v3 as ds
+    from chitu_amd import ops
+    from tests import cpu_ops_shim
+
+    cpu_ops_shim.install(setattr)
+    args = _tiny_args()
+    args.n_layers = 3  # dense, MoE, MoE: a plain pending and a 3-D (terms) pending both reach an attn_norm
+    args.dim = 1024    # (the fused launch needs >= 4 waves of K split: 8 K blocks of 128)
+    full = _full_state(args)
+    taken = []
+    real = ops.fp8_linear_add_norm
+    ops.fp8_linear_add_norm = lambda x, add, *a, **k: (taken.append(add.dim()), real(x, add, *a, **k))[1]
+    res = {}
+    for limit in (0, 1):
+        ds.FUSE_ATTN_NORM_MAX_BS = limit
+        model, cache = _build_cpu_model(args)
+        for k, p in model.named_parameters():
+            p.data.copy_(full[k])
+        cache.register_sequence("a", 70)
+        g = torch.Generator().manual_seed(3)
+        for blk in cache.block_table["a"]:
+            cache.paged_kv_cache[:, blk] = (torch.randn(args.n_layers, 64, 576, generator=g) * 0.5).to(torch.bfloat16)
+        tokens, outs = torch.tensor([7]), []
+        for _ in range(2):
+            cache.prepare_cache_decode(["a"])
+            cache.prepare_block_table_for_decode(["a"])
+            with torch.inference_mode():
+                logits = model.decode(tokens, use_graph=False)
+            outs.append(logits.clone())
+            tokens = logits.argmax(-1)
+            cache.finalize_cache_single_decode(["a"])
+        res[limit] = (outs, cache.paged_kv_cache.clone())
+        if limit == 0:
+            assert not taken
+    # two steps x layers 1 and 2 (layer 0 has no pending); the shim's fused_experts sums its top-k itself, so both are plain
+    assert len(taken) == 2 * 2 and set(taken) <= {2, 3}
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[0][1], res[1][1])
+
+
+def test_decode_bs1_with_attn_norm_in_the_first_projection_equals_the_step_without():
+    _run(_decode_bs1_fused_vs_unfused, 1)
