@@ -27,12 +27,21 @@ would pay span only the live ranks (`collectives_in_step` is 0 at N=1), so only 
 measured live with HIP events around replays of one hipGraph holding every MoE layer's launch back to back
 (`avg_launch_us`); `spaced_launch_us` = the same launches with ~70 us of near-idle kernels between them (what the step
 looks like to this kernel; an uninterrupted 22 GB stream runs ~5 % slower); `traffic` / `mfma_util` from the committed PMC
-record profiles/r03_pmc_step.json, whose git head is echoed as `pmc_head` and which is withheld if csrc/moe.hip has changed
+record profiles/r04_pmc_step.json, whose git head is echoed as `pmc_head` and which is withheld if csrc/moe.hip has changed
 since.  `collectives` (N > 1): transport, per-launch GPU time of the fused all-reduce and of the logits all-gather, and
 `per_transport`: the same norm + quant launch without a collective, with the xGMI all-reduce in its one-shot and its
 two-shot form, and the all-gather, at bs 1 / 16 / 32.  A line whose `ranks_seen_by_library` differs from --gpus, or whose
 xGMI error word is set, carries `invalid` (and no `value` in the first case).  `v2_lite`, `mixtral_8x7b_int8`, `llama3_8b`:
-BASELINE configs 3 / 4 / 2 as extra objects with their own step_algorithmic_GB and roofline_frac (N = 1 only).
+BASELINE configs 3 / 4 / 2 as extra objects with their own step_algorithmic_GB and roofline_frac (N = 1 only); `ep8_rank`: one
+expert-parallel rank of R1 the same way.  `roofline_kernels`: the dominant kernel and the second expert GEMM
+(W2) as a list, both timed as above.
+
+`graph_verified` (round 4): every timed hipGraph is replayed once more after its timed loop against the EAGER launches of the
+same step on the same state (tokens, lengths, block table; the KV row at position L is rewritten with the same bytes) and
+must equal them bit for bit -- per measured loop in `replay_vs_eager_after_timing`; `captures_checked_at_capture` /
+`captures_rejected_and_repeated` echo chitu_amd.graphs.capture_verified's log (every capture is checked by one replay
+before it is used).  Anything but equality voids the line (`invalid`, `value` null).  `cpu_baseline.reference_fields`
+says which of its fields are static records (the reference's own CPU decode cannot be timed on the GPU box: no reference tree).
 
 Prints ONE JSON line on rank 0.
 """
