@@ -219,8 +219,12 @@ class HipAttnBackend(AttnBackend):
                 kk = kk.contiguous()
             cu32 = cu_seqlens_k.to(device=dev, dtype=torch.int32).contiguous()
             out = torch.empty(T, H, C, dtype=torch.bfloat16, device=dev)
+            # CHITU_MLA_PREFILL=tiled: the one-query-token-per-wave kernel (round 4; equal within the attention bar, not bit for
+            # bit with the decode kernel -- opt-in until it has been through the GPU suite)
+            entry = (_lib.lib().chitu_hip_mla_prefill_tiled if os.environ.get("CHITU_MLA_PREFILL") == "tiled"
+                     else _lib.lib().chitu_hip_mla_prefill)
             check(
-                _lib.lib().chitu_hip_mla_prefill(
+                entry(
                     ptr(kq), i64(kq.stride(0)), i64(kq.stride(1)), ptr(kk), i64(kk.stride(0)), ptr(cu32),
                     i32(cu32.numel() - 1), i32(int(max_seqlen_k)), f32(softmax_scale), ptr(out), i32(H), i32(C), i32(R),
                     stream_ptr(),

@@ -1,5 +1,7 @@
 """HIP MLA paged decode vs the oracle and the reference-kernel fixture."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -254,6 +256,39 @@ def test_prefill_kernel_equals_per_token_decode_composition(monkeypatch):
         assert torch.equal(outs["kernel"], outs["compose"]), (H, seqs)
         ref = omla.mla_prefill(q.cpu(), kv.cpu()[:, 0], cu.cpu(), 0.1352)
         assert_close(outs["kernel"].cpu(), ref, REL_TOL)
+
+
+@pytest.mark.skipif(os.environ.get("CHITU_TEST_PREFILL_TILED") != "1", reason="opt-in kernel: CHITU_TEST_PREFILL_TILED=1 (see mla_prefill.hip)")
+def test_prefill_one_token_per_wave_kernel_vs_the_exact_kernel_and_the_oracle(monkeypatch):
+    """chitu_hip_mla_prefill_tiled (CHITU_MLA_PREFILL=tiled: a wave owns one query token, S^T = K Q^T, softmax wave-local, P
+    in registers) against chitu_hip_mla_prefill and the oracle: ragged batch, lengths around the 4-token block and the 64-key
+    tile edges, 16 / 32 / 8 heads; the reference fixture.  Another summation order than the decode kernel's: the
+    attention bar, not bit for bit."""
+    from chitu_amd.attn_backend import HipAttnBackend
+    from tests.util import mla_prefill_golden_case
+
+    g = torch.Generator().manual_seed(31)
+    for H, seqs in ((16, [1, 2, 3, 4, 5, 63, 64, 65, 66, 127, 128, 129, 300]), (32, [7, 200]), (8, [70]), (16, [700])):
+        T = sum(seqs)
+        cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32).cuda()
+        q = (torch.randn(T, H, 576, generator=g) * 0.3).to(torch.bfloat16).cuda()
+        kv = torch.randn(T, 1, 576, generator=g).to(torch.bfloat16).cuda()
+        be = HipAttnBackend(local_n_heads=H)
+        outs = {}
+        for mode in ("kernel", "tiled"):
+            monkeypatch.setenv("CHITU_MLA_PREFILL", mode)
+            outs[mode] = be.attn_varlen_func(q, kv, kv[..., :512].contiguous(), cu, cu, max(seqs), max(seqs), causal=True,
+                                             softmax_scale=0.1352).cpu()
+        assert torch.isfinite(outs["tiled"]).all()
+        assert_close(outs["tiled"], outs["kernel"], 5e-3, what=("tiled vs exact kernel", H, seqs))
+        ref = omla.mla_prefill(q.cpu(), kv.cpu()[:, 0], cu.cpu(), 0.1352)
+        assert_close(outs["tiled"], ref, REL_TOL, what=("tiled vs oracle", H, seqs))
+    monkeypatch.setenv("CHITU_MLA_PREFILL", "tiled")
+    c = mla_prefill_golden_case()
+    kv = c["kv"].cuda()
+    out = HipAttnBackend(local_n_heads=16).attn_varlen_func(c["q"].cuda(), kv, kv[..., :512].contiguous(), c["cu"].cuda(), c["cu"].cuda(),
+                                                            max(c["seqs"]), max(c["seqs"]), causal=True, softmax_scale=c["scale"])
+    assert_close(out.cpu()[c["rows"]], c["out"], REL_TOL)
 
 
 def test_merge_uv_quant_tile_major_is_the_same_output_permuted():
