@@ -200,7 +200,13 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_kernel(
 //   fragment read transposed from the same LDS tile in that key order).
 // Two barriers per tile (the staging pair), 72 + 64 independent MFMAs per wave in between, no P / max / sum traffic
 // through LDS.  Different summation order from the decode kernel: equal to it within the attention bar (1e-2 of the
-// peak), not bit for bit -- which is why the kernel above stays the default until this one has been through the GPU suite.
+// peak), not bit for bit.
+// Measured (round 4, profiles/r04_ab_prefill_wave_kernel.txt): parity-green on the first run; with Q held in registers the
+// 512-VGPR budget spilled (42 registers beside 128 accumulators + 72 staging registers) and a 2048-token layer went 1.46 ->
+// 1.73 ms; with Q read back from LDS (this form) it is 1.528 -> 1.511 ms: the same time as the kernel above.  So neither the
+// barriers (see also r04_ab_prefill_phase_order.txt) nor the softmax traffic is what bounds this attention: both forms fetch
+// two 1 KB LDS operands per 16x16x32 MFMA.  The next step is the 32x32x16 shape (two query tokens per wave: half the
+// operand bytes per MAC).  This kernel stays opt-in (CHITU_MLA_PREFILL=tiled), the bit-exact one stays the default.
 namespace pfw {
 constexpr int kC = 512;
 constexpr int kTile = 64;
@@ -240,13 +246,16 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_wave_kernel(
         }
     };
     issue(0);
-    // Q fragments (B operand of S^T = K Q^T): lane (j, g) holds q[token][head h0 + j][kk * 32 + g * 8 ..], kk = 0 .. 17
-    s16x8 qf[18];
+    // Q (B operand of S^T = K Q^T) -> LDS, the wave's own 16 rows: lane (j, g) reads q[token][head h0 + j][kk * 32 + g * 8 ..]
+    // back per K step (18 fragments in registers beside the 128 accumulators and the 72 staging registers spilled)
+    uint8_t* q_lds = smem + kTile * kRowB + wave * 16 * kRowB;  // [16][kRowB] per wave
     {
         const bf16_t* qp = q + (int64_t)(s0 + pq) * q_st + (int64_t)min(h0 + j, H - 1) * q_sh + g * 8;
 #pragma unroll
-        for (int kk = 0; kk < 18; ++kk) qf[kk] = *reinterpret_cast<const s16x8*>(qp + kk * 32);
+        for (int kk = 0; kk < 18; ++kk)
+            *reinterpret_cast<s16x8*>(q_lds + j * kRowB + g * 16 + kk * 64) = *reinterpret_cast<const s16x8*>(qp + kk * 32);
     }
+    const uint8_t* qrow = q_lds + j * kRowB + g * 16;  // (read by the lanes that wrote it: in-wave LDS ordering suffices)
     f32x4 o[32];  // O[head 4g + r][latent column c * 16 + j]
 #pragma unroll
     for (int c = 0; c < 32; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -271,7 +280,8 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_wave_kernel(
 #pragma unroll
             for (int kk = 0; kk < 18; ++kk) {
                 const s16x8 kf = *reinterpret_cast<const s16x8*>(krow + kk * 64);
-                st[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[b], 0, 0, 0);
+                const s16x8 qf = *reinterpret_cast<const s16x8*>(qrow + kk * 64);
+                st[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, st[b], 0, 0, 0);
             }
         }
         // ---- causal mask, scale, the tile's row maximum (wave-local: in-lane over b, r; two shuffles over g)
@@ -377,7 +387,7 @@ extern "C" int chitu_hip_mla_prefill_tiled(const void* q_bf16, int64_t q_stride_
     if (kv_lora_rank != pfw::kC || rope_dim != 64) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(q_stride_t % 8 == 0 && q_stride_h % 8 == 0 && kv_stride_t % 8 == 0);
     if (n_seq == 0 || max_seqlen == 0) return CHITU_OK;
-    const size_t lds = (size_t)pfw::kTile * pfw::kRowB;
+    const size_t lds = (size_t)(pfw::kTile + pfw::kBQ * 16) * pfw::kRowB;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)mla_prefill_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

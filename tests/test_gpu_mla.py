@@ -258,7 +258,6 @@ def test_prefill_kernel_equals_per_token_decode_composition(monkeypatch):
         assert_close(outs["kernel"].cpu(), ref, REL_TOL)
 
 
-@pytest.mark.skipif(os.environ.get("CHITU_TEST_PREFILL_TILED") != "1", reason="opt-in kernel: CHITU_TEST_PREFILL_TILED=1 (see mla_prefill.hip)")
 def test_prefill_one_token_per_wave_kernel_vs_the_exact_kernel_and_the_oracle(monkeypatch):
     """chitu_hip_mla_prefill_tiled (CHITU_MLA_PREFILL=tiled: a wave owns one query token, S^T = K Q^T, softmax wave-local, P
     in registers) against chitu_hip_mla_prefill and the oracle: ragged batch, lengths around the 4-token block and the 64-key

@@ -3,7 +3,7 @@
 out=$GRAFT_REPO_ROOT/gpurun_out/r04_call18
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-CHITU_TEST_PREFILL_TILED=1 timeout 60 python -m pytest tests/test_gpu_mla.py -m gpu -q --timeout 50 -k "one_token_per_wave" > $out/tests.txt 2>&1; echo "rc=$?" >> $out/tests.txt
+timeout 60 python -m pytest tests/test_gpu_mla.py -m gpu -q --timeout 50 -k "one_token_per_wave" > $out/tests.txt 2>&1; echo "rc=$?" >> $out/tests.txt
 grep -v amdgpu.ids $out/tests.txt | tail -14 | cut -c1-500
 for mode in kernel tiled; do
   echo "== CHITU_MLA_PREFILL=$mode" >> $out/prefill_ab.txt
