@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_kernel(
 // ---------------------------------------------------------------- one query token per WAVE (round 4; opt-in)
 // The kernel above keeps the decode kernel's arithmetic -- every wave takes 16 of a tile's 64 keys for every query token,
 // the row maxima and sums of a token meet through LDS, P goes through LDS -- which costs three workgroup barriers per
-// token per tile and leaves each wave 18 + 16 dependent MFMAs between them: ~29 k cycles per tile (2048-token prompt:
-// 390 us per layer, 7.6 % of the bf16 MFMA rate).  Here a wave owns ONE query token (its 16 heads) against the whole
+// token per tile and leaves each wave 18 + 16 dependent MFMAs between them (2048-token prompt: 355-390 us per layer,
+// ~8 % of the bf16 MFMA rate).  Here a wave owns ONE query token (its 16 heads) against the whole
 // staged tile, the way gqa_decode.hip's wave owns a (sequence, kv head):
 //   S^T = K Q^T  (A = K rows from LDS, B = Q fragments held in registers for the whole kernel), so a lane holds
 //   S[keys 16b + 4g + r][head j]: the softmax is wave-local (in-lane over b, r; two shuffles over g) and P, rounded to
