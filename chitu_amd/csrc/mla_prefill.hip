@@ -188,169 +188,6 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_kernel(
     }
 }
 
-// ---------------------------------------------------------------- one query token per WAVE (round 4; opt-in)
-// The kernel above keeps the decode kernel's arithmetic -- every wave takes 16 of a tile's 64 keys for every query token,
-// the row maxima and sums of a token meet through LDS, P goes through LDS -- which costs three workgroup barriers per
-// token per tile and leaves each wave 18 + 16 dependent MFMAs between them (2048-token prompt: 355-390 us per layer,
-// ~8 % of the bf16 MFMA rate).  Here a wave owns ONE query token (its 16 heads) against the whole
-// staged tile, the way gqa_decode.hip's wave owns a (sequence, kv head):
-//   S^T = K Q^T  (A = K rows from LDS, B = Q fragments held in registers for the whole kernel), so a lane holds
-//   S[keys 16b + 4g + r][head j]: the softmax is wave-local (in-lane over b, r; two shuffles over g) and P, rounded to
-//   bf16, is already the A fragment of the PV product (k-slots 8g + i <-> keys 32p + 4g + i | 32p + 16 + 4g + i, the V
-//   fragment read transposed from the same LDS tile in that key order).
-// Two barriers per tile (the staging pair), 72 + 64 independent MFMAs per wave in between, no P / max / sum traffic
-// through LDS.  Different summation order from the decode kernel: equal to it within the attention bar (1e-2 of the
-// peak), not bit for bit.
-// Measured (round 4, profiles/r04_ab_prefill_wave_kernel.txt): parity-green on the first run; with Q held in registers the
-// 512-VGPR budget spilled (42 registers beside 128 accumulators + 72 staging registers) and a 2048-token layer went 1.46 ->
-// 1.73 ms; with Q read back from LDS (this form) it is 1.528 -> 1.511 ms: the same time as the kernel above.  So neither the
-// barriers (see also r04_ab_prefill_phase_order.txt) nor the softmax traffic is what bounds this attention: both forms fetch
-// two 1 KB LDS operands per 16x16x32 MFMA.  The next step is the 32x32x16 shape (two query tokens per wave: half the
-// operand bytes per MAC).  This kernel stays opt-in (CHITU_MLA_PREFILL=tiled), the bit-exact one stays the default.
-namespace pfw {
-constexpr int kC = 512;
-constexpr int kTile = 64;
-constexpr int kRowB = 1184;
-constexpr int kBQ = 4;  // query tokens per workgroup = waves
-}  // namespace pfw
-
-__global__ __launch_bounds__(256, 1) void mla_prefill_wave_kernel(
-    const bf16_t* __restrict__ q, int64_t q_st, int64_t q_sh, const bf16_t* __restrict__ kv, int64_t kv_st,
-    const int32_t* __restrict__ cu_seqlens, float scale, bf16_t* __restrict__ out, int H) {
-    using namespace pfw;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* kv_lds = smem;  // [64][kRowB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    const int seq = blockIdx.y, hb = blockIdx.z;
-    const int s0 = cu_seqlens[seq], s1 = cu_seqlens[seq + 1];
-    const int L = s1 - s0;
-    const int p0 = blockIdx.x * kBQ;
-    if (p0 >= L) return;
-    const int nq = min(kBQ, L - p0);
-    const int h0 = hb * 16;
-    const int pq = p0 + min(wave, nq - 1);  // this wave's query position (a wave past the sequence end repeats the last token and stores nothing)
-    const int n_tiles = (p0 + nq + kTile - 1) / kTile;  // keys 0 .. p0 + nq - 1: the same trip count for the four waves
-    const bf16_t* kbase = kv + (int64_t)s0 * kv_st;
-
-    i32x4 pfr[18];
-    auto issue = [&](int tile) {
-        const int t0 = tile * kTile;
-        const int valid = min(kTile, p0 + nq - t0);
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            const int c = tid + i * 256;
-            const int row = c / 72, col = c % 72;
-            pfr[i] = i32x4{0, 0, 0, 0};  // rows past the block's last key are staged as zeros (and masked: key > pq)
-            if (row < valid) pfr[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(kbase + (int64_t)(t0 + row) * kv_st + col * 8));
-        }
-    };
-    issue(0);
-    // Q (B operand of S^T = K Q^T) -> LDS, the wave's own 16 rows: lane (j, g) reads q[token][head h0 + j][kk * 32 + g * 8 ..]
-    // back per K step (18 fragments in registers beside the 128 accumulators and the 72 staging registers spilled)
-    uint8_t* q_lds = smem + kTile * kRowB + wave * 16 * kRowB;  // [16][kRowB] per wave
-    {
-        const bf16_t* qp = q + (int64_t)(s0 + pq) * q_st + (int64_t)min(h0 + j, H - 1) * q_sh + g * 8;
-#pragma unroll
-        for (int kk = 0; kk < 18; ++kk)
-            *reinterpret_cast<s16x8*>(q_lds + j * kRowB + g * 16 + kk * 64) = *reinterpret_cast<const s16x8*>(qp + kk * 32);
-    }
-    const uint8_t* qrow = q_lds + j * kRowB + g * 16;  // (read by the lanes that wrote it: in-wave LDS ordering suffices)
-    f32x4 o[32];  // O[head 4g + r][latent column c * 16 + j]
-#pragma unroll
-    for (int c = 0; c < 32; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;  // of head j (the same in the four lane groups)
-
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int t0 = tile * kTile;
-        __syncthreads();  // the previous tile is fully consumed
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            const int c = tid + i * 256;
-            *reinterpret_cast<i32x4*>(kv_lds + (c / 72) * kRowB + (c % 72) * 16) = pfr[i];
-        }
-        __syncthreads();
-        if (tile + 1 < n_tiles) issue(tile + 1);
-        // ---- S^T[key 16b + 4g + r][head j] for the tile's four key blocks
-        f32x4 st[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            st[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const uint8_t* krow = kv_lds + (b * 16 + j) * kRowB + g * 16;
-#pragma unroll
-            for (int kk = 0; kk < 18; ++kk) {
-                const s16x8 kf = *reinterpret_cast<const s16x8*>(krow + kk * 64);
-                const s16x8 qf = *reinterpret_cast<const s16x8*>(qrow + kk * 64);
-                st[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, st[b], 0, 0, 0);
-            }
-        }
-        // ---- causal mask, scale, the tile's row maximum (wave-local: in-lane over b, r; two shuffles over g)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = (t0 + b * 16 + g * 4 + r) <= pq;
-                st[b][r] = ok ? st[b][r] * scale : -INFINITY;
-                mx = __builtin_fmaxf(mx, st[b][r]);
-            }
-        }
-        mx = __builtin_fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = __builtin_fmaxf(m_run, mx);  // finite from the first tile on: key 0 <= pq
-        const float alpha = __expf(m_run - m_new);        // first tile: exp(-inf) = 0 on zero accumulators
-        m_run = m_new;
-        float psum = 0.f;
-        s16x8 pa[2];  // A fragments of P V: k-slot 8g + i <-> key 32p + 4g + i (i < 4) | 32p + 16 + 4g + (i - 4)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(st[b][r] - m_new);  // masked keys: exp(-inf) = 0
-                psum += p;
-                pa[b >> 1][(b & 1) * 4 + r] = (short)f32_to_bf16(p);
-            }
-        }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        // O rows are heads 4g + r: their rescale factors live in lanes 4g + r of the first lane group
-        float al[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) al[r] = __shfl(alpha, g * 4 + r, 64);
-#pragma unroll
-        for (int c = 0; c < 32; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[c][r] *= al[r];
-        // ---- O += P V: V fragments read transposed from the staged tile, rows in the k-slot order above
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const uint8_t* vbase = kv_lds + (p * 32 + g * 4 + (j >> 2)) * kRowB + (j & 3) * 8;
-#pragma unroll
-            for (int c = 0; c < 32; ++c) {
-                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_pf*)(vbase + c * 32));
-                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_pf*)(vbase + 16 * kRowB + c * 32));
-                s16x8 vf;
-                vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
-                vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
-                o[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[p], vf, o[c], 0, 0, 0);
-            }
-        }
-    }
-    if (wave >= nq) return;
-    // ---- epilogue: lane holds O[head 4g + r][column c * 16 + j]; the row sums of heads 4g + r sit in lanes 4g + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float l = __shfl(l_run, g * 4 + r, 64);
-        const int h = h0 + g * 4 + r;
-        if (h >= H) continue;
-        const float inv = 1.0f / l;
-        bf16_t* dst = out + ((int64_t)(s0 + pq) * H + h) * kC + j;
-#pragma unroll
-        for (int c = 0; c < 32; ++c) dst[c * 16] = f32_to_bf16(o[c][r] * inv);
-    }
-}
-
 }  // namespace chitu
 
 extern "C" int chitu_hip_mla_prefill(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
@@ -370,31 +207,6 @@ extern "C" int chitu_hip_mla_prefill(const void* q_bf16, int64_t q_stride_t, int
     }
     const dim3 grid((unsigned)((max_seqlen + pf::kBQ - 1) / pf::kBQ), (unsigned)n_seq, (unsigned)((heads + 15) / 16));
     hipLaunchKernelGGL(mla_prefill_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q_bf16, q_stride_t,
-                       q_stride_h, (const bf16_t*)kv_bf16, kv_stride_t, cu_seqlens, softmax_scale, (bf16_t*)out_bf16,
-                       (int)heads);
-    CHITU_RETURN_LAUNCH_STATUS();
-}
-
-// The same contract on mla_prefill_wave_kernel (one query token per wave; see its header): equal to chitu_hip_mla_prefill
-// within the attention bar, not bit for bit.  Opt-in (HipAttnBackend: CHITU_MLA_PREFILL=tiled) until it has been through
-// the GPU suite.
-extern "C" int chitu_hip_mla_prefill_tiled(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
-                                           int64_t kv_stride_t, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
-                                           float softmax_scale, void* out_bf16, int32_t heads, int32_t kv_lora_rank,
-                                           int32_t rope_dim, void* stream) {
-    using namespace chitu;
-    CHITU_REQUIRE(q_bf16 && kv_bf16 && cu_seqlens && out_bf16 && n_seq >= 0 && max_seqlen >= 0 && heads >= 1);
-    if (kv_lora_rank != pfw::kC || rope_dim != 64) return CHITU_ERR_UNSUPPORTED;
-    CHITU_REQUIRE(q_stride_t % 8 == 0 && q_stride_h % 8 == 0 && kv_stride_t % 8 == 0);
-    if (n_seq == 0 || max_seqlen == 0) return CHITU_OK;
-    const size_t lds = (size_t)(pfw::kTile + pfw::kBQ * 16) * pfw::kRowB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mla_prefill_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    const dim3 grid((unsigned)((max_seqlen + pfw::kBQ - 1) / pfw::kBQ), (unsigned)n_seq, (unsigned)((heads + 15) / 16));
-    hipLaunchKernelGGL(mla_prefill_wave_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q_bf16, q_stride_t,
                        q_stride_h, (const bf16_t*)kv_bf16, kv_stride_t, cu_seqlens, softmax_scale, (bf16_t*)out_bf16,
                        (int)heads);
     CHITU_RETURN_LAUNCH_STATUS();
