@@ -34,7 +34,8 @@ two-shot form, and the all-gather, at bs 1 / 16 / 32.  A line whose `ranks_seen_
 xGMI error word is set, carries `invalid` (and no `value` in the first case).  `v2_lite`, `mixtral_8x7b_int8`, `llama3_8b`:
 BASELINE configs 3 / 4 / 2 as extra objects with their own step_algorithmic_GB and roofline_frac (N = 1 only); `ep8_rank`: one
 expert-parallel rank of R1 the same way.  `roofline_kernels`: the dominant kernel and the second expert GEMM
-(W2) as a list, both timed as above.
+(W2) as a list, both timed as above.  `prefill`: a 2048-token prompt through one R1 rank shard -- ms per layer, and
+the MFMA fraction (of the dense 2.5 PFLOP/s peak) of the MLA causal attention kernel and of the tiled fp8 GEMMs alone.
 
 `graph_verified` (round 4): every timed hipGraph is replayed once more after its timed loop against the EAGER launches of the
 same step on the same state (tokens, lengths, block table; the KV row at position L is rewritten with the same bytes) and
@@ -801,6 +802,112 @@ def v2_lite_extra(steps, warmup, ctx):
     return out
 
 
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 = non-scaled fp8 MFMA peak
+
+
+def prefill_extra(prompt_tokens=2048, n_moe_layers=6):
+    """SURVEY 8f.1 as an extra object: ONE prompt of `prompt_tokens` tokens through `DeepSeekV3Decoder.prefill` of an R1 TP=8
+    rank shard (3 dense + `n_moe_layers` MoE layers at the true per-layer shapes; eager launches, as the reference's prefill is),
+    per-layer time from HIP events around every layer; then the two MFMA-bound kernel families alone, each against the dense
+    2.5 PFLOP/s bf16 / non-scaled fp8 peak: the MLA causal attention (chitu_hip_mla_prefill_flash; FLOPs = 2 x 16 heads x
+    T(T+1)/2 pairs x (576 + 512) MACs) and the tiled block-scaled fp8 GEMMs of one layer at M = T (2 M N K each).  The
+    bit-exact attention kernel (CHITU_MLA_PREFILL=exact) is timed beside it."""
+    from chitu_amd import ops
+    from chitu_amd.attn_backend import HipAttnBackend
+    from chitu_amd.cache_manager import PagedKVCacheManager
+    from chitu_amd.deepseek_v3 import DeepSeekV3Args, DeepSeekV3Decoder, init_synthetic_
+
+    T = prompt_tokens
+    args = DeepSeekV3Args(shard_degree=SHARD, n_layers=3 + n_moe_layers)
+    max_seq = T + 64
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=2, block_size=64, max_seq_len=max_seq, device="cuda",
+                                kv_shape_per_sample=(576,), dtype=torch.bfloat16)
+    be = HipAttnBackend(local_n_heads=args.n_heads // SHARD, max_seq_len=max_seq)
+    model = DeepSeekV3Decoder(args, cache, be, max_position_embeddings=max(max_seq, 4097), device="cuda")
+    init_synthetic_(model, seed=11)
+    g = torch.Generator().manual_seed(0)
+    prompt = torch.randint(100, 1000, (T,), generator=g).tolist()
+    marks = []
+
+    def pre(_m, _i):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append(e)
+
+    hooks = [layer.register_forward_pre_hook(pre) for layer in model.layers]
+    best_total, best_layers = None, None
+    for rep in range(4):
+        marks.clear()
+        rid = f"pf{rep}"
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.prefill([prompt], [rid])
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+        cache.finalize_cache_all_decode(rid)
+        ev = marks + [end]  # the last interval also holds the final norm + head GEMM of ONE row: negligible
+        per = [ev[i].elapsed_time(ev[i + 1]) for i in range(len(ev) - 1)]
+        if rep and (best_total is None or total < best_total):
+            best_total, best_layers = total, per
+    for h in hooks:
+        h.remove()
+    dense_ms = sum(best_layers[:3]) / 3
+    moe_ms = sorted(best_layers[3:])[len(best_layers[3:]) // 2]  # median MoE layer
+    out = {"workload": f"DeepSeek-R1 FP8 TP=8 rank shard, one {T}-token prompt, eager prefill, 3 dense + {n_moe_layers} MoE layers",
+           "ms_per_moe_layer": round(moe_ms, 4), "ms_per_dense_layer": round(dense_ms, 4),
+           "rank_prompt_tok_s_at_61_layers": round(T / ((3 * dense_ms + 58 * moe_ms) * 1e-3), 1)}
+    del model, cache
+    torch.cuda.empty_cache()
+
+    def time_us(fn, n=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+
+    gd = torch.Generator(device="cuda").manual_seed(5)
+    q = (torch.randn(T, 16, 576, device="cuda", generator=gd) * 0.3).to(torch.bfloat16)
+    kv = torch.randn(T, 1, 576, device="cuda", generator=gd).to(torch.bfloat16)
+    cu = torch.tensor([0, T], dtype=torch.int32, device="cuda")
+    flop = 2.0 * 16 * (T * (T + 1) / 2) * (576 + 512)
+    prev = os.environ.get("CHITU_MLA_PREFILL")
+    att = {}
+    for mode in ("flash", "exact"):
+        os.environ["CHITU_MLA_PREFILL"] = mode
+        us = time_us(lambda: be.attn_varlen_func(q, kv, kv[..., :512], cu, cu, T, T, causal=True, softmax_scale=0.1352))
+        att[mode] = {"us": round(us, 1), "TFLOPs": round(flop / us * 1e-6, 1), "frac": round(flop / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
+    if prev is None:
+        os.environ.pop("CHITU_MLA_PREFILL", None)
+    else:
+        os.environ["CHITU_MLA_PREFILL"] = prev
+    out["attention"] = {"kernel": "chitu::mla_prefill_flash_kernel", "bound": "mfma", "peak_TFLOPs": MFMA_PEAK_TFLOPS,
+                        "GFLOP": round(flop * 1e-9, 2), **att["flash"], "exact_kernel": att["exact"]}
+    gemms, tot_flop, tot_us = {}, 0.0, 0.0
+    for name, (N, K) in {"wqkv_a": (2112, 7168), "wq_b": (3072, 1536), "wo": (7168, 2048), "shared_w1w3": (512, 7168),
+                         "shared_w2": (7168, 256), "dense_w1w3": (4608, 7168), "dense_w2": (7168, 2304)}.items():
+        x = (torch.randn(T, K, device="cuda", generator=gd)).to(torch.bfloat16)
+        xq, xs = ops.act_quant_deepseek_v3(x)
+        w = (torch.randn(N, K, device="cuda", generator=gd) * 0.5).to(torch.float8_e4m3fn)
+        ws = torch.rand((N + 127) // 128, (K + 127) // 128, device="cuda", generator=gd) * 0.02 + 0.01
+        us = time_us(lambda: ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.bfloat16))
+        f = 2.0 * T * N * K
+        gemms[name] = {"N": N, "K": K, "us": round(us, 1), "TFLOPs": round(f / us * 1e-6, 1), "frac": round(f / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
+        if not name.startswith("dense"):
+            tot_flop += f
+            tot_us += us
+    out["fp8_gemm_tiled"] = {"kernel": "chitu::fp8_gemm_tiled_kernel", "bound": "mfma", "peak_TFLOPs": MFMA_PEAK_TFLOPS, "M": T,
+                             "moe_layer_dense_gemms_TFLOPs": round(tot_flop / tot_us * 1e-6, 1),
+                             "moe_layer_dense_gemms_frac": round(tot_flop / tot_us * 1e-6 / MFMA_PEAK_TFLOPS, 4), "shapes": gemms}
+    return out
+
+
 def ep8_rank_extra(steps, warmup, ctx, moe_rank=0):
     """ONE rank of an expert-parallel R1 deployment (the reference only stubs it, fused_moe.py:163-179,
     model_deepseek_v3.py:870-871, 1004) -- attention at 1/8 of the heads as in the TP=8 shard, routed experts
@@ -982,6 +1089,7 @@ def main():
         extra["v2_lite"] = v2_lite_extra(a.steps, a.warmup, a.ctx)
         extra["mixtral_8x7b_int8"] = mixtral_extra(a.steps, a.warmup, a.ctx)
         extra["ep8_rank"] = ep8_rank_extra(a.steps, a.warmup, a.ctx)
+        extra["prefill"] = prefill_extra()
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         model = cache = None

@@ -191,11 +191,13 @@ class HipAttnBackend(AttnBackend):
         q [T, H, C+R], k [T, 1, C+R] = [kv_norm(kv_c) | rope(k_pe)], v [T, 1, C] = the latent part of k
         (the MLA identity -- v is NOT read, k[..., :C] is used), cu_seqlens_q == cu_seqlens_k.
 
-        chitu_hip_mla_prefill: the decode kernel's tile machinery with four query tokens per workgroup
-        sharing every staged 64-key tile; per query token the arithmetic is the decode step's, so prefill
-        and token-by-token decode agree.  CHITU_MLA_PREFILL=compose selects the kernel-free composition
-        instead (keys staged into 64-token pages, every query token run as one decode "sequence" over
-        them) -- the same result bit for bit, KV re-read once per token; kept as the cross-check.
+        chitu_hip_mla_prefill_flash (default): 128 Q rows (8 tokens x 16 heads) per workgroup against every 64-key tile,
+        32x32x16 MFMA, Q in registers -- within the attention bar of the decode kernel, not bit for bit.
+        CHITU_MLA_PREFILL=exact: chitu_hip_mla_prefill, the decode kernel's tile machinery with four query tokens per
+        workgroup; per query token the arithmetic is the decode step's, so prefill and token-by-token decode agree bit
+        for bit (3x slower at 2048 tokens; the cross-check).  CHITU_MLA_PREFILL=compose: the kernel-free composition
+        (keys staged into 64-token pages, every query token run as one decode "sequence" over them) -- equal to "exact"
+        bit for bit, KV re-read once per token.
         No host sync; not graph-captured (prefill never is, model.py:538-546)."""
         assert causal and dropout_p == 0.0 and tuple(window_size) == (-1, -1) and softcap == 0.0
         require_cuda(q, k, cu_seqlens_q, cu_seqlens_k)
@@ -212,17 +214,16 @@ class HipAttnBackend(AttnBackend):
         if T == 0:
             return q.new_empty(0, H, C)
         dev = q.device
-        if os.environ.get("CHITU_MLA_PREFILL", "kernel") != "compose":
+        mode = os.environ.get("CHITU_MLA_PREFILL", "flash")
+        assert mode in ("flash", "exact", "compose"), mode
+        if mode != "compose":
             kq = q if (q.stride(-1) == 1 and q.stride(0) % 8 == 0 and q.stride(1) % 8 == 0 and q.data_ptr() % 16 == 0) else q.contiguous()
             kk = k.reshape(T, Dq)
             if not (kk.stride(-1) == 1 and kk.stride(0) % 8 == 0 and kk.data_ptr() % 16 == 0):
                 kk = kk.contiguous()
             cu32 = cu_seqlens_k.to(device=dev, dtype=torch.int32).contiguous()
             out = torch.empty(T, H, C, dtype=torch.bfloat16, device=dev)
-            # CHITU_MLA_PREFILL=tiled: the one-query-token-per-wave kernel (round 4; equal within the attention bar, not bit for
-            # bit with the decode kernel -- opt-in until it has been through the GPU suite)
-            entry = (_lib.lib().chitu_hip_mla_prefill_tiled if os.environ.get("CHITU_MLA_PREFILL") == "tiled"
-                     else _lib.lib().chitu_hip_mla_prefill)
+            entry = _lib.lib().chitu_hip_mla_prefill_flash if mode == "flash" else _lib.lib().chitu_hip_mla_prefill
             check(
                 entry(
                     ptr(kq), i64(kq.stride(0)), i64(kq.stride(1)), ptr(kk), i64(kk.stride(0)), ptr(cu32),

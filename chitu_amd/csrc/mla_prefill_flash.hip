@@ -62,14 +62,15 @@ __device__ __forceinline__ void glds16_vaddr(const void* gsrc, uint32_t lds_dst)
                  : "memory");
 }
 
-// ---- the 32 x 512 fp32 accumulator lives in a[0:255], named literally: hipcc's allocator, given 400 live registers in a
-// 512-register kernel, shuttles the accumulator between the two register files every tile (1040 v_accvgpr moves and 184
-// scratch accesses per tile in the builtin form of this kernel).  The compiler therefore sees a 256-VGPR kernel whose PV
-// MFMAs, accumulator zeroing / rescale / read-out are asm statements on fixed AGPRs; acc_reserve()'s clobber list makes
-// the kernel descriptor allocate them.  Invariant (checked by tools/check_flash_asm.py on the -save-temps output): no
-// compiler-generated v_accvgpr_* and no scratch access in this kernel -- a compiler spill into a[] would be silent corruption.
-// Hazards hipcc does not pad inside asm (guide 5.7): VALU-written operand -> MFMA (s_nop 1), MFMA result -> v_accvgpr_read
-// (acc_settle), v_accvgpr_write -> MFMA SrcC (s_nop 3 after a rescale).
+// ---- the 32 x 512 fp32 accumulator is pinned to the AGPR file through "+a" asm operands.  With the MFMA builtins hipcc's
+// allocator, given 400 live registers in a 512-register kernel, shuttles the accumulator between the two register files every
+// tile (1040 v_accvgpr moves and 184 scratch accesses per tile in the builtin form of this kernel).  Here every PV MFMA is an
+// asm statement whose accumulator operand is constrained to "a": the 16 tiles stay where they are for the whole loop and the
+// compiler is left with a 256-VGPR problem (Q 144, S 16, fragments, addresses) that it solves without a spill;
+// tests/test_flash_asm_audit.py compiles this file and checks exactly that (no scratch, no spill, no v_accvgpr_* in the tile
+// loop outside the rescale branch).  Volatile asm pins memory operations, so the V^T fragment reads are pipelined by hand.
+// Hazards hipcc does not pad around asm (guide 5.7): VALU-written operand -> MFMA (s_nop 1), MFMA result -> v_accvgpr_read /
+// VALU read (acc_settle, s_settle), v_accvgpr_write -> MFMA SrcC (s_nop 3 after a rescale).
 __device__ __forceinline__ void acc_settle(f32x16& o) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o)); }
 // S accumulation in the VGPR form of the instruction (hipcc's builtin insists on an AGPR destination and evicts an O tile
 // for it every key block); plain (non-volatile) asm: scheduled like any pure value computation.  s_settle: the 8-pass MFMA
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_flash_kernel(
 }  // namespace chitu
 
 // The contract of chitu_hip_mla_prefill on mla_prefill_flash_kernel: equal to it within the attention bar, not bit for bit.
-extern "C" int chitu_hip_mla_prefill_tiled(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
+extern "C" int chitu_hip_mla_prefill_flash(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
                                            int64_t kv_stride_t, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
                                            float softmax_scale, void* out_bf16, int32_t heads, int32_t kv_lora_rank,
                                            int32_t rope_dim, void* stream) {

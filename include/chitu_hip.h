@@ -429,11 +429,12 @@ int chitu_hip_mla_prefill(const void* q_bf16, int64_t q_stride_t, int64_t q_stri
                           int64_t kv_stride_t, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
                           float softmax_scale, void* out_bf16, int32_t heads, int32_t kv_lora_rank,
                           int32_t rope_dim, void* stream);
-/* The same contract (attn_varlen_func for the absorb-mode MQA shape, model_deepseek_v3.py:589-599; attn_backend.py:39-90) on
- * the one-query-token-per-wave kernel: S^T = K Q^T with Q in registers, softmax wave-local, P V from registers -- two
- * workgroup barriers per 64-key tile instead of fourteen.  Equal to chitu_hip_mla_prefill within the attention bar (1e-2 of
- * the peak), not bit for bit (another summation order than the decode kernel's). */
-int chitu_hip_mla_prefill_tiled(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
+/* The same contract (attn_varlen_func for the absorb-mode MQA shape, model_deepseek_v3.py:589-599; attn_backend.py:39-90;
+ * the reference runs it on third-party flash_attn) on the flash kernel: 8 query tokens x 16 heads = 128 Q rows per workgroup,
+ * S^T = K Q^T with Q in registers, in-lane softmax with deferred rescale, O^T = V^T P^T accumulated in the AGPR file, 64-key
+ * tiles by LDS-DMA.  Equal to chitu_hip_mla_prefill within the attention bar (1e-2 of the peak), not bit for bit.
+ * All three base pointers 16-byte aligned. */
+int chitu_hip_mla_prefill_flash(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
                           int64_t kv_stride_t, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
                           float softmax_scale, void* out_bf16, int32_t heads, int32_t kv_lora_rank,
                           int32_t rope_dim, void* stream);

@@ -1,51 +1,69 @@
 #!/usr/bin/env python3
-"""Audit of the kernels whose accumulators live in literally named AGPRs (csrc/mla_prefill_flash.hip, ...):
-python tools/check_flash_asm.py <file.s> [kernel-name-substring ...]
-The compiler must not touch the accumulator file in them: no v_accvgpr_* / a[...] operand outside ;;#ASMSTART..;;#ASMEND,
-no scratch access, .vgpr_spill_count 0, .private_segment_fixed_size 0.  Exit status 1 on a violation."""
+"""Audit of the gfx950 assembly of a kernel that pins its MFMA accumulators to the AGPR file through asm operands
+(csrc/mla_prefill_flash.hip): python tools/check_flash_asm.py <file.s> <kernel-name-substring> [max_accvgpr_in_loop]
+Checks, for every kernel whose mangled name contains the substring:
+  * .private_segment_fixed_size 0 and .vgpr_spill_count 0 (no scratch: a spill in a one-wave-per-SIMD MFMA loop is the
+    3x slowdown this structure exists to avoid), no scratch_* instruction;
+  * .agpr_count 256 (the accumulator really is in the AGPR file);
+  * no basic block that holds >= 16 MFMAs (the QK and PV phases of a key block) moves accumulator registers
+    (v_accvgpr_* count <= `max_accvgpr_in_loop`, default 0): the only accumulator traffic is the rare rescale branch, the
+    zero fill and the read-out.
+Exit status 1 on a violation."""
 import re
 import sys
 
 
-def audit(path, names):
-    text = open(path).read().splitlines()
-    bad = []
-    kernel, in_asm = None, False
-    seen = set()
-    for ln, line in enumerate(text, 1):
+def kernels(text, name):
+    cur, body = None, []
+    for line in text.splitlines():
         m = re.match(r"^(_Z\w+):", line)
         if m:
-            kernel = m.group(1) if any(n in m.group(1) for n in names) else None
-            if kernel:
-                seen.add(kernel)
-        if kernel is None:
-            continue
-        if line.strip().startswith(".Lfunc_end"):
-            kernel = None
-            continue
-        if ";;#ASMSTART" in line:
-            in_asm = True
-        elif ";;#ASMEND" in line:
-            in_asm = False
-        elif not in_asm:
-            code = line.split(";")[0]
-            if re.search(r"\bv_accvgpr|\ba\[?\d+|scratch_", code):
-                bad.append((ln, line.strip()))
-    meta = "\n".join(text)
-    for n in names:
-        for m in re.finditer(r"\.name:\s+(\S*%s\S*)\n(?:.*\n){0,40}?" % re.escape(n), meta):
-            pass
-    for m in re.finditer(r"\.private_segment_fixed_size:\s*(\d+)\n(?:.*\n){0,12}?\s*\.symbol:\s*(\S+)\.kd(?:.*\n){0,12}?\s*\.vgpr_spill_count:\s*(\d+)", meta):
-        if any(n in m.group(2) for n in names) and (int(m.group(1)) or int(m.group(3))):
-            bad.append((0, f"{m.group(2)}: private_segment {m.group(1)} vgpr_spill {m.group(3)}"))
+            cur, body = (m.group(1), []) if name in m.group(1) else (None, [])
+        if cur is not None:
+            body.append(line)
+            if line.strip().startswith(".Lfunc_end"):
+                yield cur, body
+                cur = None
+
+
+def audit(path, name, max_acc=0):
+    text = open(path).read()
+    bad, seen = [], []
+    for k, body in kernels(text, name):
+        seen.append(k)
+        code = [ln.split(";")[0] for ln in body]
+        if any("scratch_" in c for c in code):
+            bad.append(f"{k}: scratch access")
+        # basic blocks (split at labels and branches): one that holds MFMAs must not move accumulator registers
+        blocks, cur = [], []
+        for c in code:
+            if re.match(r"^\.LBB", c.strip()) or "s_cbranch" in c or "s_branch" in c:
+                blocks.append(cur)
+                cur = []
+            cur.append(c)
+        blocks.append(cur)
+        n_mfma_blocks = 0
+        for b in blocks:
+            n_mfma, n_acc = sum("v_mfma" in c for c in b), sum("v_accvgpr" in c for c in b)
+            if n_mfma >= 16:
+                n_mfma_blocks += 1
+                if n_acc > max_acc:
+                    bad.append(f"{k}: a basic block with {n_mfma} MFMAs also has {n_acc} v_accvgpr_* moves")
+        if n_mfma_blocks < 2:
+            bad.append(f"{k}: expected the QK and PV MFMA blocks, found {n_mfma_blocks} blocks with >= 16 MFMAs")
+    for m in re.finditer(r"\.agpr_count:\s*(\d+)(?:.*\n)*?.*?\.name:\s*(\S+)(?:.*\n)*?.*?\.private_segment_fixed_size:\s*(\d+)(?:.*\n)*?.*?\.vgpr_spill_count:\s*(\d+)", text):
+        agpr, kname, priv, spill = int(m.group(1)), m.group(2), int(m.group(3)), int(m.group(4))
+        if name in kname:
+            if agpr != 256 or priv or spill:
+                bad.append(f"{kname}: agpr_count {agpr} private_segment {priv} vgpr_spill {spill}")
+    if not seen:
+        bad.append(f"no kernel matching {name!r} in {path}")
     return seen, bad
 
 
 if __name__ == "__main__":
-    path = sys.argv[1]
-    names = sys.argv[2:] or ["flash"]
-    seen, bad = audit(path, names)
-    print("audited:", sorted(seen))
-    for ln, line in bad:
-        print(f"VIOLATION line {ln}: {line}")
-    sys.exit(1 if bad or not seen else 0)
+    seen, bad = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "flash", int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+    print("audited:", seen)
+    for b in bad:
+        print("VIOLATION:", b)
+    sys.exit(1 if bad else 0)

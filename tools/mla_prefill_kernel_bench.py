@@ -31,8 +31,8 @@ def main():
             q = (torch.randn(T, H, 576, generator=g) * 0.3).to(torch.bfloat16).cuda()
             kv = torch.randn(T, 1, 576, generator=g).to(torch.bfloat16).cuda()
             b = HipAttnBackend(local_n_heads=H)
-            a = run(b, "kernel", q, kv, cu, max(seqs)).float().cpu()
-            f = run(b, "tiled", q, kv, cu, max(seqs)).float().cpu()
+            a = run(b, "exact", q, kv, cu, max(seqs)).float().cpu()
+            f = run(b, "flash", q, kv, cu, max(seqs)).float().cpu()
             ref = omla.mla_prefill(q.cpu(), kv.cpu()[:, 0], cu.cpu(), 0.1352).float()
             pk = ref.abs().max().item()
             print(json.dumps({"H": H, "seqs": seqs, "finite": bool(torch.isfinite(f).all()),
@@ -46,7 +46,7 @@ def main():
         q = (torch.randn(T, 16, 576, generator=g) * 0.3).to(torch.bfloat16).cuda()
         kv = torch.randn(T, 1, 576, generator=g).to(torch.bfloat16).cuda()
         flop = 2 * 16 * (T * (T + 1) / 2) * (576 + 512)
-        for mode in ("kernel", "tiled"):
+        for mode in ("exact", "flash"):
             for _ in range(3):
                 run(be, mode, q, kv, cu, T)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
