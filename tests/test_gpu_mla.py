@@ -232,7 +232,7 @@ def test_prefill_varlen_matches_reference_fixture_and_oracle():
         o = be.mla_decode(q[s1 - 1 : s1, :, :512].contiguous().cuda(), q[s1 - 1 : s1, :, 512:].contiguous().cuda(), cache.cuda(),
                           torch.tensor([n], dtype=torch.int32).cuda(), torch.arange(pages, dtype=torch.int32).view(1, -1).cuda(),
                           0.1352, num_splits=1)
-        assert_close(o.cpu(), out[s1 - 1 : s1], 5e-3)  # flash prefill vs the decode kernel: another summation order
+        assert_close(o.cpu(), out[s1 - 1 : s1], REL_TOL)  # flash prefill vs the decode kernel: one row's peak, 1-2 bf16 ulps of it
 
 
 def test_prefill_kernel_equals_per_token_decode_composition(monkeypatch):
