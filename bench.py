@@ -890,8 +890,9 @@ def prefill_extra(prompt_tokens=2048, n_moe_layers=6):
     out["attention"] = {"kernel": "chitu::mla_prefill_flash_kernel", "bound": "mfma", "peak_TFLOPs": MFMA_PEAK_TFLOPS,
                         "GFLOP": round(flop * 1e-9, 2), **att["flash"], "exact_kernel": att["exact"]}
     gemms, tot_flop, tot_us = {}, 0.0, 0.0
-    for name, (N, K) in {"wqkv_a": (2112, 7168), "wq_b": (3072, 1536), "wo": (7168, 2048), "shared_w1w3": (512, 7168),
-                         "shared_w2": (7168, 256), "dense_w1w3": (4608, 7168), "dense_w2": (7168, 2304)}.items():
+    # (the shared expert is a slot of the grouped expert GEMMs, not a dense GEMM: MoEDeepSeekV3.forward)
+    for name, (N, K) in {"wqkv_a": (2112, 7168), "wq_b": (3072, 1536), "wo": (7168, 2048), "dense_w1w3": (4608, 7168),
+                         "dense_w2": (7168, 2304)}.items():
         x = (torch.randn(T, K, device="cuda", generator=gd)).to(torch.bfloat16)
         xq, xs = ops.act_quant_deepseek_v3(x)
         w = (torch.randn(N, K, device="cuda", generator=gd) * 0.5).to(torch.float8_e4m3fn)

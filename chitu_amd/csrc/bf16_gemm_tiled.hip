@@ -14,14 +14,15 @@
 namespace chitu {
 
 constexpr int kBTile = 128;
-constexpr int kBLdsRow = 128 + 16;  // bytes per staged row (64 bf16 + pad)
+constexpr int kBLdsRow = 128 + 32;  // bytes per staged row (64 bf16 + pad: conflict-free under ds_read_b128's lane groups, fp8_gemm_tiled.hip)
 
 struct BTileRegs {
     i32x4 w[4], x[4];
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bf16_gemm_tiled_kernel(
-    const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ out, int out_dt, int M, int N, int K) {
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ out, int out_dt, int M, int N, int K,
+    float* __restrict__ partials) {
     __shared__ __attribute__((aligned(16))) uint8_t sW[2][kBTile * kBLdsRow];
     __shared__ __attribute__((aligned(16))) uint8_t sX[2][kBTile * kBLdsRow];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -29,15 +30,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int j = lane & 15, g = lane >> 4;
     const int wn = wave & 1, wm = wave >> 1;
     const int n0 = blockIdx.x * kBTile, m0 = blockIdx.y * kBTile;
-    const int KB = K >> 6;  // blocks of 64 elements = 128 bytes
+    // split-K (gridDim.z > 1): this workgroup's share of the 64-element K blocks; its fp32 tile goes to plane blockIdx.z of
+    // `partials` [S][M][N] for the consumer to sum in plane order (chitu_hip_gate_route(num_partials)).  The router's score
+    // GEMM of a 2048-token prompt is 32 tiles of 112 K blocks: one workgroup per tile leaves 7/8 of the CUs idle and
+    // is a ~1 us-per-block dependent chain (107 us, profiles/r05_*); 8 planes = 256 workgroups of 14 blocks.
+    const int KB_all = K >> 6;  // blocks of 64 elements = 128 bytes
+    const int S = gridDim.z, per = (KB_all + S - 1) / S;
+    const int kb0 = blockIdx.z * per, KB = min(per, KB_all - kb0);
+    if (KB <= 0 && S > 1) {
+        // (an empty share still owns its plane: zero it)
+        for (int idx = threadIdx.x; idx < kBTile * kBTile; idx += 256) {
+            const int m = m0 + idx / kBTile, n = n0 + idx % kBTile;
+            if (m < M && n < N) partials[((size_t)blockIdx.z * M + m) * N + n] = 0.f;
+        }
+        return;
+    }
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;  // 8 bf16 = 16 bytes
     const bf16_t* wg[4];
     const bf16_t* xg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        wg[i] = W + (size_t)min(n0 + srow + 32 * i, N - 1) * K + scol;
-        xg[i] = X + (size_t)min(m0 + srow + 32 * i, M - 1) * K + scol;
+        wg[i] = W + (size_t)min(n0 + srow + 32 * i, N - 1) * K + scol + (size_t)kb0 * 64;
+        xg[i] = X + (size_t)min(m0 + srow + 32 * i, M - 1) * K + scol + (size_t)kb0 * 64;
     }
     auto fetch = [&](BTileRegs& r, int kb) {
         const int off = kb << 6;
@@ -103,8 +118,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int n = n0 + wn * 64 + nt * 16 + 4 * g;
             if (n >= N) continue;
             const f32x4 v = acc[nt][mt];
-            if (out_dt == 2) {
-                float* dst = (float*)out + (size_t)m * N + n;
+            if (S > 1 || out_dt == 2) {
+                float* dst = (S > 1 ? partials + (size_t)blockIdx.z * M * N : (float*)out) + (size_t)m * N + n;
                 if (n + 3 < N && (N & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
                 else
                     for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = v[r];
@@ -128,9 +143,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // chitu_hip_bf16_gemm's large-M form (declared in gemm_common.h, called from gate.hip)
 void launch_bf16_gemm_tiled(const bf16_t* x, const bf16_t* w, void* out, int out_dt, int64_t M, int64_t N, int64_t K,
-                            hipStream_t st) {
-    const dim3 grid((unsigned)((N + kBTile - 1) / kBTile), (unsigned)((M + kBTile - 1) / kBTile));
-    hipLaunchKernelGGL(bf16_gemm_tiled_kernel, grid, dim3(256), 0, st, x, w, out, out_dt, (int)M, (int)N, (int)K);
+                            int num_splits, float* partials, hipStream_t st) {
+    const dim3 grid((unsigned)((N + kBTile - 1) / kBTile), (unsigned)((M + kBTile - 1) / kBTile), (unsigned)num_splits);
+    hipLaunchKernelGGL(bf16_gemm_tiled_kernel, grid, dim3(256), 0, st, x, w, out, out_dt, (int)M, (int)N, (int)K, partials);
 }
 
 }  // namespace chitu

@@ -9,9 +9,12 @@
 //
 //   workgroup = 128 weight rows x 128 tokens, 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles
 //   (v_mfma_f32_16x16x32_fp8_fp8, weights = A operand, tokens = B operand, as in the decode kernels);
-//   K advances in the quantisation's own 128-wide blocks: both operand tiles (16 KB each) go global -> registers ->
-//   LDS (rows padded to 144 B: the 16 rows a wave-load touches start in 16 different bank groups), double-buffered,
-//   the next block's global loads in flight while the current one is multiplied; per block every 16 x 16 tile is a
+//   K advances in the quantisation's own 128-wide blocks: both operand tiles (16 KB each) go global -> LDS by LDS-DMA
+//   (global_load_lds_dwordx4, lds_dma.h: no staging registers, no ds_write pass -- rounds 2-4 staged through registers and
+//   the ds_write_b128 stream of two resident workgroups alone took ~830 LDS cycles per K block against 1024 MFMA cycles),
+//   rows unpadded with the 16-byte chunks XOR-permuted on the source side (conflict-free under ds_read_b128's lane groups;
+//   the 144-B padded rows of rounds 2-4 measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33), double-buffered: block
+//   kb + 1 lands while block kb is multiplied.  Per block every 16 x 16 tile is a
 //   fresh 4-MFMA dot that is folded in as (dot * a_s[token]) * b_s -- the reference's order (triton_kernels.py:357);
 //   b_s is one scalar per workgroup and block (128-row tiles are scale-block aligned), a_s one value per lane and
 //   token tile.
@@ -19,6 +22,7 @@
 // 16 ds_read_b128 and ~130 VALU instructions of scale folding.
 #include "common.h"
 #include "gemm_common.h"
+#include "lds_dma.h"
 
 namespace chitu {
 
@@ -26,10 +30,9 @@ namespace chitu {
 #define CHITU_TILED_XCD 1  // 0: row-major tile order (A/B builds, tools/build_variant.sh)
 #endif
 constexpr int kTileN = 128, kTileM = 128, kTileK = 128;
-constexpr int kLdsRow = kTileK + 16;  // bytes per staged row
+constexpr int kTileBytes = 128 * kTileK;  // one operand tile of one K block in LDS
 
-struct TileRegs {
-    i32x4 w[4], x[4];
+struct TileScales {
     float xs[4];
     float ws;
 };
@@ -37,8 +40,8 @@ struct TileRegs {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fp8_gemm_tiled_kernel(
     const fp8_t* __restrict__ X, const float* __restrict__ XS, const fp8_t* __restrict__ W, const float* __restrict__ WS,
     void* __restrict__ out, int out_dt, int M, int N, int K) {
-    __shared__ __attribute__((aligned(16))) uint8_t sW[2][kTileN * kLdsRow];
-    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kTileM * kLdsRow];
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][kTileBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kTileBytes];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -52,39 +55,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
     const int KB = K >> 7;
 
-    // staging role: thread t moves 16 B of rows (t / 8) + 32 i at byte (t % 8) * 16, i < 4, of both tiles
-    const int srow = tid >> 3, scol = (tid & 7) * 16;
-    const fp8_t* wg[4];
-    const fp8_t* xg[4];
+    // staging role: wave w brings rows 32 w .. 32 w + 31 of both tiles, four 8-row pieces each (lds_dma.h: lane i -> row
+    // 8 n + (i >> 3), source chunk kblock_src_chunk); byte offsets from the tiles' first rows, rows past the matrix re-read
+    // its last row (never stored)
+    uint32_t woff[4], xoff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        wg[i] = W + (size_t)min(n0 + srow + 32 * i, N - 1) * K + scol;
-        xg[i] = X + (size_t)min(m0 + srow + 32 * i, M - 1) * K + scol;
+        const int n = wave * 4 + i, r = n * 8 + (lane >> 3), c = kblock_src_chunk(lane, n);
+        woff[i] = (uint32_t)(min(r, N - 1 - n0) * K + c * 16);
+        xoff[i] = (uint32_t)(min(r, M - 1 - m0) * K + c * 16);
     }
+    const fp8_t* wbase = W + (size_t)n0 * K;
+    const fp8_t* xbase = X + (size_t)m0 * K;
+    const uint32_t ldsW = lds_offset_of(&sW[0][0]), ldsX = lds_offset_of(&sX[0][0]);
+    auto issue = [&](int kb) {
+        const uint32_t dst = (uint32_t)((kb & 1) * kTileBytes + wave * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16_sbase(wbase + (size_t)kb * 128, woff[i], ldsW + dst + i * 1024);
+            glds16_sbase(xbase + (size_t)kb * 128, xoff[i], ldsX + dst + i * 1024);
+        }
+    };
     // the token of this lane's column in each of the wave's 4 token tiles: its per-block activation scale
     const float* xsp[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) xsp[mt] = XS + (size_t)min(m0 + wm * 64 + mt * 16 + j, M - 1) * KB;
     const float* wsp = WS + (size_t)(n0 >> 7) * KB;
-
-    auto fetch = [&](TileRegs& r, int kb) {
-        const int off = kb << 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r.w[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wg[i] + off));
-            r.x[i] = *reinterpret_cast<const i32x4*>(xg[i] + off);
-        }
+    auto fetch_scales = [&](TileScales& r, int kb) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) r.xs[mt] = xsp[mt][kb];
         r.ws = wsp[kb];
     };
-    auto stage = [&](const TileRegs& r, int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<i32x4*>(&sW[buf][(srow + 32 * i) * kLdsRow + scol]) = r.w[i];
-            *reinterpret_cast<i32x4*>(&sX[buf][(srow + 32 * i) * kLdsRow + scol]) = r.x[i];
-        }
-    };
+    const int foff = kblock_frag_off(j, g);  // this lane's fragment inside a 16-row tile (second half: ^ 64)
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -92,27 +94,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    TileRegs cur, nxt;
-    fetch(cur, 0);
-    stage(cur, 0);
+    TileScales cur, nxt;
+    issue(0);
+    fetch_scales(cur, 0);
+    glds_wait_all();
     __syncthreads();
     for (int kb = 0; kb < KB; ++kb) {
         const int buf = kb & 1;
-        if (kb + 1 < KB) fetch(nxt, kb + 1);
-        // fragments: lane (j, g) takes bytes [g*16, g*16+16) of both 64-byte halves of row j of each tile -- the same
-        // k subset for the weight rows and the token rows, which is all the dot product needs
+        if (kb + 1 < KB) {  // the other buffer was last read one step ago, before the barrier that closed it
+            issue(kb + 1);
+            fetch_scales(nxt, kb + 1);
+        }
+        // fragments: lane (j, g) takes chunks g and g + 4 of row j of each tile -- the same k subset for the weight rows and
+        // the token rows, which is all the dot product needs
         i32x4 wa[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const uint8_t* wr = &sW[buf][(wn * 64 + t * 16 + j) * kLdsRow + g * 16];
-            wa[t][0] = *reinterpret_cast<const i32x4*>(wr);
-            wa[t][1] = *reinterpret_cast<const i32x4*>(wr + 64);
+            const uint8_t* wr = &sW[buf][(wn * 64 + t * 16) * 128];
+            wa[t][0] = *reinterpret_cast<const i32x4*>(wr + foff);
+            wa[t][1] = *reinterpret_cast<const i32x4*>(wr + (foff ^ 64));
         }
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16 + j) * kLdsRow + g * 16];
-            const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr), xb1 = *reinterpret_cast<const i32x4*>(xr + 64);
+            const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16) * 128];
+            const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr + foff), xb1 = *reinterpret_cast<const i32x4*>(xr + (foff ^ 64));
             const float sc = cur.xs[mt];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -124,11 +130,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * cur.ws;
             }
         }
-        if (kb + 1 < KB) {
-            stage(nxt, buf ^ 1);
-            cur = nxt;
-        }
-        __syncthreads();
+        if (kb + 1 < KB) cur = nxt;
+        glds_wait_all();  // block kb + 1 has landed (this wave's pieces) ...
+        __syncthreads();  // ... and everyone's; block kb's buffer is free
     }
 
     // C tile (nt, mt): lane holds weight rows n = 4g .. 4g+3 of token column j -> 4 consecutive outputs of one token

@@ -187,7 +187,7 @@ void launch_fp8_gemm_tiled(const fp8_t* a, const float* a_s, const fp8_t* b, con
 
 // The same for bf16 weights (router scores, unquantised linears) at prefill-sized M.  Defined in bf16_gemm_tiled.hip.
 void launch_bf16_gemm_tiled(const bf16_t* x, const bf16_t* w, void* out, int out_dt, int64_t M, int64_t N, int64_t K,
-                            hipStream_t st);
+                            int num_splits, float* partials, hipStream_t st);
 
 // out[m][n] = sum_s partial[s][m][n] (s ascending), cast to out_dt.  Defined in fp8_gemm.hip.
 void launch_splitk_reduce(const float* partial, void* out, int out_dt, int S, int64_t MN, hipStream_t st);

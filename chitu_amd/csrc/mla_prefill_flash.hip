@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "lds_dma.h"
 
 namespace chitu {
 
@@ -43,24 +44,6 @@ constexpr float kDefer = 8.0f;           // deferred-rescale threshold (exp2 dom
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_ff;
-
-// One 1 KiB LDS-DMA piece: lane i's 16 bytes at (sbase + voff_i) land at LDS byte lds_dst + 16 i.  The compiler does not
-// count it (asm): the kernel waits with its own s_waitcnt vmcnt(0) ahead of the tile barrier.  s_nop 4: an SGPR written
-// by VALU (readfirstlane) feeding a VMEM address; s_nop 0: M0 written by SALU feeding the LDS-DMA.
-__device__ __forceinline__ void glds16_sbase(const void* sbase, uint32_t voff, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
-}
-__device__ __forceinline__ void glds16_vaddr(const void* gsrc, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
 
 // ---- the 32 x 512 fp32 accumulator is pinned to the AGPR file through "+a" asm operands.  With the MFMA builtins hipcc's
 // allocator, given 400 live registers in a 512-register kernel, shuttles the accumulator between the two register files every
@@ -178,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_flash_kernel(
 
     for (int tile = 0; tile < n_tiles; ++tile) {
         const int t0 = tile * kTile;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the tile have landed
+        glds_wait_all();                                   // this wave's pieces of the tile have landed
         __syncthreads();                                   // everyone's have; the other ring slot is no longer being read
         if (tile + 1 < n_tiles) issue(tile + 1);
         const uint8_t* bufA = smem + (tile & 1) * kBuf;

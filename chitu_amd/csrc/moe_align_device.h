@@ -30,7 +30,6 @@ __device__ __forceinline__ void moe_align_workgroup(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int i = tid; i < E; i += nthreads) counts[i] = 0;
     for (int i = tid; i < nwaves * E; i += nthreads) wave_hist[i] = 0;
     if (fill) {
         // The reference allocator's sentinels (fused_moe.py:493-502), done here so a
@@ -41,17 +40,35 @@ __device__ __forceinline__ void moe_align_workgroup(
     __syncthreads();
     CHITU_PROBE_MARK(20);
 
-    // Pass 1: per-expert totals (order-free, LDS atomics are exact for integers).
-    for (int64_t i = tid; i < numel; i += nthreads) {
-        const int64_t e = (int64_t)ids[i];
-        if (e >= 0 && e < E) atomicAdd(&counts[(int)e], 1);
+    // Every wave owns one CONTIGUOUS run of the flat ids (a multiple of 64 long): the stable order is then "by wave, then by
+    // position", each wave's share of an expert's segment is known after ONE cross-wave scan, and the scatter needs no
+    // workgroup barrier at all -- three barriers for any numel.  (Rounds 1-4 walked the ids in 1024-token rounds of three
+    // barriers each with per-round cross-wave offsets: 54 us for the 18432 slots of a 2048-token prompt, 5 % of its layer.)
+    const int64_t per = (((numel + nwaves - 1) / nwaves) + 63) & ~(int64_t)63;
+    const int64_t w0 = (int64_t)wave * per, w1 = w0 + per < numel ? w0 + per : numel;
+    int* my_hist = wave_hist + wave * E;
+
+    // Pass 1: this wave's per-expert counts (order-free, LDS atomics are exact for integers).  Four loads in flight per
+    // lane: a step is one dependent global load otherwise, ~1.5 us each.
+    for (int64_t i0 = w0 + lane; i0 < w1; i0 += 256) {
+        int64_t e4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e4[u] = i0 + 64 * u < w1 ? (int64_t)ids[i0 + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e4[u] >= 0 && e4[u] < E) atomicAdd(&my_hist[(int)e4[u]], 1);
     }
     __syncthreads();
     CHITU_PROBE_MARK(21);
 
     // Pass 2: exclusive scan of padded counts -> segment starts; thread t owns expert t.
     int padded = 0;
-    if (tid < E) padded = ((counts[tid] + block_size - 1) / block_size) * block_size;
+    if (tid < E) {
+        int total = 0;
+        for (int w = 0; w < nwaves; ++w) total += wave_hist[w * E + tid];
+        counts[tid] = total;
+        padded = ((total + block_size - 1) / block_size) * block_size;
+    }
     int incl = padded;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -66,7 +83,14 @@ __device__ __forceinline__ void moe_align_workgroup(
     const int start = incl - padded;
     if (tid < E) {
         const int32_t own_id = expert_map ? expert_map[tid] : (int32_t)tid;  // local id or -1 (expert parallelism)
-        cursor[tid] = start;
+        // wave w's slots of this expert start where the earlier waves' end: counts -> exclusive cursors, in place
+        int run = start;
+        for (int w = 0; w < nwaves; ++w) {
+            const int c = wave_hist[w * E + tid];
+            wave_hist[w * E + tid] = run;
+            run += c;
+        }
+        cursor[tid] = run;  // (one past the expert's last real slot; kept for probes)
         cumsum[tid + 1] = incl;
         for (int i = start; i < incl; i += block_size) {
             const int b = i / block_size;
@@ -86,44 +110,42 @@ __device__ __forceinline__ void moe_align_workgroup(
     __syncthreads();
     CHITU_PROBE_MARK(22);
 
-    // Pass 3: stable scatter, 1024 tokens per round.
+    // Pass 3: stable scatter, each wave over its own run, 64 ids per step, no workgroup barrier: a step's lanes read the
+    // wave's cursor of their expert, then the first lane of every group of equal ids advances it (one wave's LDS
+    // operations are served in program order).
     int nbits = 0;
     while ((1 << nbits) < E) ++nbits;
-    for (int64_t base = 0; base < numel; base += nthreads) {
-        const int64_t i = base + tid;
-        int64_t e64 = -1;
-        if (i < numel) e64 = (int64_t)ids[i];
-        const bool valid = (e64 >= 0 && e64 < E);
-        const int e = valid ? (int)e64 : 0;
+    for (int64_t base4 = w0; base4 < w1; base4 += 256) {
+        int64_t e4[4];  // four steps' ids requested together (see pass 1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e4[u] = base4 + 64 * u + lane < w1 ? (int64_t)ids[base4 + 64 * u + lane] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t base = base4 + 64 * u;
+            if (base >= w1) break;  // wave-uniform
+            const int64_t i = base + lane;
+            const int64_t e64 = e4[u];
+            const bool valid = (e64 >= 0 && e64 < E);
+            const int e = valid ? (int)e64 : 0;
 
-        // wave64 match-any: lanes holding the same expert id as this lane.
-        unsigned long long same = __ballot(valid);
-        for (int b = 0; b < nbits; ++b) {
-            const bool bit = (e >> b) & 1;
-            const unsigned long long bal = __ballot(valid && bit);
-            same &= bit ? bal : ~bal;
-        }
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const int rank = __popcll(same & lt);
-        if (valid && rank == 0) wave_hist[wave * E + e] = __popcll(same);
-        __syncthreads();
-
-        if (valid) {
-            int pos = cursor[e] + rank;
-            for (int w = 0; w < wave; ++w) pos += wave_hist[w * E + e];
-            if (pos < sorted_cap) sorted_ids[pos] = (int32_t)i;
-        }
-        __syncthreads();
-
-        if (tid < E) {
-            int add = 0;
-            for (int w = 0; w < nwaves; ++w) {
-                add += wave_hist[w * E + tid];
-                wave_hist[w * E + tid] = 0;
+            // wave64 match-any: lanes holding the same expert id as this lane.
+            unsigned long long same = __ballot(valid);
+            for (int b = 0; b < nbits; ++b) {
+                const bool bit = (e >> b) & 1;
+                const unsigned long long bal = __ballot(valid && bit);
+                same &= bit ? bal : ~bal;
             }
-            cursor[tid] += add;
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const int rank = __popcll(same & lt);
+            int pos = 0;
+            if (valid) pos = my_hist[e] + rank;
+            __builtin_amdgcn_wave_barrier();  // (compiler: every lane's cursor read stays ahead of the updates below)
+            if (valid) {
+                if (rank == 0) my_hist[e] = pos + __popcll(same);
+                if (pos < sorted_cap) sorted_ids[pos] = (int32_t)i;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
     }
 }
 

@@ -17,11 +17,17 @@
 // Scales: (dot * a_s[slot row]) * w_s per K block, the reference's order (fused_moe.py:281).
 #include "common.h"
 #include "gemm_common.h"
+#include "lds_dma.h"
 
 namespace chitu {
 
-constexpr int kMoeTileM = 64;            // slots per tile = the moe_align block size of this path
-constexpr int kMoeLdsRow = 128 + 16;     // bytes per staged row
+constexpr int kMoeTileM = 64;  // slots per tile = the moe_align block size of this path
+// (128-slot tiles -- one block for nearly every expert of a 2048-token prompt, so no expert's weights are streamed twice: 1.06 GB
+// fetched per GEMM1 launch instead of 1.41-1.72 -- were built and measured in round 5: slower, 374-394 us against 342-346;
+// the launch is not traffic-bound at these sizes but issue-bound, and the padded half of a 128-slot tile doubles its MFMAs
+// and scale folds.  profiles/r05_ab_moe_tiled.txt)
+// Both tiles of a K block arrive by LDS-DMA (lds_dma.h): unpadded [rows][128 B] with the 16-byte chunks XOR-permuted on the
+// source side -- no staging registers, no ds_write pass, conflict-free fragment reads.
 
 __device__ __forceinline__ float moe_tiled_routed_weight(const void* topk_w, int w_dt, int slot) {
     if (w_dt == 0) return bf16_to_f32(((const bf16_t*)topk_w)[slot]);
@@ -33,13 +39,12 @@ __device__ __forceinline__ float moe_tiled_routed_weight(const void* topk_w, int
 #define CHITU_MOE_TILED_NREP 4  // 1: a workgroup per tile always (A/B builds, tools/build_variant.sh)
 #endif
 
-struct MoeTileRegs {
-    i32x4 w[4], x[2];
-    float xs[4];
+struct MoeTileScales {
+    float xs[kMoeTileM / 16];
     float ws0, ws1;
 };
 
-// grid (weight-row tiles, max m-blocks); block 256.
+// grid: GEMM1 form 1-D (XCD-ordered (m-block, n-tile) pairs); GEMM2 form (weight-row tile groups, max m-blocks); block 256.
 //   SILU: Nw = 2I rows per expert, blockIdx.x covers output columns [64 bx, 64 bx + 64); `out` = h [numel, I].
 //   else: Nw = N rows per expert, blockIdx.x covers rows [128 bx, +128); `out` = [numel, Nw] scaled by the routed weight.
 // row_div: activation row of slot s = s / row_div (topk for GEMM1: the token; 1 for GEMM2: the slot's own h row).
@@ -53,23 +58,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int32_t* __restrict__ sorted_ids, const int32_t* __restrict__ expert_ids,
     const int32_t* __restrict__ num_post_pad, bf16_t* __restrict__ out, const void* __restrict__ topk_w, int w_dt,
     int numel, int row_div, int Nw, int K) {
-    __shared__ __attribute__((aligned(16))) uint8_t sW[2][128 * kMoeLdsRow];
-    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kMoeTileM * kMoeLdsRow];
-    const int mb = blockIdx.y;
-    if (mb * kMoeTileM >= *num_post_pad) return;
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][128 * 128];
+    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kMoeTileM * 128];
+    // GEMM1 form: a 1-D grid walked XCD-aware.  Workgroup L of every run of 8 * n_tiles goes to XCD L % 8 (round-robin
+    // dispatch); XCD x is given the CONTIGUOUS m-blocks [x C, x C + C) (C = an eighth of the padded blocks), one per run, all
+    // n-tiles of it inside the run: the n-tiles of one m-block -- they stage the same gathered activation rows, 459 KB per 64
+    // slots at K = 7168 -- share one L2, and so do the m-blocks of one expert (consecutive in the sorted order).
+    constexpr int MT = kMoeTileM / 16;  // slot tiles per workgroup (every wave multiplies all of them)
+    int mb, ntile;
+    if (SILU) {
+        const int n_tiles = Nw >> 7;  // (2I / 128) = I / 64 output-column tiles
+        const int L = blockIdx.x, run = L / (8 * n_tiles), within = L % (8 * n_tiles);
+        const int nb = (*num_post_pad + kMoeTileM - 1) / kMoeTileM, C = (nb + 7) >> 3;
+        if (run >= C) return;
+        mb = (within & 7) * C + run;
+        ntile = within >> 3;
+        if (mb >= nb) return;
+    } else {
+        mb = blockIdx.y;
+        ntile = blockIdx.x;
+        if (mb * kMoeTileM >= *num_post_pad) return;
+    }
+    // a block whose first slot is already padding holds no token at all (real slots come first in an expert's segment):
+    // nothing to multiply, nothing to store
+    if (sorted_ids[mb * kMoeTileM] >= numel) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int e = expert_ids[mb];
     const int I = Nw >> 1;
     static_assert(!SILU || NREP == 1, "the GEMM1 form keeps one tile per workgroup");
-    const int n0 = SILU ? blockIdx.x * 64 : blockIdx.x * 128 * NREP;
+    const int n0 = SILU ? ntile * 64 : ntile * 128 * NREP;
     const int KB = K >> 7;
 
     // this lane's output slots (token column j of each of the 4 slot tiles)
-    int slot[4];
+    int slot[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) slot[mt] = sorted_ids[mb * kMoeTileM + mt * 16 + j];
+    for (int mt = 0; mt < MT; ++mt) slot[mt] = sorted_ids[mb * kMoeTileM + mt * 16 + j];
     if (e < 0) {  // another rank's expert (expert parallelism): its slots are zero-filled, fused_moe.py:40-59
         const int cols = SILU ? 64 : 128 * NREP, ldo = SILU ? I : Nw;
         for (int idx = tid; idx < kMoeTileM * (cols / 8); idx += 256) {
@@ -80,71 +105,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
 
-    // staging roles: weights 128 rows (4 x 16 B per thread), activations 64 gathered rows (2 x 16 B per thread)
-    const int srow = tid >> 3, scol = (tid & 7) * 16;
-    const fp8_t* wg[4];
-    const fp8_t* xg[2];
+    // staging roles (LDS-DMA pieces of 8 rows, lds_dma.h): wave w brings weight pieces 4 w .. 4 w + 3 and activation pieces
+    // (kMoeTileM / 32) w ..; byte offsets from the expert's first weight row / the activation matrix (32-bit: the launcher
+    // bounds both), rows past the matrix re-read its last row, padded slots a valid row (never stored)
+    constexpr int XP = kMoeTileM / 32;  // activation pieces per wave
     const fp8_t* We = W + (size_t)e * Nw * K;
+    auto w_off = [&](int i, int rep) -> uint32_t {
+        const int n = wave * 4 + i, r = n * 8 + (lane >> 3);
+        const int row = SILU ? (r < 64 ? n0 + r : I + n0 + (r - 64)) : n0 + rep * 128 + r;
+        return (uint32_t)(min(row, Nw - 1) * K + kblock_src_chunk(lane, n) * 16);
+    };
+    uint32_t woff[4], xoff[XP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = srow + 32 * i;  // tile row
-        const int row = SILU ? (r < 64 ? n0 + r : I + n0 + (r - 64)) : n0 + r;
-        wg[i] = We + (size_t)min(row, Nw - 1) * K + scol;
+    for (int i = 0; i < 4; ++i) woff[i] = w_off(i, 0);
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int n = wave * XP + i;
+        const int s = sorted_ids[mb * kMoeTileM + n * 8 + (lane >> 3)];
+        xoff[i] = (uint32_t)((min(s, numel - 1) / row_div) * K + kblock_src_chunk(lane, n) * 16);
     }
+    int xso[MT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int s = sorted_ids[mb * kMoeTileM + srow + 32 * i];
-        xg[i] = Xq + (size_t)(min(s, numel - 1) / row_div) * K + scol;  // padded slots re-read a valid row (never stored)
-    }
-    const float* xsp[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) xsp[mt] = Xs + (size_t)(min(slot[mt], numel - 1) / row_div) * KB;
+    for (int mt = 0; mt < MT; ++mt) xso[mt] = (min(slot[mt], numel - 1) / row_div) * KB;
     const float* wsb = Ws + (size_t)e * ((Nw + 127) >> 7) * KB;
     const float* wsp0 = wsb + (size_t)(n0 >> 7) * KB;
     const float* wsp1 = SILU ? wsb + (size_t)((I + n0) >> 7) * KB : wsp0;
+    const uint32_t ldsW = lds_offset_of(&sW[0][0]), ldsX = lds_offset_of(&sX[0][0]);
 
-    auto fetch = [&](MoeTileRegs& r, int kb, int rep = 0) {
-        const int off = kb << 7;
+    using Scales = MoeTileScales;
+    auto issue = [&](int t, int kb) {
+        const uint32_t b = (uint32_t)(t & 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // tile `rep` of this workgroup: 128 rows further down (rows past the matrix re-read its last row, never stored)
-            const fp8_t* wp = NREP == 1 ? wg[i] : We + (size_t)min(n0 + rep * 128 + srow + 32 * i, Nw - 1) * K + scol;
-            r.w[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp + off));
-        }
+        for (int i = 0; i < 4; ++i)
+            glds16_sbase(We + (size_t)kb * 128, woff[i], ldsW + b * (128 * 128) + (uint32_t)((wave * 4 + i) * 1024));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) r.x[i] = *reinterpret_cast<const i32x4*>(xg[i] + off);
+        for (int i = 0; i < XP; ++i)
+            glds16_sbase(Xq + (size_t)kb * 128, xoff[i], ldsX + b * (kMoeTileM * 128) + (uint32_t)((wave * XP + i) * 1024));
+    };
+    auto fetch_scales = [&](Scales& r, int kb, int rep) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) r.xs[mt] = xsp[mt][kb];
+        for (int mt = 0; mt < MT; ++mt) r.xs[mt] = Xs[xso[mt] + kb];
         r.ws0 = wsp0[(size_t)rep * KB + kb];  // one 128-row tile = one row of block scales
         r.ws1 = SILU ? wsp1[kb] : r.ws0;
     };
-    auto stage = [&](const MoeTileRegs& r, int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(&sW[buf][(srow + 32 * i) * kMoeLdsRow + scol]) = r.w[i];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<i32x4*>(&sX[buf][(srow + 32 * i) * kMoeLdsRow + scol]) = r.x[i];
-    };
+    const int foff = kblock_frag_off(j, g);  // this lane's fragment inside a 16-row tile (second half: ^ 64)
 
     // the wave's two weight-row tiles inside the staged 128 rows
     const int wrow0 = SILU ? 16 * wave : 32 * wave, wrow1 = SILU ? 64 + 16 * wave : 32 * wave + 16;
-    f32x4 acc[2][4];
+    f32x4 acc[2][MT];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // C tile (nt, mt): lane holds weight rows 4g .. 4g+3 of the tile for slot column j
-    float rw[4] = {1.f, 1.f, 1.f, 1.f};
-    if (!SILU && topk_w) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-            if (slot[mt] < numel) rw[mt] = moe_tiled_routed_weight(topk_w, w_dt, slot[mt]);
-    }
     auto store_tile = [&](int nb) {  // nb = first weight row (GEMM2) / output column (GEMM1) of the finished tile
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int s = slot[mt];
             if (s >= numel) continue;
+            // (the routed weight is fetched when a tile leaves, not held across the K loop)
+            const float rwm = (!SILU && topk_w) ? moe_tiled_routed_weight(topk_w, w_dt, s) : 1.f;
             if (SILU) {
                 const int n = nb + 16 * wave + 4 * g;  // output column of r = 0
                 uint16_t h[4];
@@ -169,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int n = nb + 32 * wave + 16 * nt + 4 * g;
                     uint16_t h[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) h[r] = f32_to_bf16(acc[nt][mt][r] * rw[mt]);
+                    for (int r = 0; r < 4; ++r) h[r] = f32_to_bf16(acc[nt][mt][r] * rwm);
                     bf16_t* dst = out + (size_t)s * Nw + n;
                     if (n + 3 < Nw) {
                         i32x2 o;
@@ -184,33 +205,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    // (tile, K block) steps: the next step's operands are fetched while this one is multiplied
+    // (tile, K block) steps: the next step's operands land while this one is multiplied
     const int reps = NREP == 1 ? 1 : min(NREP, (Nw - n0 + 127) >> 7);
     const int steps = reps * KB;
-    MoeTileRegs cur, nxt;
-    fetch(cur, 0, 0);
-    stage(cur, 0);
+    Scales cur, nxt;
+    issue(0, 0);
+    fetch_scales(cur, 0, 0);
+    glds_wait_all();
     __syncthreads();
     int rep = 0, kb = 0;
     for (int t = 0; t < steps; ++t) {
         const int buf = t & 1;
         int nkb = kb + 1, nrep = rep;
         if (nkb == KB) nkb = 0, nrep = rep + 1;
-        if (t + 1 < steps) fetch(nxt, nkb, nrep);
+        if (t + 1 < steps) {  // the other buffer was last read one step ago, before the barrier that closed it
+            if (NREP > 1 && nkb == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) woff[i] = w_off(i, nrep);
+            }
+            issue(t + 1, nkb);
+            fetch_scales(nxt, nkb, nrep);
+        }
         i32x4 wa[2][2];
         {
-            const uint8_t* w0 = &sW[buf][(wrow0 + j) * kMoeLdsRow + g * 16];
-            const uint8_t* w1 = &sW[buf][(wrow1 + j) * kMoeLdsRow + g * 16];
-            wa[0][0] = *reinterpret_cast<const i32x4*>(w0);
-            wa[0][1] = *reinterpret_cast<const i32x4*>(w0 + 64);
-            wa[1][0] = *reinterpret_cast<const i32x4*>(w1);
-            wa[1][1] = *reinterpret_cast<const i32x4*>(w1 + 64);
+            const uint8_t* w0 = &sW[buf][wrow0 * 128];
+            const uint8_t* w1 = &sW[buf][wrow1 * 128];
+            wa[0][0] = *reinterpret_cast<const i32x4*>(w0 + foff);
+            wa[0][1] = *reinterpret_cast<const i32x4*>(w0 + (foff ^ 64));
+            wa[1][0] = *reinterpret_cast<const i32x4*>(w1 + foff);
+            wa[1][1] = *reinterpret_cast<const i32x4*>(w1 + (foff ^ 64));
         }
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const uint8_t* xr = &sX[buf][(mt * 16 + j) * kMoeLdsRow + g * 16];
-            const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr), xb1 = *reinterpret_cast<const i32x4*>(xr + 64);
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint8_t* xr = &sX[buf][mt * 16 * 128];
+            const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr + foff), xb1 = *reinterpret_cast<const i32x4*>(xr + (foff ^ 64));
             const float sc = cur.xs[mt];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -223,18 +252,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * wsc;
             }
         }
-        if (t + 1 < steps) {
-            stage(nxt, buf ^ 1);
-            cur = nxt;
-        }
         if (kb == KB - 1) {  // this tile's last K block: its C leaves now, under the next tile's loads
             store_tile(n0 + rep * 128);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();
+        if (t + 1 < steps) cur = nxt;
+        glds_wait_all();  // step t + 1 has landed (this wave's pieces) ...
+        __syncthreads();  // ... and everyone's; this step's buffer is free
         kb = nkb, rep = nrep;
     }
 }
@@ -250,10 +277,11 @@ extern "C" int chitu_hip_moe_gemm1_silu_fp8_tiled(const void* a_fp8, const float
     CHITU_REQUIRE(a_fp8 && a_scale && w1_fp8 && w1_scale && sorted_token_ids && expert_ids && num_tokens_post_pad && h_bf16);
     CHITU_REQUIRE(numel >= 0 && numel < (1ll << 31) && topk >= 1 && inter_size >= 1 && K >= 128 && max_mblocks >= 0);
     if (K % 128 != 0 || inter_size % 128 != 0 || inter_size >= (1 << 29) || K >= (1 << 30)) return CHITU_ERR_UNSUPPORTED;
+    if (2 * inter_size * K >= (1ll << 31) || (numel / topk + 1) * K >= (1ll << 31)) return CHITU_ERR_UNSUPPORTED;  // 32-bit tile offsets
     if (numel == 0 || max_mblocks == 0) return CHITU_OK;
     CHITU_REQUIRE(max_mblocks <= 65535);
-    const dim3 grid((unsigned)(inter_size / 64), (unsigned)max_mblocks);
-    hipLaunchKernelGGL((moe_gemm_tiled_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, (const fp8_t*)a_fp8, a_scale,
+    const dim3 grid((unsigned)((inter_size / 64) * ((max_mblocks + 7) / 8 * 8)));  // (m-block, n-tile) pairs in XCD order, see the kernel
+    hipLaunchKernelGGL((moe_gemm_tiled_kernel<true, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const fp8_t*)a_fp8, a_scale,
                        (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)h_bf16,
                        (const void*)nullptr, 0, (int)numel, (int)topk, (int)(2 * inter_size), (int)K);
     CHITU_RETURN_LAUNCH_STATUS();
@@ -270,6 +298,7 @@ extern "C" int chitu_hip_moe_gemm2_fp8_tiled(const void* h_fp8, const float* h_s
     CHITU_REQUIRE(numel >= 0 && numel < (1ll << 31) && N >= 1 && inter_size >= 128 && max_mblocks >= 0);
     CHITU_REQUIRE(!mul_routed_weight || (topk_weights && weights_dtype >= 0 && weights_dtype <= 2));
     if (inter_size % 128 != 0 || N % 8 != 0 || N >= (1 << 30) || inter_size >= (1 << 30)) return CHITU_ERR_UNSUPPORTED;
+    if (N * inter_size >= (1ll << 31) || (numel + 1) * inter_size >= (1ll << 31)) return CHITU_ERR_UNSUPPORTED;  // 32-bit tile offsets
     if (numel == 0 || max_mblocks == 0) return CHITU_OK;
     CHITU_REQUIRE(max_mblocks <= 65535);
     const int n_tiles = (int)((N + 127) / 128);

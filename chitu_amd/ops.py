@@ -647,8 +647,15 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
         assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.is_contiguous() and weight.is_contiguous()
         M, K = x.shape
         dev = x.device
-        # decode: K cut over 16 workgroups per tile, the routing launch sums the fp32 planes; prefill-sized M: one tiled GEMM
-        splits = _GATE_SPLITS if K % (64 * _GATE_SPLITS) == 0 and M < 256 else 1
+        # decode: K cut over 16 workgroups per tile, the routing launch sums the fp32 planes; prefill-sized M: the tiled GEMM,
+        # its K range cut so that (128 x 128 tiles) x planes fills the 256 CUs (a 2048-token prompt against 256 experts is 32 tiles)
+        if M < 256:
+            splits = _GATE_SPLITS if K % (64 * _GATE_SPLITS) == 0 else 1
+        else:
+            tiles = ((M + 127) // 128) * ((E + 127) // 128)
+            splits = 1
+            while splits < 8 and tiles * splits < 256 and (K // 64) // (splits * 2) >= 4:
+                splits *= 2
     cols = topk + (extra_count if extra_expert_id >= 0 else 0)
     w_out = torch.empty(M, cols, dtype=torch.bfloat16, device=dev)
     ids = torch.empty(M, cols, dtype=torch.int64, device=dev)

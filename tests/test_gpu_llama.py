@@ -250,6 +250,28 @@ def test_bf16_gemm_tiled_prefill_form_vs_streaming_form(M, N, K):
     assert_close(ops.bf16_linear(x, w), ref, 8e-3)# one bf16 ulp of the peak binade
 
 
+@pytest.mark.parametrize("M,N,K,S", [(2048, 256, 7168, 8), (300, 200, 1024, 4), (256, 256, 7168, 16), (512, 128, 192, 3)])
+def test_bf16_gemm_tiled_split_k_planes_sum_to_the_gemm(M, N, K, S):
+    """The tiled kernel with the K range cut over S workgroups per tile (the router's score GEMM of a long prompt: few tiles,
+    long K): the fp32 planes [S, M, N] summed in plane order equal the one-pass fp32 output to summation order, every plane
+    is fully written (NaN-poisoned buffer), ragged tiles and a K block count that S does not divide included."""
+    from chitu_amd import _lib, ops
+    from chitu_amd._lib import check, i32, i64, ptr, stream_ptr
+
+    g = torch.Generator().manual_seed(M + N + K + S)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    planes = torch.full((S, M, N), float("nan"), dtype=torch.float32, device="cuda")
+    check(_lib.lib().chitu_hip_bf16_gemm(ptr(x), ptr(w), ptr(None), i32(0), i64(M), i64(N), i64(K), i32(S), ptr(planes), stream_ptr()),
+          "bf16_gemm split-K")
+    assert torch.isfinite(planes).all()
+    total = planes[0].clone()
+    for i in range(1, S):
+        total += planes[i]
+    assert_close(total, ops.bf16_linear(x, w, out_dtype=torch.float32), 1e-4)
+    assert_close(total, torch.nn.functional.linear(x.float(), w.float()), 1e-4)
+
+
 def test_prefill_equals_token_by_token_decode_and_generate():
     args = tiny_args(2)
     model, cache = build(args)

@@ -52,6 +52,9 @@ def test_golden_fixtures(case, via):
         (5000, 7, 3, torch.int16),     # ragged, many rounds, odd block
         (4096, 1024, 8, torch.int64),  # max experts (needs >48 KiB LDS)
         (300, 200, 32, torch.uint8),
+        (18432, 257, 64, torch.int64),  # a 2048-token R1 prompt: 8 routed + 1 shared slot per token
+        (63, 257, 64, torch.int64),     # fewer ids than one wave's run
+        (1024 * 64 + 1, 16, 64, torch.int32),  # runs of 4160 ids per wave, the last one ragged
     ],
 )
 def test_against_oracle(numel, E, block, dtype):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prefill timing of one TP=8 rank shard of DeepSeek-R1 FP8: python tools/prefill_bench.py [layers=8]
+"""Prefill timing of one TP=8 rank shard of DeepSeek-R1 FP8: python tools/prefill_bench.py [layers=8] [T ...]
 One prompt of T tokens through `DeepSeekV3Decoder.prefill` (eager launches: absorb-mode MLA prefill kernel, fp8 GEMMs
 that stream the weights once per 64 rows, fused MoE over T * 8 slots), T in {128, 512, 2048}; ms per layer and the
 rank's tokens/s extrapolated to 61 layers.  Decode is the metric; this records where the step before it stands."""
@@ -27,7 +27,7 @@ def main():
                               device="cuda")
     init_synthetic_(model, seed=1)
     g = torch.Generator().manual_seed(0)
-    for T in (128, 512, 2048):
+    for T in [int(a) for a in sys.argv[2:]] or (128, 512, 2048):
         prompt = torch.randint(100, 1000, (T,), generator=g).tolist()
         times = []
         for rep in range(3):
