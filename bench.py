@@ -379,14 +379,24 @@ def roofline_array(roof):
     return [first] + ([roof["second_kernel"]] if roof.get("second_kernel") else [])
 
 
-def graph_report():
+def graph_report(world=1):
     """What stands behind every graph this run timed: the replay checks above, and the capture-time checks of
     chitu_amd.graphs.capture_verified (a capture whose first replay differs from the eager step is rejected and repeated;
-    any such event is listed)."""
+    any such event is listed).  Both verdicts are reduced (MIN) over the ranks: `all_equal_eager` is true only if every
+    rank's replays equalled its eager steps, `captures_clean_on_every_rank` only if no rank repeated a capture."""
     from chitu_amd import graphs
 
-    return {"all_equal_eager": all(GRAPH_CHECKS.values()) if GRAPH_CHECKS else None, "replay_vs_eager_after_timing": dict(GRAPH_CHECKS),
-            "captures_checked_at_capture": len(graphs.capture_log), "captures_rejected_and_repeated": graphs.unverified_or_retried()}
+    ok_local = all(GRAPH_CHECKS.values()) if GRAPH_CHECKS else None
+    clean_local = not graphs.unverified_or_retried()
+    ok_all, clean_all = ok_local, clean_local
+    if world > 1:
+        v = torch.tensor([1 if ok_local else 0, 1 if clean_local else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        ok_all = bool(v[0].item()) if ok_local is not None else None
+        clean_all = bool(v[1].item())
+    return {"all_equal_eager": ok_all, "captures_clean_on_every_rank": clean_all,
+            "replay_vs_eager_after_timing": dict(GRAPH_CHECKS), "captures_checked_at_capture": len(graphs.capture_log),
+            "captures_rejected_and_repeated": graphs.unverified_or_retried()}
 
 
 def capture_step_routing(model, cache, bs, ctx):
@@ -1097,6 +1107,7 @@ def main():
         torch.cuda.empty_cache()
         cpu = cpu_baseline(margs, a.bs, a.ctx)
 
+    graph_rep = graph_report(world)  # (a collective at N > 1: every rank calls it)
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -1118,15 +1129,16 @@ def main():
             "step_hbm_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
             "step_roofline_frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": roof, "roofline_kernels": roofline_array(roof), "cpu_baseline": cpu, "build_s": round(build_s, 1),
-            "graph_verified": graph_report(),
+            "graph_verified": graph_rep,
             "device_state_under_load": dev_state.summary(),
         }
         res.update(extra)
         if a.opt:
             res["launch_variant_overrides"] = a.opt
-        if use_graph and res["graph_verified"]["all_equal_eager"] is not True:
-            res["invalid"] = ("a timed hipGraph did not reproduce the eager launches of the same step, or was not checked "
-                              "(graph_verified): the line is void")
+        if use_graph and (res["graph_verified"]["all_equal_eager"] is not True
+                          or not res["graph_verified"]["captures_clean_on_every_rank"]):
+            res["invalid"] = ("a timed hipGraph did not reproduce the eager launches of the same step, was not checked, or a "
+                              "capture had to be rejected and repeated on some rank (graph_verified): the line is void")
             res["value"] = None
         elif dinfo["ranks_seen"] != a.gpus:
             # the library's own all-reduce of ones must have seen every rank the line claims

@@ -160,9 +160,11 @@ class PagedKVCacheManager:
         h = self._lens_np[slot]
         h[0, :n] = seq_lens
         h[1, :n] = h[0, :n] + 1
-        # both vectors, one enqueued copy of the live columns only (the tail keeps its old values: a ring slot's tail holds
-        # whatever step last used that slot)
-        self._lens_dev[:, :n].copy_(self._host_lens[slot][:, :n], non_blocking=True)
+        # the live columns of both vectors: TWO contiguous row copies from the pinned slot (a strided [2, n] slice of a
+        # [2, max] buffer is not one async memcpy for torch: it goes through a pageable temporary and a device copy kernel).
+        # The tail keeps its old values: a ring slot's tail holds whatever step last used that slot.
+        self._lens_dev[0, :n].copy_(self._host_lens[slot][0, :n], non_blocking=True)
+        self._lens_dev[1, :n].copy_(self._host_lens[slot][1, :n], non_blocking=True)
         self._stage_done("lens", slot)
 
     def get_free_block(self):

@@ -73,6 +73,7 @@ struct Comm {
     int64_t two_shot_bytes;  // all-reduces of at least this many bytes per rank take the two-shot form (host-side choice)
     uint32_t* state;  // device, ordinary memory: epoch_ar[max_rows] | epoch_ag (word 0: the all-gather CALL counter) [max_blocks] | err[4]
     int64_t total;
+    int64_t buf_bytes;  // size of this rank's exchange allocation (>= total when a larger parked buffer was reused)
 };
 
 __device__ __forceinline__ uint32_t sys_load(const uint32_t* p) {
@@ -357,16 +358,18 @@ static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 static std::mutex g_park_mutex;
 static std::vector<std::pair<void*, int64_t>> g_parked;  // (uncached buffer, bytes)
 
-static void* take_parked(int64_t bytes) {
+static void* take_parked(int64_t bytes, int64_t* got_bytes) {
     std::lock_guard<std::mutex> lock(g_park_mutex);
-    for (size_t i = 0; i < g_parked.size(); ++i) {
-        if (g_parked[i].second == bytes) {
-            void* p = g_parked[i].first;
-            g_parked.erase(g_parked.begin() + (long)i);
-            return p;
-        }
-    }
-    return nullptr;
+    // the smallest parked buffer that is large enough (an exact-size match only would let create / destroy cycles of
+    // differing sizes grow the parked set without bound)
+    long best = -1;
+    for (size_t i = 0; i < g_parked.size(); ++i)
+        if (g_parked[i].second >= bytes && (best < 0 || g_parked[i].second < g_parked[(size_t)best].second)) best = (long)i;
+    if (best < 0) return nullptr;
+    void* p = g_parked[(size_t)best].first;
+    *got_bytes = g_parked[(size_t)best].second;
+    g_parked.erase(g_parked.begin() + best);
+    return p;
 }
 
 static void park(void* p, int64_t bytes) {
@@ -418,7 +421,8 @@ extern "C" int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_ro
     cm->two_shot_bytes = 256 << 10;
     g.timeout_ticks = (uint64_t)timeout_ms * 100000ull;  // wall_clock64: 100 MHz
     for (int i = 0; i < kCommMaxRanks; ++i) cm->peers.buf[i] = nullptr, cm->ipc_opened[i] = false;
-    void* p = take_parked(cm->total);
+    cm->buf_bytes = cm->total;
+    void* p = take_parked(cm->total, &cm->buf_bytes);
     hipError_t e = hipSuccess;
     if (!p) {
         e = hipExtMallocWithFlags(&p, (size_t)cm->total, hipDeviceMallocUncached);
@@ -432,7 +436,7 @@ extern "C" int chitu_hip_comm_create(int32_t rank, int32_t world, int32_t max_ro
     if (e == hipSuccess) *g.host_err = 0;
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
-        if (p) park(p, cm->total);
+        if (p) park(p, cm->buf_bytes);
         if (cm->state) (void)hipFree(cm->state);
         if (g.host_err) (void)hipHostFree(g.host_err);
         delete cm;
@@ -513,7 +517,7 @@ extern "C" int chitu_hip_comm_destroy(void* comm) {
     (void)hipDeviceSynchronize();
     for (int i = 0; i < kCommMaxRanks; ++i)
         if (cm->ipc_opened[i]) (void)hipIpcCloseMemHandle(cm->peers.buf[i]);
-    park(cm->peers.buf[cm->g.rank], cm->total);  // never back to the allocator: see "uncached memory must not be recycled"
+    park(cm->peers.buf[cm->g.rank], cm->buf_bytes);  // never back to the allocator: see "uncached memory must not be recycled"
     (void)hipFree(cm->state);
     (void)hipHostFree(cm->g.host_err);
     delete cm;

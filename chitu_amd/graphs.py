@@ -175,26 +175,35 @@ def capture_verified(run_eager, static_out, mode, pool, what="decode step"):
         ok = torch.equal(static_out, reference)
         if _ranks_agree(ok):
             return g, new_pool, static_out
+        # The vote failed somewhere in the TP group.  What follows must be the SAME sequence of device work on every rank:
+        # a replay of the step contains the step's collectives (in-graph xGMI, or RCCL between the pieces), so a diagnostic
+        # replay taken only by the rank(s) whose own check failed would leave them one collective step ahead of their peers
+        # (xGMI: time-out and error word; RCCL: mismatched collectives, a hang).  Under tensor parallelism the diagnostic
+        # replays (and the on_mismatch hook, which replays again) are therefore skipped on every rank; one rank keeps them.
+        solo = tp.get_tp_size() <= 1
         if not ok:
             info = _describe_mismatch(static_out, reference)
             info["attempt"] = attempt
-            # does the same graph object give the same wrong answer again?  (a property of the graph vs a one-off)
-            again = static_out.clone()
-            g.replay()
-            torch.cuda.synchronize()
-            info["second_replay_equals_first"] = bool(torch.equal(static_out, again))
-            info["second_replay_equals_eager"] = bool(torch.equal(static_out, reference))
+            if solo:
+                # does the same graph object give the same wrong answer again?  (a property of the graph vs a one-off)
+                again = static_out.clone()
+                g.replay()
+                torch.cuda.synchronize()
+                info["second_replay_equals_first"] = bool(torch.equal(static_out, again))
+                info["second_replay_equals_eager"] = bool(torch.equal(static_out, reference))
             record["mismatches"].append(info)
             print(f"[chitu_amd] hipGraph capture of {what} ({mode}) failed its replay check, attempt {attempt + 1}: {info}",
                   file=sys.stderr, flush=True)
-            if on_mismatch is not None:
+            if on_mismatch is not None and solo:
                 on_mismatch({"graph": g, "run_eager": run_eager, "static_out": static_out, "reference": reference,
                              "mode": mode, "pool": new_pool, "info": info, "launch_logs": logs})
-            # Round 4's finding: such a replay read stale L2 lines on one XCD -- the capture's private pool had been served
-            # memory that was an uncached allocation earlier in the process.  The graph object itself was fine and a NEW
-            # capture read the same stale lines; ordinary traffic larger than all L2s cured both for good.  So before the
-            # capture is repeated every L2 is swept.
-            sweep_l2()
+        else:
+            record["mismatches"].append({"attempt": attempt, "outvoted": True})  # this rank's replay was right, a peer's was not
+        # Round 4's finding: such a replay read stale L2 lines on one XCD -- the capture's private pool had been served
+        # memory that was an uncached allocation earlier in the process.  The graph object itself was fine and a NEW
+        # capture read the same stale lines; ordinary traffic larger than all L2s cured both for good.  So before the
+        # capture is repeated every L2 is swept -- on every rank (local work, no collective).
+        sweep_l2()
         del g
         # the rejected graph's pool is not reused: the next attempt allocates its intermediates elsewhere
         pool = None
@@ -202,14 +211,31 @@ def capture_verified(run_eager, static_out, mode, pool, what="decode step"):
                        f"refusing to decode through it: {record['mismatches']}")
 
 
+_sweep_buffer = None  # allocated once and kept: a sweep must not become the allocation that runs a full HBM out of memory
+
+
 def sweep_l2(nbytes: int = 256 << 20):
-    """Ordinary write traffic larger than every L2 of the device (8 x 4 MB): evicts whatever lines they hold."""
-    junk = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    junk.fill_(0)
+    """Ordinary write traffic larger than every L2 of the device (8 x 4 MB): evicts whatever lines they hold.  The buffer is
+    allocated on first use and kept for the life of the process; if even that allocation fails (KV cache sized to fill the
+    HBM) the sweep falls back to smaller buffers written several times, and is skipped -- loudly -- below 32 MB."""
+    global _sweep_buffer
+    if _sweep_buffer is None or _sweep_buffer.numel() < nbytes:
+        size = nbytes
+        while True:
+            try:
+                _sweep_buffer = torch.empty(size, dtype=torch.uint8, device="cuda")
+                break
+            except torch.OutOfMemoryError:
+                size //= 2
+                if size < (32 << 20):
+                    print("[chitu_amd] sweep_l2: no memory for a sweep buffer; L2 sweep skipped", file=sys.stderr, flush=True)
+                    return
+    for _ in range(max(1, nbytes // _sweep_buffer.numel())):
+        _sweep_buffer.fill_(0)
     torch.cuda.synchronize()
-    del junk
 
 
 def unverified_or_retried():
-    """Captures of this process that needed more than one attempt (bench.py voids its line on any; tests assert [])."""
+    """Captures of this process that needed more than one attempt or were outvoted by a peer rank (bench.py voids its
+    line on any, after a MIN over the ranks; tests assert [])."""
     return [r for r in capture_log if r["attempts"] > 1 or r["mismatches"]]

@@ -12,11 +12,15 @@ import torch.multiprocessing as mp
 
 
 class _FakeGraph:
-    def __init__(self, static_out, value):
-        self.static_out, self.value, self.replays = static_out, value, 0
+    def __init__(self, static_out, value, collective=False):
+        self.static_out, self.value, self.replays, self.collective = static_out, value, 0, collective
 
     def replay(self):
         self.replays += 1
+        if self.collective:  # a real decode graph holds the step's collectives: every rank must replay the same number of times
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == dist.get_world_size()
         self.static_out.copy_(self.value)
 
 
@@ -100,7 +104,7 @@ def _vote_worker(rank, world, port, q):
             eager = torch.arange(12, dtype=torch.float32).view(3, 4)
             # rank 1's FIRST graph is wrong; everything else is faithful
             bad = rank == 1 and len(made) == 0
-            g = _FakeGraph(fake_capture.static_out, eager * (3.0 if bad else 1.0))
+            g = _FakeGraph(fake_capture.static_out, eager * (3.0 if bad else 1.0), collective=True)
             made.append(g)
             return g, None
 
@@ -111,10 +115,15 @@ def _vote_worker(rank, world, port, q):
         fake_capture.static_out = out
         g, _, _ = graphs.capture_verified(lambda: torch.arange(12, dtype=torch.float32).view(3, 4), out, "full", None, what="vote")
         rec = graphs.capture_log[-1]
-        # both ranks captured twice (the verification replay holds the step's collectives: they must move together); only
-        # rank 1 has a mismatch on record
+        # both ranks captured twice and replayed every graph exactly ONCE: the replays hold the step's collectives (the fake
+        # graph all-reduces), so the diagnostic second replay of a failing rank -- which round 4 took on that rank only --
+        # would leave it one collective ahead of its peer and hang this test.  Rank 1 has the mismatch on record, rank 0
+        # that it was outvoted; both count as a repeated capture.
         assert len(made) == 2 and g is made[1] and rec["attempts"] == 2, (rank, len(made), rec)
-        assert len(rec["mismatches"]) == (1 if rank == 1 else 0), (rank, rec)
+        assert [m.replays for m in made] == [1, 1], (rank, [m.replays for m in made])
+        assert len(rec["mismatches"]) == 1 and bool(rec["mismatches"][0].get("outvoted")) == (rank == 0), (rank, rec)
+        assert "second_replay_equals_first" not in rec["mismatches"][0]
+        assert graphs.unverified_or_retried()[-1] is rec
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
