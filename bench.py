@@ -37,6 +37,9 @@ expert-parallel rank of R1 the same way.  `roofline_kernels`: the 
 (W2) as a list, both timed as above.  `prefill`: a 2048-token prompt through one R1 rank shard -- ms per layer, and
 the MFMA fraction (of the dense 2.5 PFLOP/s peak) of the MLA causal attention kernel and of the tiled fp8 GEMMs alone.
 
+`box_calibration` / `value_normalised` (round 5): three probes of the box itself (device copy bandwidth, the per-launch time of a
+16-workgroup dependent chain in a hipGraph, the W2 expert GEMM) and the step time mapped to a fixed reference box by a two-term model.
+
 `graph_verified` (round 4): every timed hipGraph is replayed once more after its timed loop against the EAGER launches of the
 same step on the same state (tokens, lengths, block table; the KV row at position L is rewritten with the same bytes) and
 must equal them bit for bit -- per measured loop in `replay_vs_eager_after_timing`; `captures_checked_at_capture` /
@@ -281,6 +284,75 @@ class DeviceStateSampler:
             if v:
                 out[name] = {"min": min(v), "max": max(v)}
         return out
+
+
+# ---- box calibration (round 5): the pool's boxes differ by up to 5 % on the same binary (rounds 2-4: 9.76 vs 10.28 ms at bs 16
+# with identical sclk / mclk / fclk under load; the <= 32-workgroup launches and the W2 GEMM stretch on the slow ones).  Three
+# probes of the box itself, run in this process right after the timed loops, and a two-term model that maps the step time to
+# what the reference box of these constants would have measured.
+CAL_REF = {"copy_GBs": 2550.0, "chain_us": 2.45}  # a "fast" box of rounds 4-5 (profiles/r05_box_calibration.txt)
+CAL_WEIGHTS = {"bandwidth": 0.55, "latency": 0.45}  # share of the bs-16 step's kernel time in HBM-bound launches (expert GEMMs,
+# dense GEMMs, logits) / in the latency-bound tail (profiles/r04_step_breakdown_bs16_final.txt: 5.45 ms / 4.43 ms)
+
+
+@torch.inference_mode()
+def box_calibration(local_index, w2_launch_us=None):
+    """{copy_GBs: 1 GB device-to-device copy (bytes copied per second; traffic is twice that), chain_us: one launch of a
+    16-workgroup kernel inside a 400-launch dependent chain replayed as a hipGraph (the latency-bound tail's unit), w2_launch_us:
+    the W2 expert GEMM at the step's own routing (roofline_kernels), static device facts, and `step_time_factor`: the factor
+    by which this box's step is expected to be slower than the reference box's, 0.55 * ref_bw / bw + 0.45 * chain / ref_chain}."""
+    from chitu_amd import ops
+
+    dev = torch.device("cuda")
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 10 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    # dependent chain: RMSNorm of 16 rows x 7168 (16 workgroups), each launch reading the previous one's output
+    w = torch.ones(7168, dtype=torch.bfloat16, device=dev)
+    x = torch.randn(16, 7168, device=dev).to(torch.bfloat16)
+    for _ in range(3):
+        y = ops.rms_norm(x, w, 1e-6)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    n_chain = 400
+    with torch.cuda.graph(g):
+        y = x
+        for _ in range(n_chain):
+            y = ops.rms_norm(y, w, 1e-6)
+    g.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    chain_us = e0.elapsed_time(e1) * 1e3 / (5 * n_chain)
+    del g
+    prop = torch.cuda.get_device_properties(0)
+    out = {"copy_GBs": round(copy_gbs, 1), "chain_us": round(chain_us, 3), "w2_launch_us": w2_launch_us,
+           "compute_units": prop.multi_processor_count, "device": prop.name, "hbm_GB": round(prop.total_memory / 1e9, 1),
+           "reference_box": CAL_REF, "model_weights": CAL_WEIGHTS}
+    out["step_time_factor"] = round(CAL_WEIGHTS["bandwidth"] * CAL_REF["copy_GBs"] / copy_gbs
+                                    + CAL_WEIGHTS["latency"] * chain_us / CAL_REF["chain_us"], 4)
+    try:
+        import subprocess
+
+        smi = subprocess.run(["rocm-smi", "-d", str(local_index), "--showperflevel", "--showmemuse", "--showclocks"],
+                             capture_output=True, text=True, timeout=10).stdout
+        keep = [ln.strip() for ln in smi.splitlines() if any(k in ln for k in ("Performance Level", "Memory", "sclk", "mclk", "fclk"))]
+        out["rocm_smi_idle"] = keep[:12]
+    except Exception as exc:  # noqa: BLE001 -- diagnostics only
+        out["rocm_smi_idle"] = f"unavailable: {type(exc).__name__}"
+    return out
 
 
 def barrier_sync(world):
@@ -1090,6 +1162,15 @@ def main():
             roof = roofline_dominant_kernel(model, routing, margs, a.bs)
         if world > 1:
             dist.barrier()
+    calib = None
+    if rank == 0:
+        w2_us = None
+        for k in (roofline_array(roof) or []):
+            if "gemm2" in str(k.get("kernel", "")):
+                w2_us = k.get("avg_launch_us")
+        calib = box_calibration(local if not dinfo["shared_device"] else 0, w2_us)
+    if world > 1:
+        dist.barrier()
     distinct = (roof["distinct_experts"] - 1) if roof else min(256, a.bs * 8)  # routed only; shared counted in the formula
     step_bytes = algorithmic_bytes_per_step(margs, a.bs, a.ctx, distinct)
     if world == 1 and not a.no_llama and a.layers == 61:
@@ -1123,7 +1204,13 @@ def main():
                             f"bs={a.bs}, ctx={a.ctx}, greedy, hipGraph={graph_mode}",
                 "batch": a.bs, "context": a.ctx, "parallelism": f"tp8-shard x{world}", "layers": margs.n_layers,
             },
+            "value_is": "the N/8 share of node_tok_s (N of the node's 8 rank shards live); collectives between the live ranks only "
+                        "(none at N=1): only N=8 is the TP=8 metric itself",
             "node_tok_s": round(node_tok_s, 2),
+            "box_calibration": calib,
+            "value_normalised": round(value * calib["step_time_factor"], 3) if calib else None,
+            "value_normalised_is": "value x box_calibration.step_time_factor: what the reference box of the calibration constants "
+                                   "would be expected to measure (two-term model; the measured `value` stands)",
             "collectives": coll,
             "step_algorithmic_GB": round(step_bytes / 1e9, 3),
             "step_hbm_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
