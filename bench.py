@@ -63,6 +63,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 = non-scaled fp8 MFMA peak
 PMC_FILE = "r04_pmc_step.json"  # tools/pmc_passes.sh + tools/pmc_report.py, stamped with git head + source digests
 
 
@@ -822,7 +823,7 @@ def llama3_8b_extra(steps, warmup, ctx):
     from chitu_amd.llama import LlamaArgs, LlamaDecoder, init_synthetic_
 
     args = LlamaArgs()
-    max_seq = ctx + steps + warmup + 512
+    max_seq = max(ctx + steps + warmup + 512, 2048 + 256)
     cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=16, block_size=256, max_seq_len=max_seq, device="cuda",
                                 n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
     model = LlamaDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=max_seq),
@@ -838,6 +839,47 @@ def llama3_8b_extra(steps, warmup, ctx):
         out[f"bs{bs}"] = {"ms_per_step": round(dt / steps * 1e3, 4), "tok_s": round(bs * steps / dt, 1),
                           "hbm_GBs": round((w_bytes + kv) / (dt / steps) / 1e9, 1),
                           "roofline_frac": round((w_bytes + kv) / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    # config 2's prefill (SURVEY 8f.1 for the GQA family): one 2048-token prompt through the whole model (eager launches), and
+    # the causal GQA attention kernel alone against the dense bf16 MFMA peak, beside the round-2 decode composition it replaced
+    T = 2048
+    gp = torch.Generator().manual_seed(0)
+    prompt = torch.randint(100, 1000, (T,), generator=gp).tolist()
+    times = []
+    for rep in range(3):
+        rid = f"lp{rep}"
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.prefill([prompt], [rid])
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        cache.finalize_cache_all_decode(rid)
+    be = model.layers[0].attn.attn_backend
+    gd = torch.Generator(device="cuda").manual_seed(5)
+    q = (torch.randn(T, args.n_heads, args.head_dim, device="cuda", generator=gd) * 0.5).to(torch.bfloat16)
+    k = torch.randn(T, args.n_kv_heads, args.head_dim, device="cuda", generator=gd).to(torch.bfloat16)
+    v = torch.randn(T, args.n_kv_heads, args.head_dim, device="cuda", generator=gd).to(torch.bfloat16)
+    cu = torch.tensor([0, T], dtype=torch.int32, device="cuda")
+    flop = 2.0 * args.n_heads * (T * (T + 1) / 2) * 2 * args.head_dim
+    att, prev = {}, os.environ.get("CHITU_GQA_PREFILL")
+    for mode, n in (("flash", 20), ("compose", 2)):
+        os.environ["CHITU_GQA_PREFILL"] = mode
+        for _ in range(2):
+            be.attn_varlen_func(q, k, v, cu, cu, T, T, causal=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            be.attn_varlen_func(q, k, v, cu, cu, T, T, causal=True)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / n
+        att[mode] = {"us": round(us, 1), "TFLOPs": round(flop / us * 1e-6, 1), "frac": round(flop / us * 1e-6 / MFMA_PEAK_TFLOPS, 4)}
+    if prev is None:
+        os.environ.pop("CHITU_GQA_PREFILL", None)
+    else:
+        os.environ["CHITU_GQA_PREFILL"] = prev
+    out["prefill_2048"] = {"ms": round(min(times[1:]) * 1e3, 3), "prompt_tok_s": round(T / min(times[1:]), 1),
+                           "attention": {"kernel": "chitu::gqa_prefill_flash_kernel<4>", "bound": "mfma", "peak_TFLOPs": MFMA_PEAK_TFLOPS,
+                                         **att["flash"], "decode_composition": att["compose"]}}
     del model, cache
     torch.cuda.empty_cache()
     return out
@@ -882,9 +924,6 @@ def v2_lite_extra(steps, warmup, ctx):
     del model, cache
     torch.cuda.empty_cache()
     return out
-
-
-MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 = non-scaled fp8 MFMA peak
 
 
 def prefill_extra(prompt_tokens=2048, n_moe_layers=6):

@@ -257,15 +257,34 @@ class HipAttnBackend(AttnBackend):
 
     def _gqa_varlen_causal(self, q, k, v, cu_seqlens, max_seqlen, softmax_scale):
         """Causal GQA / MHA prefill attention (Attention.prefill_forward, models/model.py:104-132), head_dim 128:
-        q [T, Hq, 128], k / v [T, Hkv, 128].  First cut, built from the decode kernel: keys / values are staged
-        once into 256-token pages and every query token runs as one decode "sequence" of length pos + 1 over
-        its own sequence's pages (chitu_hip_gqa_decode) -- exact causal attention with the decode numerics,
-        KV re-read once per query token (fine for prompts of a few hundred tokens; no host sync)."""
+        q [T, Hq, 128], k / v [T, Hkv, 128].  Default: the flash kernel chitu_hip_gqa_prefill.  CHITU_GQA_PREFILL=compose
+        (and shapes the kernel does not take): the round-2 composition from the decode kernel -- keys / values staged once
+        into 256-token pages, every query token one decode "sequence" of length pos + 1 over its own sequence's pages
+        (chitu_hip_gqa_decode): exact causal attention with the decode numerics, KV re-read once per query token; kept
+        as the cross-check.  No host sync either way."""
         T, Hq, D = q.shape
         Hkv = k.shape[1]
         if T == 0:
             return q.new_empty(0, Hq, D)
         dev = q.device
+        G = Hq // Hkv
+        if (os.environ.get("CHITU_GQA_PREFILL", "flash") != "compose" and D == 128 and Hq % Hkv == 0 and G <= 32
+                and (G & (G - 1)) == 0):
+            # chitu_hip_gqa_prefill (csrc/gqa_prefill_flash.hip): 128 Q rows (128 / G tokens x G heads of one KV head) per
+            # workgroup against 64-key K / V tiles; KV read once per 128 / G query tokens instead of once per token
+            def ok(t):
+                return t.stride(-1) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
+
+            qq, kk, vv = (t if ok(t) else t.contiguous() for t in (q, k, v))
+            cu32 = cu_seqlens.to(device=dev, dtype=torch.int32).contiguous()
+            out = torch.empty(T, Hq, D, dtype=torch.bfloat16, device=dev)
+            if softmax_scale is None:
+                softmax_scale = D ** -0.5
+            check(_lib.lib().chitu_hip_gqa_prefill(
+                ptr(qq), i64(qq.stride(0)), i64(qq.stride(1)), ptr(kk), i64(kk.stride(0)), i64(kk.stride(1)), ptr(vv),
+                i64(vv.stride(0)), i64(vv.stride(1)), ptr(cu32), i32(cu32.numel() - 1), i32(int(max_seqlen)), f32(softmax_scale),
+                ptr(out), i32(Hq), i32(Hkv), i32(D), stream_ptr()), "gqa_prefill")
+            return out
         page = 256
         n_seq = cu_seqlens.numel() - 1
         cu = cu_seqlens.to(device=dev, dtype=torch.long)

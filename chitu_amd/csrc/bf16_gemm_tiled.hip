@@ -1,6 +1,6 @@
 // Compute-shaped bf16 GEMM for PREFILL-sized M (router scores, every linear of an unquantised model, the LM head over
 // a whole prompt), gfx950.  Same tiling as fp8_gemm_tiled.hip -- 128 weight rows x 128 tokens per workgroup, 4 waves as
-// 2 x 2, both operand tiles staged through LDS per 128-byte K block (64 bf16), double-buffered -- without block scales:
+// 2 x 2, both operand tiles staged through LDS per 128-byte K block (64 bf16) by LDS-DMA (lds_dma.h), double-buffered -- without block scales:
 // the 16 accumulator tiles of a wave run across the whole K range (v_mfma_f32_16x16x32_bf16, weights = A operand).
 //
 // Replaces (reference, read-only), for M >= 128: torch.nn.functional.linear on bf16 weights as used by
@@ -10,21 +10,19 @@
 // 4.7 us for the router of a 2048-token prompt (profiles/r02_prefill_*), one launch here.
 #include "common.h"
 #include "gemm_common.h"
+#include "lds_dma.h"
 
 namespace chitu {
 
 constexpr int kBTile = 128;
-constexpr int kBLdsRow = 128 + 32;  // bytes per staged row (64 bf16 + pad: conflict-free under ds_read_b128's lane groups, fp8_gemm_tiled.hip)
-
-struct BTileRegs {
-    i32x4 w[4], x[4];
-};
+constexpr int kBTileBytes = kBTile * 128;  // one operand tile of one 64-element K block in LDS: [128 rows][128 B], staged by LDS-DMA
+// with the 16-byte chunks XOR-permuted on the source side (lds_dma.h; fp8_gemm_tiled.hip has the measurements)
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bf16_gemm_tiled_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ W, void* __restrict__ out, int out_dt, int M, int N, int K,
     float* __restrict__ partials) {
-    __shared__ __attribute__((aligned(16))) uint8_t sW[2][kBTile * kBLdsRow];
-    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kBTile * kBLdsRow];
+    __shared__ __attribute__((aligned(16))) uint8_t sW[2][kBTileBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kBTileBytes];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -46,29 +44,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         return;
     }
 
-    const int srow = tid >> 3, scol = (tid & 7) * 8;  // 8 bf16 = 16 bytes
-    const bf16_t* wg[4];
-    const bf16_t* xg[4];
+    // staging role: wave w brings rows 32 w .. 32 w + 31 of both tiles, four 8-row LDS-DMA pieces each; byte offsets from the
+    // tiles' first rows (32-bit: the launcher bounds 128 K), rows past the matrix re-read its last row (never stored)
+    uint32_t woff[4], xoff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        wg[i] = W + (size_t)min(n0 + srow + 32 * i, N - 1) * K + scol + (size_t)kb0 * 64;
-        xg[i] = X + (size_t)min(m0 + srow + 32 * i, M - 1) * K + scol + (size_t)kb0 * 64;
+        const int n = wave * 4 + i, r = n * 8 + (lane >> 3), c = kblock_src_chunk(lane, n);
+        woff[i] = (uint32_t)(min(r, N - 1 - n0) * K * 2 + c * 16);
+        xoff[i] = (uint32_t)(min(r, M - 1 - m0) * K * 2 + c * 16);
     }
-    auto fetch = [&](BTileRegs& r, int kb) {
-        const int off = kb << 6;
+    const bf16_t* wbase = W + (size_t)n0 * K + (size_t)kb0 * 64;
+    const bf16_t* xbase = X + (size_t)m0 * K + (size_t)kb0 * 64;
+    const uint32_t ldsW = lds_offset_of(&sW[0][0]), ldsX = lds_offset_of(&sX[0][0]);
+    auto issue = [&](int kb) {
+        const uint32_t dst = (uint32_t)((kb & 1) * kBTileBytes + wave * 4096);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            r.w[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wg[i] + off));
-            r.x[i] = *reinterpret_cast<const i32x4*>(xg[i] + off);
+            glds16_sbase(wbase + (size_t)kb * 64, woff[i], ldsW + dst + i * 1024);
+            glds16_sbase(xbase + (size_t)kb * 64, xoff[i], ldsX + dst + i * 1024);
         }
     };
-    auto stage = [&](const BTileRegs& r, int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<i32x4*>(&sW[buf][(srow + 32 * i) * kBLdsRow + scol * 2]) = r.w[i];
-            *reinterpret_cast<i32x4*>(&sX[buf][(srow + 32 * i) * kBLdsRow + scol * 2]) = r.x[i];
-        }
-    };
+    const int foff = kblock_frag_off(j, g);  // this lane's fragment inside a 16-row tile (second half: ^ 64)
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -76,36 +72,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    BTileRegs cur, nxt;
-    fetch(cur, 0);
-    stage(cur, 0);
+    issue(0);
+    glds_wait_all();
     __syncthreads();
     for (int kb = 0; kb < KB; ++kb) {
         const int buf = kb & 1;
-        if (kb + 1 < KB) fetch(nxt, kb + 1);
+        if (kb + 1 < KB) issue(kb + 1);  // the other buffer was last read one step ago, before the barrier that closed it
         // lane (j, g): elements [8g, 8g+8) of each 32-element half of row j -- one MFMA operand per half
         s16x8 wa[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const uint8_t* wr = &sW[buf][(wn * 64 + t * 16 + j) * kBLdsRow + g * 16];
-            wa[t][0] = *reinterpret_cast<const s16x8*>(wr);
-            wa[t][1] = *reinterpret_cast<const s16x8*>(wr + 64);
+            const uint8_t* wr = &sW[buf][(wn * 64 + t * 16) * 128];
+            wa[t][0] = *reinterpret_cast<const s16x8*>(wr + foff);
+            wa[t][1] = *reinterpret_cast<const s16x8*>(wr + (foff ^ 64));
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16 + j) * kBLdsRow + g * 16];
-            const s16x8 xb0 = *reinterpret_cast<const s16x8*>(xr), xb1 = *reinterpret_cast<const s16x8*>(xr + 64);
+            const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16) * 128];
+            const s16x8 xb0 = *reinterpret_cast<const s16x8*>(xr + foff), xb1 = *reinterpret_cast<const s16x8*>(xr + (foff ^ 64));
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nt][0], xb0, acc[nt][mt], 0, 0, 0);
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nt][1], xb1, acc[nt][mt], 0, 0, 0);
             }
         }
-        if (kb + 1 < KB) {
-            stage(nxt, buf ^ 1);
-            cur = nxt;
-        }
-        __syncthreads();
+        glds_wait_all();  // block kb + 1 has landed (this wave's pieces) ...
+        __syncthreads();  // ... and everyone's; block kb's buffer is free
     }
 
     // C tile (nt, mt): lane holds weight rows n = 4g .. 4g+3 of token column j -> 4 consecutive outputs of one token

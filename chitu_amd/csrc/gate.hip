@@ -834,7 +834,7 @@ extern "C" int chitu_hip_bf16_gemm(const void* x_bf16, const void* w_bf16, void*
     const int KB = (int)(K / 64);
     const int tiles = (int)((N + 15) / 16);
     if (num_splits > KB) return CHITU_ERR_BAD_ARG;
-    if ((M >= 256 || (M >= 128 && N >= 1024)) && debug_option(kOptBf16GemmTiled) != 0) {
+    if ((M >= 256 || (M >= 128 && N >= 1024)) && K < (1 << 23) && debug_option(kOptBf16GemmTiled) != 0) {  // (32-bit byte offsets inside a tile)
         // prefill-sized M: a GEMM, not a weight stream (bf16_gemm_tiled.hip); a 128-row prompt against the 256-row router
         // matrix would be two workgroups -- that one stays with the split-K stream.  num_splits > 1: the K range cut over
         // that many workgroups per tile, fp32 planes left in `partials` (the router of a long prompt: few tiles, long K)

@@ -415,8 +415,15 @@ def bf16_linear_silu(x: torch.Tensor, w13: torch.Tensor) -> torch.Tensor:
     K = x.shape[-1]
     inter = w13.shape[0] // 2
     assert w13.shape[0] == 2 * inter and w13.shape[1] == K
+    M = x.numel() // K
+    if M >= 256:
+        # prefill-sized M: the fused kernel streams w13 once per 32 rows (64 passes over 235 MB for a 2048-token Llama-3-8B
+        # prompt: 54 % of that prefill's FLOPs at ~2 % of the MFMA peak); the compute-shaped GEMM + SiluAndMul on its bf16
+        # output is the same arithmetic with the same rounding points (F.silu and the product each round to bf16, model.py:201-214)
+        y = bf16_linear(x.reshape(M, K), w13)
+        return (torch.nn.functional.silu(y[:, :inter]) * y[:, inter:]).view(*x.shape[:-1], inter)
     out = torch.empty(*x.shape[:-1], inter, dtype=torch.bfloat16, device=x.device)
-    check(_lib.lib().chitu_hip_bf16_gemm_silu(ptr(x), ptr(w13), ptr(out), i64(x.numel() // K), i64(inter), i64(K), stream_ptr()),
+    check(_lib.lib().chitu_hip_bf16_gemm_silu(ptr(x), ptr(w13), ptr(out), i64(M), i64(inter), i64(K), stream_ptr()),
           "bf16_linear_silu")
     return out
 

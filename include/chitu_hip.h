@@ -439,6 +439,18 @@ int chitu_hip_mla_prefill_flash(const void* q_bf16, int64_t q_stride_t, int64_t 
                           float softmax_scale, void* out_bf16, int32_t heads, int32_t kv_lora_rank,
                           int32_t rope_dim, void* stream);
 
+/* Causal GQA / MHA prefill attention, head_dim 128: the attn_varlen_func call of Attention.prefill_forward
+ * (chitu/models/model.py:104-132; chitu/attn_backend.py:39-90; the reference runs it on third-party flash_attn, :167-206).
+ *   out[t,h,:] = softmax over keys s <= t of the same sequence ( scale * q[t,h,:] . k[s,h/G,:] ) . v[s,h/G,:],  G = q_heads / kv_heads
+ *   q [T, q_heads, 128], k / v [T, kv_heads, 128] bf16 (token / head strides in elements, multiples of 8; 16-byte aligned
+ *   bases); cu_seqlens [n_seq + 1] i32 (device); max_seqlen bounds the grid; out [T, q_heads, 128] bf16 contiguous.
+ * G must be a power of two <= 32.  Flash form (csrc/gqa_prefill_flash.hip): KV read once per 128 / G query tokens. */
+int chitu_hip_gqa_prefill(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* k_bf16,
+                          int64_t k_stride_t, int64_t k_stride_h, const void* v_bf16, int64_t v_stride_t,
+                          int64_t v_stride_h, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
+                          float softmax_scale, void* out_bf16, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
+                          void* stream);
+
 /* Split-KV merge + W_UV projection (model_deepseek_v3.py:697) + act_quant of wo's input in one
  * launch, for small batches (one workgroup per (head, token)): the same arithmetic and rounding
  * points as chitu_hip_mla_decode's merge pass followed by chitu_hip_absorb_uv_quant_fp8.
