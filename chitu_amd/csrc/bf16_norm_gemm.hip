@@ -519,53 +519,6 @@ extern "C" int chitu_hip_bf16_gemm_add_norm_qkv_post(
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
-// The router's score GEMM with ffn_norm in front of it (decode batches of <= 3 rows at dim 7168): x_new = x + add,
-// y = RMSNorm(x_new), partial planes [S][M][N] of y . W^T (geometry, K split and accumulation order of
-// chitu_hip_bf16_gemm(num_splits = S), so the planes are bit-identical to that launch fed chitu_hip_rmsnorm's y), and --
-// from the one workgroup that also writes x_new -- y itself and / or its fp8 form for the expert GEMMs (quant_mode 1 =
-// act_quant, 2 = per_token_group_quant with quant_eps; chitu_hip_rmsnorm's codes and scales).  Replaces the stand-alone
-// add + norm + quant launch in front of GateDeepSeekV3.forward (model_deepseek_v3.py:1107-1113, 810-820).
-extern "C" int chitu_hip_bf16_gemm_add_norm_splitk(
-    const void* x_bf16, int64_t x_row_stride, const void* add_bf16, int64_t add_row_stride, void* sum_out_bf16,
-    int64_t sum_row_stride, const void* norm_weight_bf16, float eps, const void* w_bf16, float* partials, int64_t M, int64_t N,
-    int64_t K, int32_t num_splits, void* y_out_bf16, void* q_out_fp8, float* q_scales, int32_t quant_mode, float quant_eps,
-    void* stream) {
-    using namespace chitu;
-    CHITU_REQUIRE(x_bf16 && add_bf16 && sum_out_bf16 && norm_weight_bf16 && w_bf16 && partials);
-    CHITU_REQUIRE(M >= 0 && N >= 1 && N < (1 << 30) && K >= 64 && K < (1 << 30) && num_splits >= 2 && num_splits <= 64);
-    CHITU_REQUIRE(x_row_stride % 8 == 0 && add_row_stride % 8 == 0 && sum_row_stride % 8 == 0);
-    CHITU_REQUIRE(quant_mode >= 0 && quant_mode <= 2 && (quant_mode == 0 || (q_out_fp8 && q_scales)));
-    if (M == 0) return CHITU_OK;
-    if (!fused_norm_shape_ok(M, K) || (quant_mode != 0 && K % 128 != 0)) return CHITU_ERR_UNSUPPORTED;
-    const int KB = (int)(K / 64), tiles = (int)((N + 15) / 16), S = (int)num_splits;
-    if (S > KB) return CHITU_ERR_BAD_ARG;
-    int WK = 8;  // chitu_hip_bf16_gemm's choice for this shape and split (gate.hip), so the planes agree bit for bit
-    while (WK > 1 && (WK * S > KB || (int64_t)tiles * S * WK > 4096)) WK >>= 1;
-    if (WK < 2 || (WK == 2 && M > 2)) return CHITU_ERR_UNSUPPORTED;  // two waves: eight chunks per thread and row, two rows at most
-    const size_t lds = (size_t)M * K * 2;
-    hipStream_t st = (hipStream_t)stream;
-    const NormOut po{(bf16_t*)y_out_bf16, (fp8_t*)q_out_fp8, q_scales, quant_eps, (int)quant_mode};
-    const dim3 grid((unsigned)tiles, (unsigned)S);
-#define LAUNCH_MR(WKV, MRV)                                                                                              \
-    hipLaunchKernelGGL((bf16_gemm_add_norm_kernel<WKV, 4, MRV, false, true>), grid, dim3(64 * WKV), lds, st,             \
-                       (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)add_bf16, add_row_stride, (bf16_t*)sum_out_bf16, \
-                       sum_row_stride, (const bf16_t*)norm_weight_bf16, eps, (const bf16_t*)w_bf16, (void*)nullptr, 2,   \
-                       (int)M, (int)N, (int)K, QkvPostArgs{}, po, partials, S)
-#define LAUNCH(WKV)                        \
-    do {                                   \
-        if (M == 1) LAUNCH_MR(WKV, 1);     \
-        else if (M == 2) LAUNCH_MR(WKV, 2);\
-        else LAUNCH_MR(WKV, 4);            \
-    } while (0)
-    if (WK == 8) LAUNCH(8);
-    else if (WK == 4) LAUNCH(4);
-    else if (M == 1) LAUNCH_MR(2, 1);
-    else LAUNCH_MR(2, 2);
-#undef LAUNCH
-#undef LAUNCH_MR
-    CHITU_RETURN_LAUNCH_STATUS();
-}
-
 extern "C" int chitu_hip_bf16_gemm_silu_add_norm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
                                                  int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
                                                  const void* norm_weight_bf16, float eps, const void* w13_bf16,

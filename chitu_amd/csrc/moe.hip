@@ -527,126 +527,10 @@ __global__ __launch_bounds__(256) void moe_gemm2_q_kernel(
     }
 }
 
-// The same launch for WIDE experts (512 < I <= 2048: DeepSeek-V2-Lite's 1408, an expert-parallel rank's 2048): the
-// 16 x I activation fragment no longer fits the registers next to the weights, so the quantised bytes stay in LDS
-// (2 KB per 128-group) and every K block's B operand is read from there (two ds_read_b128), the weights stream
-// through a 3-deep register ring, NT tiles per wave share each block's activation reads.  Prologue in two passes over
-// the slot rows (group maxima, then the codes; the second pass re-reads the rows from L1 / L2 instead of holding
-// 16 x I / 4 floats per wave in registers).  Same quantisation and the same K order as moe_silu_quant_kernel +
-// moe_gemm2_generic_kernel<1>.  grid (ceil(n_tiles / (4 * NT)), max_mblocks); block 256; dynamic LDS (I/64) * (64 + 1024) B.
-template <int NT>
-__global__ __launch_bounds__(256) void moe_gemm2_qw_kernel(
-    const bf16_t* __restrict__ Hb, const fp8_t* __restrict__ W, const float* __restrict__ Ws,
-    const int32_t* __restrict__ sorted_ids, const int32_t* __restrict__ expert_ids,
-    const int32_t* __restrict__ num_post_pad, const void* __restrict__ topk_w, int w_dt,
-    bf16_t* __restrict__ out, int numel, int N, int I, int mul_weight, float eps) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t qw_lds[];
-    const int KB = I >> 7, HB = 2 * KB;
-    i32x4* xq_lds = reinterpret_cast<i32x4*>(qw_lds);                       // [HB][64]
-    float* amax_lds = reinterpret_cast<float*>(qw_lds + (size_t)HB * 1024);  // [HB][16]
-    const int mb = blockIdx.y;
-    if (mb * 16 >= *num_post_pad) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    const int slot = sorted_ids[mb * 16 + j];
-    const bool valid = slot < numel;
-    const int e = expert_ids[mb];
-    const int tile0 = (blockIdx.x * 4 + wave) * NT;
-    if (e < 0) {  // expert not on this rank (expert_map): the slot's contribution is zero
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n0 = (tile0 + t) * 16;
-            if (n0 < N && valid) moe_store_tile(out + (size_t)slot * N, n0, g, N, f32x4{0.f, 0.f, 0.f, 0.f}, 1.0f);
-        }
-        return;
-    }
-    // the first weight blocks are requested before the activations are quantised: they do not depend on them
-    const float rw = (mul_weight && valid) ? moe_routed_weight(topk_w, w_dt, slot) : 1.0f;
-    const int last_tile = (N - 1) >> 4;
-    const fp8_t* We = W + (size_t)e * N * I;
-    const float* wse = Ws + (size_t)e * ((N + 127) >> 7) * KB;
-    const fp8_t* wp[NT][2];
-    const float* wsp[NT];
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n0 = min(tile0 + t, last_tile) * 16;  // tail tiles re-read the last one, never stored
-        w8_lane_ptrs(We, n0, N, I, j, g, wp[t][0], wp[t][1]);
-        wsp[t] = wse + (size_t)(n0 >> 7) * KB;
-        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    constexpr int D = 3;
-    W8Frag ring[D][NT];
-    auto load_w = [&](W8Frag (&dst)[NT], int kb) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            dst[t].w[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp[t][0] + (kb << 7)));
-            dst[t].w[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wp[t][1] + (kb << 7)));
-        }
-    };
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (d < KB) load_w(ring[d], d);
-    const bf16_t* hrow = Hb + (size_t)(valid ? slot : 0) * I;
-    auto load_h = [&](int hb, float (&h)[16]) {
-        const i32x4 a = *reinterpret_cast<const i32x4*>(hrow + hb * 64 + g * 16);
-        const i32x4 b = *reinterpret_cast<const i32x4*>(hrow + hb * 64 + g * 16 + 8);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t u = (uint32_t)(i < 8 ? a : b)[(i >> 1) & 3];
-            h[i] = (i & 1) ? __uint_as_float(u & 0xffff0000u) : __uint_as_float(u << 16);
-        }
-    };
-    for (int hb = wave; hb < HB; hb += 4) {  // pass 1: maxima of the 64-column half-blocks
-        float h[16];
-        load_h(hb, h);
-        float amax = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) amax = __builtin_fmaxf(amax, __builtin_fabsf(h[i]));
-        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
-        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
-        if (g == 0) amax_lds[hb * 16 + j] = amax;
-    }
-    __syncthreads();
-    for (int hb = wave; hb < HB; hb += 4) {  // pass 2: the codes, parked in MFMA-fragment order
-        float h[16];
-        load_h(hb, h);
-        const float sc = __builtin_fmaxf(__builtin_fmaxf(amax_lds[(hb & ~1) * 16 + j], amax_lds[(hb | 1) * 16 + j]), eps) / 448.0f;
-        float lo[8], hi[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            lo[i] = h[i];
-            hi[i] = h[8 + i];
-        }
-        const i32x2 a = quant8_fp8<true>(lo, sc), b = quant8_fp8<true>(hi, sc);
-        xq_lds[hb * 64 + lane] = i32x4{a[0], a[1], b[0], b[1]};
-    }
-    __syncthreads();
-    for (int kb = 0; kb < KB; kb += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (kb + d < KB) {
-                const int k = kb + d;
-                const i32x4 x0 = xq_lds[(2 * k) * 64 + lane], x1 = xq_lds[(2 * k + 1) * 64 + lane];
-                const float xs = __builtin_fmaxf(__builtin_fmaxf(amax_lds[(2 * k) * 16 + j], amax_lds[(2 * k + 1) * 16 + j]), eps) / 448.0f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 blk = w8a8_block_dot(ring[d][t], x0, x1);
-                    const float ws = wsp[t][k];
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) acc[t][rr] += (blk[rr] * xs) * ws;
-                }
-                if (k + D < KB) load_w(ring[d], k + D);
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n0 = (tile0 + t) * 16;
-        if (valid && n0 < N) moe_store_tile(out + (size_t)slot * N, n0, g, N, acc[t], rw);
-    }
-}
-
+// (Experts wider than 512 had a variant of this launch with the quantised bytes in LDS, moe_gemm2_qw_kernel, rounds 3-4:
+// measured slower than silu_mul_quant + the generic GEMM2 at DeepSeek-V2-Lite's 1408-wide experts -- 39.0 us against
+// 4.95 + 27.2, profiles/r03_v2lite_wide_experts.txt -- never the default, removed in round 5: wide experts take the
+// three-launch form.)
 // Generic-K GEMM2 (any I): reuses the GEMM1 kernel shape with slot-indexed activations.
 template <int WK>
 __global__ __launch_bounds__(64 * WK) void moe_gemm2_generic_kernel(
@@ -887,33 +771,6 @@ extern "C" int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_sc
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
-extern "C" int chitu_hip_moe_gemm1_silu_quant_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
-                                                  const float* w1_scale, const int32_t* sorted_token_ids,
-                                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
-                                                  void* h_fp8, float* h_scales, int64_t numel, int32_t topk,
-                                                  int64_t inter_size, int64_t K, int64_t max_mblocks, float eps,
-                                                  void* stream) {
-    using namespace chitu;
-    CHITU_REQUIRE(a_fp8 && a_scale && w1_fp8 && w1_scale && sorted_token_ids && expert_ids);
-    CHITU_REQUIRE(num_tokens_post_pad && h_fp8 && h_scales);
-    CHITU_REQUIRE(numel >= 0 && topk >= 1 && inter_size >= 128 && K >= 128 && max_mblocks >= 0);
-    if (K % 128 != 0 || inter_size % 128 != 0) return CHITU_ERR_UNSUPPORTED;
-    if (numel == 0 || max_mblocks == 0) return CHITU_OK;
-    int D = 3;
-    debug_override(kOptMoeGemm1D, D);
-    const dim3 grid((unsigned)(inter_size / 128), (unsigned)max_mblocks);
-#define LAUNCH1Q(DV)                                                                                              \
-    hipLaunchKernelGGL((moe_gemm1_silu_kernel<1, DV, true>), grid, dim3(512), 0, (hipStream_t)stream,              \
-                       (const fp8_t*)a_fp8, a_scale, (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids, \
-                       num_tokens_post_pad, (bf16_t*)nullptr, (int)numel, (int)topk, (int)inter_size, (int)K,     \
-                       (fp8_t*)h_fp8, h_scales, eps)
-    if (D == 4) LAUNCH1Q(4);
-    else if (D == 2) LAUNCH1Q(2);
-    else LAUNCH1Q(3);
-#undef LAUNCH1Q
-    CHITU_RETURN_LAUNCH_STATUS();
-}
-
 extern "C" int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_fp8, const float* w2_scale,
                                              const int32_t* sorted_token_ids, const int32_t* expert_ids,
                                              const int32_t* num_tokens_post_pad, const void* topk_weights,
@@ -925,26 +782,12 @@ extern "C" int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_
     CHITU_REQUIRE(num_tokens_post_pad && out_bf16 && (topk_weights || !mul_routed_weight));
     CHITU_REQUIRE(numel >= 0 && N >= 1 && inter_size >= 128 && max_mblocks >= 0);
     CHITU_REQUIRE(weights_dtype >= 0 && weights_dtype <= 2);
-    if (inter_size % 128 != 0 || inter_size > 2048) return CHITU_ERR_UNSUPPORTED;
+    if (inter_size % 128 != 0 || inter_size > 512) return CHITU_ERR_UNSUPPORTED;  // wider experts: the three-launch form
     if (numel == 0 || max_mblocks == 0) return CHITU_OK;
     hipStream_t st = (hipStream_t)stream;
     const int n_tiles = (int)((N + 15) / 16);
     const int KB = (int)(inter_size / 128);
     const int64_t mbs = numel < max_mblocks ? numel : max_mblocks;
-    if (inter_size > 512) {
-        // wide experts: quantised activations in LDS, weights through a register ring (moe_gemm2_qw_kernel)
-        const size_t lds = (size_t)(2 * KB) * (1024 + 64);
-        const bool many = (int64_t)(n_tiles / 16) * mbs >= 512;  // 4 tiles per wave once that still fills the chip twice
-#define LAUNCH2W(NTV)                                                                                               \
-    hipLaunchKernelGGL((moe_gemm2_qw_kernel<NTV>), dim3((unsigned)((n_tiles + 4 * NTV - 1) / (4 * NTV)), (unsigned)max_mblocks), \
-                       dim3(256), lds, st, (const bf16_t*)h_bf16, (const fp8_t*)w2_fp8, w2_scale, sorted_token_ids,   \
-                       expert_ids, num_tokens_post_pad, topk_weights, weights_dtype, (bf16_t*)out_bf16, (int)numel,  \
-                       (int)N, (int)inter_size, (int)mul_routed_weight, eps)
-        if (many) LAUNCH2W(4);
-        else LAUNCH2W(2);
-#undef LAUNCH2W
-        CHITU_RETURN_LAUNCH_STATUS();
-    }
 #define LAUNCH2Q(KBV, NTV, RV)                                                                       \
     hipLaunchKernelGGL((moe_gemm2_q_kernel<KBV, NTV, RV>),                                           \
                        dim3((unsigned)((n_tiles + 4 * NTV * RV - 1) / (4 * NTV * RV)), (unsigned)max_mblocks), \

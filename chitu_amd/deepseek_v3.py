@@ -387,8 +387,7 @@ class GateDeepSeekV3(torch.nn.Module):
     def forward(self, x, extra_expert_id: int = -1, extra_count: int = 1, align=None, logits_partials=None):
         """(weights [bs, topk(+extra)] bf16, indices int64).  Two HIP launches (ops.gate_deepseek_v3).
         align=(num_experts, block, expert_map): also the moe_align triple, sorted inside the routing launch.
-        logits_partials: the score GEMM's split-K planes when the launch in front already produced them
-        (ops.gate_scores_add_norm); x is then not read."""
+        logits_partials: the score GEMM's split-K planes when a launch in front already produced them; x is then not read."""
         return ops.gate_deepseek_v3(x, self.weight, self.bias, self.n_groups, self.topk_groups, self.topk,
                                     self.score_func, self.route_scale, extra_expert_id=extra_expert_id,
                                     extra_count=extra_count, align=align, logits_partials=logits_partials)
@@ -516,15 +515,7 @@ class TransformerBlockDeepSeekV3(torch.nn.Module):
 
     def ffn_part(self, x, a, cos, sin, varlens):
         """The layer's second half: ffn_norm (+ the residual add of the attention output) and the MLP / MoE."""
-        if self.is_moe and varlens is None and _fuses_ffn_norm_into_router(x, a, self.ffn):
-            # small decode batches: ffn_norm (+ residual add + the experts' fp8 input) runs as the prologue of the router's
-            # score GEMM, redone by each of its workgroups -- one launch less per MoE layer, bit-identical
-            x, _, hq, hs, planes = ops.gate_scores_add_norm(x, a, self.ffn_norm.weight, self.ffn_norm.eps, self.ffn.gate.weight,
-                                                            quant="group")
-            defer = (tp.defers_topk_sum(x.shape[0], x.shape[1], self.ffn.gate.topk + self.ffn.n_shared)
-                     and os.environ.get("CHITU_DEFER_TOPK_SUM", "1") != "0")
-            f = self.ffn(torch.empty_like(x), (hq, hs), defer_sum=defer, logits_partials=planes)
-        elif self.is_moe:
+        if self.is_moe:
             x, hn, hq, hs = add_norm(x, a, self.ffn_norm, out_bf16=True, quant="group")
             # the experts' top-k sum moves into the next norm launch whenever nothing else needs the summed
             # tensor: always on one rank, and under TP when the all-reduce is that launch too
@@ -556,21 +547,9 @@ def _fuses_attn_norm_into_first_projection(x, pending, attn) -> bool:
             and ops.fp8_linear_add_norm_fits(x.shape[0], proj.out_features, proj.in_features, terms))
 
 
-# Decode batches up to this size run ffn_norm as the prologue of the router's score GEMM (ops.gate_scores_add_norm).
-# Built, bit-identical, and measured SLOWER on the R1 step, so OFF by default (0): same-box A/B, bs 1 4.587 -> 4.668 ms/step
-# (4.451 -> 4.518 with the attn_norm fusion on), bs 2 5.14 -> 5.49 (profiles/r04_ab_norm_prologues.txt).  The score GEMM
-# runs 256 workgroups of 14 KB of weights each; the prologue makes every one of them read 43 KB of rows and norm weights
-# and redo the norm first -- the launch it removes (4.6 us) is cheaper than that.  wqkv_a's workgroups stream 114 KB
-# each: there the same trade wins (FUSE_ATTN_NORM_MAX_BS).  The rows must fit the GEMM workgroups' LDS: 3 at dim 7168.
-FUSE_ROUTER_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_ROUTER_NORM_MAX_BS", "0"))
-
-
-def _fuses_ffn_norm_into_router(x, pending, ffn) -> bool:
-    """pending must be a plain [bs, dim] tensor (not a partial whose all-reduce the norm launch itself performs); one MoE
-    rank layout (expert parallel ranks quantise the shared slice's input differently); a shape the fused launch takes."""
-    return (isinstance(pending, torch.Tensor) and pending.dim() == 2 and x.shape[0] <= FUSE_ROUTER_NORM_MAX_BS
-            and ffn.moe_world_size == 1 and ffn.gate.weight.dtype == torch.bfloat16
-            and ops.gate_scores_add_norm_fits(x.shape[0], ffn.gate.weight.shape[0], x.shape[1]))
+# (ffn_norm as the prologue of the router's score GEMM was built in round 4, bit-identical, measured slower on the R1 step --
+# bs 1 4.587 -> 4.668 ms, profiles/r04_ab_norm_prologues.txt: the score GEMM's 256 workgroups stream 14 KB of weights each and
+# would each redo a 43 KB norm -- and removed in round 5.)
 
 
 def add_norm(x, pending, norm, out_bf16=True, quant=None, tile_major=False):

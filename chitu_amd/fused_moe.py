@@ -369,15 +369,11 @@ def fused_experts_impl(
             ),
             "moe gemm2 (tiled)",
         )
-    elif (I % 128 == 0 and I <= int(os.environ.get("CHITU_MOE_TWO_LAUNCH_MAX_I", "512"))
-          and os.environ.get("CHITU_MOE_FUSE_SILU", "1") != "0"):
+    elif I % 128 == 0 and I <= 512 and os.environ.get("CHITU_MOE_FUSE_SILU", "1") != "0":
         # two launches: GEMM1 with SiLU-and-mul in its epilogue (gate and up tile of the same columns
-        # in one wave), GEMM2 with the fp8 re-quantisation of h in its prologue.  Experts wider than 512 have the
-        # same two launches in the library (up to 2048) but take the three-launch form by default: measured on
-        # MI355X at V2-Lite's 1408-wide experts, bs 16, GEMM2-with-prologue 39.0 us against SiLU + quant 4.95 us +
-        # generic GEMM2 27.2 us (profiles/r03_v2lite_wide_experts.txt) -- every workgroup of an m-block repeats the
-        # quantisation of its 16 x I activations before its first MFMA, which a 512-wide expert hides and a 1408-wide
-        # one does not.  CHITU_MOE_TWO_LAUNCH_MAX_I=2048 selects the two-launch form for them.
+        # in one wave), GEMM2 with the fp8 re-quantisation of h in its prologue.  Experts wider than 512 take the three-launch
+        # form: every workgroup of an m-block repeats the quantisation of its 16 x I activations before its first MFMA, which a
+        # 512-wide expert hides and a 1408-wide one does not (profiles/r03_v2lite_wide_experts.txt).
         check(
             lib.chitu_hip_moe_gemm1_silu_fp8(
                 a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("c1"),
@@ -394,32 +390,20 @@ def fused_experts_impl(
             "moe gemm2 (quant fused)",
         )
     else:
-        # wide experts: GEMM1, SiLU + quant, GEMM2.  The library also has GEMM1 with SiLU-and-mul AND the fp8
-        # re-quantisation in its epilogue (one workgroup = the 8 tiles of a 128-wide group of h; two launches), for grids
-        # with enough m-blocks that GEMM1 would not split K over waves anyway -- opt-in (CHITU_MOE_GEMM1_QUANT=1): on
-        # MI355X at V2-Lite's shapes, bs 16, it takes 64.5 us against 50.7 + 4.95 us (148 VGPRs leave room for 12
-        # one-wave workgroups per CU but only ONE 8-wave workgroup; profiles/r03_v2lite_wide_experts.txt).
-        wgs = 2 * (I // 16) * min(numel, max_mblocks)
-        if I % 128 == 0 and wgs > 3200 and os.environ.get("CHITU_MOE_GEMM1_QUANT", "0") == "1":
-            check(
-                lib.chitu_hip_moe_gemm1_silu_quant_fp8(
-                    a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("a2q"), P("a2s"),
-                    i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), f32(1e-10), st,
-                ),
-                "moe gemm1 (silu + quant fused)",
-            )
-        else:
-            check(
-                lib.chitu_hip_moe_gemm1_fp8(
-                    a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("c1"),
-                    i64(numel), i32(topk), i64(N), i64(K), i64(max_mblocks), st,
-                ),
-                "moe gemm1",
-            )
-            check(
-                lib.chitu_hip_moe_silu_mul_quant_fp8(P("c1"), i64(numel), i64(I), i32(1), f32(1e-10), P("a2q"), P("a2s"), st),
-                "moe silu_mul_quant",
-            )
+        # wide experts: GEMM1, SiLU + quant, GEMM2.  (GEMM1 with SiLU-and-mul AND the fp8 re-quantisation in its epilogue was
+        # built in round 3 and measured slower at V2-Lite's shapes -- 64.5 us against 50.7 + 4.95, profiles/r03_v2lite_wide_experts.txt:
+        # its 8-wave workgroups halve the resident waves per CU -- and removed in round 5.)
+        check(
+            lib.chitu_hip_moe_gemm1_fp8(
+                a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("c1"),
+                i64(numel), i32(topk), i64(N), i64(K), i64(max_mblocks), st,
+            ),
+            "moe gemm1",
+        )
+        check(
+            lib.chitu_hip_moe_silu_mul_quant_fp8(P("c1"), i64(numel), i64(I), i32(1), f32(1e-10), P("a2q"), P("a2s"), st),
+            "moe silu_mul_quant",
+        )
         check(
             lib.chitu_hip_moe_gemm2_fp8(
                 P("a2q"), P("a2s"), ptr(w2), ptr(w2_scale), sorted_p, experts_ptr, npost_p,

@@ -223,7 +223,8 @@ def sweep_l2(nbytes: int = 256 << 20):
         size = nbytes
         while True:
             try:
-                _sweep_buffer = torch.empty(size, dtype=torch.uint8, device="cuda")
+                with torch.inference_mode(False):  # a normal tensor: it is filled from inference-mode and ordinary callers alike
+                    _sweep_buffer = torch.empty(size, dtype=torch.uint8, device="cuda")
                 break
             except torch.OutOfMemoryError:
                 size //= 2

@@ -485,49 +485,6 @@ def fp8_linear_add_norm(x, add, norm_weight, eps, weight, weight_scale, out_dtyp
     return x_new, out
 
 
-def gate_scores_add_norm_fits(M: int, E: int, K: int) -> bool:
-    """Shapes chitu_hip_bf16_gemm_add_norm_splitk takes for the router scores: the rows must fit one workgroup's LDS beside
-    the GEMM (M * K * 2 <= 48 KB: 3 rows at dim 7168), the K range must split _GATE_SPLITS ways with >= 4 waves each
-    (2 waves for at most two rows: V2-Lite's dim 2048)."""
-    if not (1 <= M <= 4 and K % 128 == 0 and 512 <= K <= 8192 and M * K <= 24576 and K % (64 * _GATE_SPLITS) == 0):
-        return False
-    tiles, kb, wk = (E + 15) // 16, K // 64, 8
-    while wk > 1 and (wk * _GATE_SPLITS > kb or tiles * _GATE_SPLITS * wk > 4096):
-        wk >>= 1
-    return wk >= 4 or (wk == 2 and M <= 2)
-
-
-def gate_scores_add_norm(x, add, norm_weight, eps, gate_weight, quant="group", out_bf16=False):
-    """ffn_norm and the router's score GEMM in ONE launch (decode batches of 1-3 rows): x_new = x + add,
-    y = RMSNorm(x_new) * norm_weight, the fp32 split-K planes of y . gate_weight^T for gate_deepseek_v3(logits_partials=...),
-    and y's fp8 form for the expert GEMMs -- what rms_norm(x, add=add, quant=quant) followed by the score GEMM of
-    gate_deepseek_v3 return, bit for bit (TransformerBlockDeepSeekV3.forward + GateDeepSeekV3.forward,
-    model_deepseek_v3.py:1107-1113, 810-820).  Returns (x_new, y or None, q, s, partials [_GATE_SPLITS, M, E])."""
-    require_cuda(x, add, norm_weight, gate_weight)
-    assert x.dtype == torch.bfloat16 and add.dtype == torch.bfloat16 and gate_weight.dtype == torch.bfloat16
-    assert x.dim() == 2 and add.shape == x.shape and x.stride(1) == 1 and add.stride(1) == 1
-    assert gate_weight.is_contiguous() and norm_weight.is_contiguous()
-    M, K = x.shape
-    E = gate_weight.shape[0]
-    assert gate_weight.shape[1] == K and gate_scores_add_norm_fits(M, E, K)
-    x_new = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
-    y = torch.empty(M, K, dtype=torch.bfloat16, device=x.device) if out_bf16 else None
-    q = s = None
-    mode = {None: 0, "act": 1, "group": 2}[quant]
-    if mode:
-        q = torch.empty(M, K, dtype=torch.float8_e4m3fn, device=x.device)
-        s = torch.empty(M, K // 128, dtype=torch.float32, device=x.device)
-    part = torch.empty(_GATE_SPLITS, M, E, dtype=torch.float32, device=x.device)
-    check(
-        _lib.lib().chitu_hip_bf16_gemm_add_norm_splitk(
-            ptr(x), i64(x.stride(0)), ptr(add), i64(add.stride(0)), ptr(x_new), i64(K), ptr(norm_weight), f32(eps),
-            ptr(gate_weight), ptr(part), i64(M), i64(E), i64(K), i32(_GATE_SPLITS), ptr(y), ptr(q), ptr(s), i32(mode),
-            f32(1e-10), stream_ptr()),
-        "gate_scores_add_norm",
-    )
-    return x_new, y, q, s, part
-
-
 def bf16_linear_add_norm(x, add, norm_weight, eps, weight, out_dtype=None):
     """(x_new, F.linear(rms_norm(x_new), weight)) with x_new = x + add, ONE launch (the add and the norm run as the
     GEMM's prologue in every workgroup; bit-identical to rms_norm(x, add=add) followed by bf16_linear).
@@ -645,7 +602,7 @@ def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, r
     require_cuda(weight)
     E = weight.shape[0]
     if logits_partials is not None:
-        # the score GEMM already ran (gate_scores_add_norm: ffn_norm + scores in one launch); x is not read
+        # the score GEMM already ran in a launch in front; x is not read
         assert logits_partials.dtype == torch.float32 and logits_partials.dim() == 3 and logits_partials.is_contiguous()
         assert logits_partials.shape[2] == E
         M, dev = logits_partials.shape[1], logits_partials.device

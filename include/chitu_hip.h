@@ -173,29 +173,13 @@ int chitu_hip_moe_gemm2_fp8(const void* h_fp8, const float* h_scale, const void*
  * gemm1_silu: a wave owns the gate tile and the up tile of the same 16 columns of W1 [E, 2I, K] and
  *   writes h[slot, :] = bf16(bf16(silu(bf16(gate))) * bf16(up)) as bf16 [numel, I]; inter_size % 16 == 0.
  * gemm2_quant: per_token_group_quant_fp8 (eps rule, 128-wide groups) of h in the prologue, then gemm2.
- *   inter_size % 128 == 0 and <= 2048 (CHITU_ERR_UNSUPPORTED otherwise: use the three-launch form); above 512 the
- *   quantised activations stay in LDS instead of registers (moe_gemm2_qw_kernel: DeepSeek-V2-Lite's 1408-wide experts,
- *   an expert-parallel rank's 2048-wide ones) -- measured slower there than silu_mul_quant + gemm2 (39 us against
- *   4.95 + 27.2 us at V2-Lite's shapes, bs 16), so chitu_amd.fused_moe takes the three-launch form above 512 unless
- *   CHITU_MOE_TWO_LAUNCH_MAX_I raises the limit. */
+ *   inter_size % 128 == 0 and <= 512 (CHITU_ERR_UNSUPPORTED otherwise: wider experts take the three-launch form). */
 int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
                                  const float* w1_scale, const int32_t* sorted_token_ids,
                                  const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
                                  void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size, int64_t K,
                                  int64_t max_mblocks, void* stream);
 
-/* gemm1_silu with per_token_group_quant_fp8 (eps rule, 128-wide groups) of h in the epilogue as well: h leaves as
- * e4m3 codes h_fp8 [numel, I] and scales h_scales [numel, I/128] -- exactly what chitu_hip_moe_silu_mul_quant_fp8 writes
- * after chitu_hip_moe_gemm1_fp8 (bit for bit) and what chitu_hip_moe_gemm2_fp8 reads.  A workgroup owns the 8 tiles
- * of one 128-wide group, each wave the whole K (no K split: meant for grids that fill the chip without one, the wide
- * experts of DeepSeek-V2-Lite / expert-parallel ranks at batch >= 4).  inter_size % 128 == 0, K % 128 == 0.
- * Measured on MI355X (V2-Lite shapes, bs 16): 64.5 us against 50.7 + 4.95 us for the two separate launches -- the
- * 8-wave workgroups halve the resident waves per CU -- so chitu_amd.fused_moe uses it only under CHITU_MOE_GEMM1_QUANT=1. */
-int chitu_hip_moe_gemm1_silu_quant_fp8(const void* a_fp8, const float* a_scale, const void* w1_fp8,
-                                       const float* w1_scale, const int32_t* sorted_token_ids,
-                                       const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
-                                       void* h_fp8, float* h_scales, int64_t numel, int32_t topk,
-                                       int64_t inter_size, int64_t K, int64_t max_mblocks, float eps, void* stream);
 /* The same two grouped GEMMs tiled for PREFILL-sized batches (64 sorted slots x 128 weight rows per workgroup through
  * LDS, fused_moe.py:62-307 with its BLOCK_SIZE_M = 64): sorted_token_ids / expert_ids / num_tokens_post_pad must come from
  * chitu_hip_moe_align_block_size with block_size 64; max_mblocks <= 65535.
@@ -293,21 +277,6 @@ int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_stride, const
                                  int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
                                  const void* norm_weight_bf16, float eps, const void* w_bf16, void* out,
                                  int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* stream);
-/* chitu_hip_bf16_gemm_add_norm with the K range cut over `num_splits` workgroups per tile (2..64), for a GEMM whose N is
- * tiny -- the router scores of GateDeepSeekV3.forward (model_deepseek_v3.py:810-820: F.linear(ffn_norm(h), gate.weight),
- * N = n_routed_experts) behind TransformerBlockDeepSeekV3's ffn_norm (:1107-1113): partials [num_splits, M, N] fp32 are
- * left for the routing launch to sum in plane order (chitu_hip_gate_route / _align, num_partials = num_splits), and are
- * bit-identical to chitu_hip_bf16_gemm(num_splits) fed chitu_hip_rmsnorm's output.  The workgroup that writes sum_out
- * also writes, when asked, the normalised rows y_out [M, K] bf16 and / or their fp8 form q_out [M, K] + q_scales
- * [M, K/128] (quant_mode 1 = act_quant_deepseek_v3, ops.py:330-353; 2 = per_token_group_quant_fp8 with quant_eps,
- * fused_moe.py:613-714; 0 = none): chitu_hip_rmsnorm's codes and scales, for the expert GEMMs behind the router.
- * Limits as chitu_hip_bf16_gemm_add_norm; K % 128 == 0 with a quant_mode. */
-int chitu_hip_bf16_gemm_add_norm_splitk(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
-                                        int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
-                                        const void* norm_weight_bf16, float eps, const void* w_bf16, float* partials,
-                                        int64_t M, int64_t N, int64_t K, int32_t num_splits, void* y_out_bf16,
-                                        void* q_out_fp8, float* q_scales, int32_t quant_mode, float quant_eps,
-                                        void* stream);
 /* chitu_hip_bf16_gemm_add_norm for the merged q|k|v projection of a GQA / MHA layer with chitu_hip_gqa_qkv_post
  * (layout 0: interleaved rotary pairs) applied in the epilogue: qkv_out [M, (q_heads + 2*kv_heads) * head_dim] receives
  * the ROTATED q heads only; the rotated k heads and the v heads go straight into the token's page rows of k_cache /

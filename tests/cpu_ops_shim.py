@@ -105,7 +105,7 @@ def absorb_uv_quant_fp8(x, w, scale, scale_offset, sh, sk):
 
 def gate_deepseek_v3(x, weight, bias, n_groups, topk_groups, topk, score_func, route_scale, extra_expert_id=-1,
                      extra_weight=1.0, extra_count=1, align=None, logits_partials=None):
-    assert logits_partials is None  # (gate_scores_add_norm_fits is False under the shim: the score GEMM always runs here)
+    assert logits_partials is None  # (the score GEMM always runs here)
     # align (the fused route + sort launch) is a launch-count optimisation: the 2-tuple makes the caller sort itself
     if score_func == "softmax_renorm":  # Mixtral: softmax -> top-k -> renormalise (model_hf_mixtral.py:60-75)
         from oracle import mixtral as omix
@@ -250,10 +250,6 @@ def fp8_linear_add_norm(x, add, norm_weight, eps, weight, weight_scale, out_dtyp
     return x_new, fp8_gemm_deepseek_v3(q, s, weight, weight_scale, out_dtype=out_dtype)
 
 
-def gate_scores_add_norm_fits(M, E, K):
-    return False
-
-
 def tile_major_ok(rows):
     """The CPU shim keeps the reference's row-major (q, s) pairs: tile-major is a device-side layout."""
     return False
@@ -265,7 +261,7 @@ def install(monkeypatch_setattr):
 
     for name in ("tile_major_ok", "rms_norm", "act_quant_deepseek_v3", "fp8_gemm_deepseek_v3", "mla_kv_prep", "absorb_bmm_fp8",
                  "absorb_uv_quant_fp8", "gate_deepseek_v3", "bf16_linear", "mla_qkv_post", "mla_q_proj", "mla_q_proj_fits", "absorb_bmm_rope_fp8",
-                 "absorb_bmm_rope_kv_fp8", "fp8_linear_add_norm", "gate_scores_add_norm_fits",
+                 "absorb_bmm_rope_kv_fp8", "fp8_linear_add_norm",
                  "embed_rope_gather"):
         monkeypatch_setattr(ops, name, globals()[name])
     monkeypatch_setattr(fused_moe, "fused_experts", fused_experts)

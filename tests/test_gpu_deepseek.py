@@ -790,42 +790,7 @@ def test_tile_major_activations_leave_the_decode_step_bit_identical(make_args, m
         assert torch.equal(a, b)
 
 
-# ---------------------------------------------------------------- ffn_norm as the prologue of the router's score GEMM
-@pytest.mark.parametrize("M", [1, 2, 3])
-@pytest.mark.parametrize("E,K", [(256, 7168), (64, 4096), (160, 6144), (64, 2048)])
-def test_ffn_norm_in_the_router_gemm_prologue_is_bit_identical(M, E, K):
-    """ops.gate_scores_add_norm (ONE launch) against rms_norm(add=..., quant="group") followed by the score GEMM of
-    gate_deepseek_v3: the residual stream, the fp8 codes and scales the experts read, the normalised rows and every fp32
-    split-K plane of the router scores are identical bit for bit; so are the routing results computed from them."""
-    from chitu_amd import _lib, ops
-
-    if not ops.gate_scores_add_norm_fits(M, E, K):
-        pytest.skip("shape outside the fused launch")
-    g = torch.Generator().manual_seed(M * 1000 + E + K)
-    x = (torch.randn(M, K, generator=g) * 2).to(torch.bfloat16).cuda()
-    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
-    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(torch.bfloat16).cuda()
-    gw = (torch.randn(E, K, generator=g) * K ** -0.5).to(torch.bfloat16).cuda()
-    a[0, 128:256] = 0
-    x[0, 128:256] = 0  # an all-zero 128-group: the eps rule of the group quantiser
-    x_ref, y_ref, q_ref, s_ref = ops.rms_norm(x, nw, 1e-6, quant="group", add=a)
-    planes_ref = torch.empty(ops._GATE_SPLITS, M, E, dtype=torch.float32, device="cuda")
-    _lib.check(_lib.lib().chitu_hip_bf16_gemm(_lib.ptr(y_ref), _lib.ptr(gw), _lib.ptr(None), _lib.i32(0), _lib.i64(M), _lib.i64(E),
-                                              _lib.i64(K), _lib.i32(ops._GATE_SPLITS), _lib.ptr(planes_ref), _lib.stream_ptr()), "scores")
-    for quant in ("group", "act", None):
-        x_new, y, q, s, planes = ops.gate_scores_add_norm(x, a, nw, 1e-6, gw, quant=quant, out_bf16=True)
-        assert torch.equal(x_new, x_ref) and torch.equal(y, y_ref) and torch.equal(planes, planes_ref), quant
-        if quant is not None:
-            _, _, q2, s2 = ops.rms_norm(x, nw, 1e-6, quant=quant, add=a)
-            assert torch.equal(q.view(torch.uint8), q2.view(torch.uint8)) and torch.equal(s, s2), quant
-    if E % 32 == 0:
-        bias = (torch.randn(E, generator=g) * 0.01).to(torch.bfloat16).cuda()
-        args = (gw, bias, E // 32, max(1, E // 64), 8, "sigmoid", 2.5)
-        w1, i1 = ops.gate_deepseek_v3(y_ref, *args)
-        w2, i2 = ops.gate_deepseek_v3(None, *args, logits_partials=planes)
-        assert torch.equal(w1, w2) and torch.equal(i1, i2)
-
-
+# ---------------------------------------------------------------- attn_norm as the prologue of the first projection
 @pytest.mark.parametrize("M,N,K,terms", [(1, 2112, 7168, 9), (1, 2112, 7168, 1), (2, 2112, 7168, 1), (1, 3648, 2048, 8),
                                          (1, 4608, 7168, 1), (2, 4608, 7168, 1), (1, 832, 512, 5), (1, 2112, 7168, 16),
                                          (1, 1000, 1024, 3)])
@@ -860,9 +825,8 @@ def test_attn_norm_in_the_first_projection_prologue_is_bit_identical(M, N, K, te
 
 @pytest.mark.parametrize("bs", [1, 2])
 def test_decode_step_with_norms_in_the_gemm_prologues_equals_the_step_without(bs, monkeypatch):
-    """A model wide enough for both fused launches (dim 4096), three decode steps eagerly and through the graph, with
-    attn_norm inside the first projection (batch 1) and ffn_norm inside the router's score GEMM (batch <= 2) switched on
-    one at a time and together, against both off: identical logits and KV rows."""
+    """A model wide enough for the fused launch (dim 4096), three decode steps eagerly and through the graph, with attn_norm
+    inside the first projection switched on against off: identical logits and KV rows."""
     from chitu_amd import deepseek_v3 as ds
     from chitu_amd.deepseek_v3 import DeepSeekV3Args
 
@@ -870,13 +834,11 @@ def test_decode_step_with_norms_in_the_gemm_prologues_equals_the_step_without(bs
                           n_routed_experts=32, n_shared_experts=1, n_activated_experts=4, n_expert_groups=4, n_limited_groups=2,
                           q_lora_rank=256, gate_bias=True)
     model, cache = build(args, max_reqs=2, max_seq=256)
-    taken = {"router": 0, "attn": 0}
-    real_r, real_a = ds.ops.gate_scores_add_norm, ds.ops.fp8_linear_add_norm
-    monkeypatch.setattr(ds.ops, "gate_scores_add_norm", lambda *a, **k: (taken.__setitem__("router", taken["router"] + 1), real_r(*a, **k))[1])
+    taken = {"attn": 0}
+    real_a = ds.ops.fp8_linear_add_norm
     monkeypatch.setattr(ds.ops, "fp8_linear_add_norm", lambda *a, **k: (taken.__setitem__("attn", taken["attn"] + 1), real_a(*a, **k))[1])
 
-    def run(tag, router_limit, attn_limit, use_graph):
-        monkeypatch.setattr(ds, "FUSE_ROUTER_NORM_MAX_BS", router_limit)
+    def run(tag, attn_limit, use_graph):
         monkeypatch.setattr(ds, "FUSE_ATTN_NORM_MAX_BS", attn_limit)
         model.graphs.clear()
         reqs = [f"{tag}{i}" for i in range(bs)]
@@ -900,13 +862,12 @@ def test_decode_step_with_norms_in_the_gemm_prologues_equals_the_step_without(bs
             cache.finalize_cache_all_decode(r)
         return out, kv
 
-    base = run("a", 0, 0, False)
-    assert taken == {"router": 0, "attn": 0}
-    for i, (router_limit, attn_limit, use_graph) in enumerate([(2, 0, False), (0, 2, False), (2, 2, False), (2, 2, True)]):
+    base = run("a", 0, False)
+    assert taken == {"attn": 0}
+    for i, (attn_limit, use_graph) in enumerate([(2, False), (2, True)]):
         before = dict(taken)
-        got = run(f"v{i}", router_limit, attn_limit, use_graph)
-        assert (taken["router"] > before["router"]) == (router_limit > 0), "ffn_norm fusion taken / not taken as asked"
+        got = run(f"v{i}", attn_limit, use_graph)
         # attn_norm fusion: one row with the experts' terms, two rows only behind a plain add (the dense layer)
         assert (taken["attn"] > before["attn"]) == (attn_limit > 0), "attn_norm fusion taken / not taken as asked"
         for a, b in zip(base[0] + base[1], got[0] + got[1]):
-            assert torch.equal(a, b), (router_limit, attn_limit, use_graph)
+            assert torch.equal(a, b), (attn_limit, use_graph)
