@@ -1008,7 +1008,7 @@ def prefill_extra(prompt_tokens=2048, n_moe_layers=6):
         os.environ.pop("CHITU_MLA_PREFILL", None)
     else:
         os.environ["CHITU_MLA_PREFILL"] = prev
-    out["attention"] = {"kernel": "chitu::mla_prefill_flash_kernel", "bound": "mfma", "peak_TFLOPs": MFMA_PEAK_TFLOPS,
+    out["attention"] = {"kernel": "chitu::mla_prefill_flash_pipe_kernel", "bound": "mfma", "peak_TFLOPs": MFMA_PEAK_TFLOPS,
                         "GFLOP": round(flop * 1e-9, 2), **att["flash"], "exact_kernel": att["exact"]}
     gemms, tot_flop, tot_us = {}, 0.0, 0.0
     # (the shared expert is a slot of the grouped expert GEMMs, not a dense GEMM: MoEDeepSeekV3.forward)

@@ -14,11 +14,11 @@
 //   * O^T = V^T P^T: rounded to bf16, a lane's P values are already the B fragment (k-slot 8*hi+e <-> key 16t + 8*(e>>2) +
 //     4*hi + (e&3)); V^T fragments come from the staged tile by ds_read_b64_tr_b16 in that key order; the 32 x 512 fp32
 //     accumulator (256 registers) is per Q row in-lane, so the rescale and the final 1/l are lane-local too;
-//   * 64-key tiles arrive by LDS-DMA (global_load_lds_dwordx4, no staging VGPRs) into a 2-deep ring, one tile ahead of the
-//     MFMAs, one workgroup barrier per tile.
-// LDS image of a tile (conflict-free for both readers): latent part [64][1088 B] (1024 + 64 pad: four consecutive keys
+//   * 32-key blocks arrive by LDS-DMA (global_load_lds_dwordx4, no staging VGPRs) into a 4-slot ring, two blocks ahead of the
+//     MFMAs, one workgroup barrier per block; the QK^T MFMAs of block b + 1 carry the softmax of block b between them.
+// LDS image of a block (conflict-free for both readers): latent part [32][1088 B] (1024 + 64 pad: four consecutive keys
 // sit in four different 64-B bank quarters for the transposed reads), 16-B chunk c of key r stored at c ^ ((r >> 2) & 3)
-// (sixteen keys x one chunk column = sixteen different bank groups for the ds_read_b128 K fragments); rope part [64][128 B],
+// (sixteen keys x one chunk column = sixteen different bank groups for the ds_read_b128 K fragments); rope part [32][128 B],
 // chunk c of key r at c ^ ((r >> 1) & 7).  The DMA writes lane-linear, so the XOR is applied to the per-lane SOURCE address.
 // Causal work per workgroup grows with the block index: blocks are issued heaviest first.
 // Not bit-equal to the decode kernel (other summation order, deferred max): the attention bar, 1e-2 of the peak.
@@ -31,13 +31,9 @@ namespace chitu {
 
 namespace pff {
 constexpr int kC = 512, kR = 64;
-constexpr int kTile = 64;                // keys per staged tile
 constexpr int kBQ = 8;                   // query tokens per workgroup (x 16 heads = 128 Q rows, 32 per wave)
 constexpr int kRowA = 1088;              // latent part: LDS row stride in bytes
 constexpr int kRowB = 128;               // rope part
-constexpr int kBufA = kTile * kRowA;     // 69632
-constexpr int kBufB = kTile * kRowB;     // 8192
-constexpr int kBuf = kBufA + kBufB;      // 77824 per ring slot
 constexpr int kORow = 1040;              // epilogue: O rows staged as bf16 [128][1040 B] over the ring
 constexpr float kDefer = 8.0f;           // deferred-rescale threshold (exp2 domain): P <= 2^8 before the next rescale
 }  // namespace pff
@@ -45,16 +41,6 @@ constexpr float kDefer = 8.0f;           // deferred-rescale threshold (exp2 dom
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4_ff;
 
-// ---- the 32 x 512 fp32 accumulator is pinned to the AGPR file through "+a" asm operands.  With the MFMA builtins hipcc's
-// allocator, given 400 live registers in a 512-register kernel, shuttles the accumulator between the two register files every
-// tile (1040 v_accvgpr moves and 184 scratch accesses per tile in the builtin form of this kernel).  Here every PV MFMA is an
-// asm statement whose accumulator operand is constrained to "a": the 16 tiles stay where they are for the whole loop and the
-// compiler is left with a 256-VGPR problem (Q 144, S 16, fragments, addresses) that it solves without a spill;
-// tests/test_flash_asm_audit.py compiles this file and checks exactly that (no scratch, no spill, no v_accvgpr_* in the tile
-// loop outside the rescale branch).  Volatile asm pins memory operations, so the V^T fragment reads are pipelined by hand.
-// Hazards hipcc does not pad around asm (guide 5.7): VALU-written operand -> MFMA (s_nop 1), MFMA result -> v_accvgpr_read /
-// VALU read (acc_settle, s_settle), v_accvgpr_write -> MFMA SrcC (s_nop 3 after a rescale).
-__device__ __forceinline__ void acc_settle(f32x16& o) { asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o)); }
 // S accumulation in the VGPR form of the instruction (hipcc's builtin insists on an AGPR destination and evicts an O tile
 // for it every key block); plain (non-volatile) asm: scheduled like any pure value computation.  s_settle: the 8-pass MFMA
 // result -> VALU read wait states hipcc does not insert for asm.
@@ -65,13 +51,16 @@ __device__ __forceinline__ void s_mfma(f32x16& s, const s16x8& a, const s16x8& b
     asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void s_settle(f32x16& s) { asm("s_nop 15\n\ts_nop 3" : "+v"(s)); }
-// o += A(vf) x B(pb)   (o pinned to the accumulator file)
-template <bool PAD>
-__device__ __forceinline__ void acc_mfma(f32x16& o, const s16x8& vf, const s16x8& pb) {
-    if (PAD)
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pb));
-    else
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(vf), "v"(pb));
+// the same, pinned in program order (volatile): the pipelined kernel places softmax work of the previous key block between them
+__device__ __forceinline__ void s_mfma0_v(f32x16& s, const s16x8& a, const s16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void s_mfma_v(f32x16& s, const s16x8& a, const s16x8& b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(a), "v"(b));
+}
+template <int N>
+__device__ __forceinline__ void glds_wait_leaving() {  // all but the N most recent LDS-DMA pieces of this wave have landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -81,10 +70,70 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__global__ __launch_bounds__(256, 1) void mla_prefill_flash_kernel(
+// ---- the 32 x 512 fp32 accumulator lives in a[0:255], named literally in the asm text, so the compiler does not allocate (or
+// move) it at all.  hipcc's own allocation of a 400-register live set does not work here: with the MFMA builtins it shuttled the
+// accumulator between the two register files every tile (1040 v_accvgpr moves, 184 scratch accesses per tile); with "+a" asm
+// operands it held it still inside one loop body but shuffled the 16 tiles through scratch at the seams of this kernel's four
+// inlined iteration bodies (1240 spilled registers).  So: every PV MFMA, the zero fill, the rescale and the read-out are asm
+// statements on fixed AGPRs; fa_reserve()'s clobber list makes the kernel descriptor allocate the AGPR file; the compiler is
+// left with a 256-VGPR problem (Q 144, two S tiles 32, fragments, addresses) that it solves without a spill -- and must never
+// touch the AGPR file itself: tests/test_flash_asm_audit.py compiles this file and requires that no v_accvgpr_* / a[...]
+// operand appears outside ;;#ASMSTART .. ;;#ASMEND and that there is no scratch access (tools/check_flash_asm.py, literal mode).
+// Volatile asm pins memory operations, so the K and V^T fragment reads are pipelined by hand in source order.
+// Hazards hipcc does not pad around asm (guide 5.7): VALU-written operand -> MFMA (s_nop 1), MFMA result -> v_accvgpr_read
+// (fa_settle) / VALU read (s_settle), v_accvgpr_write -> MFMA SrcC (s_nop 3 after a rescale).
+#define A4(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+__device__ __forceinline__ void fa_reserve() {
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", A4(1), A4(2), A4(3), A4(4), A4(5), A4(6), A4(7),
+                 A4(8), A4(9), A4(10), A4(11), A4(12), A4(13), A4(14), A4(15), A4(16), A4(17), A4(18), A4(19), A4(20), A4(21),
+                 A4(22), A4(23), A4(24), "a250", "a251", "a252", "a253", "a254", "a255");
+}
+#undef A4
+template <int I>
+__device__ __forceinline__ void fa_zero() {
+    asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"i"(I));
+}
+template <int I>
+__device__ __forceinline__ float fa_read() {
+    float t;
+    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(t) : "i"(I));
+    return t;
+}
+template <int I>
+__device__ __forceinline__ void fa_write(float t) {
+    asm volatile("v_accvgpr_write_b32 a%c0, %1" ::"i"(I), "v"(t));
+}
+__device__ __forceinline__ void fa_settle() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+template <int CB, bool PAD>  // a[16 CB : 16 CB + 15] += A(vf) x B(pb)
+__device__ __forceinline__ void fa_mfma(const s16x8& vf, const s16x8& pb) {
+    if (PAD)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pb), "i"(CB * 16), "i"(CB * 16 + 15));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(vf), "v"(pb), "i"(CB * 16), "i"(CB * 16 + 15));
+}
+
+// ---------------------------------------------------------------- the kernel: software-pipelined over 32-key blocks
+// A wave is alone on its SIMD, so a key block run as QK^T -> softmax -> PV in series idles the matrix pipe during the ~100 VALU
+// instructions of the softmax (the first form of this kernel, round 5: PMC at 2048 tokens MFMA busy 24 %, 3 VALU per MFMA).
+// Here the unit is the 32-key block in a FOUR-slot ring, and the 36 QK^T MFMAs of block b + 1 are issued with the softmax of
+// block b between them in program order (two or three VALU per MFMA: inside the 32-cycle shadow of each), then the 32 PV MFMAs
+// of block b with their V^T reads.  One barrier per block; block b + 3's DMA is issued two blocks before its K fragments are
+// needed (a counted s_waitcnt leaves the younger block in flight).  Measured against the serial form (same box): 2048 tokens
+// 125.9 -> 120.9 us, 8192 tokens 1086 -> 1148 TFLOP/s (0.46 of the MFMA peak) with five fragments in flight.
+namespace pfp {
+constexpr int kKeys = 32;
+constexpr int kSlotA = kKeys * pff::kRowA;   // 34816
+constexpr int kSlotB = kKeys * pff::kRowB;   // 4096
+constexpr int kSlot = kSlotA + kSlotB;       // 38912
+constexpr int kRing = 4;                     // 155648 B
+constexpr int kPieces = 9;                   // LDS-DMA pieces per wave and block: 8 latent rows + 8 rope rows
+}  // namespace pfp
+
+__global__ __launch_bounds__(256, 1) void mla_prefill_flash_pipe_kernel(
     const bf16_t* __restrict__ q, int64_t q_st, int64_t q_sh, const bf16_t* __restrict__ kv, int64_t kv_st,
     const int32_t* __restrict__ cu_seqlens, float scale, bf16_t* __restrict__ out, int H) {
     using namespace pff;
+    using namespace pfp;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,183 +143,194 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_flash_kernel(
     const int p0 = ((int)gridDim.x - 1 - (int)blockIdx.x) * kBQ;  // heaviest (latest) block first
     if (p0 >= L) return;
     const int nq = min(kBQ, L - p0);
-    const int n_keys = p0 + nq;  // keys 0 .. n_keys - 1 are visible to this block's last token
-    const int n_tiles = (n_keys + kTile - 1) / kTile;
-    const int tq = 2 * wave + (row >> 4);   // this lane's query token within the block (a token past the end repeats the last one, stores nothing)
-    const int pq = p0 + min(tq, nq - 1);    // its position: keys 0 .. pq
+    const int n_keys = p0 + nq;
+    const int nb = (n_keys + kKeys - 1) / kKeys;  // key blocks 0 .. nb - 1; only the last one reaches into the block's own tokens
+    const int tq = 2 * wave + (row >> 4);
+    const int pq = p0 + min(tq, nq - 1);
     const int head = min(h0 + (row & 15), H - 1);
     const bf16_t* kbase = kv + (int64_t)s0 * kv_st;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    const uint32_t lds0 = lds_offset_of(smem);
 
-    // ---- tile DMA: wave w brings rows 16w .. 16w+15 (one 1 KiB piece per latent row, two pieces of 8 rope rows)
-    uint32_t voffx[4];
+    // ---- block DMA: wave w brings keys 8 w .. 8 w + 7 of the block (a piece per latent row, one piece of 8 rope rows)
+    const int rope_chunk = 64 + ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7));
+    auto issue = [&](int b) {
+        const int t0 = b * kKeys;
+        const uint32_t dst = lds0 + (uint32_t)((b & (kRing - 1)) * kSlot);
 #pragma unroll
-    for (int x = 0; x < 4; ++x) voffx[x] = (uint32_t)((lane ^ x) * 16);
-    const int rope_chunk[2] = {64 + ((lane & 7) ^ (lane >> 4)), 64 + ((lane & 7) ^ (4 + (lane >> 4)))};
-    auto issue = [&](int tile) {
-        const int t0 = tile * kTile;
-        const uint32_t dst = lds0 + (uint32_t)((tile & 1) * kBuf);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = wave * 16 + i;
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave * 8 + i;
             const int grow = min(t0 + r, L - 1);  // rows past the sequence repeat its last key (finite, masked by causality)
-            glds16_sbase(kbase + (int64_t)grow * kv_st, voffx[(i >> 2) & 3], dst + (uint32_t)(r * kRowA));
+            const uint32_t voff = (uint32_t)((lane ^ ((r >> 2) & 3)) << 4);
+            glds16_sbase(kbase + (int64_t)grow * kv_st, voff, dst + (uint32_t)(r * kRowA));
         }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int r = wave * 16 + e * 8 + (lane >> 3);
-            const int grow = min(t0 + r, L - 1);
-            glds16_vaddr(kbase + (int64_t)grow * kv_st + rope_chunk[e] * 8, dst + (uint32_t)(kBufA + (wave * 2 + e) * 1024));
-        }
+        const int r = wave * 8 + (lane >> 3);
+        const int grow = min(t0 + r, L - 1);
+        glds16_vaddr(kbase + (int64_t)grow * kv_st + rope_chunk * 8, dst + (uint32_t)(kSlotA + wave * 1024));
     };
     issue(0);
+    if (nb > 1) issue(1);
+    if (nb > 2) issue(2);
 
-    // ---- Q fragments (B operand of S^T = K Q^T): lane (row, hi) holds q[token][head][16 kk + 8 hi .. + 8]
     s16x8 qf[36];
     {
         const bf16_t* qp = q + (int64_t)(s0 + pq) * q_st + (int64_t)head * q_sh + hi * 8;
 #pragma unroll
         for (int kk = 0; kk < 36; ++kk) qf[kk] = *reinterpret_cast<const s16x8*>(qp + kk * 16);
-        // make hipcc wait for these loads HERE: left to the first use, its counted s_waitcnt vmcnt(35 .. 0) ladder sits inside
-        // the tile loop and, on every later tile, drains the LDS-DMA pieces of the next tile it knows nothing about
 #pragma unroll
-        for (int kk = 0; kk < 36; ++kk) asm volatile("" : "+v"(qf[kk]));
+        for (int kk = 0; kk < 36; ++kk) asm volatile("" : "+v"(qf[kk]));  // (hipcc waits here, not in the loop: see the kernel above)
     }
-
-    // O^T[column 32 cb + crow(reg, hi)][this lane's Q row] = a[16 cb + reg]
-    f32x16 o[16];
-#pragma unroll
-    for (int cb = 0; cb < 16; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[cb][r] = 0.f;
-    float m = -INFINITY, l = 0.f;  // running maximum (exp2 domain; equal in lanes l and l^32) and this lane's share of the row sum
+    fa_reserve();  // O^T[column 32 cb + crow(reg, hi)][this lane's Q row] = a[16 cb + reg]
+    static_for<0, 256>([&](auto i) { fa_zero<decltype(i)::value>(); });
+    float m = -INFINITY, l = 0.f;
     const float c2 = scale * 1.4426950408889634f;
 
-    // lane-constant LDS offsets
-    const int xl = (lane >> 2) & 3;           // chunk XOR of this lane's K row (row & 15 = lane & 15)
-    const int gbl = (lane >> 1) & 7;          // rope-part chunk XOR of this lane's K row
+    const int xl = (lane >> 2) & 3, gbl = (lane >> 1) & 7;
     const int k_off = row * kRowA + ((hi ^ (xl & 1)) * 16);
     const int k_sw = xl >> 1;
-    const int kb_off = row * kRowB;
-    // V^T fragment (transposed read): 16-lane group g16 = lane >> 4 reads [4 keys][16 columns]; this lane's 8 bytes
+    const int kb_off = kSlotA + row * kRowB;
     const int v_row = 4 * hi + ((lane & 15) >> 2);
     const int v_cl = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
     int v_off[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) v_off[u] = (v_row + 8 * u) * kRowA + ((v_cl ^ (hi | (2 * u))) * 16) + (lane & 1) * 8;
 
-    for (int tile = 0; tile < n_tiles; ++tile) {
-        const int t0 = tile * kTile;
-        glds_wait_all();                                   // this wave's pieces of the tile have landed
-        __syncthreads();                                   // everyone's have; the other ring slot is no longer being read
-        if (tile + 1 < n_tiles) issue(tile + 1);
-        const uint8_t* bufA = smem + (tile & 1) * kBuf;
-        const uint8_t* bufB = bufA + kBufA;
-        const bool last = tile == n_tiles - 1;
+    // K fragment kk of a block (slot base sb): chunk 2 kk + hi of row `row`, latent part kk < 32, rope part above
+    auto kread = [&](const uint8_t* sb, auto kk_) -> s16x8 {
+        constexpr int kk = decltype(kk_)::value;
+        if constexpr (kk < 32) return *reinterpret_cast<const s16x8*>(sb + k_off + (((kk & 1) ^ k_sw) * 32) + (kk >> 1) * 64);
+        else return *reinterpret_cast<const s16x8*>(sb + kb_off + (((2 * (kk - 32) + hi) ^ gbl) * 16));
+    };
+
+    // ---- block 0's scores, not overlapped with anything
+    if (nb > 2) glds_wait_leaving<2 * kPieces>();
+    else if (nb > 1) glds_wait_leaving<kPieces>();
+    else glds_wait_all();
+    __syncthreads();
+    f32x16 sA, sB;
+    static_for<0, 36>([&](auto kk_) {
+        constexpr int kk = decltype(kk_)::value;
+        const s16x8 kf = kread(smem, kk_);
+        if constexpr (kk == 0) s_mfma0(sA, kf, qf[0]);
+        else s_mfma(sA, kf, qf[kk]);
+    });
+    s_settle(sA);
+
+    // iteration b: [scores of block b + 1 into sN, with the softmax of block b (scores sC) between the MFMAs] then O^T += V^T P^T of b
+    auto iter = [&](auto last_, int b, f32x16& sC, f32x16& sN) {
+        constexpr bool LAST = decltype(last_)::value;  // b == nb - 1: no next block, causal mask on this one
+        const uint8_t* sbV = smem + (b & (kRing - 1)) * kSlot;
+        const uint8_t* sbK = smem + ((b + 1) & (kRing - 1)) * kSlot;
+        if constexpr (!LAST) {
+            // block b + 1 has landed (this wave's pieces; block b + 2's, issued one iteration ago, may still fly)
+            if (b + 2 < nb) glds_wait_leaving<kPieces>();
+            else glds_wait_all();
+        }
+        __syncthreads();  // everyone's pieces of b + 1 are there; nobody reads slot (b - 1) & 3 any more
+        if (b + 3 < nb) issue(b + 3);
+
+        float pmax = -INFINITY, psum = 0.f;  // (the scaled scores overwrite sC in place)
+        s16x8 pb[2];
+        constexpr int kR = 5;  // K fragments in flight
+        s16x8 kf[kR];
+        if constexpr (!LAST) static_for<0, kR>([&](auto i) { kf[decltype(i)::value] = kread(sbK, i); });
+        // softmax of block b in slices: slots 0-7 scale (+ mask) and the lane's maximum, slot 8 the (rare) rescale decision,
+        // slots 9-24 exp2 / row sum / bf16 packing, two elements each
+        auto soft = [&](auto k_) {
+            constexpr int k = decltype(k_)::value;
+            if constexpr (k < 8) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (last && t0 + kb * 32 >= n_keys) break;  // the block's last key is before this half tile (workgroup-uniform)
-            // ---- S^T[key 32 kb + crow(reg, hi)][Q row] = K Q^T
-            f32x16 s;
-            {
-                const uint8_t* ka = bufA + kb * 32 * kRowA + k_off;
-#pragma unroll
-                for (int kk = 0; kk < 32; ++kk) {
-                    const s16x8 kf = *reinterpret_cast<const s16x8*>(ka + (((kk & 1) ^ k_sw) * 32) + (kk >> 1) * 64);
-                    if (kk == 0) s_mfma0(s, kf, qf[0]);
-                    else s_mfma(s, kf, qf[kk]);
+                for (int r = 2 * k; r < 2 * k + 2; ++r) {
+                    if constexpr (LAST) {
+                        const int key = b * kKeys + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        sC[r] = key <= pq ? sC[r] * c2 : -INFINITY;
+                    } else {
+                        sC[r] = sC[r] * c2;
+                    }
+                    pmax = __builtin_fmaxf(pmax, sC[r]);
                 }
-                const uint8_t* kr = bufB + kb * 32 * kRowB + kb_off;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const s16x8 kf = *reinterpret_cast<const s16x8*>(kr + (((2 * j + hi) ^ gbl) * 16));
-                    s_mfma(s, kf, qf[32 + j]);
+            } else if constexpr (k == 8) {
+                if (__builtin_amdgcn_ballot_w64(pmax > m + kDefer) != 0) {  // m = -inf (first block): every lane votes
+                    const float mx = __builtin_fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+                    const float m_new = __builtin_fmaxf(m, mx);
+                    const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+                    m = m_new;
+                    l *= alpha;
+                    fa_settle();  // (the PV MFMAs of the previous block finished 36 S MFMAs ago at the earliest; belt and braces)
+                    static_for<0, 32>([&](auto g) {
+                        constexpr int base = decltype(g)::value * 8;
+                        float t[8];
+                        static_for<0, 8>([&](auto i) { t[decltype(i)::value] = fa_read<base + decltype(i)::value>(); });
+                        static_for<0, 8>([&](auto i) { fa_write<base + decltype(i)::value>(t[decltype(i)::value] * alpha); });
+                    });
+                    asm volatile("s_nop 3" ::: "memory");
                 }
-                s_settle(s);
-            }
-            // ---- scale, causal mask (diagonal tile only), the lane's maximum
-            float pmax = -INFINITY;
-            if (last) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    s[r] = key <= pq ? s[r] * c2 : -INFINITY;
-                    pmax = __builtin_fmaxf(pmax, s[r]);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[r] *= c2;
-                    pmax = __builtin_fmaxf(pmax, s[r]);
-                }
-            }
-            // ---- deferred rescale: move the maximum only when some row's scores outgrow it by more than kDefer
-            if (__builtin_amdgcn_ballot_w64(pmax > m + kDefer) != 0) {  // m = -inf (first block): every lane votes
-                const float mx = __builtin_fmaxf(pmax, __shfl_xor(pmax, 32, 64));
-                const float m_new = __builtin_fmaxf(m, mx);  // finite: key 0 is visible to every row
-                const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-                m = m_new;
-                l *= alpha;
-#pragma unroll
-                for (int cb = 0; cb < 16; ++cb) {
-                    acc_settle(o[cb]);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[cb][r] *= alpha;
-                    asm volatile("s_nop 3" : "+a"(o[cb]));
-                }
-            }
-            // ---- P = exp2(S - m); bf16 P is the B fragment of O^T += V^T P^T
-            s16x8 pb[2];
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float a = __builtin_amdgcn_exp2f(s[r] - m);  // masked keys: exp2(-inf) = 0
-                const float b = __builtin_amdgcn_exp2f(s[r + 1] - m);
-                psum += a + b;
-                const uint32_t pk = f32x2_to_bf16x2(a, b);
+            } else if constexpr (k >= 9 && k < 17) {
+                constexpr int r = 2 * (k - 9);
+                const float a = __builtin_amdgcn_exp2f(sC[r] - m);  // masked keys: exp2(-inf) = 0
+                const float c = __builtin_amdgcn_exp2f(sC[r + 1] - m);
+                psum += a + c;
+                const uint32_t pk = f32x2_to_bf16x2(a, c);
                 pb[r >> 3][r & 7] = (short)(pk & 0xffffu);
                 pb[r >> 3][(r & 7) + 1] = (short)(pk >> 16);
             }
-            l += psum;
-            // ---- O^T += V^T P^T over the block's 32 keys: 32 MFMAs n = 16 t + cb (key step t, column block cb), V^T fragments
-            // read kAhead MFMAs ahead in SOURCE order (memory operations do not move across the asm statements)
-            {
-                const uint8_t* vb = bufA + kb * 32 * kRowA;
-                constexpr int kAhead = 4;
-                s16x8 vf[kAhead];
-                auto vread = [&](auto n_) {
-                    constexpr int n = decltype(n_)::value;
-                    const uint8_t* p = vb + (n >> 4) * 16 * kRowA + (n & 15) * 64;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ff*)(p + v_off[0]));
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ff*)(p + v_off[1]));
-                    s16x8 r;
-                    r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
-                    r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
-                    vf[n % kAhead] = r;
-                };
-                static_for<0, kAhead>(vread);
-                static_for<0, 32>([&](auto n_) {
-                    constexpr int n = decltype(n_)::value;
-                    acc_mfma<(n & 15) == 0>(o[n & 15], vf[n % kAhead], pb[n >> 4]);
-                    if constexpr (n + kAhead < 32) vread(std::integral_constant<int, n + kAhead>{});
-                });
-            }
+        };
+        if constexpr (!LAST) {
+            static_for<0, 36>([&](auto kk_) {
+                constexpr int kk = decltype(kk_)::value;
+                if constexpr (kk == 0) s_mfma0_v(sN, kf[0], qf[0]);
+                else s_mfma_v(sN, kf[kk % kR], qf[kk]);
+                if constexpr (kk + kR < 36) kf[kk % kR] = kread(sbK, std::integral_constant<int, kk + kR>{});
+                soft(kk_);
+            });
+        } else {
+            static_for<0, 17>(soft);
         }
+        l += psum;
+        {
+            constexpr int kAhead = 5;
+            s16x8 vf[kAhead];
+            auto vread = [&](auto n_) {
+                constexpr int n = decltype(n_)::value;
+                const uint8_t* p = sbV + (n >> 4) * 16 * kRowA + (n & 15) * 64;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ff*)(p + v_off[0]));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ff*)(p + v_off[1]));
+                s16x8 r;
+                r[0] = v0[0]; r[1] = v0[1]; r[2] = v0[2]; r[3] = v0[3];
+                r[4] = v1[0]; r[5] = v1[1]; r[6] = v1[2]; r[7] = v1[3];
+                vf[n % kAhead] = r;
+            };
+            static_for<0, kAhead>(vread);
+            static_for<0, 32>([&](auto n_) {
+                constexpr int n = decltype(n_)::value;
+                fa_mfma<(n & 15), (n & 15) == 0>(vf[n % kAhead], pb[n >> 4]);
+                if constexpr (n + kAhead < 32) vread(std::integral_constant<int, n + kAhead>{});
+            });
+        }
+    };
+    int b = 0;
+    for (; b + 2 < nb; b += 2) {
+        iter(std::false_type{}, b, sA, sB);
+        iter(std::false_type{}, b + 1, sB, sA);
+    }
+    if (b + 1 < nb) {
+        iter(std::false_type{}, b, sA, sB);
+        iter(std::true_type{}, b + 1, sB, sA);
+    } else {
+        iter(std::true_type{}, b, sA, sB);
     }
 
-    // ---- epilogue: normalise, stage this wave's 32 rows through LDS (the ring is free after the barrier), store whole rows
+    // ---- epilogue (as above)
     __syncthreads();
     const float inv = 1.0f / (l + __shfl_xor(l, 32, 64));
     uint8_t* ostage = smem + wave * 32 * kORow;
+    fa_settle();
     static_for<0, 64>([&](auto g) {
-        constexpr int cb = decltype(g)::value >> 2, rq = decltype(g)::value & 3, b = rq * 4;
-        if constexpr (rq == 0) acc_settle(o[cb]);
+        constexpr int cb = decltype(g)::value >> 2, rq = decltype(g)::value & 3, bb = cb * 16 + rq * 4;
         i32x2 pk;
-        pk[0] = (int)f32x2_to_bf16x2(o[cb][b] * inv, o[cb][b + 1] * inv);
-        pk[1] = (int)f32x2_to_bf16x2(o[cb][b + 2] * inv, o[cb][b + 3] * inv);
+        pk[0] = (int)f32x2_to_bf16x2(fa_read<bb>() * inv, fa_read<bb + 1>() * inv);
+        pk[1] = (int)f32x2_to_bf16x2(fa_read<bb + 2>() * inv, fa_read<bb + 3>() * inv);
         *reinterpret_cast<i32x2*>(ostage + row * kORow + (32 * cb + 8 * rq + 4 * hi) * 2) = pk;
     });
-    // (rows are read back by the wave that wrote them: in-wave LDS ordering suffices)
 #pragma unroll 4
     for (int r = 0; r < 32; ++r) {
         const int t = 2 * wave + (r >> 4), h = h0 + (r & 15);
@@ -282,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void mla_prefill_flash_kernel(
 
 }  // namespace chitu
 
-// The contract of chitu_hip_mla_prefill on mla_prefill_flash_kernel: equal to it within the attention bar, not bit for bit.
+// The contract of chitu_hip_mla_prefill on mla_prefill_flash_pipe_kernel: equal to it within the attention bar, not bit for bit.
 extern "C" int chitu_hip_mla_prefill_flash(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
                                            int64_t kv_stride_t, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
                                            float softmax_scale, void* out_bf16, int32_t heads, int32_t kv_lora_rank,
@@ -293,14 +353,14 @@ extern "C" int chitu_hip_mla_prefill_flash(const void* q_bf16, int64_t q_stride_
     CHITU_REQUIRE(q_stride_t % 8 == 0 && q_stride_h % 8 == 0 && kv_stride_t % 8 == 0);
     CHITU_REQUIRE(((uintptr_t)q_bf16 | (uintptr_t)kv_bf16 | (uintptr_t)out_bf16) % 16 == 0);
     if (n_seq == 0 || max_seqlen == 0) return CHITU_OK;
-    const size_t lds = 2 * (size_t)pff::kBuf;
+    const size_t lds = (size_t)pfp::kRing * pfp::kSlot;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mla_prefill_flash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)mla_prefill_flash_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const dim3 grid((unsigned)((max_seqlen + pff::kBQ - 1) / pff::kBQ), (unsigned)n_seq, (unsigned)((heads + 15) / 16));
-    hipLaunchKernelGGL(mla_prefill_flash_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q_bf16, q_stride_t,
+    hipLaunchKernelGGL(mla_prefill_flash_pipe_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q_bf16, q_stride_t,
                        q_stride_h, (const bf16_t*)kv_bf16, kv_stride_t, cu_seqlens, softmax_scale, (bf16_t*)out_bf16,
                        (int)heads);
     CHITU_RETURN_LAUNCH_STATUS();

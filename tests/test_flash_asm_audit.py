@@ -13,8 +13,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-@pytest.mark.parametrize("src,kernel", [("mla_prefill_flash.hip", "mla_prefill_flash_kernel")])
-def test_flash_kernel_assembly_has_no_spills_and_no_accumulator_traffic(tmp_path, src, kernel):
+@pytest.mark.parametrize("src,kernel,literal", [("mla_prefill_flash.hip", "mla_prefill_flash_pipe_kernel", True)])
+def test_flash_kernel_assembly_has_no_spills_and_no_accumulator_traffic(tmp_path, src, kernel, literal):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_flash_asm
 
@@ -23,5 +23,5 @@ def test_flash_kernel_assembly_has_no_spills_and_no_accumulator_traffic(tmp_path
            "-S", "--cuda-device-only", os.path.join(csrc, src), "-o", str(tmp_path / "k.s")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
-    seen, bad = check_flash_asm.audit(str(tmp_path / "k.s"), kernel)
+    seen, bad = (check_flash_asm.audit_literal if literal else check_flash_asm.audit)(str(tmp_path / "k.s"), kernel)
     assert seen and not bad, bad

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Audit of the gfx950 assembly of a kernel that pins its MFMA accumulators to the AGPR file through asm operands
-(csrc/mla_prefill_flash.hip): python tools/check_flash_asm.py <file.s> <kernel-name-substring> [max_accvgpr_in_loop]
+(csrc/mla_prefill_flash.hip): python tools/check_flash_asm.py <file.s> <kernel-name-substring> [max_accvgpr_in_loop | literal]
 Checks, for every kernel whose mangled name contains the substring:
   * .private_segment_fixed_size 0 and .vgpr_spill_count 0 (no scratch: a spill in a one-wave-per-SIMD MFMA loop is the
     3x slowdown this structure exists to avoid), no scratch_* instruction;
@@ -24,6 +24,33 @@ def kernels(text, name):
             if line.strip().startswith(".Lfunc_end"):
                 yield cur, body
                 cur = None
+
+
+def audit_literal(path, name):
+    """Kernels that name a[0:255] literally in their asm statements: the compiler must not touch the AGPR file at all --
+    no v_accvgpr_* and no a[...] / aN operand outside ;;#ASMSTART .. ;;#ASMEND -- and must not spill."""
+    text = open(path).read()
+    bad, seen = [], []
+    for k, body in kernels(text, name):
+        seen.append(k)
+        in_asm = False
+        for ln in body:
+            if ";;#ASMSTART" in ln:
+                in_asm = True
+            elif ";;#ASMEND" in ln:
+                in_asm = False
+            elif not in_asm:
+                code = ln.split(";")[0]
+                if re.search(r"\bv_accvgpr|\ba\[\d+:\d+\]|\ba\d+\b|scratch_", code):
+                    bad.append(f"{k}: compiler-generated accumulator / scratch access: {code.strip()}")
+                    if len(bad) > 8:
+                        break
+    for m in re.finditer(r"\.name:\s*(\S+)(?:.*\n)*?.*?\.private_segment_fixed_size:\s*(\d+)(?:.*\n)*?.*?\.vgpr_spill_count:\s*(\d+)", text):
+        if name in m.group(1) and (int(m.group(2)) or int(m.group(3))):
+            bad.append(f"{m.group(1)}: private_segment {m.group(2)} vgpr_spill {m.group(3)}")
+    if not seen:
+        bad.append(f"no kernel matching {name!r} in {path}")
+    return seen, bad
 
 
 def audit(path, name, max_acc=0):
@@ -62,6 +89,12 @@ def audit(path, name, max_acc=0):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "literal":
+        seen, bad = audit_literal(sys.argv[1], sys.argv[2])
+        print("audited (literal AGPR form):", seen)
+        for b in bad:
+            print("VIOLATION:", b)
+        sys.exit(1 if bad else 0)
     seen, bad = audit(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "flash", int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     print("audited:", seen)
     for b in bad:
