@@ -603,6 +603,9 @@ class DeepSeekV3Decoder(torch.nn.Module):
         """tokens: list of per-request token-id lists; req_ids: their cache keys.  Runs the prompt
         through every layer, fills the KV pages, returns fp32 logits [n_req, vocab] of each prompt's
         LAST token (prefill_single_device, model.py:451-465).  Eager launches."""
+        from . import graphs
+
+        graphs.sweep_if_memory_was_recycled()  # the eager path's canary: once after an xGMI communicator came or went
         varlens = VarLens(tokens, self.device)
         self.cache.curr_varlens, self.cache.curr_req_ids = varlens, list(req_ids)
         flat = torch.tensor([t for seq in tokens for t in seq], dtype=torch.int64, device=self.device)

@@ -236,6 +236,29 @@ def sweep_l2(nbytes: int = 256 << 20):
     torch.cuda.synchronize()
 
 
+# ---- the eager path's canary (round 5).  capture_verified protects graph captures; eager launches (prefill, eager decode)
+# that receive recycled memory have no replay to compare with.  The one known source of stale L2 lines is the life cycle of an
+# xGMI communicator's uncached, IPC-shared exchange buffer (DESIGN, "graph replay"): XgmiComm marks the process dirty when such
+# a buffer is created, mapped from a peer, or torn down, and the model entry points that launch eagerly (prefill) sweep every L2
+# once before their first launch after such an event.  ~0.1 ms, only ever after a communicator event.
+_recycled_memory_pending = False
+
+
+def mark_memory_recycled():
+    global _recycled_memory_pending
+    _recycled_memory_pending = True
+
+
+def sweep_if_memory_was_recycled() -> bool:
+    """Called by eager entry points before their first launch; True if a sweep ran."""
+    global _recycled_memory_pending
+    if not _recycled_memory_pending or not torch.cuda.is_available():
+        return False
+    _recycled_memory_pending = False
+    sweep_l2()
+    return True
+
+
 def unverified_or_retried():
     """Captures of this process that needed more than one attempt or were outvoted by a peer rank (bench.py voids its
     line on any, after a MIN over the ranks; tests assert [])."""

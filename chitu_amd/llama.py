@@ -214,6 +214,9 @@ class LlamaDecoder(torch.nn.Module):
         (prefill_single_device, model.py:451-465)."""
         from .deepseek_v3 import VarLens
 
+        from . import graphs
+
+        graphs.sweep_if_memory_was_recycled()  # the eager path's canary: once after an xGMI communicator came or went
         varlens = VarLens(tokens, self.device)
         self.cache.curr_varlens, self.cache.curr_req_ids = varlens, list(req_ids)
         flat = torch.tensor([t for seq in tokens for t in seq], dtype=torch.int64, device=self.device)

@@ -23,6 +23,12 @@ _QUANT_MODE = {None: 0, "act": 1, "group": 2}
 closed_buffers = []  # device addresses of the (uncached) exchange buffers this process has freed: diagnostics (tests/conftest.py)
 
 
+def _mark_recycled():
+    from . import graphs
+
+    graphs.mark_memory_recycled()
+
+
 class XgmiComm:
     def __init__(self, rank: int, world: int, max_rows: int = 64, max_dim: int = 8192,
                  gather_bytes: int = 0, timeout_ms: int = 10000):
@@ -32,6 +38,7 @@ class XgmiComm:
         check(_lib.lib().chitu_hip_comm_create(i32(rank), i32(world), i32(max_rows), i32(max_dim), i64(gather_bytes),
                                                i32(timeout_ms), ctypes.byref(h)), "comm_create")
         self._h = h
+        _mark_recycled()  # an uncached exchange buffer came to life: eager launches sweep the L2s once (graphs.py, the canary)
         self.two_shot_bytes = 256 << 10  # the library's default (chitu_hip_comm_set_two_shot)
         # Split-phase mode (tensor_parallel.enable_xgmi under CHITU_XGMI_SPLIT_PHASE=1): a process group over which every
         # whole collective (phase 0) is run as contribute -> host barrier -> complete, so that no kernel ever waits for
@@ -48,6 +55,7 @@ class XgmiComm:
     def open_peer(self, peer: int, handle: bytes):
         assert len(handle) == 64
         check(_lib.lib().chitu_hip_comm_open_peer(self._h, i32(peer), ctypes.c_char_p(handle)), "comm_open_peer")
+        _mark_recycled()
 
     def local_ptr(self) -> int:
         p = ctypes.c_void_p()
@@ -145,6 +153,7 @@ class XgmiComm:
                 pass
             _lib.lib().chitu_hip_comm_destroy(self._h)
             self._h = None
+            _mark_recycled()
 
     # ------------------------------------------------------------------ collectives
     def fits(self, rows: int, dim: int, terms: int = 1) -> bool:

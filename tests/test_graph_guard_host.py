@@ -147,3 +147,19 @@ def test_one_ranks_mismatch_repeats_the_capture_on_every_rank():
         p.join(timeout=30)
     for r in results:
         assert r[1] == "ok", r
+
+
+def test_eager_canary_sweeps_once_after_a_communicator_event(monkeypatch):
+    """graphs.mark_memory_recycled (called by XgmiComm on create / open_peer / close) arms ONE L2 sweep in front of the next
+    eager entry point (model.prefill calls sweep_if_memory_was_recycled); nothing is swept otherwise."""
+    from chitu_amd import graphs
+
+    sweeps = []
+    monkeypatch.setattr(graphs, "sweep_l2", lambda *a, **k: sweeps.append(1))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(graphs, "_recycled_memory_pending", False)
+    assert graphs.sweep_if_memory_was_recycled() is False and sweeps == []
+    graphs.mark_memory_recycled()
+    graphs.mark_memory_recycled()
+    assert graphs.sweep_if_memory_was_recycled() is True and sweeps == [1]
+    assert graphs.sweep_if_memory_was_recycled() is False and sweeps == [1]
