@@ -378,11 +378,19 @@ static void park(void* p, int64_t bytes) {
 }
 
 static hipError_t sweep_all_l2(void) {
-    constexpr size_t kSweepBytes = (size_t)256 << 20;  // 8 x the 8 x 4 MB of L2
+    // 8 x the 8 x 4 MB of L2 in one buffer; when the HBM is nearly full (KV cache sized to fill it) a smaller buffer written
+    // several times does the same job -- the sweep must not be the allocation that fails communicator creation
+    constexpr size_t kSweepBytes = (size_t)256 << 20;
     void* t = nullptr;
-    hipError_t e = hipMalloc(&t, kSweepBytes);
+    size_t size = kSweepBytes;
+    hipError_t e = hipMalloc(&t, size);
+    while (e != hipSuccess && size > ((size_t)32 << 20)) {
+        (void)hipGetLastError();
+        size >>= 1;
+        e = hipMalloc(&t, size);
+    }
     if (e != hipSuccess) return e;
-    e = hipMemset(t, 0, kSweepBytes);
+    for (size_t done = 0; done < kSweepBytes && e == hipSuccess; done += size) e = hipMemset(t, (int)(done / size) & 1, size);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     (void)hipFree(t);
     return e;
