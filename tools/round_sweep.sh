@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call that refreshes every trace and counter DESIGN.md section 5 quotes, on the current code:
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- "tools/round_sweep.sh r03_sweep $(git rev-parse --short HEAD)"
+#   /usr/local/graft/bin/gpurun --timeout 1800 -- "tools/round_sweep.sh r05_sweep $(git rev-parse --short HEAD)"
 # (the GPU box has no .git: the head the numbers belong to is handed in and stamped into the PMC record).
 # Writes gpurun_out/<tag>/: the bench line, step breakdowns (bs 16 / 1 / 32) + whole-process kernel traces, the PMC
 # passes (tools/pmc_passes.sh -> pmc_step.json, what bench.py reads as profiles/r03_pmc_step.json), Llama bs-1 trace,
@@ -25,6 +25,13 @@ rm -rf /tmp/pl; rocprofv3 --kernel-trace --stats -d /tmp/pl -o t -- python $GRAF
 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pl/t_results.db --last-fraction 0.45 > $out/kerneltrace_llama_bs1.txt
 rm -rf /tmp/pp; rocprofv3 --kernel-trace --stats -d /tmp/pp -o t -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py 8 > $out/prefill.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pp/t_results.db --last-fraction 0.4 > $out/kerneltrace_prefill.txt
+# round 5: the 2048-token prefill layer alone (trace + counters), the two prefill attention kernels, the hardware-golden cases
+rm -rf /tmp/pp2; rocprofv3 --kernel-trace --stats -d /tmp/pp2 -o t -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py 8 2048 > $out/prefill_2048.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pp2/t_results.db --last-fraction 0.3 > $out/kerneltrace_prefill_2048.txt
+bash $GRAFT_REPO_ROOT/tools/pmc_prefill.sh $tag/pmc_prefill > $out/pmc_prefill.log 2>&1
+PARITY=0 python $GRAFT_REPO_ROOT/tools/mla_prefill_kernel_bench.py 512 1024 2048 4096 8192 > $out/mla_prefill_kernel.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/gqa_prefill_kernel_bench.py 512 2048 8192 > $out/gqa_prefill_kernel.txt 2>&1
+python $GRAFT_REPO_ROOT/tools/hw_cases_bench.py > $out/hw_cases_bench.txt 2>/dev/null
 for bs in 4 8 64; do
   python $GRAFT_REPO_ROOT/bench.py --bs $bs --steps 32 --warmup 4 --no-bs1 --no-llama --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 >> $out/bs_sweep.jsonl
 done
