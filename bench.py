@@ -27,7 +27,7 @@ would pay span only the live ranks (`collectives_in_step` is 0 at N=1), so only 
 measured live with HIP events around replays of one hipGraph holding every MoE layer's launch back to back
 (`avg_launch_us`); `spaced_launch_us` = the same launches with ~70 us of near-idle kernels between them (what the step
 looks like to this kernel; an uninterrupted 22 GB stream runs ~5 % slower); `traffic` / `mfma_util` from the committed PMC
-record profiles/r04_pmc_step.json, whose git head is echoed as `pmc_head` and which is withheld if csrc/moe.hip has changed
+record profiles/r05_pmc_step.json, whose git head is echoed as `pmc_head` and which is withheld if csrc/moe.hip has changed
 since.  `collectives` (N > 1): transport, per-launch GPU time of the fused all-reduce and of the logits all-gather, and
 `per_transport`: the same norm + quant launch without a collective, with the xGMI all-reduce in its one-shot and its
 two-shot form, and the all-gather, at bs 1 / 16 / 32.  A line whose `ranks_seen_by_library` differs from --gpus, or whose
@@ -64,7 +64,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 = non-scaled fp8 MFMA peak
-PMC_FILE = "r04_pmc_step.json"  # tools/pmc_passes.sh + tools/pmc_report.py, stamped with git head + source digests
+PMC_FILE = "r05_pmc_step.json"  # tools/pmc_passes.sh + tools/pmc_report.py, stamped with git head + source digests
 
 
 def _sha256(path):
@@ -338,8 +338,41 @@ def box_calibration(local_index, w2_launch_us=None):
     torch.cuda.synchronize()
     chain_us = e0.elapsed_time(e1) * 1e3 / (5 * n_chain)
     del g
+
+    # dependent LOADS (round 5, second probe set): the slow boxes stretch exactly the launches that are chains of dependent
+    # memory round trips (mla_q_proj 7.6 -> 9.9 us, route + align 8.9 -> 9.8) while the two probes above read the same there.
+    # One-element gathers through a random cycle, 400 launches in a hipGraph: over a 512 MB table (every hop an HBM miss past
+    # the 256 MB Infinity Cache) and over a 4 KB one (L2 hits); the difference is the memory round trip itself.
+    def gather_chain(n_entries, hops=400):
+        perm = torch.randperm(n_entries, device=dev)
+        table = torch.empty(n_entries, dtype=torch.int64, device=dev)
+        table[perm] = torch.roll(perm, -1)  # one cycle through all entries, in random order
+        cur = perm[:1].clone()
+        for _ in range(3):
+            cur = table[cur]
+        torch.cuda.synchronize()
+        gg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gg):
+            c = cur
+            for _ in range(hops):
+                c = table[c]
+        gg.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            gg.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / (5 * hops)
+        del gg, table, perm
+        return us
+
+    hop_hbm_us = gather_chain(1 << 26)
+    hop_l2_us = gather_chain(512)
     prop = torch.cuda.get_device_properties(0)
     out = {"copy_GBs": round(copy_gbs, 1), "chain_us": round(chain_us, 3), "w2_launch_us": w2_launch_us,
+           "dependent_gather_us": {"hbm_table_512MB": round(hop_hbm_us, 3), "l2_table_4KB": round(hop_l2_us, 3),
+                                   "memory_round_trip_ns": round((hop_hbm_us - hop_l2_us) * 1e3, 1)},
            "compute_units": prop.multi_processor_count, "device": prop.name, "hbm_GB": round(prop.total_memory / 1e9, 1),
            "reference_box": CAL_REF, "model_weights": CAL_WEIGHTS}
     out["step_time_factor"] = round(CAL_WEIGHTS["bandwidth"] * CAL_REF["copy_GBs"] / copy_gbs
