@@ -10,12 +10,20 @@
 namespace chitu {
 
 // source = (wave-uniform base) + (per-lane 32-bit byte offset)
+// NT: the `nt` (streaming) cache hint -- data read once per launch (a KV tile) should not displace the L2's resident lines
+template <bool NT = false>
 __device__ __forceinline__ void glds16_sbase(const void* sbase, uint32_t voff, uint32_t lds_dst) {
     unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(sbase), "s"(lds_dst)
-                 : "memory");
+    if constexpr (NT)
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
+    else
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(lds_dst)
+                     : "memory");
 }
 // source = per-lane 64-bit address
 __device__ __forceinline__ void glds16_vaddr(const void* gsrc, uint32_t lds_dst) {

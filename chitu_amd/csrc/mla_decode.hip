@@ -11,20 +11,15 @@
 // tile is staged in LDS once and used for both products.
 //
 // Design.  One workgroup (4 waves) = 16 heads x one KV split of one sequence.  Per 64-token
-// tile: coalesced 16-B global loads of the 64 x 576 bf16 rows, register-staged one tile ahead,
-// into LDS (row stride padded to 1184 B for the ds_read_b128 K fragments); QK^T: each wave owns
-// 16 tokens, 18 x v_mfma_f32_16x16x32_bf16 with Q (A operand) read from its own LDS copy;
+// tile (64 x 576 bf16 rows, brought into LDS by LDS-DMA, double-buffered; layout below): QK^T: each wave owns
+// 16 tokens, 18 x v_mfma_f32_16x16x32_bf16 with Q (A operand) in registers;
 // online softmax in fp32 with 16-lane shuffles + a 4-wave LDS exchange; P -> bf16 -> LDS;
 // PV: each wave owns 128 latent columns, V^T fragments come straight from the row-major tile
 // with ds_read_b64_tr_b16 (gfx950 transpose read), 16 MFMAs per wave per tile.  Splits are
 // sized on the host from the batch only (graph-static); a split's token range is derived from
 // the device-side sequence length, empty splits publish LSE = -inf.  Stage 2 merges splits.
 #include "common.h"
-// Profiling aid, compile-time only: a probe build (hipcc -DCHITU_MLA_PHASE_MASK=<bits>) drops phases of the tile loop
-// (1: KV loads, 2: QK^T, 8: PV, 16: LDS staging) to price them; such a build computes garbage and is never shipped.
-#ifndef CHITU_MLA_PHASE_MASK
-#define CHITU_MLA_PHASE_MASK 0
-#endif
+#include "lds_dma.h"
 
 namespace chitu {
 
@@ -32,71 +27,94 @@ constexpr int kC = 512;        // kv_lora_rank (latent / V width)
 constexpr int kR = 64;         // qk_rope_head_dim
 constexpr int kD = kC + kR;    // cached row width (576)
 constexpr int kTile = 64;      // KV tokens per tile
-constexpr int kRowB = 1184;    // LDS row stride in bytes (1152 + 32 pad): 296 dwords = 40 mod 64 banks, which makes the 16 rows of a
-                               // ds_read_b128 lane group land on 16 distinct 16-B slots (1168 left them 2-way conflicted: 34 % of the
-                               // LDS cycles, r02 PMC); the transpose reads of PV stay 2-way at any 16-B-aligned stride
 constexpr int kPStride = 72;   // P row stride in bf16 elements (64 + 8 pad)
 constexpr int kMaxTilesLds = 512;  // page ids cached in LDS per split (32k tokens)
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-// grid (num_splits, batch, heads/16); block 256, one workgroup per CU (96 KB LDS).
-// Per-tile pipeline (register-staged, one tile ahead): the 18 x 16 B per thread of tile t+1 are
-// in flight while tile t is multiplied, so a CU is bound by its share of HBM bandwidth
-// (~74 KB / tile) rather than by load latency + compute in series.
+// grid (num_splits, batch, heads/16); block 256, one workgroup per CU (152 KB LDS).
+//
+// How bytes move (round 5; the arithmetic and its order are those of rounds 1-4, output bit-identical).  The KV tile is brought
+// by LDS-DMA -- no staging registers, no ds_write pass (phase masks priced them at 4.3 of 19.4 us at bs 16 / ctx 1024 and 17
+// of 44 us at ctx 8192, profiles/r03_phase_masks.txt) -- into one of TWO 64-key buffers: the next tile lands while this one
+// is multiplied, one barrier per tile instead of two.  Q lives in registers (72 VGPRs: the A operand never changes), which is
+// what lets two buffers fit; it gets there coalesced, through buffer 1 while that is still free.  The table's first 256
+// entries are requested BESIDE seqlens, not behind it (the chain that heads the kernel is seqlens -> KV rows, not seqlens ->
+// page id -> KV rows), and the DMA carries the `nt` hint: a KV row is read once per launch, left to displace the L2's
+// resident lines it cost 0.55 us per launch in the step (same-box kernel trace, profiles/r05_ab_mla_decode_dma.txt:
+// register-staged 13.29 us, DMA 12.07, DMA + nt 11.52; ctx 8192: 36.1 -> 27.1 us).
+//
+// LDS image of a tile: [64 rows][1152 B] unpadded, the 16-byte chunk c of row r stored at c ^ swz(r),
+// swz(r) = 5 * bit3(r) + 2 * bit1(r).  A DMA piece is 1 KiB of the image, lane-linear (lds_dma.h): image chunk q = 64 n + lane
+// -> row q / 72, position q % 72, source chunk (q % 72) ^ swz(row).  Readers: K fragments (ds_read_b128, lane groups
+// {0-3,12-15,20-27},...: 16 rows with chunk g or g ^ 1) and V^T fragments (ds_read_b64_tr_b16, 32 lanes = 8 rows x 32 B)
+// both land on 16 distinct 16-byte slots of the 256-byte bank row (checked exhaustively for every wave / k step;
+// the padded 1184-byte rows of rounds 2-4 left the transpose reads 2-way conflicted).
+constexpr int kRowU = kD * 2;            // 1152
+constexpr int kTileU = kTile * kRowU;    // 73728
+constexpr int kDmaPieces = kTileU / 1024 / 4;  // 18 per wave
+__device__ __forceinline__ int kv_swz(int r) { return ((r >> 3) & 1) * 5 + ((r >> 1) & 1) * 2; }
+
 __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     const bf16_t* __restrict__ q_nope, int64_t qn_sb, int64_t qn_sh, const bf16_t* __restrict__ q_pe,
     int64_t qp_sb, int64_t qp_sh, const bf16_t* __restrict__ cache, int64_t num_pages, int page_size,
     const int32_t* __restrict__ block_table, int table_stride, const int32_t* __restrict__ seqlens,
     float scale, bf16_t* __restrict__ part_o, float* __restrict__ part_lse, bf16_t* __restrict__ out,
     int H, int num_splits) {
-    constexpr int dbg = CHITU_MLA_PHASE_MASK;  // 0 in every shipped build (see the macro)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* kv_lds = smem;                                   // [64][kRowB]
-    uint8_t* q_lds = smem + kTile * kRowB;                    // [16][kRowB]
-    bf16_t* p_lds = reinterpret_cast<bf16_t*>(q_lds + 16 * kRowB);  // [16][72]
-    float* red_max = reinterpret_cast<float*>(q_lds + 16 * kRowB + 16 * kPStride * 2);  // [4][16]
-    float* red_sum = red_max + 64;                                                      // [4][16]
-    int* pages_lds = reinterpret_cast<int*>(red_sum + 64);                              // [kMaxTilesLds]
+    uint8_t* kv_lds = smem;                                               // [2][64][kRowU]
+    bf16_t* p_lds = reinterpret_cast<bf16_t*>(smem + 2 * kTileU);         // [16][72]
+    float* red_max = reinterpret_cast<float*>(smem + 2 * kTileU + 16 * kPStride * 2);  // [4][16]
+    float* red_sum = red_max + 64;                                        // [4][16]
+    int* pages_lds = reinterpret_cast<int*>(red_sum + 64);                // [kMaxTilesLds]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: SGPR index math
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int split = blockIdx.x, b = blockIdx.y, hb = blockIdx.z;
     const int h0 = hb * 16;
     const int32_t* tbl = block_table + (int64_t)b * table_stride;
+    const int max_page_idx = table_stride - 1;
+    // The chain that heads this kernel is seqlens -> KV rows: the table's first 256 entries are requested with seqlens,
+    // not behind it (lane l of every wave: entries l, l + 64, ...), and the one this split starts at is picked by readlane.
+    // (asm: as plain loads the compiler sinks the table loads behind the selection below, i.e. behind seqlens again, and
+    // schedules the seqlens load itself behind Q's address arithmetic)
     CHITU_PROBE_MARK(8);
-    // The prologue is ONE chain of dependent loads -- seqlens -> page id -> KV rows -- and everything else rides in
-    // its shadow: seqlens is requested first, then Q (independent of it), then the wait; every load below is
-    // unconditional (indices clamped, the unwanted values dropped when they are stored to LDS), so the code is
-    // straight-line and the compiler's s_waitcnt counts past the loads that are not needed yet.
-    const int L = max(seqlens[b], 0);  // a corrupt negative length is an empty sequence (the unsigned split arithmetic below)
-    // Q (A operand of QK^T; 16 heads x 576, same padded stride as the KV rows): 1152 chunks, <= 5 per thread
+    int L_raw;
+    asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(L_raw) : "s"(seqlens + b) : "memory");
+    int spec[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        asm volatile("global_load_dword %0, %1, off" : "=v"(spec[k]) : "v"(tbl + min(lane + 64 * k, max_page_idx)) : "memory");
+    // Q (16 heads x 576): 1152 chunks of 16 B, <= 5 per thread, coalesced; it passes through buffer 1 (free until the second
+    // tile is requested) on its way to the registers of the four waves, each of which needs all of it as the A operand
     i32x4 qreg[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         const int c = min(tid + i * 256, 16 * 72 - 1);
         const int row = c / 72, col = c % 72;
         const int h = min(h0 + row, H - 1);
-        const bf16_t* src = col < 64 ? q_nope + b * qn_sb + h * qn_sh + col * 8
-                                     : q_pe + b * qp_sb + h * qp_sh + (col - 64) * 8;
+        const bf16_t* src = col < 64 ? q_nope + b * qn_sb + h * qn_sh + col * 8 : q_pe + b * qp_sb + h * qp_sh + (col - 64) * 8;
         qreg[i] = *reinterpret_cast<const i32x4*>(src);
     }
-    if (L == -12345) CHITU_PROBE_MARK(15);  // (probe builds: forces the seqlens wait here)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(L_raw)::"memory");
     CHITU_PROBE_MARK(9);
+    const int L = max(L_raw, 0);  // a corrupt negative length is an empty sequence
     const int n_tiles = (L + kTile - 1) / kTile;
-    // 32-bit unsigned quotients (a 64-bit division is a software LOOP on this chain; the launcher bounds
-    // tiles * splits below 2^31)
     const int tile0 = (int)((unsigned)n_tiles * (unsigned)split / (unsigned)num_splits);
     const int tile1 = (int)((unsigned)n_tiles * (unsigned)(split + 1) / (unsigned)num_splits);
-
-    // this split's page ids: the first tile's straight from the table (it heads the chain), the following tiles'
-    // (two per thread, up to kMaxTilesLds) parked in LDS so that no later tile pays a table lookup
     const bool pages_in_lds = (tile1 - tile0) <= kMaxTilesLds;
-    const int max_page_idx = table_stride - 1;
-    const int first_pg = tbl[min((tile0 * kTile) / page_size, max_page_idx)];
-    int pg_ahead[2];
+    const int p_first = (tile0 * kTile) / page_size;
+    // the table entries have landed (and Q, requested just behind them: same round trip, nothing lost)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(spec[0]), "+v"(spec[1]), "+v"(spec[2]), "+v"(spec[3])::"memory");
 #pragma unroll
-    for (int i = 0; i < 2; ++i) pg_ahead[i] = tbl[min(((tile0 + tid + i * 256) * kTile) / page_size, max_page_idx)];
+    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(qreg[i]));  // (the compiler's own wait for Q sits here, not behind the DMA below)
+    int first_pg;
+    if (p_first < 256) {
+        const int pick = p_first < 64 ? spec[0] : p_first < 128 ? spec[1] : p_first < 192 ? spec[2] : spec[3];
+        first_pg = __builtin_amdgcn_readlane(pick, p_first & 63);
+    } else {
+        first_pg = tbl[min(p_first, max_page_idx)];
+    }
     auto page_src = [&](int64_t page, int t0) -> const bf16_t* {
         if (page < 0 || page >= num_pages) page = 0;  // corrupt table: stay in bounds
         return cache + (page * page_size + (t0 % page_size)) * (int64_t)kD;
@@ -105,28 +123,57 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         const int t0 = tile * kTile;
         return page_src(pages_in_lds ? pages_lds[tile - tile0] : tbl[min(t0 / page_size, max_page_idx)], t0);
     };
-    // this thread's 18 chunks of a tile: chunk c = tid + i*256 -> (row, col); rows past the sequence end read the
-    // tile's last valid row instead (unconditional loads) and are zeroed when staged
-    i32x4 pf[18];
-    auto issue = [&](const bf16_t* src, int valid) {
+    // this wave's 18 pieces of a tile: piece n = wave + 4 i; lane's image chunk 64 n + lane -> (row, source byte offset)
+    int prow[kDmaPieces];
+    uint32_t pswz[kDmaPieces];
 #pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            const int c = tid + i * 256;
-            const int row = min(c / 72, valid - 1), col = c % 72;
-            if (!(dbg & 1)) pf[i] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(src + row * kD + col * 8));
-        }
-    };
-    if (tile0 < tile1) issue(page_src(first_pg, tile0 * kTile), min(kTile, L - tile0 * kTile));
-    // ---- only now the first stores: Q and the page list (visible to all waves after the loop's first barrier)
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int c = tid + i * 256;
-        if (c < 16 * 72) *reinterpret_cast<i32x4*>(q_lds + (c / 72) * kRowB + (c % 72) * 16) = qreg[i];
+    for (int i = 0; i < kDmaPieces; ++i) {
+        const int qi = 64 * (wave + 4 * i) + lane;
+        prow[i] = qi / 72;
+        pswz[i] = (uint32_t)(((qi % 72) ^ kv_swz(prow[i])) << 4);
     }
-    if (pages_in_lds) {
+    const uint32_t lds0 = lds_offset_of(smem);
+    // rows past the sequence end re-read the tile's last valid row: finite, and their probabilities are exactly 0
+    auto issue = [&](const bf16_t* src, int valid, int buf) {
+        const uint64_t a = (uint64_t)src;
+        const bf16_t* sb = (const bf16_t*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+#pragma unroll
+        for (int i = 0; i < kDmaPieces; ++i)
+            glds16_sbase<true>(sb, (uint32_t)(min(prow[i], valid - 1) * kRowU) + pswz[i],
+                             lds0 + (uint32_t)(buf * kTileU + (wave + 4 * i) * 1024));
+    };
+    if (tile0 >= tile1) {  // an empty split publishes LSE = -inf and zero rows (nothing of it is read by the merge)
+        if (num_splits > 1) {
+            if (tid < 16 && h0 + tid < H) part_lse[((int64_t)b * H + h0 + tid) * num_splits + split] = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int chunk = tid + i * 256, hr = chunk >> 6, c8 = chunk & 63;
+                if (h0 + hr < H)
+                    *reinterpret_cast<i32x4*>(part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c8 * 8) = i32x4{0, 0, 0, 0};
+            }
+        } else {
+            for (int i = tid; i < 16 * kC / 8; i += 256)
+                if (h0 + (i >> 6) < H) *reinterpret_cast<i32x4*>(out + ((int64_t)b * H + h0 + (i >> 6)) * kC + (i & 63) * 8) = i32x4{0, 0, 0, 0};
+        }
+        return;
+    }
+    issue(page_src(first_pg, tile0 * kTile), min(kTile, L - tile0 * kTile), 0);
+    {   // Q into buffer 1, in the tile image's own layout (row = head, chunk c at c ^ swz(row)): read back like a K fragment
+        uint8_t* q_lds = kv_lds + kTileU;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int c = tid + i * 256;
+            if (c < 16 * 72) *reinterpret_cast<i32x4*>(q_lds + (c / 72) * kRowU + (((c % 72) ^ kv_swz(c / 72)) << 4)) = qreg[i];
+        }
+    }
+    // page ids of the following tiles (none at one tile per split, the short-context shape: no table load, and no wait of the
+    // compiler's for one -- which, counting in order, would also wait for the tile requested above)
+    if (pages_in_lds && tile1 - tile0 > 1) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            if (tid + i * 256 < tile1 - tile0) pages_lds[tid + i * 256] = pg_ahead[i];
+            if (tid + i * 256 < tile1 - tile0)
+                pages_lds[tid + i * 256] = tbl[min(((tile0 + tid + i * 256) * kTile) / page_size, max_page_idx)];
     }
 
     f32x4 o[8];
@@ -138,36 +185,50 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         m_run[r] = -INFINITY;
         l_run[r] = 0.f;
     }
+    // fragment addressing inside a tile image (see the layout note above)
+    const int ksw = kv_swz(j);                                    // row wave*16 + j: bits 1 and 3 are j's
+    const int koff0 = (wave * 16 + j) * kRowU + ((g ^ ksw) << 4);  // even k steps; odd ones: chunk ^ 4
+    const int koff1 = (wave * 16 + j) * kRowU + (((g ^ ksw) ^ 4) << 4);
+    const int vsw = (g & 1) * 5 + ((j >> 3) & 1) * 2;             // rows ks*32 + g*8 + (j>>2) (+4): bit 3 = g & 1, bit 1 = j >> 3
+    const int vrow_off = (g * 8 + (j >> 2)) * kRowU + wave * 256 + ((((j >> 1) & 1) ^ (vsw & 1)) << 4) + (j & 1) * 8;
+    int vx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vx[k] = ((2 * k) ^ (vsw & 6)) << 4;
+
+    __syncthreads();  // Q and the page list are visible (the first tile may still be in flight)
+    s16x8 qf[18];     // lane (j, g): elements [32 kk + 8 g, +8) of head j
+    {
+        const uint8_t* q_lds = kv_lds + kTileU;
+        const int ksw0 = kv_swz(j);
+#pragma unroll
+        for (int kk = 0; kk < 18; ++kk)
+            qf[kk] = *reinterpret_cast<const s16x8*>(q_lds + j * kRowU + (kk >> 1) * 128 + (((g + 4 * (kk & 1)) ^ ksw0) << 4));
+    }
+    if (tile0 + 1 < tile1) {
+        __syncthreads();  // every wave has its copy of Q: buffer 1 may be overwritten
+        issue(tile_src(tile0 + 1), min(kTile, L - (tile0 + 1) * kTile), 1);
+    }
 
     for (int tile = tile0; tile < tile1; ++tile) {
+        const int buf = (tile - tile0) & 1;
         const int valid = min(kTile, L - tile * kTile);
-        __syncthreads();  // previous tile fully consumed (and Q staged, first time round)
-        if (!(dbg & 16)) {
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            const int c = tid + i * 256;
-            const i32x4 zero = {0, 0, 0, 0};
-            *reinterpret_cast<i32x4*>(kv_lds + (c / 72) * kRowB + (c % 72) * 16) = (c / 72) < valid ? pf[i] : zero;
-        }
-        }
-        __syncthreads();
+        if (tile == tile0 && tile0 + 1 < tile1)
+            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");  // the first tile's pieces; the second tile's 18 stay in flight
+        else
+            glds_wait_all();  // this wave's pieces of the tile
+        __syncthreads();   // everyone's; the other buffer and the softmax exchange areas of the previous tile are free
+        if (tile > tile0 && tile + 1 < tile1) issue(tile_src(tile + 1), min(kTile, L - (tile + 1) * kTile), buf ^ 1);
+        const uint8_t* kv = kv_lds + buf * kTileU;
         CHITU_PROBE_MARK(10);
-        if (tile + 1 < tile1) issue(tile_src(tile + 1), min(kTile, L - (tile + 1) * kTile));
 
         // ---- S = Q K^T for this wave's 16 tokens (two accumulators: no 18-deep dependent chain)
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (!(dbg & 2)) {
-            const uint8_t* krow = kv_lds + (wave * 16 + j) * kRowB + g * 16;
-            const uint8_t* qrow = q_lds + j * kRowB + g * 16;
 #pragma unroll
-            for (int kk = 0; kk < 18; kk += 2) {
-                const s16x8 q0 = *reinterpret_cast<const s16x8*>(qrow + kk * 64);
-                const s16x8 k0 = *reinterpret_cast<const s16x8*>(krow + kk * 64);
-                const s16x8 q1 = *reinterpret_cast<const s16x8*>(qrow + kk * 64 + 64);
-                const s16x8 k1 = *reinterpret_cast<const s16x8*>(krow + kk * 64 + 64);
-                s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q0, k0, s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(q1, k1, s1, 0, 0, 0);
-            }
+        for (int kk = 0; kk < 18; kk += 2) {
+            const s16x8 k0 = *reinterpret_cast<const s16x8*>(kv + koff0 + (kk >> 1) * 128);
+            const s16x8 k1 = *reinterpret_cast<const s16x8*>(kv + koff1 + (kk >> 1) * 128);
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk], k0, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[kk + 1], k1, s1, 0, 0, 0);
         }
         // lane holds S[head 4g+r][token wave*16+j]
         CHITU_PROBE_MARK(11);
@@ -212,16 +273,15 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         }
 
         // ---- O += P V : this wave owns latent columns [wave*128, wave*128+128)
-        if (!(dbg & 8))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const s16x8 pfrag = *reinterpret_cast<const s16x8*>(p_lds + j * kPStride + ks * 32 + g * 8);
-            // transpose-read addressing: lane t of a 16-lane group supplies key row t/4, column chunk t%4
-            const uint8_t* vbase = kv_lds + (ks * 32 + g * 8 + (j >> 2)) * kRowB + (wave * 128 + (j & 3) * 4) * 2;
+            const uint8_t* vbase = kv + vrow_off + ks * 32 * kRowU;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + c * 32));
-                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vbase + 4 * kRowB + c * 32));
+                const uint8_t* va = vbase + vx[c & 3] + (c >> 2) * 128;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(va + 4 * kRowU));
                 s16x8 vf;
                 vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
                 vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
@@ -232,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
 
     // ---- epilogue: lane holds O[head 4g+r][col wave*128 + c*16 + j]
     CHITU_PROBE_MARK(12);
-    const bool empty = tile1 <= tile0;
+    constexpr bool empty = false;  // (empty splits left above)
     if (num_splits == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -245,11 +305,9 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         }
         return;
     }
-    // split partials: transposed through LDS (the KV tile is dead) so every thread stores 16-B pieces of whole rows
-    // instead of scattered elements.  Partials leave as BF16 (the normalised o of a split is an attention output:
-    // the merge's convex combination keeps the 2^-9 rounding below the final output's own) + the fp32 LSE: half the
-    // bytes of the write here and of the read-back in the merge -- 4.2 MB instead of 8.4 per bs-16 launch, which at one
-    // tile per workgroup were 45 % of the KV bytes.
+    // split partials: transposed through LDS (the KV tiles are dead) so every thread stores 16-B pieces of whole rows; they
+    // leave as BF16 (the normalised o of a split is an attention output: the merge's convex combination keeps the 2^-9
+    // rounding below the final output's own) + the fp32 LSE
     __syncthreads();
     bf16_t* o_lds = reinterpret_cast<bf16_t*>(kv_lds);  // [16][512] bf16 = 16 KB
 #pragma unroll
@@ -267,10 +325,10 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         const int chunk = tid + i * 256;
         const int hr = chunk >> 6, c8 = chunk & 63;
         if (h0 + hr < H) {
-            // write-through (sc1): partials left DIRTY in the L2s would be flushed by the end-of-kernel release, in
-            // front of the launch that reads them back; streamed out here they overlap the other workgroups
             const i32x4 v = *reinterpret_cast<const i32x4*>(o_lds + hr * kC + c8 * 8);
             bf16_t* dst = part_o + (((int64_t)b * H + h0 + hr) * num_splits + split) * kC + c8 * 8;
+            // write-through (sc1): partials left DIRTY in the L2s would be flushed by the end-of-kernel release, in
+            // front of the launch that reads them back; streamed out here they overlap the other workgroups
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         }
     }
@@ -352,7 +410,7 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
         part_o = (bf16_t*)workspace;
         part_lse = (float*)(part_o + (int64_t)batch * heads * num_splits * kC);
     }
-    const size_t lds = (kTile + 16) * kRowB + 16 * kPStride * 2 + 2 * 64 * sizeof(float) + kMaxTilesLds * sizeof(int);
+    const size_t lds = 2 * kTileU + 16 * kPStride * 2 + 2 * 64 * sizeof(float) + kMaxTilesLds * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)mla_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
