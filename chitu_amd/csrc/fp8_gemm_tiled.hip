@@ -32,16 +32,12 @@ namespace chitu {
 constexpr int kTileN = 128, kTileM = 128, kTileK = 128;
 constexpr int kTileBytes = 128 * kTileK;  // one operand tile of one K block in LDS
 
-struct TileScales {
-    float xs[4];
-    float ws;
-};
-
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fp8_gemm_tiled_kernel(
     const fp8_t* __restrict__ X, const float* __restrict__ XS, const fp8_t* __restrict__ W, const float* __restrict__ WS,
     void* __restrict__ out, int out_dt, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) uint8_t sW[2][kTileBytes];
     __shared__ __attribute__((aligned(16))) uint8_t sX[2][kTileBytes];
+    __shared__ __attribute__((aligned(16))) float sS[2][kTileM];  // the K block's activation scale of every token row of the tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
@@ -67,7 +63,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const fp8_t* wbase = W + (size_t)n0 * K;
     const fp8_t* xbase = X + (size_t)m0 * K;
-    const uint32_t ldsW = lds_offset_of(&sW[0][0]), ldsX = lds_offset_of(&sX[0][0]);
+    const uint32_t ldsW = lds_offset_of(&sW[0][0]), ldsX = lds_offset_of(&sX[0][0]), ldsS = lds_offset_of(&sS[0][0]);
+    // the activation scales of the block ride with it: waves 0 and 1 bring 64 tokens' values each (a 4-byte DMA piece).  As
+    // plain loads one step ahead (rounds 2-5a) they put an `s_waitcnt vmcnt(0)` of the compiler's into the middle of the MFMA
+    // stream -- for `cur = nxt` -- which also waited for the tile just requested: no overlap left within a wave.
+    const uint32_t soff = (uint32_t)(min(m0 + 64 * (wave & 1) + lane, M - 1) * KB * 4);
     auto issue = [&](int kb) {
         const uint32_t dst = (uint32_t)((kb & 1) * kTileBytes + wave * 4096);
 #pragma unroll
@@ -75,17 +75,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             glds16_sbase(wbase + (size_t)kb * 128, woff[i], ldsW + dst + i * 1024);
             glds16_sbase(xbase + (size_t)kb * 128, xoff[i], ldsX + dst + i * 1024);
         }
+        if (wave < 2) glds4_sbase(XS + kb, soff, ldsS + (uint32_t)((kb & 1) * (kTileM * 4) + wave * 256));
     };
-    // the token of this lane's column in each of the wave's 4 token tiles: its per-block activation scale
-    const float* xsp[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) xsp[mt] = XS + (size_t)min(m0 + wm * 64 + mt * 16 + j, M - 1) * KB;
-    const float* wsp = WS + (size_t)(n0 >> 7) * KB;
-    auto fetch_scales = [&](TileScales& r, int kb) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) r.xs[mt] = xsp[mt][kb];
-        r.ws = wsp[kb];
-    };
+    const float* wsp = WS + (size_t)(n0 >> 7) * KB;  // b_s: one scalar per workgroup and block (scalar loads)
     const int foff = kblock_frag_off(j, g);  // this lane's fragment inside a 16-row tile (second half: ^ 64)
 
     f32x4 acc[4][4];
@@ -94,16 +86,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    TileScales cur, nxt;
     issue(0);
-    fetch_scales(cur, 0);
+    float ws_cur = wsp[0], ws_nxt = ws_cur;
     glds_wait_all();
     __syncthreads();
     for (int kb = 0; kb < KB; ++kb) {
         const int buf = kb & 1;
         if (kb + 1 < KB) {  // the other buffer was last read one step ago, before the barrier that closed it
             issue(kb + 1);
-            fetch_scales(nxt, kb + 1);
+            ws_nxt = wsp[kb + 1];
         }
         // fragments: lane (j, g) takes chunks g and g + 4 of row j of each tile -- the same k subset for the weight rows and
         // the token rows, which is all the dot product needs
@@ -119,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int mt = 0; mt < 4; ++mt) {
             const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16) * 128];
             const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr + foff), xb1 = *reinterpret_cast<const i32x4*>(xr + (foff ^ 64));
-            const float sc = cur.xs[mt];
+            const float sc = sS[buf][wm * 64 + mt * 16 + j];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][0]), frag_lo(xb0), z, 0, 0, 0);
@@ -127,10 +118,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][1]), frag_lo(xb1), d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][1]), frag_hi(xb1), d, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * cur.ws;
+                for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * ws_cur;
             }
         }
-        if (kb + 1 < KB) cur = nxt;
+        ws_cur = ws_nxt;
         glds_wait_all();  // block kb + 1 has landed (this wave's pieces) ...
         __syncthreads();  // ... and everyone's; block kb's buffer is free
     }

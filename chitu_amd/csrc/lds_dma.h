@@ -25,6 +25,16 @@ __device__ __forceinline__ void glds16_sbase(const void* sbase, uint32_t voff, u
                      : "v"(voff), "s"(sbase), "s"(lds_dst)
                      : "memory");
 }
+// 4 bytes per lane (256 B per wave-instruction, lane i -> LDS byte lds_dst + 4 i): per-row values that ride with a tile (block
+// scales) -- brought this way they are counted by the same vmcnt as the tile and the K loop holds no load the compiler would
+// wait for (its s_waitcnt counts in order, so a wait for ANY of its own loads also waits for the DMA issued before it)
+__device__ __forceinline__ void glds4_sbase(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
 // source = per-lane 64-bit address
 __device__ __forceinline__ void glds16_vaddr(const void* gsrc, uint32_t lds_dst) {
     unsigned keep;

@@ -39,8 +39,7 @@ __device__ __forceinline__ float moe_tiled_routed_weight(const void* topk_w, int
 #define CHITU_MOE_TILED_NREP 4  // 1: a workgroup per tile always (A/B builds, tools/build_variant.sh)
 #endif
 
-struct MoeTileScales {
-    float xs[kMoeTileM / 16];
+struct MoeTileScales {  // the weight tile's block scales of a K block (workgroup-uniform: scalar loads)
     float ws0, ws1;
 };
 
@@ -60,6 +59,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int numel, int row_div, int Nw, int K) {
     __shared__ __attribute__((aligned(16))) uint8_t sW[2][128 * 128];
     __shared__ __attribute__((aligned(16))) uint8_t sX[2][kMoeTileM * 128];
+    __shared__ __attribute__((aligned(16))) float sS[2][kMoeTileM];  // the K block's activation scale of every slot of the tile
     // GEMM1 form: a 1-D grid walked XCD-aware.  Workgroup L of every run of 8 * n_tiles goes to XCD L % 8 (round-robin
     // dispatch); XCD x is given the CONTIGUOUS m-blocks [x C, x C + C) (C = an eighth of the padded blocks), one per run, all
     // n-tiles of it inside the run: the n-tiles of one m-block -- they stage the same gathered activation rows, 459 KB per 64
@@ -124,13 +124,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int s = sorted_ids[mb * kMoeTileM + n * 8 + (lane >> 3)];
         xoff[i] = (uint32_t)((min(s, numel - 1) / row_div) * K + kblock_src_chunk(lane, n) * 16);
     }
-    int xso[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xso[mt] = (min(slot[mt], numel - 1) / row_div) * KB;
+    // the slots' activation scales ride with the tile: wave 0 brings the block's 64 values (one 4-byte DMA piece, lane =
+    // slot).  As plain loads one step ahead they put a vmcnt(0) of the compiler's into the MFMA stream (fp8_gemm_tiled.hip).
+    const uint32_t soff = (uint32_t)((min(sorted_ids[mb * kMoeTileM + lane], numel - 1) / row_div) * KB * 4);
     const float* wsb = Ws + (size_t)e * ((Nw + 127) >> 7) * KB;
     const float* wsp0 = wsb + (size_t)(n0 >> 7) * KB;
     const float* wsp1 = SILU ? wsb + (size_t)((I + n0) >> 7) * KB : wsp0;
-    const uint32_t ldsW = lds_offset_of(&sW[0][0]), ldsX = lds_offset_of(&sX[0][0]);
+    const uint32_t ldsW = lds_offset_of(&sW[0][0]), ldsX = lds_offset_of(&sX[0][0]), ldsS = lds_offset_of(&sS[0][0]);
 
     using Scales = MoeTileScales;
     auto issue = [&](int t, int kb) {
@@ -141,10 +141,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < XP; ++i)
             glds16_sbase(Xq + (size_t)kb * 128, xoff[i], ldsX + b * (kMoeTileM * 128) + (uint32_t)((wave * XP + i) * 1024));
+        if (wave == 0) glds4_sbase(Xs + kb, soff, ldsS + b * (kMoeTileM * 4));
     };
     auto fetch_scales = [&](Scales& r, int kb, int rep) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) r.xs[mt] = Xs[xso[mt] + kb];
         r.ws0 = wsp0[(size_t)rep * KB + kb];  // one 128-row tile = one row of block scales
         r.ws1 = SILU ? wsp1[kb] : r.ws0;
     };
@@ -158,14 +157,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // the slots' routed weights (GEMM2 form), fetched once up front: fetched when a tile leaves (round 5a) they were loads inside
+    // the step loop, whose wait also drained the next step's DMA
+    float rw[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rw[mt] = 1.f;
+    if (!SILU && topk_w) {  // (one uniform branch per element type: the four loads of a lane are in flight together)
+        if (w_dt == 2) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) rw[mt] = ((const float*)topk_w)[min(slot[mt], numel - 1)];
+        } else {
+            uint16_t raw[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) raw[mt] = ((const uint16_t*)topk_w)[min(slot[mt], numel - 1)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) rw[mt] = w_dt == 0 ? bf16_to_f32(raw[mt]) : f16_to_f32(raw[mt]);
+        }
+    }
     // C tile (nt, mt): lane holds weight rows 4g .. 4g+3 of the tile for slot column j
     auto store_tile = [&](int nb) {  // nb = first weight row (GEMM2) / output column (GEMM1) of the finished tile
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int s = slot[mt];
             if (s >= numel) continue;
-            // (the routed weight is fetched when a tile leaves, not held across the K loop)
-            const float rwm = (!SILU && topk_w) ? moe_tiled_routed_weight(topk_w, w_dt, s) : 1.f;
+            const float rwm = rw[mt];
             if (SILU) {
                 const int n = nb + 16 * wave + 4 * g;  // output column of r = 0
                 uint16_t h[4];
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int mt = 0; mt < MT; ++mt) {
             const uint8_t* xr = &sX[buf][mt * 16 * 128];
             const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr + foff), xb1 = *reinterpret_cast<const i32x4*>(xr + (foff ^ 64));
-            const float sc = cur.xs[mt];
+            const float sc = sS[buf][mt * 16 + j];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][0]), frag_lo(xb0), z, 0, 0, 0);
