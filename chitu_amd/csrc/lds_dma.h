@@ -9,6 +9,14 @@
 
 namespace chitu {
 
+// a wave-uniform pointer the compiler cannot prove uniform (it depends on a loop-carried index, a value read from LDS, ...): an
+// "s" asm operand fed from VGPRs does not assemble.  Free when the value already lives in SGPRs.
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+    const uint64_t a = (uint64_t)p;
+    return (const T*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a));
+}
 // source = (wave-uniform base) + (per-lane 32-bit byte offset)
 // NT: the `nt` (streaming) cache hint -- data read once per launch (a KV tile) should not displace the L2's resident lines
 template <bool NT = false>
@@ -44,6 +52,12 @@ __device__ __forceinline__ void glds16_vaddr(const void* gsrc, uint32_t lds_dst)
                  : "memory");
 }
 __device__ __forceinline__ void glds_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// all but the N most recent pieces have landed (a ring: the newest stage stays in flight)
+template <int N>
+__device__ __forceinline__ void glds_wait_leaving() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
 
 // LDS byte offset of a __shared__ object (the low half of its flat address)
 template <typename T>

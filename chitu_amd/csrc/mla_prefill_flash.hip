@@ -58,10 +58,6 @@ __device__ __forceinline__ void s_mfma0_v(f32x16& s, const s16x8& a, const s16x8
 __device__ __forceinline__ void s_mfma_v(f32x16& s, const s16x8& a, const s16x8& b) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(a), "v"(b));
 }
-template <int N>
-__device__ __forceinline__ void glds_wait_leaving() {  // all but the N most recent LDS-DMA pieces of this wave have landed
-    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
-}
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (B < E) {

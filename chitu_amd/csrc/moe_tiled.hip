@@ -39,6 +39,7 @@ __device__ __forceinline__ float moe_tiled_routed_weight(const void* topk_w, int
 #define CHITU_MOE_TILED_NREP 4  // 1: a workgroup per tile always (A/B builds, tools/build_variant.sh)
 #endif
 
+constexpr int kMoeRing = 3;
 struct MoeTileScales {  // the weight tile's block scales of a K block (workgroup-uniform: scalar loads)
     float ws0, ws1;
 };
@@ -57,9 +58,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int32_t* __restrict__ sorted_ids, const int32_t* __restrict__ expert_ids,
     const int32_t* __restrict__ num_post_pad, bf16_t* __restrict__ out, const void* __restrict__ topk_w, int w_dt,
     int numel, int row_div, int Nw, int K) {
-    __shared__ __attribute__((aligned(16))) uint8_t sW[2][128 * 128];
-    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kMoeTileM * 128];
-    __shared__ __attribute__((aligned(16))) float sS[2][kMoeTileM];  // the K block's activation scale of every slot of the tile
+    // a ring of kMoeRing stages (one K block of both operand tiles + the slots' scales each): 25 KB a stage, two resident
+    // workgroups per CU.  Two stages are in flight while one is multiplied: a step is ~300 MFMA cycles, an L2 round trip several
+    // times that, so one stage of lookahead (rounds 2-5a) left every step waiting for its operands.
+    __shared__ __attribute__((aligned(16))) uint8_t sW[kMoeRing][128 * 128];
+    __shared__ __attribute__((aligned(16))) uint8_t sX[kMoeRing][kMoeTileM * 128];
+    __shared__ __attribute__((aligned(16))) float sS[kMoeRing][4 * 64];  // the K block's activation scales: wave w's piece = slots 16 w ..
     // GEMM1 form: a 1-D grid walked XCD-aware.  Workgroup L of every run of 8 * n_tiles goes to XCD L % 8 (round-robin
     // dispatch); XCD x is given the CONTIGUOUS m-blocks [x C, x C + C) (C = an eighth of the padded blocks), one per run, all
     // n-tiles of it inside the run: the n-tiles of one m-block -- they stage the same gathered activation rows, 459 KB per 64
@@ -124,24 +128,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int s = sorted_ids[mb * kMoeTileM + n * 8 + (lane >> 3)];
         xoff[i] = (uint32_t)((min(s, numel - 1) / row_div) * K + kblock_src_chunk(lane, n) * 16);
     }
-    // the slots' activation scales ride with the tile: wave 0 brings the block's 64 values (one 4-byte DMA piece, lane =
-    // slot).  As plain loads one step ahead they put a vmcnt(0) of the compiler's into the MFMA stream (fp8_gemm_tiled.hip).
-    const uint32_t soff = (uint32_t)((min(sorted_ids[mb * kMoeTileM + lane], numel - 1) / row_div) * KB * 4);
+    // the slots' activation scales ride with the tile: every wave brings the block's values of 16 slots (one 4-byte DMA piece,
+    // lanes 0-15; the other lanes repeat them into the piece's unused part -- the same number of pieces for every wave keeps
+    // the counted wait below one constant).  As plain loads one step ahead they put a vmcnt(0) of the compiler's into the
+    // MFMA stream (fp8_gemm_tiled.hip).
+    const uint32_t soff = (uint32_t)((min(sorted_ids[mb * kMoeTileM + wave * 16 + (lane & 15)], numel - 1) / row_div) * KB * 4);
     const float* wsb = Ws + (size_t)e * ((Nw + 127) >> 7) * KB;
     const float* wsp0 = wsb + (size_t)(n0 >> 7) * KB;
     const float* wsp1 = SILU ? wsb + (size_t)((I + n0) >> 7) * KB : wsp0;
     const uint32_t ldsW = lds_offset_of(&sW[0][0]), ldsX = lds_offset_of(&sX[0][0]), ldsS = lds_offset_of(&sS[0][0]);
 
     using Scales = MoeTileScales;
-    auto issue = [&](int t, int kb) {
-        const uint32_t b = (uint32_t)(t & 1);
+    constexpr int kPieces = 4 + XP + 1;  // DMA pieces per wave and stage
+    auto issue = [&](int stage, int kb) {
+        const uint32_t b = (uint32_t)stage;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            glds16_sbase(We + (size_t)kb * 128, woff[i], ldsW + b * (128 * 128) + (uint32_t)((wave * 4 + i) * 1024));
+            glds16_sbase(uniform_ptr(We + (size_t)kb * 128), woff[i], ldsW + b * (128 * 128) + (uint32_t)((wave * 4 + i) * 1024));
 #pragma unroll
         for (int i = 0; i < XP; ++i)
-            glds16_sbase(Xq + (size_t)kb * 128, xoff[i], ldsX + b * (kMoeTileM * 128) + (uint32_t)((wave * XP + i) * 1024));
-        if (wave == 0) glds4_sbase(Xs + kb, soff, ldsS + b * (kMoeTileM * 4));
+            glds16_sbase(uniform_ptr(Xq + (size_t)kb * 128), xoff[i], ldsX + b * (kMoeTileM * 128) + (uint32_t)((wave * XP + i) * 1024));
+        glds4_sbase(uniform_ptr(Xs + kb), soff, ldsS + b * 1024 + (uint32_t)(wave * 256));
     };
     auto fetch_scales = [&](Scales& r, int kb, int rep) {
         r.ws0 = wsp0[(size_t)rep * KB + kb];  // one 128-row tile = one row of block scales
@@ -224,23 +231,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int reps = NREP == 1 ? 1 : min(NREP, (Nw - n0 + 127) >> 7);
     const int steps = reps * KB;
     Scales cur, nxt;
-    issue(0, 0);
+    // the issue pointer runs kMoeRing - 1 steps ahead of the multiply pointer
+    int ikb = 0, irep = 0, istage = 0;
+    auto issue_next = [&]() {
+        if (NREP > 1 && ikb == 0 && irep > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) woff[i] = w_off(i, irep);
+        }
+        issue(istage, ikb);
+        if (++ikb == KB) ikb = 0, ++irep;
+        if (++istage == kMoeRing) istage = 0;
+    };
+    // every load of the prologue is consumed HERE, ahead of the first request: a wait of the compiler's placed behind it would,
+    // counting in order, wait for the tiles as well
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(woff[i]));
+#pragma unroll
+    for (int i = 0; i < XP; ++i) asm volatile("" ::"v"(xoff[i]));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(rw[mt]), "v"(slot[mt]));
+    asm volatile("" ::"v"(soff));
+    issue_next();
+    if (steps > 1) issue_next();
     fetch_scales(cur, 0, 0);
-    glds_wait_all();
-    __syncthreads();
-    int rep = 0, kb = 0;
+    int rep = 0, kb = 0, buf = 0;
     for (int t = 0; t < steps; ++t) {
-        const int buf = t & 1;
         int nkb = kb + 1, nrep = rep;
         if (nkb == KB) nkb = 0, nrep = rep + 1;
-        if (t + 1 < steps) {  // the other buffer was last read one step ago, before the barrier that closed it
-            if (NREP > 1 && nkb == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) woff[i] = w_off(i, nrep);
-            }
-            issue(t + 1, nkb);
-            fetch_scales(nxt, nkb, nrep);
-        }
+        // stage t has landed (this wave's pieces; stage t + 1, requested a step ago, may still be in flight) ...
+        if (t + 1 < steps) glds_wait_leaving<kPieces>();
+        else glds_wait_all();
+        __syncthreads();  // ... and everyone's; everyone is done with stage t - 1, whose buffer the request below overwrites
+        if (t + 2 < steps) issue_next();
+        if (t + 1 < steps) fetch_scales(nxt, nkb, nrep);
         i32x4 wa[2][2];
         {
             const uint8_t* w0 = &sW[buf][wrow0 * 128];
@@ -255,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int mt = 0; mt < MT; ++mt) {
             const uint8_t* xr = &sX[buf][mt * 16 * 128];
             const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr + foff), xb1 = *reinterpret_cast<const i32x4*>(xr + (foff ^ 64));
-            const float sc = sS[buf][mt * 16 + j];
+            const float sc = sS[buf][mt * 64 + j];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][0]), frag_lo(xb0), z, 0, 0, 0);
@@ -275,9 +298,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (t + 1 < steps) cur = nxt;
-        glds_wait_all();  // step t + 1 has landed (this wave's pieces) ...
-        __syncthreads();  // ... and everyone's; this step's buffer is free
         kb = nkb, rep = nrep;
+        if (++buf == kMoeRing) buf = 0;
     }
 }
 
