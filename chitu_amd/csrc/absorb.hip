@@ -180,6 +180,158 @@ __global__ __launch_bounds__(512) void absorb_uv_quant_kernel(
     if (wave == 0 && g == 0) qs[(int64_t)(m0 + j) * H + h] = sc;
 }
 
+// ---- The two projections over PREFILL-sized row counts (hundreds to thousands of tokens).  Same arithmetic per output as
+// absorb_bmm_kernel / absorb_uv_quant_kernel (bit-identical results); what changes is the work per workgroup: run over a
+// 2048-token prompt the decode kernels are 67 584 one-wave workgroups of 4 MFMAs each (50 us for 42 MB) and 2048 workgroups
+// that each re-read and re-dequantise their head's 64 KB of W_UV (47 us).  Here a workgroup de-quantises its weight
+// fragments ONCE into registers and walks kRowsTM token tiles with them.
+constexpr int kRowsTM = 8;  // token tiles (of 16) per workgroup
+constexpr int kRowsMinBatch = 256;  // below this the decode kernels (more workgroups) are the better shape
+
+// grid (ceil(N/64), H, ceil(batch / (16 kRowsTM))); block 256: wave w owns output columns [64 bx + 16 w, +16), so the four
+// waves of a workgroup write whole 128-byte lines of a token row between them; K = 64 KC (KC <= 4: the W_UK half has K = 128).
+// The token tiles are walked with two register buffers: tile t + 1's activations are requested before tile t is multiplied.
+template <int KC>
+__global__ __launch_bounds__(256) void absorb_bmm_rows_kernel(
+    const bf16_t* __restrict__ x, int64_t x_sb, int64_t x_sh, const fp8_t* __restrict__ W, int64_t w_sh,
+    const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sn, int64_t s_sk,
+    bf16_t* __restrict__ out, int64_t o_sb, int64_t o_sh, int batch, int N) {
+    constexpr int K = 64 * KC;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, g = lane >> 4;
+    const int n0 = (blockIdx.x * 4 + wave) * 16, h = blockIdx.y;
+    if (n0 >= N) return;
+    const fp8_t* wp = W + (int64_t)h * w_sh + (int64_t)min(n0 + j, N - 1) * K + g * 16;
+    const float* sp = scale + s_off + h * s_sh + (n0 >> 7) * s_sn;
+    s16x8 wa[KC], wb[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const i32x4 w = *reinterpret_cast<const i32x4*>(wp + c * 64);
+        const float sc = sp[(c >> 1) * s_sk];
+        wa[c] = dequant8_bf16((uint32_t)w[0], (uint32_t)w[1], sc);
+        wb[c] = dequant8_bf16((uint32_t)w[2], (uint32_t)w[3], sc);
+    }
+    const int n = n0 + g * 4;
+    const int t0 = blockIdx.z * kRowsTM;
+    struct XTile {
+        s16x8 a[KC], b[KC];
+    };
+    auto load = [&](XTile& t, int tile) {  // (rows past the batch re-read its last row: never stored)
+        const bf16_t* xp = x + (int64_t)min(tile * 16 + j, batch - 1) * x_sb + h * x_sh + g * 16;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            t.a[c] = *reinterpret_cast<const s16x8*>(xp + c * 64);
+            t.b[c] = *reinterpret_cast<const s16x8*>(xp + c * 64 + 8);
+        }
+    };
+    auto finish = [&](const XTile& t, int tile) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c], t.a[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[c], t.b[c], acc, 0, 0, 0);
+        }
+        const int m = tile * 16 + j;
+        if (m >= batch) return;
+        bf16_t* dst = out + (int64_t)m * o_sb + h * o_sh + n;
+        if (n + 3 < N) {
+            i32x2 o;
+            o[0] = (int)((uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16));
+            o[1] = (int)((uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16));
+            *reinterpret_cast<i32x2*>(dst) = o;
+        } else {
+            for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = f32_to_bf16(acc[r]);
+        }
+    };
+    XTile A, B;
+    load(A, t0);
+#pragma unroll
+    for (int tm = 0; tm < kRowsTM; tm += 2) {
+        load(B, t0 + tm + 1);
+        finish(A, t0 + tm);
+        if (tm + 2 < kRowsTM) load(A, t0 + tm + 2);
+        finish(B, t0 + tm + 1);
+    }
+}
+
+// grid (H, ceil(batch / (16 kRowsTM))); block 512; K = 512 (kv_lora_rank), N = 128.  Two activation buffers as above.
+__global__ __launch_bounds__(512) void absorb_uv_quant_rows_kernel(
+    const bf16_t* __restrict__ x, int64_t x_sb, int64_t x_sh, const fp8_t* __restrict__ W, int64_t w_sh,
+    const float* __restrict__ scale, int64_t s_off, int64_t s_sh, int64_t s_sk, fp8_t* __restrict__ q,
+    float* __restrict__ qs, int batch, int H) {
+    constexpr int KC = 8, K = 512;
+    __shared__ float red[2][8][16];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), j = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x;
+    const fp8_t* wp = W + (int64_t)h * w_sh + (int64_t)(wave * 16 + j) * K + g * 16;
+    const float* sp = scale + s_off + h * s_sh;
+    s16x8 wa[KC], wb[KC];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const i32x4 w = *reinterpret_cast<const i32x4*>(wp + c * 64);
+        const float sc = sp[(c >> 1) * s_sk];
+        wa[c] = dequant8_bf16((uint32_t)w[0], (uint32_t)w[1], sc);
+        wb[c] = dequant8_bf16((uint32_t)w[2], (uint32_t)w[3], sc);
+    }
+    const int t0 = blockIdx.y * kRowsTM;
+    struct XTile {
+        s16x8 a[KC], b[KC];
+    };
+    auto load = [&](XTile& t, int tile) {  // (rows past the batch re-read its last row: never stored)
+        const bf16_t* xp = x + (int64_t)min(tile * 16 + j, batch - 1) * x_sb + h * x_sh + g * 16;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            t.a[c] = *reinterpret_cast<const s16x8*>(xp + c * 64);
+            t.b[c] = *reinterpret_cast<const s16x8*>(xp + c * 64 + 8);
+        }
+    };
+    auto finish = [&](const XTile& t, int tile, int parity) {  // (every wave of the workgroup runs every tile: one barrier each)
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[c], t.a[c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[c], t.b[c], acc, 0, 0, 0);
+        }
+        float v[4], amax = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = round_bf16(acc[r]);
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(v[r]));
+        }
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
+        if (g == 0) red[parity][wave][j] = amax;
+        __syncthreads();  // (the other half of `red` is not rewritten before every wave has read this one)
+        amax = red[parity][0][j];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) amax = __builtin_fmaxf(amax, red[parity][w][j]);
+        const float sc = amax / 448.0f;
+        float tq[4];
+        if (__builtin_amdgcn_ballot_w64(!group_div_fast(sc)) == 0) {
+            const float r = group_rcp(sc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tq[k] = group_div(v[k], sc, r);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tq[k] = v[k] / sc;
+        }
+        const int m = tile * 16 + j;
+        if (m < batch) {
+            const uint32_t packed = f32x2_to_fp8x2(tq[0], tq[1]) | (f32x2_to_fp8x2(tq[2], tq[3]) << 16);
+            *reinterpret_cast<uint32_t*>(q + ((int64_t)m * H + h) * 128 + wave * 16 + g * 4) = packed;
+            if (wave == 0 && g == 0) qs[(int64_t)m * H + h] = sc;
+        }
+    };
+    XTile A, B;
+    load(A, t0);
+#pragma unroll
+    for (int tm = 0; tm < kRowsTM; tm += 2) {
+        load(B, t0 + tm + 1);
+        finish(A, t0 + tm, 0);
+        if (tm + 2 < kRowsTM) load(A, t0 + tm + 2);
+        finish(B, t0 + tm + 1, 1);
+    }
+}
+
 // MLA split-KV merge + W_UV projection + act_quant in one launch (small batches): replaces
 // mla_merge_kernel (mla_decode.hip) followed by absorb_uv_quant_kernel, same arithmetic and rounding
 // points (merged o -> bf16, projection -> bf16, e4m3 group quantisation), two dependent launches and
@@ -310,6 +462,13 @@ static int launch_absorb_bmm(const void* x, int64_t x_sb, int64_t x_sh, const vo
                              int64_t o_sh, int batch, int heads, int N, int K, void* q_pe, int64_t p_sb, int64_t p_sh,
                              const float* cos, const float* sin, void* stream, const chitu::AbsorbKvRow* kv = nullptr) {
     using namespace chitu;
+    if (!q_pe && !kv && batch >= kRowsMinBatch && (K == 64 || K == 128 || K == 256)) {  // prefill-sized, no riders
+        const dim3 grid_rows((unsigned)((N + 63) / 64), (unsigned)heads, (unsigned)((batch + 16 * kRowsTM - 1) / (16 * kRowsTM)));
+        auto* kern = K == 64 ? absorb_bmm_rows_kernel<1> : K == 128 ? absorb_bmm_rows_kernel<2> : absorb_bmm_rows_kernel<4>;
+        hipLaunchKernelGGL(kern, grid_rows, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_sb, x_sh, (const fp8_t*)w, w_sh,
+                           scale, s_off, s_sh, s_sn, s_sk, (bf16_t*)out, o_sb, o_sh, batch, N);
+        CHITU_RETURN_LAUNCH_STATUS();
+    }
     // the riders' columns are found by n0 >= N (+ 16): N itself a multiple of 16 when they are present
     const dim3 grid((unsigned)((N + 15) / 16 + (q_pe ? 1 : 0) + (kv ? 1 : 0)), (unsigned)heads, (unsigned)((batch + 15) / 16));
     hipLaunchKernelGGL(absorb_bmm_kernel, grid, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)x, x_sb, x_sh,
@@ -329,6 +488,13 @@ extern "C" int chitu_hip_absorb_uv_quant_fp8(const void* x_bf16, int64_t x_strid
     if (K % 64 != 0) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(x_stride_b % 8 == 0 && x_stride_h % 8 == 0);
     if (batch == 0) return CHITU_OK;
+    if (K == 512 && batch >= chitu::kRowsMinBatch) {  // prefill-sized: weights de-quantised once per kRowsTM token tiles
+        const dim3 grid_rows((unsigned)heads, (unsigned)((batch + 16 * kRowsTM - 1) / (16 * kRowsTM)));
+        hipLaunchKernelGGL(absorb_uv_quant_rows_kernel, grid_rows, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+                           x_stride_b, x_stride_h, (const fp8_t*)w_fp8, w_stride_h, scale, scale_offset, scale_stride_h,
+                           scale_stride_k, (fp8_t*)q_fp8, q_scales, (int)batch, (int)heads);
+        CHITU_RETURN_LAUNCH_STATUS();
+    }
     const dim3 grid((unsigned)heads, (unsigned)((batch + 15) / 16));
     if (K == 512)
         hipLaunchKernelGGL(absorb_uv_quant_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,

@@ -345,6 +345,31 @@ def test_absorb_uv_quant_equals_absorb_then_act_quant(bs):
     assert np.array_equal(bits8(q), bits8(q_ref)) and torch.equal(s, s_ref)
 
 
+@pytest.mark.parametrize("rows,H", [(256, 16), (300, 16), (1031, 5), (2048, 16)])
+def test_absorb_projections_over_prefill_rows_equal_the_decode_kernels(rows, H):
+    """>= 256 rows take the prefill forms (absorb.hip: weights de-quantised once per 8 token tiles); the same rows in chunks
+    below that size take the decode kernels: bit-identical outputs for the W_UK absorb (K = 128, N = 512), the W_UV projection
+    as plain bmm (K = 512: stays on the decode kernel) and the W_UV projection + act_quant (codes and scales)."""
+    from chitu_amd import ops
+
+    C = 512
+    g = torch.Generator().manual_seed(rows + H)
+    wkv_b = (torch.randn(H * 256, C, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    sc = (torch.rand(H * 2, C // 128, generator=g) * 0.02 + 0.01).cuda()
+    w_uk_t = wkv_b.view(torch.uint8).view(H, 256, C)[:, :128].transpose(1, 2).contiguous().view(torch.float8_e4m3fn).cuda()
+    w_uv = wkv_b.cuda().view(H, 256, C)[:, 128:]
+    q_nope = torch.randn(rows, H, 192, generator=g).to(torch.bfloat16).cuda()[..., :128]
+    o = torch.randn(rows, H, C, generator=g).to(torch.bfloat16).cuda()
+    chunks = [(a, min(a + 200, rows)) for a in range(0, rows, 200)]
+    full = ops.absorb_bmm_fp8(q_nope, w_uk_t, sc, 0, 8, 1, 0)
+    parts = torch.cat([ops.absorb_bmm_fp8(q_nope[a:b], w_uk_t, sc, 0, 8, 1, 0) for a, b in chunks])
+    assert tuple(full.shape) == (rows, H, C) and np.array_equal(bits16(full), bits16(parts))
+    qf, sf = ops.absorb_uv_quant_fp8(o, w_uv, sc, 4, 8, 1)
+    qp, sp = zip(*[ops.absorb_uv_quant_fp8(o[a:b], w_uv, sc, 4, 8, 1) for a, b in chunks])
+    assert np.array_equal(bits8(qf), bits8(torch.cat(qp))) and torch.equal(sf, torch.cat(sp))
+    assert torch.equal(full, ops.absorb_bmm_fp8(q_nope, w_uk_t, sc, 0, 8, 1, 0))
+
+
 @pytest.mark.parametrize("bs,lens,splits", [(1, [1000], 17), (16, [1024] * 16, 16), (5, [1, 64, 65, 700, 130], 2), (3, [10, 20, 30], 4)])
 def test_merge_folded_into_uv_projection_is_bit_identical(bs, lens, splits):
     """chitu_hip_mla_decode(out=NULL) + chitu_hip_mla_merge_absorb_uv_quant_fp8 ==
