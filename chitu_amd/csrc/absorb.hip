@@ -462,10 +462,9 @@ static int launch_absorb_bmm(const void* x, int64_t x_sb, int64_t x_sh, const vo
                              int64_t o_sh, int batch, int heads, int N, int K, void* q_pe, int64_t p_sb, int64_t p_sh,
                              const float* cos, const float* sin, void* stream, const chitu::AbsorbKvRow* kv = nullptr) {
     using namespace chitu;
-    if (!q_pe && !kv && batch >= kRowsMinBatch && (K == 64 || K == 128 || K == 256)) {  // prefill-sized, no riders
+    if (!q_pe && !kv && batch >= kRowsMinBatch && K == 128) {  // prefill-sized W_UK absorb (qk_nope_head_dim 128), no riders
         const dim3 grid_rows((unsigned)((N + 63) / 64), (unsigned)heads, (unsigned)((batch + 16 * kRowsTM - 1) / (16 * kRowsTM)));
-        auto* kern = K == 64 ? absorb_bmm_rows_kernel<1> : K == 128 ? absorb_bmm_rows_kernel<2> : absorb_bmm_rows_kernel<4>;
-        hipLaunchKernelGGL(kern, grid_rows, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_sb, x_sh, (const fp8_t*)w, w_sh,
+        hipLaunchKernelGGL(absorb_bmm_rows_kernel<2>, grid_rows, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_sb, x_sh, (const fp8_t*)w, w_sh,
                            scale, s_off, s_sh, s_sn, s_sk, (bf16_t*)out, o_sb, o_sh, batch, N);
         CHITU_RETURN_LAUNCH_STATUS();
     }
