@@ -8,7 +8,6 @@ FlashMLABackend:504-572 / FlashInferBackend:575-684 (graph-capturable third-part
 the KV split count from the batch (graph-static) and keeps a persistent scratch buffer.
 """
 
-import ctypes
 import os
 from typing import Optional, Union
 
