@@ -59,8 +59,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int32_t* __restrict__ num_post_pad, bf16_t* __restrict__ out, const void* __restrict__ topk_w, int w_dt,
     int numel, int row_div, int Nw, int K) {
     // a ring of kMoeRing stages (one K block of both operand tiles + the slots' scales each): 25 KB a stage, two resident
-    // workgroups per CU.  Two stages are in flight while one is multiplied: a step is ~300 MFMA cycles, an L2 round trip several
-    // times that, so one stage of lookahead (rounds 2-5a) left every step waiting for its operands.
+    // workgroups per CU; two stages are in flight while one is multiplied.  (Measured against a ring of two once the K loop held
+    // no compiler wait any more: within noise -- at 2048 tokens these launches are HBM-bound, profiles/r05_ab_moe_tiled.txt.
+    // Also measured and not kept: the XCD sequence in groups of four m-blocks, n-tile by n-tile, so that the blocks of one
+    // expert stream the same weight rows back to back: 275 vs 270-274 us.)
     __shared__ __attribute__((aligned(16))) uint8_t sW[kMoeRing][128 * 128];
     __shared__ __attribute__((aligned(16))) uint8_t sX[kMoeRing][kMoeTileM * 128];
     __shared__ __attribute__((aligned(16))) float sS[kMoeRing][4 * 64];  // the K block's activation scales: wave w's piece = slots 16 w ..
