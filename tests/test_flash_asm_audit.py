@@ -25,3 +25,24 @@ def test_flash_kernel_assembly_has_no_spills_and_no_accumulator_traffic(tmp_path
     assert res.returncode == 0, res.stderr
     seen, bad = (check_flash_asm.audit_literal if literal else check_flash_asm.audit)(str(tmp_path / "k.s"), kernel)
     assert seen and not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+@pytest.mark.parametrize("src,kernel", [("fp8_gemm_tiled.hip", "fp8_gemm_tiled_kernel"), ("bf16_gemm_tiled.hip", "bf16_gemm_tiled_kernel"),
+                                        ("moe_tiled.hip", "moe_gemm_tiled_kernel"), ("gqa_prefill_flash.hip", "gqa_prefill_flash_kernel")])
+def test_no_compiler_wait_inside_the_dma_fed_loops(tmp_path, src, kernel):
+    """The loops fed by LDS-DMA hold no `s_waitcnt vmcnt` of the compiler's: it cannot see the DMA requests, its counter is
+    in-order, so any such wait also drains the tiles in flight (check_flash_asm.audit_dma_loops).  (mla_decode.hip is not in
+    the list: its tile loop keeps one compiler wait -- for the page-table fallback of splits above 32k tokens -- at the request
+    point, right behind the kernel's own vmcnt(0) + barrier, where nothing is in flight; the compiler lays that loop out rotated
+    and twice, which the audit's linear reading of the body cannot follow.)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_flash_asm
+
+    csrc = os.path.join(ROOT, "chitu_amd", "csrc")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+           "-S", "--cuda-device-only", os.path.join(csrc, src), "-o", str(tmp_path / "k.s")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    seen, bad = check_flash_asm.audit_dma_loops(str(tmp_path / "k.s"), kernel)
+    assert seen and not bad, bad

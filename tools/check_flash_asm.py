@@ -26,6 +26,48 @@ def kernels(text, name):
                 cur = None
 
 
+
+def audit_dma_loops(path, name, min_mfma=8):
+    """Kernels whose operand tiles arrive by LDS-DMA (global_load_lds, requested through asm: the compiler does not count
+    them): inside a loop that multiplies (>= `min_mfma` MFMAs between its header and its back edge) no `s_waitcnt vmcnt`
+    of the compiler's may sit where a DMA request is in flight (between a global_load_lds and the kernel's own
+    `s_waitcnt vmcnt(0)`, which is inside ;;#ASMSTART .. ;;#ASMEND).  A wait the compiler inserts there -- for any plain
+    load it sees in the loop -- counts in order and therefore also waits for the tiles just requested: the K loops of the
+    tiled GEMMs lost 20 % that way (profiles/r05_ab_moe_tiled.txt).  Returns (kernels seen, violations)."""
+    text = open(path).read()
+    bad, seen = [], []
+    for k, body in kernels(text, name):
+        seen.append(k)
+        labels = {}
+        for i, ln in enumerate(body):
+            m = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if m:
+                labels[m.group(1)] = i
+        for i, ln in enumerate(body):
+            m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", ln)
+            if not m or m.group(1) not in labels or labels[m.group(1)] >= i:
+                continue
+            loop = body[labels[m.group(1)]:i + 1]  # a back edge: header .. branch
+            if sum("v_mfma" in x for x in loop) < min_mfma or not any("global_load_lds" in x for x in loop):
+                continue
+            # two passes over the body = two iterations: requests made late in one are in flight at the top of the next, until
+            # the kernel's own `s_waitcnt vmcnt(0)`; a compiler wait is a violation only while a request is in flight
+            in_asm, in_flight = False, False
+            for rnd in range(2):
+                for x in loop:
+                    if ";;#ASMSTART" in x:
+                        in_asm = True
+                    elif ";;#ASMEND" in x:
+                        in_asm = False
+                    elif "global_load_lds" in x:
+                        in_flight = True
+                    elif in_asm and re.search(r"s_waitcnt\s+vmcnt\(0\)", x):
+                        in_flight = False
+                    elif not in_asm and in_flight and rnd == 1 and re.search(r"s_waitcnt\s+.*vmcnt", x):
+                        bad.append((k, m.group(1), x.strip()))
+    return seen, bad
+
+
 def audit_literal(path, name):
     """Kernels that name a[0:255] literally in their asm statements: the compiler must not touch the AGPR file at all --
     no v_accvgpr_* and no a[...] / aN operand outside ;;#ASMSTART .. ;;#ASMEND -- and must not spill."""
