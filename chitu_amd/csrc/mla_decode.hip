@@ -395,6 +395,7 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
     CHITU_REQUIRE(q_nope && q_pe && kv_cache && block_table && seqlens);
     CHITU_REQUIRE(out_bf16 || num_splits > 1);  // no out: leave the split partials for a fused consumer
     CHITU_REQUIRE(batch >= 0 && heads >= 1 && num_pages >= 1 && table_stride >= 1);
+    CHITU_REQUIRE(((uintptr_t)kv_cache & 15) == 0 && ((uintptr_t)q_nope & 15) == 0 && ((uintptr_t)q_pe & 15) == 0);  // 16-byte loads
     if (kv_lora_rank != kC || rope_dim != kR) return CHITU_ERR_UNSUPPORTED;
     if (page_size < kTile || page_size % kTile != 0) return CHITU_ERR_UNSUPPORTED;
     CHITU_REQUIRE(num_splits >= 1 && num_splits <= 256);

@@ -370,7 +370,8 @@ int chitu_hip_moe_i8_gemm2(const void* a_int8, const float* a_scale, const void*
  * (attn_backend.py:561-571, 678-684):
  *   out[b,h,:] = softmax_t(scale * (q_nope[b,h,:].c[t,:C] + q_pe[b,h,:].c[t,C:])) . c[t,:C]
  *   q_nope [batch, heads, C=512] bf16 (element strides given, multiples of 8); q_pe [batch, heads, R=64];
- *   kv_cache [num_pages, page_size, C+R] bf16 (one layer), page_size % 64 == 0;
+ *   kv_cache [num_pages, page_size, C+R] bf16 (one layer), page_size % 64 == 0, base 16-byte aligned (the 64-key tiles
+ *   go global -> LDS by LDS-DMA, 16 bytes per lane; the launch needs 152 KB of the CU's 160 KB of LDS);
  *   block_table [batch, table_stride] i32; seqlens [batch] i32 = tokens to attend (incl. the
  *   row appended this step -- append is chitu_hip_append_paged_kv); out [batch, heads, C] bf16.
  *   num_splits: KV splits per sequence (graph-static; any value >= 1 gives the same result up to
@@ -400,8 +401,8 @@ int chitu_hip_mla_prefill(const void* q_bf16, int64_t q_stride_t, int64_t q_stri
                           int32_t rope_dim, void* stream);
 /* The same contract (attn_varlen_func for the absorb-mode MQA shape, model_deepseek_v3.py:589-599; attn_backend.py:39-90;
  * the reference runs it on third-party flash_attn) on the flash kernel: 8 query tokens x 16 heads = 128 Q rows per workgroup,
- * S^T = K Q^T with Q in registers, in-lane softmax with deferred rescale, O^T = V^T P^T accumulated in the AGPR file, 64-key
- * tiles by LDS-DMA.  Equal to chitu_hip_mla_prefill within the attention bar (1e-2 of the peak), not bit for bit.
+ * S^T = K Q^T with Q in registers, in-lane softmax with deferred rescale, O^T = V^T P^T accumulated in the AGPR file, 32-key
+ * blocks by LDS-DMA into a 4-slot ring.  Equal to chitu_hip_mla_prefill within the attention bar (1e-2 of the peak), not bit for bit.
  * All three base pointers 16-byte aligned. */
 int chitu_hip_mla_prefill_flash(const void* q_bf16, int64_t q_stride_t, int64_t q_stride_h, const void* kv_bf16,
                           int64_t kv_stride_t, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
