@@ -20,7 +20,7 @@ def _run(soft: int):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", REF_MASTER_PORT=str(29560 + soft))
     env.pop("TRITON_INTERPRET", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_worker.py"), REF, str(soft)], capture_output=True,
-                       text=True, timeout=900, env=env, cwd=ROOT)
+                       text=True, timeout=200, env=env, cwd=ROOT)  # (on expiry subprocess.run kills the worker: no orphan on the GPU)
     lines = [l for l in p.stdout.splitlines() if l.startswith("DROPIN ")]
     assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-4000:]
     res = json.loads(lines[-1][len("DROPIN "):])
