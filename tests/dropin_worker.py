@@ -23,6 +23,11 @@ soft_fp8 = 1 takes the reference's non-NVIDIA soft-fp8 branches: linears dequant
 run F.linear (model_deepseek_v3.py:85-98), the MoE dequantises the experts and calls fused_experts(use_fp8_w8a8=False)
 (:975-993) -- the bf16 mode of chitu_amd.fused_moe.
 Prints one JSON line.
+
+DROPIN_TRACE=1 is the per-op watchdog asked for by VERDICT r05 item 1: every patched op, torch's F.linear and the model's
+prefill / decode calls write "enter" (name, shapes, seconds since start) to stderr, flushed, BEFORE they run, and "leave"
+with the elapsed time after a device synchronize; faulthandler dumps the Python stack every 30 s.  A hang therefore names the
+launch that never retired, and a slow first call (library warm-up) shows up as one long "leave".
 """
 
 import json
@@ -40,6 +45,46 @@ class AD(dict):
     __setattr__ = dict.__setitem__
 
 
+def _install_trace(torch, modules):
+    """Wrap the named callables of `modules` (list of (module, [names])) with enter / leave lines on stderr."""
+    import faulthandler
+    import time
+
+    faulthandler.dump_traceback_later(30, repeat=True, file=sys.stderr)
+    t0 = time.time()
+    seen = {}
+
+    def describe(a):
+        if isinstance(a, torch.Tensor):
+            return f"{str(a.dtype).replace('torch.', '')}{list(a.shape)}"
+        if isinstance(a, (list, tuple)) and len(a) < 6:
+            return "[" + ",".join(describe(x) for x in a) + "]"
+        return type(a).__name__ if not isinstance(a, (int, float, bool, str, type(None))) else repr(a)
+
+    def wrap(label, fn):
+        def traced(*a, **k):
+            sig = label + "(" + ", ".join(describe(x) for x in a) + ")"
+            first = sig not in seen
+            seen[sig] = seen.get(sig, 0) + 1
+            if first:
+                sys.stderr.write(f"TRACE {time.time() - t0:8.3f} enter {sig}\n")
+                sys.stderr.flush()
+            t = time.time()
+            out = fn(*a, **k)
+            if first or time.time() - t > 0.5:
+                torch.cuda.synchronize()
+                sys.stderr.write(f"TRACE {time.time() - t0:8.3f} leave {label} {1e3 * (time.time() - t):.1f} ms\n")
+                sys.stderr.flush()
+            return out
+
+        return traced
+
+    for mod, names in modules:
+        for n in names:
+            setattr(mod, n, wrap(f"{mod.__name__.split('.')[-1]}.{n}", getattr(mod, n)))  # (a class: plain functions, self is a[0])
+    return lambda msg: (sys.stderr.write(f"TRACE {time.time() - t0:8.3f} {msg}\n"), sys.stderr.flush())
+
+
 def main(ref_dir: str, soft_fp8: bool):
     import numpy as np
     import torch
@@ -52,6 +97,18 @@ def main(ref_dir: str, soft_fp8: bool):
     import chitu_amd.fused_moe as a_moe
     import chitu_amd.ops as a_ops
 
+    note = lambda msg: None
+    if os.environ.get("DROPIN_TRACE") == "1":
+        import torch.nn.functional as F_
+
+        note = _install_trace(torch, [
+            (a_ops, ["apply_rotary_pos_emb", "act_quant_deepseek_v3", "weight_dequant_deepseek_v3", "weight_dequant_soft_fp8_deepseek_v3",
+                     "fp8_gemm_deepseek_v3", "soft_fp8_gemm_deepseek_v3", "append_to_paged_kv_cache"]),
+            (a_moe, ["fused_experts", "moe_align_block_size"]),
+            (F_, ["linear", "silu", "embedding"]),
+            (a_attn.HipAttnBackend, ["mla_attn_with_kvcache", "attn_varlen_func", "prepare_metadata_for_decode"]),
+        ])
+        note("imports done, tracing on")
     sys.modules["chitu_backend"] = a_backend
     for name in ("tiktoken", "tiktoken.load"):
         m = types.ModuleType(name)
@@ -123,17 +180,21 @@ def main(ref_dir: str, soft_fp8: bool):
             layer.attn.cache = cache
         vl = VarLens(PROMPTS, "cuda")
         cache.curr_varlens, cache.curr_req_ids = vl, ids
+        note("prefill")
         res = [model.prefill(PROMPTS).float().clone()]
         cache.finalize_cache_all_prefill(ids, vl)
         for step in range(2):
             cache.prepare_cache_decode(ids)
             cache.prepare_block_table_for_decode(ids)
+            note(f"decode step {step}")
             lg = model.decode(fed[step].view(-1, 1).cuda(), [cache.seq_lens[r] for r in ids]).view(len(ids), -1).float()
             cache.finalize_cache_single_decode(ids)
             res.append(lg.clone())
         torch.cuda.synchronize()
+        note("run done")
         return res
 
+    note("model built and on the device")
     outs = run_reference_model(cache)
 
     def rel(a, b):
@@ -165,6 +226,7 @@ def main(ref_dir: str, soft_fp8: bool):
     run_reference_model(a_cache.PagedKVCacheManager(0, models.n_layers, num_hot_req=4, block_size=64, max_seq_len=256, device="cuda",
                                                     kv_shape_per_sample=(576,), dtype=torch.bfloat16))
     res["fused_experts_calls"] = sorted(set(calls))
+    note("re-run with the CPU oracle's fused_experts")
     rds.fused_experts = oracle_fused_experts
     oouts = run_reference_model(a_cache.PagedKVCacheManager(0, models.n_layers, num_hot_req=4, block_size=64, max_seq_len=256,
                                                             device="cuda", kv_shape_per_sample=(576,), dtype=torch.bfloat16))
@@ -176,6 +238,7 @@ def main(ref_dir: str, soft_fp8: bool):
     res["reference_top2_margin_over_peak"] = [float(((w.topk(2).values[:, 0] - w.topk(2).values[:, 1]) / w.abs().max()).min()) for w in want]
 
     # ---- (b) chitu_amd's own decoder on the same weights
+    note("chitu_amd decoder on the same weights")
     from chitu_amd.deepseek_v3 import DeepSeekV3Args, DeepSeekV3Decoder, refresh_derived_layouts
     from tests.util import ref_model_case
 

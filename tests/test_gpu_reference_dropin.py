@@ -17,10 +17,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(soft: int):
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", REF_MASTER_PORT=str(29560 + soft))
+    # DROPIN_TRACE: the worker's per-op watchdog (enter / leave lines + a Python stack every 30 s on stderr), so a run that
+    # does not finish names the op it stopped in (round 5 had one such run and no record of where: profiles/r06_reference_dropin.txt)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", REF_MASTER_PORT=str(29560 + soft), DROPIN_TRACE="1", GLOO_SOCKET_IFNAME="lo")
     env.pop("TRITON_INTERPRET", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_worker.py"), REF, str(soft)], capture_output=True,
-                       text=True, timeout=200, env=env, cwd=ROOT)  # (on expiry subprocess.run kills the worker: no orphan on the GPU)
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_worker.py"), REF, str(soft)], capture_output=True,
+                           text=True, timeout=200, env=env, cwd=ROOT)  # (on expiry subprocess.run kills the worker: no orphan on the GPU)
+    except subprocess.TimeoutExpired as e:
+        tail = (e.stderr or b"")
+        tail = tail.decode(errors="replace") if isinstance(tail, bytes) else tail
+        pytest.fail("drop-in worker did not finish in 200 s; last trace lines:\n" + tail[-3000:])
     lines = [l for l in p.stdout.splitlines() if l.startswith("DROPIN ")]
     assert p.returncode == 0 and lines, p.stdout[-2000:] + p.stderr[-4000:]
     res = json.loads(lines[-1][len("DROPIN "):])
