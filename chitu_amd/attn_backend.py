@@ -66,6 +66,32 @@ def choose_num_splits(batch: int, head_blocks: int, max_tiles: int, target_wgs: 
     return min(s, 64)
 
 
+_tickets = {}
+
+
+def _fuse_tickets(device) -> torch.Tensor:
+    """The arrival / departure words of chitu_hip_mla_decode_merge_uv_quant_fp8 (+ its sticky error word, the last one): zero
+    at creation, left zero by every launch.  One buffer per (device, workspace namespace) for the life of the process --
+    launches that share it must not overlap, and captured launches keep a valid address; created on the first EAGER call
+    (decode() warms up eagerly before it captures)."""
+    key = (torch.device(device).index or 0, workspace._namespace)
+    t = _tickets.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("mla_decode_merge_uv_quant must run once eagerly before graph capture")
+        import ctypes
+
+        n = ctypes.c_int64(0)
+        check(_lib.lib().chitu_hip_mla_decode_tickets_bytes(ctypes.byref(n)), "mla_decode_tickets_bytes")
+        t = _tickets[key] = torch.zeros(n.value // 4, dtype=torch.int32, device=device)
+    return t
+
+
+def fused_tail_timed_out(device) -> bool:
+    """Did any fused MLA decode launch on this device give up waiting for a split (its 200 ms bound)?  Synchronises."""
+    return any(int(t[-1].item()) != 0 for (dev, _), t in _tickets.items() if dev == (torch.device(device).index or 0))
+
+
 class HipAttnBackend(AttnBackend):
     """MLA absorb-mode paged decode (+ GQA paged decode) on hand-written HIP kernels.
 
@@ -142,6 +168,56 @@ class HipAttnBackend(AttnBackend):
             "mla_decode",
         )
         return (ws, num_splits) if partials else out
+
+    def mla_decode_merge_uv_quant(self, q_nope, q_pe, kv_cache, cache_seqlens_incl, block_table, softmax_scale, w_uv, scale,
+                                  scale_offset, scale_stride_h, scale_stride_k, num_splits: Optional[int] = None,
+                                  tile_major: bool = False):
+        """mla_decode(return_partials=True) + ops.mla_merge_absorb_uv_quant_fp8 in ONE launch (round 6,
+        chitu_hip_mla_decode_merge_uv_quant_fp8): every split workgroup waits for its sequence's other splits and finishes one
+        head -- merge, o . W_UV^T (model_deepseek_v3.py:697), act_quant of wo's input.  Bit-identical to the two launches.
+        Returns what the merge op returns, or None when the shape takes the two-launch form (one split, > 4096 groups)."""
+        from . import ops
+
+        require_cuda(q_nope, q_pe, kv_cache, cache_seqlens_incl, block_table, w_uv, scale)
+        assert kv_cache.ndim == 3 and kv_cache.is_contiguous() and kv_cache.dtype == torch.bfloat16
+        assert q_nope.dtype == torch.bfloat16 and q_pe.dtype == torch.bfloat16
+        assert block_table.dtype == torch.int32 and cache_seqlens_incl.dtype == torch.int32
+        assert block_table.stride(1) == 1 and cache_seqlens_incl.is_contiguous()
+        B, H, C = q_nope.shape
+        R = q_pe.shape[-1]
+        assert kv_cache.shape[-1] == C + R and C == 512
+        assert w_uv.element_size() == 1 and scale.dtype == torch.float32 and w_uv.dim() == 3 and tuple(w_uv.shape) == (H, 128, C)
+        assert w_uv.stride(2) == 1 and w_uv.stride(1) == C
+
+        def ok(t):
+            return t.stride(-1) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
+
+        if not ok(q_nope):
+            q_nope = q_nope.contiguous()
+        if not ok(q_pe):
+            q_pe = q_pe.contiguous()
+        if num_splits is None:
+            max_tiles = max(1, (int(block_table.shape[1]) * int(kv_cache.shape[1]) + 63) // 64)
+            num_splits = self.num_splits or choose_num_splits(B, (H + 15) // 16, max_tiles)
+        if num_splits < 2 or B * ((H + 15) // 16) > 4096 or w_uv.data_ptr() % 16 != 0:
+            return None
+        ws = workspace.get(B * H * num_splits * (C * 2 + 4), q_nope.device, "mla")
+        if tile_major:
+            q, s = ops._tiled_buffers(B, H * 128, w_uv.device)
+        else:
+            q = torch.empty(B, H * 128, dtype=torch.float8_e4m3fn, device=w_uv.device)
+            s = torch.empty(B, H, dtype=torch.float32, device=w_uv.device)
+        check(
+            _lib.lib().chitu_hip_mla_decode_merge_uv_quant_fp8(
+                ptr(q_nope), i64(q_nope.stride(0)), i64(q_nope.stride(1)), ptr(q_pe), i64(q_pe.stride(0)), i64(q_pe.stride(1)),
+                ptr(kv_cache), i64(kv_cache.shape[0]), i32(kv_cache.shape[1]), ptr(block_table), i32(block_table.stride(0)),
+                ptr(cache_seqlens_incl), f32(softmax_scale), i32(B), i32(H), i32(C), i32(R), i32(num_splits), ptr(ws),
+                i64(ws.numel()), ptr(w_uv), i64(w_uv.stride(0)), ptr(scale), i64(scale_offset), i64(scale_stride_h),
+                i64(scale_stride_k), ptr(q), ptr(s), i32(1 if tile_major else 0), ptr(_fuse_tickets(q_nope.device)), stream_ptr(),
+            ),
+            "mla_decode_merge_uv_quant_fp8",
+        )
+        return (ops.TiledQuant(q, s, B, H * 128), None) if tile_major else (q, s)
 
     def mla_attn_with_kvcache(
         self,

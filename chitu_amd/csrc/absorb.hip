@@ -32,19 +32,6 @@ struct AbsorbKvRow {
     const int32_t* old_lens;
 };
 
-__device__ __forceinline__ s16x8 dequant8_bf16(uint32_t w0, uint32_t w1, float s) {
-    s16x8 r;
-    r[0] = (short)f32_to_bf16(fp8_to_f32<0>(w0) * s);
-    r[1] = (short)f32_to_bf16(fp8_to_f32<1>(w0) * s);
-    r[2] = (short)f32_to_bf16(fp8_to_f32<2>(w0) * s);
-    r[3] = (short)f32_to_bf16(fp8_to_f32<3>(w0) * s);
-    r[4] = (short)f32_to_bf16(fp8_to_f32<0>(w1) * s);
-    r[5] = (short)f32_to_bf16(fp8_to_f32<1>(w1) * s);
-    r[6] = (short)f32_to_bf16(fp8_to_f32<2>(w1) * s);
-    r[7] = (short)f32_to_bf16(fp8_to_f32<3>(w1) * s);
-    return r;
-}
-
 // grid (N/16 [+1 [+1]], H, ceil(batch/16)); block 64.  The optional extra block column (rope != null)
 // rotates q_pe[b, h, :64] in place for the tile's 16 tokens (the q half of mla_kv_prep_kernel,
 // same arithmetic): it needs wq_b's output just like the absorb itself, so it rides in this launch.
@@ -375,7 +362,7 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
         for (int i = 0; i < 16; ++i) {
             const float ws = i < S ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), i)) : 0.f;
             wsum += ws;
-            acc += ws * (ws != 0.f ? v[i] : 0.f);
+            acc = merge_term(acc, ws, v[i]);
         }
         const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
         xs[tid] = f32_to_bf16(acc * inv);
@@ -399,7 +386,7 @@ __global__ __launch_bounds__(512) void mla_merge_uv_quant_kernel(
                 for (int i = 0; i < 16; ++i) {
                     const float ws = i0 + i < n ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (i0 + i) & 63)) : 0.f;
                     wsum += ws;
-                    acc += ws * (ws != 0.f ? v[i] : 0.f);
+                    acc = merge_term(acc, ws, v[i]);
                 }
             }
         }

@@ -101,6 +101,21 @@ __device__ __forceinline__ float fp8_to_f32(uint32_t packed) {
     return __builtin_amdgcn_cvt_f32_fp8((int)packed, BYTE);
 }
 
+// 8 OCP e4m3fn bytes x one block scale -> 8 bf16, each rounded as the reference's materialised weight_dequant tensor is
+// (triton_kernels.py:217-247): the MFMA operand of the absorb projections (absorb.hip, mla_decode.hip's fused tail).
+__device__ __forceinline__ s16x8 dequant8_bf16(uint32_t w0, uint32_t w1, float s) {
+    s16x8 r;
+    r[0] = (short)f32_to_bf16(fp8_to_f32<0>(w0) * s);
+    r[1] = (short)f32_to_bf16(fp8_to_f32<1>(w0) * s);
+    r[2] = (short)f32_to_bf16(fp8_to_f32<2>(w0) * s);
+    r[3] = (short)f32_to_bf16(fp8_to_f32<3>(w0) * s);
+    r[4] = (short)f32_to_bf16(fp8_to_f32<0>(w1) * s);
+    r[5] = (short)f32_to_bf16(fp8_to_f32<1>(w1) * s);
+    r[6] = (short)f32_to_bf16(fp8_to_f32<2>(w1) * s);
+    r[7] = (short)f32_to_bf16(fp8_to_f32<3>(w1) * s);
+    return r;
+}
+
 // Two f32 -> two OCP e4m3fn bytes, RNE, NaN stays NaN (act_quant_deepseek_v3 has
 // no clamp: an all-zero group is 0/0 = NaN in the reference, triton_kernels.py:210-212).
 __device__ __forceinline__ uint32_t f32x2_to_fp8x2(float a, float b) {
@@ -150,6 +165,12 @@ __device__ __forceinline__ i32x2 quant8_fp8(const float (&v)[8], float sc) {
     }
     return o;
 }
+
+// One term of the MLA split merge, acc + w_s * v_s, as ONE fused multiply-add spelt out: the three merge forms (mla_merge_kernel,
+// mla_merge_uv_quant_kernel, the fused tail of mla_decode_kernel<true>) are bit-identical to each other by construction, not by
+// the compiler happening to contract (or pack) `acc += w * v` the same way in three places.  A split without tokens (w = 0) adds
+// exactly 0 whatever its row holds.
+__device__ __forceinline__ float merge_term(float acc, float ws, float v) { return __builtin_fmaf(ws, ws != 0.f ? v : 0.f, acc); }
 
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll

@@ -313,7 +313,8 @@ static int fp8_gemm_blockscale_launch(const void* a_fp8, const float* a_scale, c
     if (K % 128 != 0) return CHITU_ERR_UNSUPPORTED;  // act_quant's contract, ops.py:345-348
     if (M == 0) return CHITU_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (!tile_major && M >= kTiledMinRows && K < (1 << 24) && debug_option(kOptFp8GemmTiled) != 0) {  // (32-bit byte offsets inside a 128-row tile)
+    if (!tile_major && M >= kTiledMinRows && K < (1 << 24) && M * (K / 128) < (1ll << 29) &&
+        debug_option(kOptFp8GemmTiled) != 0) {  // (32-bit byte offsets inside a 128-row tile, and of a row's scales: 4 M K/128 < 2^31)
         // prefill-sized M: a GEMM, not a weight stream (fp8_gemm_tiled.hip)
         launch_fp8_gemm_tiled((const fp8_t*)a_fp8, a_scale, (const fp8_t*)b_fp8, b_scale, out, out_dtype, M, N, K, st);
         CHITU_RETURN_LAUNCH_STATUS();

@@ -55,12 +55,194 @@ constexpr int kTileU = kTile * kRowU;    // 73728
 constexpr int kDmaPieces = kTileU / 1024 / 4;  // 18 per wave
 __device__ __forceinline__ int kv_swz(int r) { return ((r >> 3) & 1) * 5 + ((r >> 1) & 1) * 2; }
 
+// ---- Round 6: the split merge + W_UV projection + act_quant INSIDE the decode launch (FUSED = true).
+//
+// Two launches (decode, then mla_merge_uv_quant_kernel of absorb.hip) cost the pair two fixed launch costs, a cold W_UV fetch
+// behind the boundary and the partials' trip through memory between them: 11.6 + 6.6 us at bs 16 / ctx 1024
+// (profiles/r05_step_breakdown_bs16_final.txt).  Fused, every split workgroup of a (sequence, head block) publishes its partial
+// rows as before (write-through), counts itself on the group's arrival word, and -- instead of leaving -- waits for the other
+// splits and then does the merge + projection + quantisation of ONE head (split s takes head s, s + S, ...): the tail of a
+// sequence runs on as many CUs as it has splits, not on one last arriver, and each workgroup's 64 KB of W_UV was requested
+// before its first KV tile was multiplied.  Arithmetic and its order are mla_merge_uv_quant_kernel's: outputs bit-identical to
+// the two launches (tests/test_gpu_mla.py), which stay as the cross-check.
+//
+// Hand-off (guide: "sc1 payload -> vmcnt(0) -> sc1 flag" both sides): partial rows and LSE leave as write-through (sc1) stores,
+// every wave drains them, the workgroup meets, one lane adds 1 to arrive[group] (agent scope); a waiter's one lane polls that
+// word with sc1 loads + s_sleep until it reads S, the workgroup meets, and the partials are read with sc1 loads (L1 bypassed:
+// no acquire needed).  The words reset themselves: every waiter counts itself on depart[group] after its poll, the last one
+// stores 0 to both (all S arrivals have happened: it saw S).  Forward progress: a waiter needs the other splits of its group to
+// be scheduled; they precede or directly follow it in dispatch order, and a launch has at most ~one workgroup per CU
+// (attn_backend.choose_num_splits), so a waiter never holds a CU that an unscheduled split of an EARLIER group needs.  The wait is
+// bounded all the same (guide: bound every spin): after kFuseTimeoutTicks the waiter sets the sticky error word behind the
+// counters and carries on with what is there -- a wrong row and a reported error instead of a hung GPU.
+struct MlaFuse {
+    const fp8_t* W;        // W_UV [H, 128, 512] e4m3, head stride w_sh
+    int64_t w_sh;
+    const float* scale;    // block scales of wkv_b: scale[s_off + h * s_sh + kblock * s_sk]
+    int64_t s_off, s_sh, s_sk;
+    fp8_t* q;              // wo's quantised input rows [batch, H * 128] (or tile-major, gemm_common.h)
+    float* qs;
+    int tile_major;
+    uint32_t* tickets;     // [2 * kFuseMaxGroups + 1]: (arrive, depart) per (sequence, head block), then the error word; zero at creation
+};
+constexpr int kFuseMaxGroups = 4096;
+constexpr uint64_t kFuseTimeoutTicks = 20000000ull;  // 200 ms of the 100 MHz wall clock
+
+__device__ __forceinline__ void store16_sc1(void* dst, i32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint32_t load_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// This wave's two 16-column tiles of W_UV[h] (wave w owns output columns [32 w, 32 w + 32)) and the head's four K-block scales.
+struct MlaUvW {
+    i32x4 w[2][8];
+    float sv[4];
+};
+__device__ __forceinline__ void mla_uv_load(MlaUvW& r, const MlaFuse& f, int h, int wave, int j, int g) {
+    const float* sp = f.scale + f.s_off + h * f.s_sh;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const fp8_t* wp = f.W + (int64_t)h * f.w_sh + (int64_t)((2 * wave + t) * 16 + j) * kC + g * 16;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) r.w[t][c] = *reinterpret_cast<const i32x4*>(wp + c * 64);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r.sv[c] = sp[c * f.s_sk];
+}
+
+// The tail of a split workgroup under FUSED: count, wait, then one head per round.  `scratch`: >= 2 KB of LDS nobody else uses
+// any more.  `uw` holds the weights of the first head, head h0 + split (requested long ago), whenever there is one to do.
+__device__ __forceinline__ void mla_fused_tail(const MlaFuse& f, MlaUvW& uw, const bf16_t* part_o, const float* part_lse, int b,
+                                               int H, int h0, int split, int S, int group, uint8_t* scratch) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, g = lane >> 4;
+    bf16_t* xs = reinterpret_cast<bf16_t*>(scratch);            // [512] merged row
+    float* red = reinterpret_cast<float*>(scratch + 1024);      // [8] tile maxima
+    uint32_t* arrive = f.tickets + 2 * group;
+    uint32_t* depart = arrive + 1;
+    uint32_t* err = f.tickets + 2 * kFuseMaxGroups;
+    const int nh = min(16, H - h0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through partial stores have left
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (split >= nh) return;  // more splits than heads: nothing to merge here
+    if (tid == 0) {
+        if (load_sc1(arrive) < (uint32_t)S) {
+            const uint64_t t0 = wall_clock64();
+            for (unsigned spins = 0;; ++spins) {
+                if (load_sc1(arrive) >= (uint32_t)S) break;
+                __builtin_amdgcn_s_sleep(1);
+                if ((spins & 255) == 255 && (load_sc1(err) != 0 || wall_clock64() - t0 > kFuseTimeoutTicks)) {
+                    __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 64) {  // (a lane of another wave than the poller's, behind the barrier: its returning atomic is nobody's critical path)
+        const uint32_t waiters = (uint32_t)min(S, nh);
+        if (__hip_atomic_fetch_add(depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == waiters - 1) {
+            __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch starts from 0
+            __hip_atomic_store(depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    for (int hm = split; hm < nh; hm += S) {
+        const int h = h0 + hm;
+        const int64_t bh = (int64_t)b * H + h;
+        if (hm != split) mla_uv_load(uw, f, h, wave, j, g);  // (fewer splits than heads: the further heads' weights are fetched here)
+        // ---- merge (mla_merge_uv_quant_kernel's sums in its order): thread t owns latent columns 2 t, 2 t + 1.  The first 16
+        // partial rows are requested BEFORE the lse values are looked at (their addresses do not depend on them): one memory
+        // round trip, not two, at the usual S <= 16
+        const float* lse = part_lse + bh * S;
+        uint32_t pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = load_sc1(reinterpret_cast<const uint32_t*>(part_o + (bh * S + min(i, S - 1)) * kC + 2 * tid));
+        float m = -INFINITY;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const float l = s0 + lane < S ? __uint_as_float(load_sc1(reinterpret_cast<const uint32_t*>(lse + s0 + lane))) : -INFINITY;
+            m = __builtin_fmaxf(m, wave_reduce_max(l));
+        }
+        float a0 = 0.f, a1 = 0.f, wsum = 0.f;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const float l = s0 + lane < S ? __uint_as_float(load_sc1(reinterpret_cast<const uint32_t*>(lse + s0 + lane))) : -INFINITY;
+            const float wl = l == -INFINITY ? 0.f : __expf(l - m);
+            const int n = min(64, S - s0);
+            for (int i0 = 0; i0 < n; i0 += 16) {
+                if (s0 + i0 > 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        pv[i] = load_sc1(reinterpret_cast<const uint32_t*>(part_o + (bh * S + s0 + min(i0 + i, n - 1)) * kC + 2 * tid));
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float ws = i0 + i < n ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wl), (i0 + i) & 63)) : 0.f;
+                    wsum += ws;
+                    a0 = merge_term(a0, ws, __uint_as_float(pv[i] << 16));
+                    a1 = merge_term(a1, ws, __uint_as_float(pv[i] & 0xffff0000u));
+                }
+            }
+        }
+        const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+        *reinterpret_cast<uint32_t*>(xs + 2 * tid) = (uint32_t)f32_to_bf16(a0 * inv) | ((uint32_t)f32_to_bf16(a1 * inv) << 16);
+        __syncthreads();
+        // ---- o . W_UV[h]^T: the MFMA tile's 16 token columns all carry this token (LDS broadcast)
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const s16x8 xa = *reinterpret_cast<const s16x8*>(&xs[c * 64 + g * 16]);
+            const s16x8 xb = *reinterpret_cast<const s16x8*>(&xs[c * 64 + g * 16 + 8]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dequant8_bf16((uint32_t)uw.w[t][c][0], (uint32_t)uw.w[t][c][1], uw.sv[c >> 1]), xa, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dequant8_bf16((uint32_t)uw.w[t][c][2], (uint32_t)uw.w[t][c][3], uw.sv[c >> 1]), xb, acc[t], 0, 0, 0);
+            }
+        }
+        float v[2][4], amax = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[t][r] = round_bf16(acc[t][r]);
+                amax = __builtin_fmaxf(amax, __builtin_fabsf(v[t][r]));
+            }
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32, 64));
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        amax = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+        const float sc = amax / 448.0f;
+        const bool fast = __builtin_amdgcn_ballot_w64(!group_div_fast(sc)) == 0;
+        const float rc = group_rcp(sc);
+        if (j == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float q4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q4[k] = fast ? group_div(v[t][k], sc, rc) : v[t][k] / sc;
+                const uint32_t packed = f32x2_to_fp8x2(q4[0], q4[1]) | (f32x2_to_fp8x2(q4[2], q4[3]) << 16);
+                const int T = 2 * wave + t;
+                if (f.tile_major) {  // row b of a [batch, H * 128] matrix, tile-major (gemm_common.h): 16-B chunk index h * 8 + T
+                    const int64_t tile = b >> 4;
+                    *reinterpret_cast<uint32_t*>(f.q + ((tile * (H * 8) + h * 8 + T) * 16 + (b & 15)) * 16 + g * 4) = packed;
+                    if (T == 0 && g == 0) f.qs[(tile * H + h) * 16 + (b & 15)] = sc;
+                } else {
+                    *reinterpret_cast<uint32_t*>(f.q + bh * 128 + T * 16 + g * 4) = packed;
+                    if (T == 0 && g == 0) f.qs[bh] = sc;
+                }
+            }
+        }
+        // (the next round's xs / red writes come behind its own loads and the barrier above: no third barrier needed for red;
+        // xs is rewritten only after every wave has passed the red barrier, i.e. has finished its MFMA reads of xs)
+    }
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
     const bf16_t* __restrict__ q_nope, int64_t qn_sb, int64_t qn_sh, const bf16_t* __restrict__ q_pe,
     int64_t qp_sb, int64_t qp_sh, const bf16_t* __restrict__ cache, int64_t num_pages, int page_size,
     const int32_t* __restrict__ block_table, int table_stride, const int32_t* __restrict__ seqlens,
     float scale, bf16_t* __restrict__ part_o, float* __restrict__ part_lse, bf16_t* __restrict__ out,
-    int H, int num_splits) {
+    int H, int num_splits, MlaFuse fuse) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* kv_lds = smem;                                               // [2][64][kRowU]
     bf16_t* p_lds = reinterpret_cast<bf16_t*>(smem + 2 * kTileU);         // [16][72]
@@ -143,7 +325,9 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
             glds16_sbase<true>(sb, (uint32_t)(min(prow[i], valid - 1) * kRowU) + pswz[i],
                              lds0 + (uint32_t)(buf * kTileU + (wave + 4 * i) * 1024));
     };
-    if (tile0 >= tile1) {  // an empty split publishes LSE = -inf and zero rows (nothing of it is read by the merge)
+    // FUSED: an empty split still has a head of the tail to do -- it runs the rest of the kernel over zero tiles (zero rows, LSE = -inf)
+    const bool empty = FUSED && tile0 >= tile1;
+    if (!FUSED && tile0 >= tile1) {  // an empty split publishes LSE = -inf and zero rows (nothing of it is read by the merge)
         if (num_splits > 1) {
             if (tid < 16 && h0 + tid < H) part_lse[((int64_t)b * H + h0 + tid) * num_splits + split] = -INFINITY;
 #pragma unroll
@@ -158,7 +342,12 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         }
         return;
     }
-    issue(page_src(first_pg, tile0 * kTile), min(kTile, L - tile0 * kTile), 0);
+    if (!empty) issue(page_src(first_pg, tile0 * kTile), min(kTile, L - tile0 * kTile), 0);
+    // FUSED: this workgroup's head of the tail (split s -> head s) -- its 64 KB of W_UV are requested once the LAST KV tile has
+    // landed (no DMA is issued behind them: the counted waits stay what they are) and arrive while that tile is multiplied
+    MlaUvW uvw;
+    const bool uv_mine = FUSED && num_splits > 1 && split < min(16, H - h0);
+    if (empty && uv_mine) mla_uv_load(uvw, fuse, h0 + split, wave, j, g);
     {   // Q into buffer 1, in the tile image's own layout (row = head, chunk c at c ^ swz(row)): read back like a K fragment
         uint8_t* q_lds = kv_lds + kTileU;
 #pragma unroll
@@ -218,6 +407,7 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
             glds_wait_all();  // this wave's pieces of the tile
         __syncthreads();   // everyone's; the other buffer and the softmax exchange areas of the previous tile are free
         if (tile > tile0 && tile + 1 < tile1) issue(tile_src(tile + 1), min(kTile, L - (tile + 1) * kTile), buf ^ 1);
+        if (FUSED && tile + 1 == tile1 && uv_mine) mla_uv_load(uvw, fuse, h0 + split, wave, j, g);
         const uint8_t* kv = kv_lds + buf * kTileU;
         CHITU_PROBE_MARK(10);
 
@@ -292,7 +482,6 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
 
     // ---- epilogue: lane holds O[head 4g+r][col wave*128 + c*16 + j]
     CHITU_PROBE_MARK(12);
-    constexpr bool empty = false;  // (empty splits left above)
     if (num_splits == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -316,8 +505,12 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
 #pragma unroll
         for (int c = 0; c < 8; ++c) o_lds[(g * 4 + r) * kC + wave * 128 + c * 16 + j] = f32_to_bf16(o[c][r] * inv);
         const int h = h0 + g * 4 + r;
-        if (wave == 0 && j == 0 && h < H)
-            part_lse[((int64_t)b * H + h) * num_splits + split] = empty ? -INFINITY : m_run[r] + __logf(l_run[r]);
+        if (wave == 0 && j == 0 && h < H) {
+            float* lp = part_lse + ((int64_t)b * H + h) * num_splits + split;
+            const float lv = empty ? -INFINITY : m_run[r] + __logf(l_run[r]);
+            if (FUSED) __hip_atomic_store(lp, lv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through, like the rows
+            else *lp = lv;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -333,6 +526,10 @@ __global__ __launch_bounds__(256, 1) void mla_decode_kernel(
         }
     }
     CHITU_PROBE_MARK(13);
+    if (FUSED) {
+        // scratch: the second tile buffer's first bytes (the partial transpose above used the first buffer's)
+        mla_fused_tail(fuse, uvw, part_o, part_lse, b, H, h0, split, num_splits, b * (int)gridDim.z + hb, kv_lds + kTileU);
+    }
 }
 
 // Stage 2: out[b,h,:] = sum_s w_s * part_o[b,h,s,:] / sum_s w_s, w_s = exp(lse_s - max lse).  part_o bf16, sums fp32.
@@ -362,8 +559,8 @@ __global__ __launch_bounds__(128) void mla_merge_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const uint32_t u = (uint32_t)v[i][k];
-                acc[2 * k] += w[i] * __uint_as_float(u << 16);
-                acc[2 * k + 1] += w[i] * __uint_as_float(u & 0xffff0000u);
+                acc[2 * k] = merge_term(acc[2 * k], w[i], __uint_as_float(u << 16));
+                acc[2 * k + 1] = merge_term(acc[2 * k + 1], w[i], __uint_as_float(u & 0xffff0000u));
             }
         }
     }
@@ -375,6 +572,15 @@ __global__ __launch_bounds__(128) void mla_merge_kernel(const bf16_t* __restrict
 }
 
 }  // namespace chitu
+
+// Dynamic LDS of a decode workgroup; the opt-in above 64 KB is set on every call (it is per device and cheap; a process-wide
+// "done" flag would leave the second GPU of a multi-device process without it).
+template <bool FUSED>
+static size_t mla_decode_lds_bytes() {
+    const size_t lds = 2 * chitu::kTileU + 16 * chitu::kPStride * 2 + 2 * 64 * sizeof(float) + chitu::kMaxTilesLds * sizeof(int);
+    (void)hipFuncSetAttribute((const void*)chitu::mla_decode_kernel<FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return lds;
+}
 
 extern "C" int chitu_hip_mla_decode_workspace_bytes(int32_t batch, int32_t heads, int32_t num_splits,
                                                     int64_t* bytes) {
@@ -411,21 +617,54 @@ extern "C" int chitu_hip_mla_decode(const void* q_nope, int64_t qn_stride_b, int
         part_o = (bf16_t*)workspace;
         part_lse = (float*)(part_o + (int64_t)batch * heads * num_splits * kC);
     }
-    const size_t lds = 2 * kTileU + 16 * kPStride * 2 + 2 * 64 * sizeof(float) + kMaxTilesLds * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mla_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)num_splits, (unsigned)batch, (unsigned)((heads + 15) / 16));
-    hipLaunchKernelGGL(mla_decode_kernel, grid, dim3(256), lds, st, (const bf16_t*)q_nope, qn_stride_b,
+    hipLaunchKernelGGL(mla_decode_kernel<false>, grid, dim3(256), mla_decode_lds_bytes<false>(), st, (const bf16_t*)q_nope, qn_stride_b,
                        qn_stride_h, (const bf16_t*)q_pe, qp_stride_b, qp_stride_h, (const bf16_t*)kv_cache,
                        num_pages, (int)page_size, block_table, (int)table_stride, seqlens, softmax_scale,
-                       part_o, part_lse, (bf16_t*)out_bf16, (int)heads, (int)num_splits);
+                       part_o, part_lse, (bf16_t*)out_bf16, (int)heads, (int)num_splits, MlaFuse{});
     if (num_splits > 1 && out_bf16)
         hipLaunchKernelGGL(mla_merge_kernel, dim3((unsigned)(batch * heads)), dim3(128), 0, st, part_o,
                            part_lse, (bf16_t*)out_bf16, (int)num_splits);
+    CHITU_RETURN_LAUNCH_STATUS();
+}
+
+extern "C" int chitu_hip_mla_decode_tickets_bytes(int64_t* bytes) {
+    if (!bytes) return CHITU_ERR_BAD_ARG;
+    *bytes = (int64_t)(2 * chitu::kFuseMaxGroups + 1) * 4;
+    return CHITU_OK;
+}
+
+extern "C" int chitu_hip_mla_decode_merge_uv_quant_fp8(
+    const void* q_nope, int64_t qn_stride_b, int64_t qn_stride_h, const void* q_pe, int64_t qp_stride_b, int64_t qp_stride_h,
+    const void* kv_cache, int64_t num_pages, int32_t page_size, const int32_t* block_table, int32_t table_stride,
+    const int32_t* seqlens, float softmax_scale, int32_t batch, int32_t heads, int32_t kv_lora_rank, int32_t rope_dim,
+    int32_t num_splits, void* workspace, int64_t workspace_bytes, const void* w_fp8, int64_t w_stride_h, const float* scale,
+    int64_t scale_offset, int64_t scale_stride_h, int64_t scale_stride_k, void* q_fp8, float* q_scales, int32_t tile_major,
+    uint32_t* tickets, void* stream) {
+    using namespace chitu;
+    CHITU_REQUIRE(q_nope && q_pe && kv_cache && block_table && seqlens && w_fp8 && scale && q_fp8 && q_scales && tickets);
+    CHITU_REQUIRE(batch >= 0 && heads >= 1 && num_pages >= 1 && table_stride >= 1 && w_stride_h % 16 == 0);
+    CHITU_REQUIRE(((uintptr_t)kv_cache & 15) == 0 && ((uintptr_t)q_nope & 15) == 0 && ((uintptr_t)q_pe & 15) == 0);  // 16-byte loads
+    CHITU_REQUIRE(((uintptr_t)w_fp8 & 15) == 0 && ((uintptr_t)tickets & 3) == 0);
+    if (kv_lora_rank != kC || rope_dim != kR) return CHITU_ERR_UNSUPPORTED;
+    if (page_size < kTile || page_size % kTile != 0) return CHITU_ERR_UNSUPPORTED;
+    CHITU_REQUIRE(num_splits >= 2 && num_splits <= 256);  // one split: chitu_hip_mla_decode + chitu_hip_absorb_uv_quant_fp8
+    CHITU_REQUIRE((int64_t)table_stride * (page_size / kTile) * (num_splits + 1) < (1ll << 31));
+    const int hb = (heads + 15) / 16;
+    if ((int64_t)batch * hb > kFuseMaxGroups) return CHITU_ERR_UNSUPPORTED;
+    if (batch == 0) return CHITU_OK;
+    const int64_t need = (int64_t)batch * heads * num_splits * (kC * 2 + 4);
+    CHITU_REQUIRE(workspace && workspace_bytes >= need);
+    bf16_t* part_o = (bf16_t*)workspace;
+    float* part_lse = (float*)(part_o + (int64_t)batch * heads * num_splits * kC);
+    const MlaFuse fuse{(const fp8_t*)w_fp8, w_stride_h, scale, scale_offset, scale_stride_h, scale_stride_k, (fp8_t*)q_fp8, q_scales,
+                       (int)tile_major, tickets};
+    const dim3 grid((unsigned)num_splits, (unsigned)batch, (unsigned)hb);
+    hipLaunchKernelGGL(mla_decode_kernel<true>, grid, dim3(256), mla_decode_lds_bytes<true>(), (hipStream_t)stream, (const bf16_t*)q_nope,
+                       qn_stride_b, qn_stride_h, (const bf16_t*)q_pe, qp_stride_b, qp_stride_h, (const bf16_t*)kv_cache, num_pages,
+                       (int)page_size, block_table, (int)table_stride, seqlens, softmax_scale, part_o, part_lse, (bf16_t*)nullptr,
+                       (int)heads, (int)num_splits, fuse);
     CHITU_RETURN_LAUNCH_STATUS();
 }
 

@@ -200,11 +200,8 @@ extern "C" int chitu_hip_mla_prefill(const void* q_bf16, int64_t q_stride_t, int
     CHITU_REQUIRE(q_stride_t % 8 == 0 && q_stride_h % 8 == 0 && kv_stride_t % 8 == 0);
     if (n_seq == 0 || max_seqlen == 0) return CHITU_OK;
     const size_t lds = (size_t)(pf::kTile + pf::kBQ * 16) * pf::kRowB + 16 * pf::kPStride * 2 + 2 * 64 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mla_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // (set on every call: the opt-in is per device, a process-wide "done" flag would skip the second GPU of a multi-device process)
+    (void)hipFuncSetAttribute((const void*)mla_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid((unsigned)((max_seqlen + pf::kBQ - 1) / pf::kBQ), (unsigned)n_seq, (unsigned)((heads + 15) / 16));
     hipLaunchKernelGGL(mla_prefill_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q_bf16, q_stride_t,
                        q_stride_h, (const bf16_t*)kv_bf16, kv_stride_t, cu_seqlens, softmax_scale, (bf16_t*)out_bf16,

@@ -350,11 +350,8 @@ extern "C" int chitu_hip_mla_prefill_flash(const void* q_bf16, int64_t q_stride_
     CHITU_REQUIRE(((uintptr_t)q_bf16 | (uintptr_t)kv_bf16 | (uintptr_t)out_bf16) % 16 == 0);
     if (n_seq == 0 || max_seqlen == 0) return CHITU_OK;
     const size_t lds = (size_t)pfp::kRing * pfp::kSlot;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mla_prefill_flash_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    // (set on every call: the opt-in is per device, a process-wide "done" flag would skip the second GPU of a multi-device process)
+    (void)hipFuncSetAttribute((const void*)mla_prefill_flash_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const dim3 grid((unsigned)((max_seqlen + pff::kBQ - 1) / pff::kBQ), (unsigned)n_seq, (unsigned)((heads + 15) / 16));
     hipLaunchKernelGGL(mla_prefill_flash_pipe_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)q_bf16, q_stride_t,
                        q_stride_h, (const bf16_t*)kv_bf16, kv_stride_t, cu_seqlens, softmax_scale, (bf16_t*)out_bf16,

@@ -175,6 +175,11 @@ class RMSNormW(torch.nn.Module):
 # q_norm + act_quant + wq_b GEMM + KV append as one launch (ops.mla_q_proj); CHITU_Q_PROJ_FUSED=0 keeps the two
 # launches apart (A/B timing, tests of the unfused pair).
 FUSE_Q_PROJ = os.environ.get("CHITU_Q_PROJ_FUSED", "1") != "0"
+# split merge + W_UV projection + act_quant INSIDE the MLA decode launch (round 6, chitu_hip_mla_decode_merge_uv_quant_fp8): same
+# bits, one launch less -- and slower on every box it was timed on (bs 16: 24.4 us against 11.7 + 6.8; bs 1: 15.7 against
+# 7.4 + 7.9; profiles/r06_ab_mla_fused_tail.txt): the in-launch hand-off (drain + flag + poll) costs more than the kernel
+# boundary it removes.  Off; kept as the measured experiment and a third merge form in the bit-identity tests.
+_MLA_FUSED_TAIL = os.environ.get("CHITU_MLA_FUSED_TAIL", "0") == "1"
 # ... up to one 16-token tile: with two tiles every workgroup redoes the norm + quant of 32 rows and the kernel is out of
 # registers (bench bs 32: 14.7 ms/step with the two launches, 15.1 with the fused one)
 _Q_PROJ_MAX_BS = 16
@@ -302,12 +307,21 @@ class AttentionDeepSeekV3(torch.nn.Module):
             q_abs = ops.absorb_bmm_rope_kv_fp8(q_nope, self.w_uk_transposed(), self.wkv_b.scale, 0, 2 * nblk, 1, 0, q_pe, cos, sin,
                                                q_kv[:, nq:], self.kv_norm.weight, self.kv_norm.eps, kv_cache,
                                                cache.get_gpu_block_table(), cache.get_gpu_seq_lens_excl_this_decode())
-        # small batches: the split-KV merge runs inside the W_UV projection kernel
+        # small batches: the split-KV merge runs inside the W_UV projection kernel (CHITU_MLA_FUSED_TAIL=1: both inside the
+        # decode launch, same bits, measured slower -- see _MLA_FUSED_TAIL)
         fuse_merge = bs <= 32 and C == 512
+        w_uv = self.wkv_b.weight.view(H, self.qk_nope_head_dim + self.v_head_dim, C)[:, self.qk_nope_head_dim :]
+        fused = None
+        if fuse_merge and _MLA_FUSED_TAIL and self.v_head_dim == 128:
+            fused = self.attn_backend.mla_decode_merge_uv_quant(
+                q_abs, q_pe, kv_cache, cache.get_gpu_seq_lens_incl_this_decode(), cache.get_gpu_block_table(), self.softmax_scale,
+                w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1, tile_major=ops.tile_major_ok(bs))
+        if fused is not None:
+            oq, os_ = fused
+            return self.wo(None, x_quant=(oq, os_))
         o = self.attn_backend.mla_decode(q_abs, q_pe, kv_cache, cache.get_gpu_seq_lens_incl_this_decode(),
                                          cache.get_gpu_block_table(), self.softmax_scale, return_partials=fuse_merge)
         # out = o . W_UV^T  (einsum "bshc,hdc->bshd", :697) + the act-quant of wo's input
-        w_uv = self.wkv_b.weight.view(H, self.qk_nope_head_dim + self.v_head_dim, C)[:, self.qk_nope_head_dim :]
         if isinstance(o, tuple):
             oq, os_ = ops.mla_merge_absorb_uv_quant_fp8(o[0], o[1], bs, w_uv, self.wkv_b.scale, nblk, 2 * nblk, 1,
                                                         tile_major=ops.tile_major_ok(bs))

@@ -211,28 +211,30 @@ def capture_verified(run_eager, static_out, mode, pool, what="decode step"):
                        f"refusing to decode through it: {record['mismatches']}")
 
 
-_sweep_buffer = None  # allocated once and kept: a sweep must not become the allocation that runs a full HBM out of memory
+_sweep_buffers = {}  # per device; allocated once and kept: a sweep must not become the allocation that runs a full HBM out of memory
 
 
 def sweep_l2(nbytes: int = 256 << 20):
     """Ordinary write traffic larger than every L2 of the device (8 x 4 MB): evicts whatever lines they hold.  The buffer is
     allocated on first use and kept for the life of the process; if even that allocation fails (KV cache sized to fill the
     HBM) the sweep falls back to smaller buffers written several times, and is skipped -- loudly -- below 32 MB."""
-    global _sweep_buffer
-    if _sweep_buffer is None or _sweep_buffer.numel() < nbytes:
+    dev = torch.cuda.current_device()  # one buffer per device: a sweep evicts the L2s of the device it runs on
+    buf = _sweep_buffers.get(dev)
+    if buf is None or buf.numel() < nbytes:
         size = nbytes
+        oom = getattr(torch, "OutOfMemoryError", torch.cuda.OutOfMemoryError)  # (torch < 2.5 has only the cuda-namespaced class)
         while True:
             try:
                 with torch.inference_mode(False):  # a normal tensor: it is filled from inference-mode and ordinary callers alike
-                    _sweep_buffer = torch.empty(size, dtype=torch.uint8, device="cuda")
+                    buf = _sweep_buffers[dev] = torch.empty(size, dtype=torch.uint8, device=f"cuda:{dev}")
                 break
-            except torch.OutOfMemoryError:
+            except oom:
                 size //= 2
                 if size < (32 << 20):
                     print("[chitu_amd] sweep_l2: no memory for a sweep buffer; L2 sweep skipped", file=sys.stderr, flush=True)
                     return
-    for _ in range(max(1, nbytes // _sweep_buffer.numel())):
-        _sweep_buffer.fill_(0)
+    for _ in range(max(1, nbytes // buf.numel())):
+        buf.fill_(0)
     torch.cuda.synchronize()
 
 

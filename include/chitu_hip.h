@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define CHITU_HIP_ABI_VERSION 2
+#define CHITU_HIP_ABI_VERSION 3  /* 3 (round 6): + chitu_hip_mla_decode_merge_uv_quant_fp8 / _tickets_bytes; INTEGRATION.md lists what 2 -> 3 removed or tightened */
 
 /* ---- fused MoE: token alignment -------------------------------------------------
  * Replaces chitu_backend.cuda_moe_align_block_size (reference csrc/binding.cpp:11,
@@ -420,6 +420,27 @@ int chitu_hip_gqa_prefill(const void* q_bf16, int64_t q_stride_t, int64_t q_stri
                           int64_t v_stride_h, const int32_t* cu_seqlens, int32_t n_seq, int32_t max_seqlen,
                           float softmax_scale, void* out_bf16, int32_t q_heads, int32_t kv_heads, int32_t head_dim,
                           void* stream);
+
+/* chitu_hip_mla_decode (num_splits >= 2) AND the merge + W_UV projection + act_quant of the entry below in ONE launch:
+ * AttentionDeepSeekV3.decode_forward's mla_attn_with_kvcache -> einsum("bshc,hdc->bshd") -> act_quant of wo's input
+ * (chitu/models/model_deepseek_v3.py:672-699, chitu/attn_backend.py:707-774).  Every split workgroup publishes its partial
+ * rows, counts itself on its (sequence, head block)'s word in `tickets`, waits for the other splits (bounded: 200 ms, then
+ * the word tickets[bytes/4 - 1] is set and stays set) and finishes one head.  Outputs are bit-identical to chitu_hip_mla_decode(
+ * out_bf16 = NULL) followed by chitu_hip_mla_merge_absorb_uv_quant_fp8[_tm] (tile_major = 1).
+ *   tickets: chitu_hip_mla_decode_tickets_bytes() bytes of device memory, zero when first used and never written by anyone
+ *   else (the kernel leaves it zero); launches that share it must not overlap.  batch * ceil(heads/16) <= 4096.
+ *   Other arguments: as the two entries it replaces; workspace as chitu_hip_mla_decode_workspace_bytes. */
+int chitu_hip_mla_decode_tickets_bytes(int64_t* bytes);
+int chitu_hip_mla_decode_merge_uv_quant_fp8(const void* q_nope, int64_t qn_stride_b, int64_t qn_stride_h, const void* q_pe,
+                                            int64_t qp_stride_b, int64_t qp_stride_h, const void* kv_cache,
+                                            int64_t num_pages, int32_t page_size, const int32_t* block_table,
+                                            int32_t table_stride, const int32_t* seqlens, float softmax_scale,
+                                            int32_t batch, int32_t heads, int32_t kv_lora_rank, int32_t rope_dim,
+                                            int32_t num_splits, void* workspace, int64_t workspace_bytes,
+                                            const void* w_fp8, int64_t w_stride_h, const float* scale,
+                                            int64_t scale_offset, int64_t scale_stride_h, int64_t scale_stride_k,
+                                            void* q_fp8, float* q_scales, int32_t tile_major, uint32_t* tickets,
+                                            void* stream);
 
 /* Split-KV merge + W_UV projection (model_deepseek_v3.py:697) + act_quant of wo's input in one
  * launch, for small batches (one workgroup per (head, token)): the same arithmetic and rounding

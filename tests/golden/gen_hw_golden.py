@@ -166,7 +166,70 @@ def gen_mla_decode():
         save("mla_decode", **out)
 
 
-GENS = {"fp8_linear": gen_fp8_linear, "fused_moe_fp8": gen_fused_moe_fp8, "fused_moe_bf16": gen_fused_moe_bf16,
+def gen_gqa():
+    """Round 6: the reference's pure-torch attention (RefAttnBackend) run ON THE MI355X -- torch's own bf16 / fp32 kernels on
+    ROCm instead of the CPU's (tests/golden/gqa_decode.npz, gqa_prefill.npz are the CPU runs on lattice values)."""
+    from chitu.attn_backend import RefAttnBackend
+
+    be = RefAttnBackend()
+    out = {}
+    for case in hc.GQA_DECODE_CASES:
+        q, kc, vc, kn, vn, lens = hc.gqa_decode_case(case)
+        d = [t.cuda() for t in (q, kc, vc, kn, vn, lens)]
+        shape = f"B={q.shape[0]} Hq={q.shape[2]} Hkv={kc.shape[2]} lens={lens.tolist()}"
+        try:
+            o = be.attn_with_kvcache(d[0], d[1].clone(), d[2].clone(), d[3], d[4], cache_seqlens=d[5], softmax_scale=128 ** -0.5)
+            record("RefAttnBackend.attn_with_kvcache", case, shape,
+                   time_us(lambda: be.attn_with_kvcache(d[0], d[1], d[2], d[3], d[4], cache_seqlens=d[5], softmax_scale=128 ** -0.5), n=5))
+            out[f"decode_{case}_out"] = hc.bits16(o)
+        except Exception as exc:  # noqa: BLE001
+            record("RefAttnBackend.attn_with_kvcache", case, shape, error=f"{type(exc).__name__}: {exc}")
+    for case in hc.GQA_PREFILL_CASES:
+        q, k, v, cu, seqs = hc.gqa_prefill_case(case)
+        d = [t.cuda() for t in (q, k, v, cu)]
+        shape = f"seqs={seqs} Hq={q.shape[1]} Hkv={k.shape[1]}"
+        try:
+            run = lambda: be.attn_varlen_func(d[0], d[1], d[2], d[3], d[3], max(seqs), max(seqs), causal=True)  # noqa: E731
+            o = run()
+            record("RefAttnBackend.attn_varlen_func", case, shape, time_us(run, n=5))
+            out[f"prefill_{case}_out"] = hc.bits16(o[torch.from_numpy(hc.gqa_prefill_rows(seqs)).cuda()])  # kept rows only
+        except Exception as exc:  # noqa: BLE001
+            record("RefAttnBackend.attn_varlen_func", case, shape, error=f"{type(exc).__name__}: {exc}")
+    if out:
+        save("gqa", **out)
+
+
+def gen_soft_fp8_moe():
+    """Round 6: the README configuration's MoE branch off NVIDIA (infer.soft_fp8=True): the reference's soft-fp8 dequant kernel
+    over the stacked experts, then its bf16 fused_experts -- both compiled by Triton-ROCm, on the MI355X."""
+    from chitu import ops
+    from chitu.fused_moe import fused_experts_impl
+
+    out = {}
+    torch.set_default_dtype(torch.bfloat16)  # the dequantised tensor takes torch's default dtype (ops.py:433), bf16 under the Backend
+    for case in hc.SOFT_FP8_MOE_CASES:
+        x, w1, w2, w1s, w2s, ids, wts = hc.soft_fp8_moe_case(case)
+        d = [t.cuda() for t in (x, w1, w2, w1s, w2s, ids, wts)]
+        shape = f"M={x.shape[0]} E={w1.shape[0]} topk={ids.shape[1]} K={x.shape[1]} I={w2.shape[2]}"
+        try:
+            w1d = ops.weight_dequant_soft_fp8_deepseek_v3(d[1], d[3], 128)
+            w2d = ops.weight_dequant_soft_fp8_deepseek_v3(d[2], d[4], 128)
+            record("weight_dequant_soft_fp8_deepseek_v3 (stacked w1)", case, shape,
+                   time_us(lambda: ops.weight_dequant_soft_fp8_deepseek_v3(d[1], d[3], 128), n=5))
+            run = lambda: fused_experts_impl(d[0].clone(), w1d, w2d, d[6], d[5], inplace=False, use_fp8_w8a8=False)  # noqa: E731
+            o = run()
+            record("fused_experts_impl bf16 on soft-dequantised experts", case, shape, time_us(run))
+            out[f"{case}_out"] = hc.bits16(o)
+            if case == "small":
+                out["small_w1_dequant"] = hc.bits16(w1d)
+        except Exception as exc:  # noqa: BLE001
+            record("soft-fp8 MoE branch", case, shape, error=f"{type(exc).__name__}: {exc}")
+    torch.set_default_dtype(torch.float32)
+    if out:
+        save("soft_fp8_moe", **out)
+
+
+GENS = {"gqa": gen_gqa, "soft_fp8_moe": gen_soft_fp8_moe, "fp8_linear": gen_fp8_linear, "fused_moe_fp8": gen_fused_moe_fp8, "fused_moe_bf16": gen_fused_moe_bf16,
         "mla_decode": gen_mla_decode}
 
 if __name__ == "__main__":
@@ -182,7 +245,7 @@ if __name__ == "__main__":
     print(json.dumps(meta), flush=True)
     prof = os.environ.get("HW_GOLDEN_PROFILE")
     if prof:
-        with open(prof, "w") as f:
+        with open(prof, "a" if os.environ.get("HW_GOLDEN_PROFILE_APPEND") else "w") as f:
             f.write("# The reference's own Triton kernels (thu-pacman/chitu, unmodified) compiled by Triton-ROCm and run on the MI355X:\n")
             f.write("# tests/golden/gen_hw_golden.py -- the run that produced tests/golden/hw_*.npz.  us per call, HIP events over 20 calls.\n")
             f.write("# " + json.dumps(meta) + "\n")

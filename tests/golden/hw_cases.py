@@ -82,6 +82,60 @@ def mla_decode_case(name):
 MLA_DECODE_CASES = ("ragged", "ctx4k")
 
 
+def gqa_decode_case(name):
+    """RefAttnBackend.attn_with_kvcache (chitu/attn_backend.py:457-516) on contiguous caches [B, S, Hkv, 128]: Llama-3-8B's
+    head counts (32 query / 8 KV heads), random bf16 values, ragged lengths around the 256-token page edge."""
+    B, S, Hq, Hkv, lens, seed = {"llama3": (4, 1100, 32, 8, [0, 255, 256, 1024], 501), "mha": (2, 300, 8, 8, [7, 299], 502)}[name]
+    g = torch.Generator().manual_seed(seed)
+    D = 128
+    kc = torch.randn(B, S, Hkv, D, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    vc = torch.randn(B, S, Hkv, D, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    q = (torch.randn(B, 1, Hq, D, generator=g, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    kn = torch.randn(B, 1, Hkv, D, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    vn = torch.randn(B, 1, Hkv, D, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    return q, kc, vc, kn, vn, torch.tensor(lens, dtype=torch.int64)
+
+
+GQA_DECODE_CASES = ("llama3", "mha")
+
+
+def gqa_prefill_case(name):
+    """RefAttnBackend.attn_varlen_func (chitu/attn_backend.py:394-455) as Attention.prefill_forward calls it
+    (models/model.py:104-132): causal GQA over ragged prompts, head_dim 128."""
+    seqs, Hq, Hkv, seed = {"llama3": ([1, 255, 257, 9, 600], 32, 8, 601), "g2": ([130, 64], 8, 4, 602)}[name]
+    g = torch.Generator().manual_seed(seed)
+    T = sum(seqs)
+    cu = torch.tensor([0] + list(np.cumsum(seqs)), dtype=torch.int32)
+    q = (torch.randn(T, Hq, 128, generator=g, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    k = torch.randn(T, Hkv, 128, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    v = torch.randn(T, Hkv, 128, generator=g, dtype=torch.float32).to(torch.bfloat16)
+    return q, k, v, cu, seqs
+
+
+GQA_PREFILL_CASES = ("llama3", "g2")
+
+
+def gqa_prefill_rows(seqs):
+    """Token rows of a prefill case the fixture keeps (it stays small): the first / last / page- and tile-edge tokens of every
+    sequence and a stride through the rest."""
+    keep, s0 = set(), 0
+    for n in seqs:
+        keep.update(s0 + i for i in (0, 1, 31, 32, 63, 64, 127, 128, 254, 255, 256, n - 2, n - 1) if 0 <= i < n)
+        s0 += n
+    keep.update(range(0, s0, 23))
+    return np.array(sorted(keep), dtype=np.int64)
+
+
+def soft_fp8_moe_case(name):
+    """The non-NVIDIA soft-fp8 MoE branch (chitu/models/model_deepseek_v3.py:975-996): weight_dequant_soft_fp8_deepseek_v3 of the
+    stacked fp8 experts (chitu/ops.py:396-449), then fused_experts(use_fp8_w8a8=False) on the bf16 result.  Inputs: the fp8
+    case of the same name's weights and scales."""
+    return fused_moe_fp8_case({"r1_bs16": "r1_bs16", "small": "small"}[name])
+
+
+SOFT_FP8_MOE_CASES = ("r1_bs16", "small")
+
+
 def bits16(t):
     return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
 

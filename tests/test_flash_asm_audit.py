@@ -46,3 +46,20 @@ def test_no_compiler_wait_inside_the_dma_fed_loops(tmp_path, src, kernel):
     assert res.returncode == 0, res.stderr
     seen, bad = check_flash_asm.audit_dma_loops(str(tmp_path / "k.s"), kernel)
     assert seen and not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_asm_loads_of_mla_decode_are_untouched_until_their_wait(tmp_path):
+    """mla_decode.hip requests seqlens and four page-table entries through inline-asm loads and waits for them in a LATER asm
+    statement (so that they head the kernel); the compiler treats their outputs as defined at once.  Nothing may touch those
+    registers in between (check_flash_asm.audit_async_asm_loads reads the compiled ISA of both instantiations)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_flash_asm
+
+    csrc = os.path.join(ROOT, "chitu_amd", "csrc")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
+           "-S", "--cuda-device-only", os.path.join(csrc, "mla_decode.hip"), "-o", str(tmp_path / "k.s")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    seen, bad = check_flash_asm.audit_async_asm_loads(str(tmp_path / "k.s"), "mla_decode_kernel")
+    assert len(seen) == 2 and not bad, bad

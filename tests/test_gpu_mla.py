@@ -367,3 +367,88 @@ def test_against_the_reference_kernels_run_on_the_mi355x(case, splits):
     cache, qn, qp, table, lens, scale = hc.mla_decode_case(case)
     out = backend().mla_decode(qn.cuda(), qp.cuda(), cache.cuda(), lens.cuda(), table.cuda(), scale, num_splits=splits)
     assert_close(out, bf16(g[f"{case}_out"]), REL_TOL, what=(case, splits))
+
+
+def _uv_weights(H, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.randn(H, 256, 512, generator=g) * 0.5).to(torch.float8_e4m3fn).cuda()
+    sc = (torch.rand(H * 2, 4, generator=g) * 0.02 + 0.01).cuda()
+    return w[:, 128:], sc
+
+
+@pytest.mark.parametrize(
+    "bs,H,lens,splits",
+    [
+        (16, 16, [1024] * 16, None),                   # the R1 decode shape: 16 splits, one head each
+        (1, 16, [1024], None),                         # bs 1: 16 workgroups in the whole launch
+        (5, 16, [64, 1, 300, 129, 1024], 4),           # fewer splits than heads: four heads per workgroup
+        (3, 16, [700, 0, 5], 16),                      # an empty sequence and splits without a tile
+        (2, 16, [2000, 1999], 31),                     # more splits than heads: the surplus only counts itself
+        (2, 32, [300, 77], 3),                         # two head blocks (TP=4), each its own group
+        (3, 8, [10, 200, 63], 2),                      # fewer than 16 heads
+        (32, 16, [130 + 29 * i for i in range(32)], None),  # bs 32: 8 splits, two heads per workgroup, ragged
+    ],
+)
+@pytest.mark.parametrize("tile_major", [False, True])
+def test_fused_decode_merge_uv_quant_is_bit_identical_to_the_two_launches(bs, H, lens, splits, tile_major):
+    """chitu_hip_mla_decode_merge_uv_quant_fp8 (round 6: every split workgroup waits for its sequence's other splits and
+    finishes one head inside the decode launch) against mla_decode(return_partials) + mla_merge_absorb_uv_quant_fp8: same
+    codes, same scales -- on ragged, empty and over-/under-split shapes; repeated (the arrival words must reset themselves)."""
+    from chitu_amd import attn_backend as ab
+    from chitu_amd import ops
+
+    pages = sum((l + 63) // 64 for l in lens) + 2
+    q_nope, q_pe, cache, table, sl = make_case(bs, H, lens, pages, seed=bs * 7 + H)
+    be = backend(H)
+    dev = [t.cuda() for t in (q_nope, q_pe, cache, sl, table)]
+    w_uv, sc = _uv_weights(H)
+    part = be.mla_decode(dev[0], dev[1], dev[2], dev[3], dev[4], 0.1352, return_partials=True, num_splits=splits)
+    assert isinstance(part, tuple)
+    want = ops.mla_merge_absorb_uv_quant_fp8(part[0], part[1], bs, w_uv, sc, 4, 8, 1, tile_major=tile_major)
+    want = want[0].to_row_major() if tile_major else want
+    for rep in range(3):
+        got = be.mla_decode_merge_uv_quant(dev[0], dev[1], dev[2], dev[3], dev[4], 0.1352, w_uv, sc, 4, 8, 1, num_splits=part[1],
+                                           tile_major=tile_major)
+        assert got is not None
+        got = got[0].to_row_major() if tile_major else got
+        # (NaN codes of an all-zero row -- the empty sequence: 0 / 0 as in the reference -- compare equal as bytes)
+        assert torch.equal(got[0].view(torch.uint8)[:bs], want[0].view(torch.uint8)[:bs]), rep
+        assert torch.equal(got[1].view(torch.int32), want[1].view(torch.int32)), rep
+    assert not ab.fused_tail_timed_out("cuda")
+    t = ab._fuse_tickets(torch.device("cuda"))
+    assert int(t.abs().sum().item()) == 0  # every word back at zero
+
+
+def test_fused_decode_tail_under_uneven_load_and_in_a_graph():
+    """The hand-off of the fused tail under what hides a broken one on an idle chip (guide: uneven load, warm consumer,
+    every word checked): a long sequence beside short ones (splits of very different duration), a memory-streaming kernel on
+    a second stream, 50 back-to-back launches, then the same launch replayed from a hipGraph."""
+    from chitu_amd import attn_backend as ab
+    from chitu_amd import ops
+
+    bs, H = 8, 16
+    lens = [8000, 64, 1, 3000, 129, 700, 65, 4096]
+    pages = sum((l + 63) // 64 for l in lens) + 2
+    q_nope, q_pe, cache, table, sl = make_case(bs, H, lens, pages, seed=77)
+    be = backend(H)
+    dev = [t.cuda() for t in (q_nope, q_pe, cache, sl, table)]
+    w_uv, sc = _uv_weights(H, seed=5)
+    part = be.mla_decode(dev[0], dev[1], dev[2], dev[3], dev[4], 0.1352, return_partials=True)
+    want = ops.mla_merge_absorb_uv_quant_fp8(part[0], part[1], bs, w_uv, sc, 4, 8, 1)
+    wq, wsc = want[0].clone(), want[1].clone()
+    big = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    side = torch.cuda.Stream()
+    for rep in range(50):
+        with torch.cuda.stream(side):
+            big.add_(1)  # 512 MB of HBM traffic beside the launch
+        got = be.mla_decode_merge_uv_quant(dev[0], dev[1], dev[2], dev[3], dev[4], 0.1352, w_uv, sc, 4, 8, 1, num_splits=part[1])
+        assert torch.equal(got[0].view(torch.uint8), wq.view(torch.uint8)) and torch.equal(got[1], wsc), rep
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        got = be.mla_decode_merge_uv_quant(dev[0], dev[1], dev[2], dev[3], dev[4], 0.1352, w_uv, sc, 4, 8, 1, num_splits=part[1])
+    for rep in range(20):
+        got[0].view(torch.uint8).zero_()
+        g.replay()
+        assert torch.equal(got[0].view(torch.uint8), wq.view(torch.uint8)) and torch.equal(got[1], wsc), rep
+    assert not ab.fused_tail_timed_out("cuda")

@@ -80,10 +80,15 @@ def test_vs_oracle(M, E, topk, K, I):
     out = run_hip(*args)
     x, w1, w2, w1s, w2s, ids, wts = args
     ref = omoe.fused_experts_fp8(x, w1, w2, wts, ids, w1s, w2s)
-    # peak bar for every element AND the element-wise bar (rtol 1e-2 + half the peak bar) for all but 5 in 10 000: the
-    # experts' intermediate h is re-quantised to fp8 between the two GEMMs, and where HIP's and the oracle's fp32 sums
-    # round h to different codes (one fp8 step = 6 %) the outputs fed by that element move by up to ~0.8 % of the peak
-    assert_close(out, ref, REL_TOL, what=f"fused_experts fp8 {M, E, topk, K, I}", outlier_frac=5e-4)
+    # peak bar for every element AND the element-wise bar (rtol 1e-2 + half the peak bar) for EVERY element -- except at the one
+    # shape where a census on the MI355X (tools/r06_moe_outliers.py, profiles/r06_moe_outlier_census.txt) finds any outside it:
+    # R1 at bs 16, 13 of 114 688 elements, each under 0.2 % of the peak beyond its bar.  Cause: the experts' intermediate h is
+    # re-quantised to fp8 between the two GEMMs, and where HIP's and the oracle's fp32 sums (different summation order over
+    # K = 7168) round an h value to neighbouring fp8 codes (one step = 6 %) the 7168 outputs fed by it move; the same HIP output
+    # against the reference's own kernels run on the MI355X needs no allowance at all
+    # (test_fp8_experts_against_the_reference_kernels_run_on_the_mi355x).  The count is asserted, not a fraction.
+    allowed = {(16, 32, 8, 7168, 256): 20}.get((M, E, topk, K, I), 0)
+    assert_close(out, ref, REL_TOL, what=f"fused_experts fp8 {M, E, topk, K, I}", outlier_frac=allowed / out.numel())
     assert ((out.float() - ref.float()).abs().mean() / ref.float().abs().mean()).item() < 5e-3
 
 
@@ -322,4 +327,32 @@ def test_bf16_experts_against_the_reference_kernels_run_on_the_mi355x(case):
     g = golden("hw_fused_moe_bf16")
     x, w1, w2, ids, wts = hc.fused_moe_bf16_case(case)
     out = fused_moe.fused_experts_impl(x.cuda(), w1.cuda(), w2.cuda(), wts.cuda(), ids.cuda(), inplace=False, use_fp8_w8a8=False)
+    assert_close(out, bf16(g[f"{case}_out"]), 5e-3, what=case)
+
+
+@pytest.mark.parametrize("case", ["r1_bs16", "small"])
+def test_soft_fp8_moe_branch_against_the_reference_kernels_run_on_the_mi355x(case):
+    """The README configuration's MoE branch off NVIDIA (infer.soft_fp8=True, model_deepseek_v3.py:975-996):
+    weight_dequant_soft_fp8_deepseek_v3 over the stacked experts, then fused_experts(use_fp8_w8a8=False), vs
+    tests/golden/hw_soft_fp8_moe.npz -- the reference's two soft-dequant Triton kernels (ops.py:396-449) + its bf16 fused MoE
+    compiled by Triton-ROCm and run on an MI355X on the same seeded inputs.  The dequantised tensor is bit-exact."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import hw_cases as hc
+    from chitu_amd import fused_moe, ops
+
+    g = golden("hw_soft_fp8_moe")
+    x, w1, w2, w1s, w2s, ids, wts = hc.soft_fp8_moe_case(case)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        w1d = ops.weight_dequant_soft_fp8_deepseek_v3(w1.cuda(), w1s.cuda(), 128)
+        w2d = ops.weight_dequant_soft_fp8_deepseek_v3(w2.cuda(), w2s.cuda(), 128)
+    finally:
+        torch.set_default_dtype(prev)
+    if case == "small":
+        assert np.array_equal(hc.bits16(w1d), g["small_w1_dequant"])
+    out = fused_moe.fused_experts(x.cuda(), w1d, w2d, wts.cuda(), ids.cuda(), inplace=False, use_fp8_w8a8=False)
     assert_close(out, bf16(g[f"{case}_out"]), 5e-3, what=case)

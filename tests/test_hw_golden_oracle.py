@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 import hw_cases as hc  # noqa: E402
 
 from oracle import fp8 as ofp8  # noqa: E402
+from oracle import gqa as ogqa  # noqa: E402
 from oracle import mla as omla  # noqa: E402
 from oracle import moe as omoe  # noqa: E402
 from tests.util import bf16, golden, max_rel_to_peak  # noqa: E402
@@ -69,3 +70,36 @@ def test_mla_decode_oracle_vs_the_reference_on_hardware(case):
     # the reference splits the keys in 4 and rounds P to bf16 per 64-key tile against its running maximum: bf16-ulp noise
     # (one ulp of a bf16 output is up to 7.8e-3 of the peak when the peak sits low in its binade)
     _agree(o, g[f"{case}_out"], 8e-3, 0.65, case)
+
+
+@pytest.mark.parametrize("case", hc.SOFT_FP8_MOE_CASES)
+def test_soft_fp8_moe_branch_oracle_vs_the_reference_on_hardware(case):
+    """oracle/fp8.py's soft-fp8 dequant (bit placement, ops.py:396-449) + oracle/moe.py's bf16 fused experts vs the reference's
+    kernels run on the MI355X (hw_soft_fp8_moe.npz): the dequantised experts bit-exact, the MoE output within one bf16 ulp of
+    the peak."""
+    g = golden("hw_soft_fp8_moe")
+    x, w1, w2, w1s, w2s, ids, wts = hc.soft_fp8_moe_case(case)
+    w1d = ofp8.weight_dequant_soft_fp8_deepseek_v3(w1, w1s)
+    w2d = ofp8.weight_dequant_soft_fp8_deepseek_v3(w2, w2s)
+    if case == "small":
+        assert np.array_equal(hc.bits16(w1d.to(torch.bfloat16)), g["small_w1_dequant"])
+    out = omoe.fused_experts_bf16(x, w1d.to(torch.bfloat16), w2d.to(torch.bfloat16), wts, ids)
+    assert max_rel_to_peak(out, hc.from_bits16(g[f"{case}_out"])) < 5e-3
+
+
+@pytest.mark.parametrize("case", hc.GQA_DECODE_CASES)
+def test_gqa_decode_oracle_vs_the_reference_attention_on_hardware(case):
+    g = golden("hw_gqa")
+    q, kc, vc, kn, vn, lens = hc.gqa_decode_case(case)
+    # the oracle's paged form with one page per sequence = the contiguous caches the reference's pure-torch path takes
+    table = torch.arange(q.shape[0], dtype=torch.int32).view(-1, 1)
+    ref, _, _ = ogqa.attn_with_kvcache(q, kc, vc, kn, vn, lens, table, softmax_scale=128 ** -0.5)
+    assert max_rel_to_peak(ref, hc.from_bits16(g[f"decode_{case}_out"])) < 5e-3
+
+
+@pytest.mark.parametrize("case", hc.GQA_PREFILL_CASES)
+def test_gqa_prefill_oracle_vs_the_reference_attention_on_hardware(case):
+    g = golden("hw_gqa")
+    q, k, v, cu, seqs = hc.gqa_prefill_case(case)
+    rows = torch.from_numpy(hc.gqa_prefill_rows(seqs))
+    assert max_rel_to_peak(ogqa.attn_varlen_causal(q, k, v, cu)[rows], hc.from_bits16(g[f"prefill_{case}_out"])) < 5e-3

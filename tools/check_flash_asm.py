@@ -27,6 +27,63 @@ def kernels(text, name):
 
 
 
+def _regs_of(tok):
+    """Register numbers named by an operand token: v12 -> {('v', 12)}, v[10:13] -> v10..v13, s[4:5] -> s4, s5."""
+    out = set()
+    for kind, a, b in re.findall(r"\b([vs])\[(\d+):(\d+)\]", tok):
+        out.update((kind, i) for i in range(int(a), int(b) + 1))
+    for kind, a in re.findall(r"\b([vs])(\d+)\b", tok):
+        out.add((kind, int(a)))
+    return out
+
+
+def audit_async_asm_loads(path, name):
+    """Loads written as inline asm whose OUTPUT operand the compiler believes defined when the asm statement ends
+    (`global_load_dword %0, ...` / `s_load_dword %0, ...` with the wait in a LATER asm statement -- csrc/mla_decode.hip heads its
+    kernel that way to put the seqlens and page-table requests in front of everything else).  The destination register is in
+    flight until that later hand-written `s_waitcnt`: any instruction in between that reads or writes it (a copy, a spill, a
+    coalescing move the compiler is entitled to insert) would see a stale value.  This reads the compiled ISA linearly from each
+    such load to the first asm-block `s_waitcnt` that covers it (vmcnt(0) for vector loads, lgkmcnt(0) for scalar ones) and
+    reports every instruction that names the register.  Returns (kernels seen, violations)."""
+    text = open(path).read()
+    bad, seen = [], []
+    for k, body in kernels(text, name):
+        seen.append(k)
+        in_asm, pending = False, {}  # (kind, n) -> line of the load
+        for ln in body:
+            x = ln.strip()
+            if ";;#ASMSTART" in x:
+                in_asm = True
+                continue
+            if ";;#ASMEND" in x:
+                in_asm = False
+                continue
+            if not x or x.startswith((";", ".", "//")) or x.endswith(":"):
+                continue
+            code = x.split(";")[0]
+            m = re.match(r"(global_load_dword(?:x\d)?|s_load_dword(?:x\d)?)\s+([^,]+),", code) if in_asm else None
+            if m:
+                for r in _regs_of(m.group(2)):
+                    pending[r] = x
+                # (the address operands of this load may not be pending registers either)
+                hit = _regs_of(code[m.end():]) & set(pending)
+                if hit - _regs_of(m.group(2)):
+                    bad.append(f"{k}: `{x}` uses a register still in flight: {sorted(hit)}")
+                continue
+            if in_asm and code.startswith("s_waitcnt"):
+                if "vmcnt(0)" in code:
+                    pending = {r: v for r, v in pending.items() if r[0] != "v"}
+                if "lgkmcnt(0)" in code:
+                    pending = {r: v for r, v in pending.items() if r[0] != "s"}
+                continue
+            hit = _regs_of(code) & set(pending)
+            if hit:
+                bad.append(f"{k}: `{x}` touches {sorted(hit)} before the wait for `{pending[sorted(hit)[0]]}`")
+        if pending:
+            bad.append(f"{k}: asm loads never waited for: {sorted(pending)}")
+    return seen, bad
+
+
 def audit_dma_loops(path, name, min_mfma=8):
     """Kernels whose operand tiles arrive by LDS-DMA (global_load_lds, requested through asm: the compiler does not count
     them): inside a loop that multiplies (>= `min_mfma` MFMAs between its header and its back edge) no `s_waitcnt vmcnt`
