@@ -8,7 +8,8 @@
 // projections were 54 % of a prefill layer, at ~1 % of the MFMA peak).  Here the op is tiled like a GEMM:
 //
 //   workgroup = 128 weight rows x 128 tokens, 4 waves as 2 x 2, each wave 64 x 64 = 4 x 4 MFMA tiles
-//   (v_mfma_f32_16x16x32_fp8_fp8, weights = A operand, tokens = B operand, as in the decode kernels);
+//   (round 6: ONE v_mfma_scale_f32_16x16x128_f8f6f4 per tile and K block with unit E8M0 scales -- gemm_common.h::mfma_fp8_k128 --
+//   where rounds 2-5 chained four v_mfma_f32_16x16x32_fp8_fp8; weights = A operand, tokens = B operand, as in the decode kernels);
 //   K advances in the quantisation's own 128-wide blocks: both operand tiles (16 KB each) go global -> LDS by LDS-DMA
 //   (global_load_lds_dwordx4, lds_dma.h: no staging registers, no ds_write pass -- rounds 2-4 staged through registers and
 //   the ds_write_b128 stream of two resident workgroups alone took ~830 LDS cycles per K block against 1024 MFMA cycles),
@@ -18,8 +19,12 @@
 //   fresh 4-MFMA dot that is folded in as (dot * a_s[token]) * b_s -- the reference's order (triton_kernels.py:357);
 //   b_s is one scalar per workgroup and block (128-row tiles are scale-block aligned), a_s one value per lane and
 //   token tile.
-// Bound: MFMA (this instruction runs at the bf16 rate, ~2.5 PFLOP/s dense); per block a wave issues 64 MFMAs against
-// 16 ds_read_b128 and ~130 VALU instructions of scale folding.
+// Bound: MFMA on paper (the K = 128 form runs at the fp8 rate, ~5 PFLOP/s dense: 16 MFMAs = 512 matrix-pipe cycles per wave and K
+// block, against 16 ds_read_b128 and ~90 VALU instructions of scale folding); measured 0.17-0.26 of that peak at 2048 tokens --
+// what the waves wait for is each other (one barrier per K block) and the next tile.  Two things were measured and NOT kept in
+// round 6 (profiles/r06_ab_fp8_mx_mfma.txt): 8 waves per workgroup with a four-stage ring (three K blocks in flight, one
+// workgroup per CU): 25-30 % SLOWER at every shape, as the 4-wave rings of round 5 were -- two independent workgroups per CU
+// drift out of phase and fill each other's barrier and request gaps, one workgroup of 8 waves moves in lockstep.
 #include "common.h"
 #include "gemm_common.h"
 #include "lds_dma.h"
@@ -105,7 +110,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             wa[t][0] = *reinterpret_cast<const i32x4*>(wr + foff);
             wa[t][1] = *reinterpret_cast<const i32x4*>(wr + (foff ^ 64));
         }
-        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16) * 128];
@@ -113,10 +117,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float sc = sS[buf][wm * 64 + mt * 16 + j];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][0]), frag_lo(xb0), z, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][0]), frag_hi(xb0), d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][1]), frag_lo(xb1), d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][1]), frag_hi(xb1), d, 0, 0, 0);
+                const f32x4 d = mfma_fp8_k128(wa[nt][0], wa[nt][1], xb0, xb1);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * ws_cur;
             }

@@ -84,6 +84,32 @@ __device__ __forceinline__ long frag_hi(const i32x4& v) {
     return (long)(((unsigned long long)(uint32_t)v[3] << 32) | (uint32_t)v[2]);
 }
 
+// One 16 x 16 dot over a whole 128-wide K block of the compute-shaped (prefill) GEMMs: lane (j, g) of each operand holds the two
+// 16-byte chunks g and g + 4 of its row.
+//   CHITU_FP8_MX = 1 (round 6): ONE v_mfma_scale_f32_16x16x128_f8f6f4 (both formats e4m3, both E8M0 scales 127 = 2^0: the
+//     DeepSeek block format's fp32 scales are applied on the fp32 result as before).  The instruction multiplies 128 k values per
+//     row pair where the non-scaled fp8 form multiplies 32, at twice the matrix pipe's rate per k (guide: 4.66 PF measured against
+//     2.05 PF) and a quarter of the issues; which 32 k values a lane carries is free as long as both operands agree (a dot product
+//     does not care), so the LDS fragments are the ones the four 16x16x32 instructions used.  fp32 accumulation inside the block
+//     as before; the order of the 128 products' summation inside the instruction differs from four chained 32-wide ones.
+//   CHITU_FP8_MX = 0: the four chained v_mfma_f32_16x16x32_fp8_fp8 of rounds 2-5 (A/B builds, tools/build_variant.sh).
+#ifndef CHITU_FP8_MX
+#define CHITU_FP8_MX 1
+#endif
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_fp8_k128(const i32x4& a0, const i32x4& a1, const i32x4& b0, const i32x4& b1) {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#if CHITU_FP8_MX
+    const i32x8 a = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), b = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, z, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#else
+    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(a0), frag_lo(b0), z, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(a0), frag_hi(b0), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(a1), frag_lo(b1), d, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(a1), frag_hi(b1), d, 0, 0, 0);
+#endif
+}
+
 // lane's weight pointer for K block 0: W + row*K + ((j&1)*4 + g)*16, rows clamped to n_rows-1
 __device__ __forceinline__ void w8_lane_ptrs(const fp8_t* Wbase, int n0, int n_rows, int K, int j, int g,
                                              const fp8_t*& p0, const fp8_t*& p1) {

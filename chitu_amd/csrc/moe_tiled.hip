@@ -275,7 +275,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             wa[1][0] = *reinterpret_cast<const i32x4*>(w1 + foff);
             wa[1][1] = *reinterpret_cast<const i32x4*>(w1 + (foff ^ 64));
         }
-        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const uint8_t* xr = &sX[buf][mt * 16 * 128];
@@ -283,10 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float sc = sS[buf][mt * 64 + j];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][0]), frag_lo(xb0), z, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][0]), frag_hi(xb0), d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_lo(wa[nt][1]), frag_lo(xb1), d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(frag_hi(wa[nt][1]), frag_hi(xb1), d, 0, 0, 0);
+                const f32x4 d = mfma_fp8_k128(wa[nt][0], wa[nt][1], xb0, xb1);
                 const float wsc = nt == 0 ? cur.ws0 : cur.ws1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * wsc;
