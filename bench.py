@@ -292,7 +292,10 @@ class DeviceStateSampler:
 # with identical sclk / mclk / fclk under load; the <= 32-workgroup launches and the W2 GEMM stretch on the slow ones).  Three
 # probes of the box itself, run in this process right after the timed loops, and a two-term model that maps the step time to
 # what the reference box of these constants would have measured.
-CAL_REF = {"copy_GBs": 2550.0, "chain_us": 2.45}  # a "fast" box of rounds 4-5 (profiles/r05_box_calibration.txt)
+CAL_REF = {"copy_GBs": 2550.0, "chain_us": 2.45,  # a "fast" box of rounds 4-5 (profiles/r05_box_calibration.txt)
+           # tail_launch_probe on a fast box of round 6 (step 9.72 / 4.37 / 13.83 ms; profiles/r06_bench_default_fast_box.json)
+           "tail_launch_us": {"chitu_hip_mla_q_proj": 7.34, "chitu_hip_gate_route_align": 8.32, "chitu_hip_rmsnorm": 4.46,
+                              "chitu_hip_absorb_bmm_rope_fp8": 3.63, "chitu_hip_mla_merge_absorb_uv_quant_fp8_tm": 6.73}}
 CAL_WEIGHTS = {"bandwidth": 0.55, "latency": 0.45}  # share of the bs-16 step's kernel time in HBM-bound launches (expert GEMMs,
 # dense GEMMs, logits) / in the latency-bound tail (profiles/r04_step_breakdown_bs16_final.txt: 5.45 ms / 4.43 ms)
 
@@ -388,6 +391,100 @@ def box_calibration(local_index, w2_launch_us=None):
     except Exception as exc:  # noqa: BLE001 -- diagnostics only
         out["rocm_smi_idle"] = f"unavailable: {type(exc).__name__}"
     return out
+
+
+TAIL_PROBE_ENTRIES = {  # C entry -> (kernel the step breakdown lists it as, which of a step's calls of that entry to keep)
+    "chitu_hip_mla_q_proj": "mla_q_proj_kernel<1> (q_norm + wq_b GEMM + this step's KV rows)",
+    "chitu_hip_gate_route_align": "gate_route_align_wg_kernel<32> (routing + moe_align in one workgroup)",
+    "chitu_hip_rmsnorm": "rmsnorm_add_kernel (attn_norm / ffn_norm with the deferred top-k sum, residual add, act_quant)",
+    "chitu_hip_absorb_bmm_rope_fp8": "absorb_bmm_kernel (W_UK absorb + RoPE of q_pe)",
+    "chitu_hip_mla_merge_absorb_uv_quant_fp8_tm": "mla_merge_uv_quant_kernel (split merge + W_UV + act_quant)",
+}
+
+
+@torch.inference_mode()
+def tail_launch_probe(model, cache, bs, ctx, iters=5):
+    """the launches of the latency-bound tail that stretch on a slow box (mla_q_proj, route + align,
+    the norm launches; round 5 saw 7.6 -> 9.9 us and 8.9 -> 9.8 us between boxes) timed IN THIS LINE, the way `roofline` times
+    the expert GEMM: one eager decode step is recorded at the C ABI (chitu_amd._lib.call_log_ctypes: entry + argument objects),
+    every recorded launch of an entry is issued again -- same pointers, one per layer, each on its own layer's weights -- back to
+    back inside one hipGraph, HIP events around the replays; us per launch = replay / launches.  A chain of identical launches
+    has no producer in front of it, so these are lower bounds of the in-step durations (the kernel trace has those), but they
+    move with the box exactly as the in-step ones do."""
+    from chitu_amd import _lib
+
+    reqs = [f"tail{i}" for i in range(bs)]
+    for r in reqs:
+        cache.register_sequence(r, ctx)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    tokens = torch.randint(100, 1000, (bs,), device="cuda", generator=gen)
+    cache.prepare_cache_decode(reqs)
+    cache.prepare_block_table_for_decode(reqs)
+    model.decode(tokens, use_graph=False)  # warm
+    _lib.call_log_ctypes = []
+    try:
+        model.decode(tokens, use_graph=False)
+        torch.cuda.synchronize()
+        calls = _lib.call_log_ctypes
+    finally:
+        _lib.call_log_ctypes = None
+    out = {}
+    cdll = _lib.lib()
+    for entry, label in TAIL_PROBE_ENTRIES.items():
+        sel = [args for name, args in calls if name == entry]
+        if len(sel) < 8:
+            continue
+        fn = getattr(cdll, entry)
+
+        def issue_all():
+            st = _lib.stream_ptr()
+            for args in sel:
+                rc = fn(*args[:-1], st)
+                assert rc == 0, (entry, rc)
+
+        try:
+            issue_all()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                issue_all()
+            g.replay()
+            torch.cuda.synchronize()
+            ev = []
+            for _ in range(iters):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+                ev.append((e0, e1))
+            torch.cuda.synchronize()
+            us = sorted(a.elapsed_time(b) * 1e3 / len(sel) for a, b in ev)
+            out[entry] = {"kernel": label, "launches_in_graph": len(sel), "us_per_launch": round(us[len(us) // 2], 3),
+                          "us_per_launch_min": round(us[0], 3)}
+            del g
+        except Exception as exc:  # noqa: BLE001 -- a diagnostic leg of the report
+            out[entry] = {"kernel": label, "error": f"{type(exc).__name__}: {exc}"[:200]}
+    for r in reqs:
+        cache.finalize_cache_all_decode(r)
+    return out
+
+
+def static_device_facts(local_index):
+    """Facts that do not change while the box lives, logged once: memory vendor, partition modes, voltage,
+    xGMI error counters -- whatever rocm-smi on the box answers; missing tools or fields are recorded as such, never guessed."""
+    import subprocess
+
+    facts = {}
+    for key, flags in {"unique_id": ["--showuniqueid"], "serial": ["--showserial"], "mem_vendor": ["--showmemvendor"], "partition": ["--showcomputepartition", "--showmemorypartition"],
+                       "voltage": ["--showvoltage"], "xgmi_err": ["--showxgmierr"], "vbios": ["--showvbios"],
+                       "power_cap": ["--showmaxpower"]}.items():
+        try:
+            res = subprocess.run(["rocm-smi", "-d", str(local_index)] + flags, capture_output=True, text=True, timeout=10)
+            lines = [ln.strip() for ln in res.stdout.splitlines() if ln.strip().startswith("GPU[")]
+            facts[key] = lines[:6] if lines else f"no answer (rc {res.returncode})"
+        except Exception as exc:  # noqa: BLE001
+            facts[key] = f"unavailable: {type(exc).__name__}"
+    return facts
 
 
 def barrier_sync(world):
@@ -1222,6 +1319,13 @@ def main():
 
         if tp.xgmi_comm() is not None:
             coll["xgmi_error_word"] = tp.xgmi_comm().status()
+        # the transport decision of enable_xgmi() on rank 0, the stage it reached, why it fell back if it did, and its
+        # pre-flight: per-transport us at bs 1 / 16 / 32 measured eagerly BEFORE the first capture
+        coll["xgmi_enable"] = dict(tp.xgmi_report) if os.environ.get("CHITU_ALLREDUCE", "xgmi") != "rccl" else {
+            "enabled": False, "stage": "not attempted", "reason": "CHITU_ALLREDUCE=rccl"}
+        coll["graph_form"] = ("one hipGraph per step with the collectives inside" if transport.startswith("xgmi") and not tp.xgmi_split_phase()
+                              else "eager launches (split-phase collectives carry a host barrier)" if tp.xgmi_split_phase()
+                              else "piecewise graph replay around the library's collectives (graphs.py)")
     else:
         coll = {"collectives_in_step": 0, "transport": transport,
                 "note": "one rank of eight: the 124 collectives of the TP=8 step are not paid here"}
@@ -1242,6 +1346,15 @@ def main():
             if "gemm2" in str(k.get("kernel", "")):
                 w2_us = k.get("avg_launch_us")
         calib = box_calibration(local if not dinfo["shared_device"] else 0, w2_us)
+        try:
+            calib["tail_launch_us"] = tail_launch_probe(model, cache, a.bs, a.ctx)
+            # fast-box reference values of the same probe (profiles/r06_bench_default_*.json); > 1.10 x = the slow-box signature
+            ref = CAL_REF.get("tail_launch_us", {})
+            calib["tail_launch_vs_reference_box"] = {k: round(v["us_per_launch"] / ref[k], 3) for k, v in calib["tail_launch_us"].items()
+                                                     if k in ref and "us_per_launch" in v}
+        except Exception as exc:  # noqa: BLE001 -- diagnostics only
+            calib["tail_launch_us"] = f"unavailable: {type(exc).__name__}: {exc}"[:200]
+        calib["static_device_facts"] = static_device_facts(local if not dinfo["shared_device"] else 0)
     if world > 1:
         dist.barrier()
     distinct = (roof["distinct_experts"] - 1) if roof else min(256, a.bs * 8)  # routed only; shared counted in the formula

@@ -41,6 +41,10 @@ def build(verbose: bool = False) -> str:
 # Diagnostics (tests, chitu_amd.graphs.capture_verified in its diagnostic mode): while this is a list, every C-ABI call
 # is appended to it as (entry name, (argument values ...)) -- device pointers, sizes, the stream -- before it is made.
 call_log = None
+# The same with the ctypes argument objects kept as they were passed, so that a recorded launch can be issued again (bench.py's
+# per-kernel probes replay one step's launches of a kernel back to back in a hipGraph; the stream argument -- always the last --
+# is replaced by the replaying stream).
+call_log_ctypes = None
 
 
 class _Recorder:
@@ -53,6 +57,8 @@ class _Recorder:
         def recorded(*args):
             if call_log is not None:
                 call_log.append((name, tuple(getattr(a, "value", a) for a in args)))
+            if call_log_ctypes is not None:
+                call_log_ctypes.append((name, args))
             return fn(*args)
 
         return recorded
@@ -67,7 +73,7 @@ def lib() -> ctypes.CDLL:
                 "(or `make -C chitu_amd/csrc`). There is no CPU fallback."
             )
         _lib = ctypes.CDLL(LIB_PATH)
-    return _lib if call_log is None else _Recorder(_lib)
+    return _lib if call_log is None and call_log_ctypes is None else _Recorder(_lib)
 
 
 def ptr(t):

@@ -77,6 +77,10 @@ _graph_break = None
 
 # XgmiComm of this rank when the hand-written collectives (csrc/comm.hip) carry the decode step, else None.
 _xgmi = None
+# What the last enable_xgmi() call decided on this rank and why, and what its pre-flight measured (bench.py copies it into the
+# N > 1 line: the first run on real links reports its transport decision and per-transport times even if it then falls back).
+xgmi_report = {"enabled": False, "reason": "enable_xgmi was not called"}
+PREFLIGHT_BATCHES = (1, 16, 32)
 
 
 def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, timeout_ms: int = 20000,
@@ -88,10 +92,13 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
     locally, the ranks agree on the stage's verdict (MIN over the group), and only a unanimous success moves on --
     so a failure on some ranks (IPC refused on one GPU, a mismatch on one rank) can never leave the others inside a
     collective nobody else enters.  On any failure the library path stays in place on EVERY rank and False is returned."""
-    global _xgmi
+    global _xgmi, xgmi_report
     if get_tp_size() <= 1 or not torch.cuda.is_available():
+        xgmi_report = {"enabled": False, "stage": "none", "reason": "one rank or no device: nothing to enable"}
         return False
     from .xgmi import XgmiComm
+
+    stage = ["create + map (IPC handles)"]
 
     group, rank, world = get_tp_group(), get_tp_rank(), get_tp_size()
     lib_dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"  # the library's answer is computed where its backend works
@@ -102,6 +109,9 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
         return int(verdict.item()) == 1
 
     def give_up(comm, why):
+        global xgmi_report
+        xgmi_report = {"enabled": False, "stage": stage[0], "reason": why or "a peer rank failed this stage (its own line says why)",
+                       "fallback": "library collectives (RCCL / gloo) between pieces of the step's graph (graphs.py)"}
         if why:
             print(f"[chitu_amd] rank {rank}: xGMI collectives not enabled ({why}); using the library path", flush=True)
         if comm is not None:
@@ -119,9 +129,11 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
         # every collective as contribute -> host barrier over the group -> complete: no kernel waits for a peer (rank
         # processes time-sliced on ONE GPU: tools/xgmi_world8.py, tests/test_gpu_xgmi.py); eager launches only
         comm.split_phase_group = group
+    two_shot_note = "not tested (selftest off)"
     if selftest:
         gen = torch.Generator(device="cuda").manual_seed(1234 + rank)
         dim = min(max_dim, 1024)
+        stage[0] = "one-shot all-reduce self-test"
         for rows in (1, min(max_rows, 5)):  # stage 3: the library's collective is entered by every rank, unconditionally
             part = torch.randn(rows, dim, device="cuda", generator=gen).to(torch.bfloat16)
             want = part.float().to(lib_dev)
@@ -138,6 +150,8 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
         # stage 3b: the two-shot form (reduce-scatter + all-gather inside the launch, the form of >= 256 KB messages) on the
         # same check, twice (both data-slot parities).  A timeout leaves the sticky error word set: give up as above.  A
         # group on which only its VALUES are wrong keeps the xGMI collectives in the one-shot form for every size.
+        stage[0] = "two-shot all-reduce self-test"
+        two_shot_note = "not applicable (dim / 8 not divisible by the world size)"
         if (dim // 8) % world == 0:
             default_threshold, values_ok = comm.two_shot_bytes, True
             comm.set_two_shot(0)
@@ -157,8 +171,11 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
                     return give_up(comm, why)
                 values_ok = unanimous(same) and values_ok
             comm.set_two_shot(default_threshold if values_ok else 1 << 62)
+            two_shot_note = (f"in use from {default_threshold} bytes per rank" if values_ok
+                             else "values mismatched in the self-test: one-shot form kept for every size")
             if not values_ok:
                 print(f"[chitu_amd] rank {rank}: two-shot all-reduce self-test mismatch; keeping the one-shot form for every size", flush=True)
+        stage[0] = "all-gather self-test"
         if gather_bytes >= 2 * 32 * 2:  # stage 4
             y = torch.randn(2, 32, device="cuda", generator=gen).to(torch.bfloat16)
             ref = [torch.empty(2, 32, dtype=torch.float32, device=lib_dev) for _ in range(world)]
@@ -173,7 +190,63 @@ def enable_xgmi(max_rows: int = 64, max_dim: int = 8192, gather_bytes: int = 0, 
             if not unanimous(ok):
                 return give_up(comm, why)
     _xgmi = comm
+    xgmi_report = {"enabled": True, "stage": "all stages passed" if selftest else "created (self-test skipped)", "reason": "",
+                   "two_shot": two_shot_note, "world": world,
+                   "mode": "split-phase (host barrier inside every collective: rank processes sharing one GPU)"
+                           if comm.split_phase_group is not None else "in-graph (kernels wait for their peers)"}
+    if selftest and os.environ.get("CHITU_XGMI_PREFLIGHT", "1") != "0":
+        # stage 5, never a reason to fall back: per-transport times at the bench's batch sizes, BEFORE anything is captured --
+        # the first run on real links yields the threshold data even if a later capture is rejected.  Collective: every rank runs it.
+        try:
+            xgmi_report["preflight_us"] = _preflight_times(comm, group, min(max_dim, 7168), gather_bytes)
+        except Exception as e:  # noqa: BLE001 -- a report, not a gate (a timeout here shows up in check_comm() like any other)
+            xgmi_report["preflight_us"] = f"failed: {e!r}"[:200]
     return True
+
+
+def _preflight_times(comm, group, dim, gather_bytes, iters=10):
+    """Eager us per call (HIP events over `iters` calls, after 2 warm-up calls; every rank issues the same sequence) of the
+    all-reduce in its one-shot and two-shot form and of the logits-sized all-gather, at PREFLIGHT_BATCHES rows of `dim`."""
+    out = {}
+    default = comm.two_shot_bytes
+    gen = torch.Generator(device="cuda").manual_seed(77)
+
+    def eager_us(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier(group=group)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(e0.elapsed_time(e1) * 1e3 / iters, 2)
+
+    try:
+        for b in PREFLIGHT_BATCHES:
+            if not comm.fits(b, dim):
+                continue
+            part = torch.randn(b, dim, device="cuda", generator=gen).to(torch.bfloat16)
+            row = {"message_KB_per_rank": round(b * dim * 2 / 1024, 1)}
+            comm.set_two_shot(1 << 60)
+            row["one_shot_us"] = eager_us(lambda: comm.allreduce_rmsnorm(part))
+            if (dim // 8) % comm.world == 0 and default < (1 << 61):
+                comm.set_two_shot(0)
+                row["two_shot_us"] = eager_us(lambda: comm.allreduce_rmsnorm(part))
+            comm.set_two_shot(default)
+            row["form_in_step"] = "two-shot" if comm.uses_two_shot(b, dim) else "one-shot"
+            cols = gather_bytes // (2 * max(PREFLIGHT_BATCHES)) if gather_bytes else 0
+            if cols >= 32 and comm.gather_fits(b, cols):
+                y = torch.randn(b, cols, device="cuda", generator=gen).to(torch.bfloat16)
+                row["all_gather_us"] = eager_us(lambda: comm.all_gather_last_dim(y))
+                row["all_gather_cols_per_rank"] = cols
+            out[f"bs{b}"] = row
+    finally:
+        comm.set_two_shot(default)
+    out["status_after"] = int(comm.status())
+    return out
 
 
 class CollectiveTimeout(RuntimeError):

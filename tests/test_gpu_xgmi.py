@@ -406,8 +406,19 @@ def _collectives_worker(rank, world):
 
     from chitu_amd import tensor_parallel as tp
 
-    assert tp.enable_xgmi(max_rows=32, max_dim=8192, gather_bytes=16 * 16160 * 2, timeout_ms=8000), "xGMI setup / self-test failed"
+    assert tp.xgmi_report["enabled"] is False  # before the call: says so
+    assert tp.enable_xgmi(max_rows=32, max_dim=8192, gather_bytes=32 * 16160 * 2, timeout_ms=8000), "xGMI setup / self-test failed"
     comm = tp.xgmi_comm()
+    # the transport decision and its pre-flight (bench.py copies this object into the N > 1 line): all stages passed, the
+    # three transports timed eagerly at the bench's batch sizes before anything was captured, no timeout left behind
+    rep = tp.xgmi_report
+    assert rep["enabled"] and rep["stage"] == "all stages passed" and rep["world"] == world and "two_shot" in rep, rep
+    pre = rep["preflight_us"]
+    assert isinstance(pre, dict) and pre["status_after"] == 0, pre
+    for b in tp.PREFLIGHT_BATCHES:
+        row = pre[f"bs{b}"]
+        assert row["one_shot_us"] > 0 and row["two_shot_us"] > 0 and row["all_gather_us"] > 0, row
+        assert row["form_in_step"] in ("one-shot", "two-shot")
     for salt in range(4):
         # salts 2, 3: every all-reduce in its two-shot form (both hops between real processes); set on every rank
         comm.set_two_shot(0 if salt >= 2 else 256 << 10)

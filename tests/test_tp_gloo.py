@@ -98,6 +98,11 @@ def _tp_layers(rank, world):
     # library path failed on the permuted view a plain .to() keeps)
     g64 = tp.all_gather_last_dim(y, out_dtype=torch.float64)
     assert g64.dtype == torch.float64 and g64.is_contiguous() and torch.equal(g64, gth.double())
+    # the transport decision is an object a bench line can carry: on a host without a GPU the in-graph collectives are not
+    # enabled, every rank says so with the stage and the reason, and the library path stays in place
+    assert tp.xgmi_report["enabled"] is False
+    assert tp.enable_xgmi() is False and tp.xgmi_comm() is None
+    assert tp.xgmi_report["enabled"] is False and tp.xgmi_report["stage"] == "none" and tp.xgmi_report["reason"]
 
 
 def test_tp_layers_world2():
