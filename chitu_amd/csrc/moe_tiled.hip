@@ -21,11 +21,13 @@
 
 namespace chitu {
 
-constexpr int kMoeTileM = 64;  // slots per tile = the moe_align block size of this path
-// (128-slot tiles -- one block for nearly every expert of a 2048-token prompt, so no expert's weights are streamed twice: 1.06 GB
-// fetched per GEMM1 launch instead of 1.41-1.72 -- were built and measured in round 5: slower, 374-394 us against 342-346;
-// the launch is not traffic-bound at these sizes but issue-bound, and the padded half of a 128-slot tile doubles its MFMAs
-// and scale folds.  profiles/r05_ab_moe_tiled.txt)
+// Slots per tile = the moe_align block size of this path: a template parameter TM, 64 or 128 (the launcher is told which).
+//   64 (rounds 2-5): a 2048-token prompt puts ~72 slots on every expert of a 257-expert layer, i.e. two 64-slot blocks on most of
+//   them, and the second block streams the expert's weights again -- 1.41 GB fetched per GEMM1 launch against 1.08 GB algorithmic.
+//   128 (round 6): one block for nearly every expert, its weights streamed once; the block's all-padding 16-slot sub-tiles are
+//   SKIPPED (wave-uniform count of the sub-tiles that hold a token), so the padded half costs loads of a repeated row and no MFMA /
+//   scale fold -- round 5 built 128-slot tiles without the skip (and under a compiler-placed wait in the K loop) and measured
+//   them slower; two stages instead of three keep two workgroups on a CU (66 KB each).  profiles/r05_ab_moe_tiled.txt, r06_ab_moe_tiled128.txt
 // Both tiles of a K block arrive by LDS-DMA (lds_dma.h): unpadded [rows][128 B] with the 16-byte chunks XOR-permuted on the
 // source side -- no staging registers, no ds_write pass, conflict-free fragment reads.
 
@@ -39,7 +41,7 @@ __device__ __forceinline__ float moe_tiled_routed_weight(const void* topk_w, int
 #define CHITU_MOE_TILED_NREP 4  // 1: a workgroup per tile always (A/B builds, tools/build_variant.sh)
 #endif
 
-constexpr int kMoeRing = 3;
+constexpr int moe_ring_of(int tm) { return tm == 128 ? 2 : 3; }  // stages of (W tile + X tile + scales): 25 KB each at 64 slots, 33 KB at 128
 struct MoeTileScales {  // the weight tile's block scales of a K block (workgroup-uniform: scalar loads)
     float ws0, ws1;
 };
@@ -52,7 +54,7 @@ struct MoeTileScales {  // the weight tile's block scales of a K block (workgrou
 // one sequence of steps, the next step's operands are in flight while this one is multiplied, a tile's C is stored when its
 // last K block is done.  With K = 256 (two K blocks, R1 at TP=8) a workgroup per tile is all prologue and epilogue: its
 // dependent chain (padded count -> expert id -> slot ids -> rows -> LDS -> MFMA -> store) is paid once per NREP tiles.
-template <bool SILU, int NREP = 1>
+template <bool SILU, int NREP = 1, int TM = 64>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void moe_gemm_tiled_kernel(
     const fp8_t* __restrict__ Xq, const float* __restrict__ Xs, const fp8_t* __restrict__ W, const float* __restrict__ Ws,
     const int32_t* __restrict__ sorted_ids, const int32_t* __restrict__ expert_ids,
@@ -63,9 +65,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // no compiler wait any more: within noise -- at 2048 tokens these launches are HBM-bound, profiles/r05_ab_moe_tiled.txt.
     // Also measured and not kept: the XCD sequence in groups of four m-blocks, n-tile by n-tile, so that the blocks of one
     // expert stream the same weight rows back to back: 275 vs 270-274 us.)
+    constexpr int kMoeTileM = TM, kMoeRing = moe_ring_of(TM);
+    static_assert(TM == 64 || TM == 128, "slot tiles of 64 or 128");
     __shared__ __attribute__((aligned(16))) uint8_t sW[kMoeRing][128 * 128];
     __shared__ __attribute__((aligned(16))) uint8_t sX[kMoeRing][kMoeTileM * 128];
-    __shared__ __attribute__((aligned(16))) float sS[kMoeRing][4 * 64];  // the K block's activation scales: wave w's piece = slots 16 w ..
+    __shared__ __attribute__((aligned(16))) float sS[kMoeRing][4 * 64];  // the K block's activation scales: wave w's piece = slots (TM / 4) w ..
     // GEMM1 form: a 1-D grid walked XCD-aware.  Workgroup L of every run of 8 * n_tiles goes to XCD L % 8 (round-robin
     // dispatch); XCD x is given the CONTIGUOUS m-blocks [x C, x C + C) (C = an eighth of the padded blocks), one per run, all
     // n-tiles of it inside the run: the n-tiles of one m-block -- they stage the same gathered activation rows, 459 KB per 64
@@ -101,6 +105,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int slot[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) slot[mt] = sorted_ids[mb * kMoeTileM + mt * 16 + j];
+    // 16-slot sub-tiles that hold a token (real slots come first in a block): the others are neither multiplied nor stored
+    int mt_valid = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        if (__builtin_amdgcn_ballot_w64(slot[mt] < numel) != 0) mt_valid = mt + 1;
     if (e < 0) {  // another rank's expert (expert parallelism): its slots are zero-filled, fused_moe.py:40-59
         const int cols = SILU ? 64 : 128 * NREP, ldo = SILU ? I : Nw;
         for (int idx = tid; idx < kMoeTileM * (cols / 8); idx += 256) {
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // lanes 0-15; the other lanes repeat them into the piece's unused part -- the same number of pieces for every wave keeps
     // the counted wait below one constant).  As plain loads one step ahead they put a vmcnt(0) of the compiler's into the
     // MFMA stream (fp8_gemm_tiled.hip).
-    const uint32_t soff = (uint32_t)((min(sorted_ids[mb * kMoeTileM + wave * 16 + (lane & 15)], numel - 1) / row_div) * KB * 4);
+    const uint32_t soff = (uint32_t)((min(sorted_ids[mb * kMoeTileM + wave * (TM / 4) + (lane & (TM / 4 - 1))], numel - 1) / row_div) * KB * 4);
     const float* wsb = Ws + (size_t)e * ((Nw + 127) >> 7) * KB;
     const float* wsp0 = wsb + (size_t)(n0 >> 7) * KB;
     const float* wsp1 = SILU ? wsb + (size_t)((I + n0) >> 7) * KB : wsp0;
@@ -254,17 +263,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(rw[mt]), "v"(slot[mt]));
     asm volatile("" ::"v"(soff));
     issue_next();
-    if (steps > 1) issue_next();
+    if (kMoeRing == 3 && steps > 1) issue_next();
     fetch_scales(cur, 0, 0);
     int rep = 0, kb = 0, buf = 0;
     for (int t = 0; t < steps; ++t) {
         int nkb = kb + 1, nrep = rep;
         if (nkb == KB) nkb = 0, nrep = rep + 1;
         // stage t has landed (this wave's pieces; stage t + 1, requested a step ago, may still be in flight) ...
-        if (t + 1 < steps) glds_wait_leaving<kPieces>();
+        if (kMoeRing == 3 && t + 1 < steps) glds_wait_leaving<kPieces>();
         else glds_wait_all();
         __syncthreads();  // ... and everyone's; everyone is done with stage t - 1, whose buffer the request below overwrites
-        if (t + 2 < steps) issue_next();
+        if (t + kMoeRing - 1 < steps) issue_next();
         if (t + 1 < steps) fetch_scales(nxt, nkb, nrep);
         i32x4 wa[2][2];
         {
@@ -277,9 +286,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
+            if (TM > 64 && mt >= mt_valid) continue;  // (wave-uniform) a sub-tile of padding only
             const uint8_t* xr = &sX[buf][mt * 16 * 128];
             const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr + foff), xb1 = *reinterpret_cast<const i32x4*>(xr + (foff ^ 64));
-            const float sc = sS[buf][mt * 64 + j];
+            // wave w's scale piece holds slots (TM / 4) w ..: sub-tile mt's 16 values sit in piece mt / (TM / 64) at (mt % (TM / 64)) * 16
+            const float sc = sS[buf][(mt / (TM / 64)) * 64 + (mt % (TM / 64)) * 16 + j];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const f32x4 d = mfma_fp8_k128(wa[nt][0], wa[nt][1], xb0, xb1);
@@ -307,18 +318,23 @@ extern "C" int chitu_hip_moe_gemm1_silu_fp8_tiled(const void* a_fp8, const float
                                                   const float* w1_scale, const int32_t* sorted_token_ids,
                                                   const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
                                                   void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size,
-                                                  int64_t K, int64_t max_mblocks, void* stream) {
+                                                  int64_t K, int64_t max_mblocks, int32_t block_m, void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(a_fp8 && a_scale && w1_fp8 && w1_scale && sorted_token_ids && expert_ids && num_tokens_post_pad && h_bf16);
     CHITU_REQUIRE(numel >= 0 && numel < (1ll << 31) && topk >= 1 && inter_size >= 1 && K >= 128 && max_mblocks >= 0);
     if (K % 128 != 0 || inter_size % 128 != 0 || inter_size >= (1 << 29) || K >= (1 << 30)) return CHITU_ERR_UNSUPPORTED;
     if (2 * inter_size * K >= (1ll << 31) || (numel / topk + 1) * K >= (1ll << 31)) return CHITU_ERR_UNSUPPORTED;  // 32-bit tile offsets
+    if (block_m != 64 && block_m != 128) return CHITU_ERR_UNSUPPORTED;  // the moe_align block size the ids were sorted with
     if (numel == 0 || max_mblocks == 0) return CHITU_OK;
     CHITU_REQUIRE(max_mblocks <= 65535);
     const dim3 grid((unsigned)((inter_size / 64) * ((max_mblocks + 7) / 8 * 8)));  // (m-block, n-tile) pairs in XCD order, see the kernel
-    hipLaunchKernelGGL((moe_gemm_tiled_kernel<true, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const fp8_t*)a_fp8, a_scale,
-                       (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)h_bf16,
-                       (const void*)nullptr, 0, (int)numel, (int)topk, (int)(2 * inter_size), (int)K);
+#define LAUNCH1T(TMV)                                                                                                              \
+    hipLaunchKernelGGL((moe_gemm_tiled_kernel<true, 1, TMV>), grid, dim3(256), 0, (hipStream_t)stream, (const fp8_t*)a_fp8, a_scale, \
+                       (const fp8_t*)w1_fp8, w1_scale, sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)h_bf16,           \
+                       (const void*)nullptr, 0, (int)numel, (int)topk, (int)(2 * inter_size), (int)K)
+    if (block_m == 128) LAUNCH1T(128);
+    else LAUNCH1T(64);
+#undef LAUNCH1T
     CHITU_RETURN_LAUNCH_STATUS();
 }
 
@@ -327,17 +343,25 @@ extern "C" int chitu_hip_moe_gemm2_fp8_tiled(const void* h_fp8, const float* h_s
                                              const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
                                              const void* topk_weights, int weights_dtype, int32_t mul_routed_weight,
                                              void* out_bf16, int64_t numel, int64_t N, int64_t inter_size,
-                                             int64_t max_mblocks, void* stream) {
+                                             int64_t max_mblocks, int32_t block_m, void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(h_fp8 && h_scale && w2_fp8 && w2_scale && sorted_token_ids && expert_ids && num_tokens_post_pad && out_bf16);
     CHITU_REQUIRE(numel >= 0 && numel < (1ll << 31) && N >= 1 && inter_size >= 128 && max_mblocks >= 0);
     CHITU_REQUIRE(!mul_routed_weight || (topk_weights && weights_dtype >= 0 && weights_dtype <= 2));
     if (inter_size % 128 != 0 || N % 8 != 0 || N >= (1 << 30) || inter_size >= (1 << 30)) return CHITU_ERR_UNSUPPORTED;
     if (N * inter_size >= (1ll << 31) || (numel + 1) * inter_size >= (1ll << 31)) return CHITU_ERR_UNSUPPORTED;  // 32-bit tile offsets
+    if (block_m != 64 && block_m != 128) return CHITU_ERR_UNSUPPORTED;  // the moe_align block size the ids were sorted with
     if (numel == 0 || max_mblocks == 0) return CHITU_OK;
     CHITU_REQUIRE(max_mblocks <= 65535);
     const int n_tiles = (int)((N + 127) / 128);
 #define LAUNCH2T(NREPV)                                                                                                  \
+    if (block_m == 128)                                                                                                  \
+    hipLaunchKernelGGL((moe_gemm_tiled_kernel<false, NREPV, 128>), dim3((unsigned)((n_tiles + NREPV - 1) / NREPV), (unsigned)max_mblocks), \
+                       dim3(256), 0, (hipStream_t)stream, (const fp8_t*)h_fp8, h_scale, (const fp8_t*)w2_fp8, w2_scale,         \
+                       sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)out_bf16,                                    \
+                       mul_routed_weight ? topk_weights : (const void*)nullptr, (int)weights_dtype, (int)numel, 1, (int)N,      \
+                       (int)inter_size);                                                                                        \
+    else                                                                                                                 \
     hipLaunchKernelGGL((moe_gemm_tiled_kernel<false, NREPV>), dim3((unsigned)((n_tiles + NREPV - 1) / NREPV), (unsigned)max_mblocks), \
                        dim3(256), 0, (hipStream_t)stream, (const fp8_t*)h_fp8, h_scale, (const fp8_t*)w2_fp8, w2_scale,         \
                        sorted_token_ids, expert_ids, num_tokens_post_pad, (bf16_t*)out_bf16,                                    \

@@ -147,7 +147,9 @@ _MOE_BLOCK_M = 16  # one MFMA tile of sorted slots (the reference's BLOCK_SIZE_M
 # neutral; 2048 tokens = 64: 2.03 -> 1.70 ms).
 _MOE_TILED_MIN_TOKENS = int(os.environ.get("CHITU_MOE_TILED_MIN_TOKENS", "128"))
 _MOE_TILED_MIN_PER_EXPERT = 24
-_MOE_TILED_BLOCK_M = 64
+# Slots per tile = moe_align block of the tiled path: 128 (round 6: one pass over an expert's weights for up to 128 slots, padding
+# sub-tiles skipped) or 64 (rounds 2-5, the reference's BLOCK_SIZE_M); same outputs, A/B in profiles/r06_ab_moe_tiled128.txt
+_MOE_TILED_BLOCK_M = int(os.environ.get("CHITU_MOE_TILED_BLOCK_M", "128"))
 
 
 class SiluAndMul(torch.nn.Module):
@@ -352,7 +354,7 @@ def fused_experts_impl(
         check(
             lib.chitu_hip_moe_gemm1_silu_fp8_tiled(
                 a1q_p, a1s_p, ptr(w1), ptr(w1_scale), sorted_p, experts_ptr, npost_p, P("c1"),
-                i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), st,
+                i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), i32(block_m), st,
             ),
             "moe gemm1 (tiled, silu fused)",
         )
@@ -365,7 +367,7 @@ def fused_experts_impl(
             lib.chitu_hip_moe_gemm2_fp8_tiled(
                 P("a2q"), P("a2s"), ptr(w2), ptr(w2_scale), sorted_p, experts_ptr, npost_p,
                 ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel), i64(Nout),
-                i64(I), i64(max_mblocks), st,
+                i64(I), i64(max_mblocks), i32(block_m), st,
             ),
             "moe gemm2 (tiled)",
         )

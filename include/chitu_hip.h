@@ -180,9 +180,10 @@ int chitu_hip_moe_gemm1_silu_fp8(const void* a_fp8, const float* a_scale, const 
                                  void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size, int64_t K,
                                  int64_t max_mblocks, void* stream);
 
-/* The same two grouped GEMMs tiled for PREFILL-sized batches (64 sorted slots x 128 weight rows per workgroup through
- * LDS, fused_moe.py:62-307 with its BLOCK_SIZE_M = 64): sorted_token_ids / expert_ids / num_tokens_post_pad must come from
- * chitu_hip_moe_align_block_size with block_size 64; max_mblocks <= 65535.
+/* The same two grouped GEMMs tiled for PREFILL-sized batches (block_m = 64 or 128 sorted slots x 128 weight rows per workgroup
+ * through LDS; fused_moe.py:62-307 runs BLOCK_SIZE_M = 64): sorted_token_ids / expert_ids / num_tokens_post_pad must come from
+ * chitu_hip_moe_align_block_size with block_size = block_m (128: one block, i.e. one pass over its weights, for an expert with
+ * up to 128 slots; all-padding 16-slot sub-tiles are skipped); max_mblocks <= 65535.  Same outputs for either block_m.
  *   gemm1_silu_tiled: h[slot, :] = bf16(bf16(silu(bf16(gate))) * bf16(up)) as bf16 [numel, I]; I % 128 == 0, K % 128 == 0.
  *   gemm2_tiled: out[slot, :] = bf16((h_fp8[slot] . W2[e]^T, block-scaled) * routed_weight[slot]); h quantised by the
  *   caller (chitu_hip_act_quant_fp8 mode 1); I % 128 == 0, N % 8 == 0.
@@ -191,13 +192,13 @@ int chitu_hip_moe_gemm1_silu_fp8_tiled(const void* a_fp8, const float* a_scale, 
                                        const float* w1_scale, const int32_t* sorted_token_ids,
                                        const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
                                        void* h_bf16, int64_t numel, int32_t topk, int64_t inter_size, int64_t K,
-                                       int64_t max_mblocks, void* stream);
+                                       int64_t max_mblocks, int32_t block_m, void* stream);
 int chitu_hip_moe_gemm2_fp8_tiled(const void* h_fp8, const float* h_scale, const void* w2_fp8,
                                   const float* w2_scale, const int32_t* sorted_token_ids,
                                   const int32_t* expert_ids, const int32_t* num_tokens_post_pad,
                                   const void* topk_weights, int weights_dtype, int32_t mul_routed_weight,
                                   void* out_bf16, int64_t numel, int64_t N, int64_t inter_size,
-                                  int64_t max_mblocks, void* stream);
+                                  int64_t max_mblocks, int32_t block_m, void* stream);
 int chitu_hip_moe_gemm2_quant_fp8(const void* h_bf16, const void* w2_fp8, const float* w2_scale,
                                   const int32_t* sorted_token_ids, const int32_t* expert_ids,
                                   const int32_t* num_tokens_post_pad, const void* topk_weights,
