@@ -64,6 +64,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the bf16 attention kernels are priced against it)
+EXTRA_BATCHES = tuple(int(b) for b in os.environ.get("CHITU_BENCH_EXTRA_BATCHES", "1,16").split(","))  # (profiling tools: one batch size alone)
 FP8_MFMA_PEAK_TFLOPS = 5000.0  # dense fp8 peak (MX-scaled K = 128 form, measured 4.65 PF): what the fp8 GEMMs are priced against
 PMC_FILE = "r05_pmc_step.json"  # tools/pmc_passes.sh + tools/pmc_report.py, stamped with git head + source digests
 
@@ -964,7 +965,7 @@ def llama3_8b_extra(steps, warmup, ctx):
     cache.paged_v_cache.normal_(0, 0.5)
     w_bytes = sum(p.numel() * 2 for n, p in model.named_parameters() if n != "embed_weight")
     out = {"model": "Llama-3-8B bf16 TP=1, paged KV (page 256), hipGraph, synthetic weights", "weight_GB": round(w_bytes / 1e9, 3)}
-    for bs in (1, 16):
+    for bs in EXTRA_BATCHES:
         dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"l{bs}_")
         kv = args.n_layers * bs * ctx * args.n_kv_heads * args.head_dim * 2 * 2
         out[f"bs{bs}"] = {"ms_per_step": round(dt / steps * 1e3, 4), "tok_s": round(bs * steps / dt, 1),
@@ -1041,7 +1042,7 @@ def v2_lite_extra(steps, warmup, ctx):
     attn_w = (H * 192 + 576) * d + H * 256 * args.kv_lora_rank + d * H * 128  # wq|wkv_a, wkv_b, wo (fp8: 1 B / weight)
     head_w = args.vocab_size * d * 2
     n_moe = args.n_layers - args.n_dense_layers
-    for bs in (1, 16):
+    for bs in EXTRA_BATCHES:
         dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"v{bs}_")
         # experts a step streams: the routed ones its own router picks (measured on an eager step) + both shared ones
         routing = capture_step_routing(model, cache, bs, ctx)
@@ -1187,7 +1188,7 @@ def ep8_rank_extra(steps, warmup, ctx, moe_rank=0):
     attn = (margs.q_lora_rank + margs.kv_lora_rank + margs.qk_rope_head_dim) * d \
         + (margs.n_heads * 192 // t) * margs.q_lora_rank + (margs.n_heads * 256 // t) * margs.kv_lora_rank + d * (margs.n_heads * 128 // t)
     n_moe = margs.n_layers - margs.n_dense_layers
-    for bs in (1, 16):
+    for bs in EXTRA_BATCHES:
         dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"e{bs}_")
         routing = capture_step_routing(model, cache, bs, ctx)
         # local routed experts a step streams (whole, 3 * 2048 * 7168 B each), measured on an eager step of this model
@@ -1225,7 +1226,7 @@ def mixtral_extra(steps, warmup, ctx):
     attn_w = ((args.n_heads + 2 * args.n_kv_heads) * args.head_dim * d + d * args.n_heads * args.head_dim) * 2  # bf16
     expert_w = 3 * args.ffn_dim * d  # int8: 1 B / weight
     head_w = args.vocab_size * d * 2
-    for bs in (1, 16):
+    for bs in EXTRA_BATCHES:
         dt = measure(model, cache, bs, ctx, steps, warmup, 1, True, f"x{bs}_")
         # experts a step streams: expected distinct ones under the synthetic router's near-uniform top-k (8 experts: a
         # batch of 16 hits all of them with probability 0.99 per expert)

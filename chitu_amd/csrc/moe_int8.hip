@@ -219,7 +219,11 @@ __global__ __launch_bounds__(64 * WK) void moe_i8_gemm2_kernel(
 }
 
 static int pick_wk(int64_t wgs, int KB) {
-    int WK = wgs <= 640 ? 8 : wgs <= 1536 ? 4 : wgs <= 3200 ? 2 : 1;
+    // K split over the waves of a workgroup.  Round 6 (same-box sweep on the Mixtral step, profiles/r06_mixtral_int8.txt): a one-wave
+    // workgroup per 16-row tile (the old choice above 3200 workgroups) streams at 5.0 TB/s, four waves per tile at 5.6-5.8 -- with K
+    // blocks to spare (Mixtral: 32 and 112) the split costs an LDS reduce and buys four loads in flight per tile: never below 4 there.
+    int WK = wgs <= 640 ? 8 : 4;
+    if (KB < 16) WK = wgs <= 640 ? 8 : wgs <= 1536 ? 4 : wgs <= 3200 ? 2 : 1;
     debug_override(kOptMoeI8WK, WK);
     while (WK > 1 && WK > KB) WK >>= 1;
     return WK;

@@ -248,9 +248,8 @@ def fused_experts_impl(
     if activation != "silu":
         raise ValueError(f"Unsupported FusedMoe activation: {activation}")
     if use_int8_w8a8:
-        assert aligned is None, "aligned= is wired for the fp8 path only"
         return _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts,
-                                   expert_map, w1_scale, w2_scale, reduce_topk)
+                                   expert_map, w1_scale, w2_scale, reduce_topk, aligned)
     if use_int8_w8a16 or use_int4_w4a16:
         raise NotImplementedError(
             "chitu_amd.fused_moe implements the modes the reference's DeepSeek MoE drives (bf16 experts, fp8_w8a8 "
@@ -422,7 +421,7 @@ def fused_experts_impl(
 
 
 def _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts, expert_map,
-                        w1_scale, w2_scale, reduce_topk):
+                        w1_scale, w2_scale, reduce_topk, aligned=None):
     """INT8 W8A8 experts (Mixtral + simple_w8a8, BASELINE config 4): per-token int8 activations, per-channel
     int8 weights.  w1 [E, 2I, K] int8, w1_scale [E, 2I]; w2 [E, N, I] int8, w2_scale [E, N].
     align(16) -> quant_act -> grouped GEMM1 (+ silu*mul) -> quant_act -> grouped GEMM2 (x routed weight) -> sum:
@@ -463,17 +462,25 @@ def _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, 
     P = lambda name: _ct.c_void_p(off[name])
     lib, st = _lib.lib(), stream_ptr()
     max_mblocks = min(nblk, numel)
-    emap = _expert_map_i32(expert_map, global_num_experts, hidden_states.device)
-    check(lib.chitu_hip_moe_align_block_size_mapped(ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel),
-                                                    i32(global_num_experts), i32(_MOE_BLOCK_M), P("sorted"), i64(cap),
-                                                    P("experts"), i64(nblk), P("npost"), P("cumsum"), i32(1), ptr(emap), st),
-          "moe_align_block_size")
+    if aligned is None:
+        emap = _expert_map_i32(expert_map, global_num_experts, hidden_states.device)
+        check(lib.chitu_hip_moe_align_block_size_mapped(ptr(topk_ids), int_dtype_code(topk_ids.dtype), i64(numel),
+                                                        i32(global_num_experts), i32(_MOE_BLOCK_M), P("sorted"), i64(cap),
+                                                        P("experts"), i64(nblk), P("npost"), P("cumsum"), i32(1), ptr(emap), st),
+              "moe_align_block_size")
+        sorted_p, experts_p, npost_p = P("sorted"), P("experts"), P("npost")
+    else:  # the router's launch already sorted the ids (ops.gate_deepseek_v3(align=...)): one launch less per layer
+        a_sorted, a_experts, a_npost = aligned
+        require_cuda(a_sorted, a_experts, a_npost)
+        assert a_sorted.dtype == torch.int32 and a_experts.dtype == torch.int32 and a_npost.dtype == torch.int32
+        assert a_sorted.numel() == cap and a_experts.numel() == nblk, "aligned buffers must come from block 16 over global_num_experts"
+        sorted_p, experts_p, npost_p = ptr(a_sorted), ptr(a_experts), ptr(a_npost)
     check(lib.chitu_hip_quant_act_int8(ptr(hidden_states), float_dtype_code(hidden_states.dtype), i64(num_tokens), i64(K),
                                        P("xq"), P("xs"), st), "moe int8 quant1")
-    check(lib.chitu_hip_moe_i8_gemm1_silu(P("xq"), P("xs"), ptr(w1), ptr(w1_scale), P("sorted"), P("experts"), P("npost"), P("a"),
+    check(lib.chitu_hip_moe_i8_gemm1_silu(P("xq"), P("xs"), ptr(w1), ptr(w1_scale), sorted_p, experts_p, npost_p, P("a"),
                                           i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), st), "moe int8 gemm1")
     check(lib.chitu_hip_quant_act_int8(P("a"), i32(0), i64(numel), i64(I), P("aq"), P("as"), st), "moe int8 quant2")
-    check(lib.chitu_hip_moe_i8_gemm2(P("aq"), P("as"), ptr(w2), ptr(w2_scale), P("sorted"), P("experts"), P("npost"),
+    check(lib.chitu_hip_moe_i8_gemm2(P("aq"), P("as"), ptr(w2), ptr(w2_scale), sorted_p, experts_p, npost_p,
                                      ptr(topk_weights), float_dtype_code(topk_weights.dtype), i32(1), P("c3"), i64(numel),
                                      i64(Nout), i64(I), i64(max_mblocks), st), "moe int8 gemm2")
     if not reduce_topk:

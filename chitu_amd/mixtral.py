@@ -14,7 +14,8 @@ import torch
 
 from . import fused_moe, ops
 from . import tensor_parallel as tp
-from .llama import LlamaAttention, LlamaDecoder, _param
+from .deepseek_v3 import _route_align_enabled
+from .llama import LlamaAttention, LlamaDecoder, _fuses_norm, _param
 
 
 @dataclass
@@ -51,9 +52,12 @@ class MixtralSparseMoe(torch.nn.Module):
         self.w2_scale = torch.nn.Parameter(torch.empty(self.E, args.dim, dtype=torch.float32, device=device), requires_grad=False)
 
     def forward(self, x):
-        weights, ids = ops.gate_deepseek_v3(x, self.gate, None, 1, 1, self.topk, "softmax_renorm", 1.0)
-        return fused_moe.fused_experts(x, self.w13, self.w2, weights, ids, inplace=True, use_int8_w8a8=True,
-                                       w1_scale=self.w13_scale, w2_scale=self.w2_scale)
+        # decode-sized batches: moe_align runs inside the routing launch (round 6; as the DeepSeek MoE does since round 1)
+        align = (self.E, fused_moe._MOE_BLOCK_M, None) if _route_align_enabled(x.shape[0]) else None
+        routed = ops.gate_deepseek_v3(x, self.gate, None, 1, 1, self.topk, "softmax_renorm", 1.0, align=align)
+        return fused_moe.fused_experts(x, self.w13, self.w2, routed[0], routed[1], inplace=True, use_int8_w8a8=True,
+                                       w1_scale=self.w13_scale, w2_scale=self.w2_scale, global_num_experts=self.E,
+                                       aligned=routed[2] if len(routed) > 2 else None)
 
 
 class MixtralBlock(torch.nn.Module):
@@ -66,11 +70,17 @@ class MixtralBlock(torch.nn.Module):
         self.eps = args.norm_eps
 
     def forward(self, x, pending, cos, sin, varlens=None):
-        x, hn = tp.add_norm(x, pending, self.attn_norm, self.eps)[:2]
-        if varlens is None:
-            a = tp.defer_all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+        if varlens is None and _fuses_norm(x, pending, self.attn.wqkv.shape[0]):
+            # small decode batches: residual add + attn_norm run as the prologue of the qkv projection (round 6: the Llama
+            # blocks' fusion, bit-identical, one launch less per layer)
+            x, a = self.attn.decode_from_residual(x, pending, self.attn_norm, self.eps, cos, sin)
+            a = tp.defer_all_reduce(a)
         else:
-            a = tp.defer_all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
+            x, hn = tp.add_norm(x, pending, self.attn_norm, self.eps)[:2]
+            if varlens is None:
+                a = tp.defer_all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
+            else:
+                a = tp.defer_all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
         x, hn = tp.add_norm(x, a, self.ffn_norm, self.eps)[:2]
         return x, tp.defer_all_reduce(self.ffn(hn))
 
