@@ -75,11 +75,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint32_t soff = (uint32_t)(min(m0 + 64 * (wave & 1) + lane, M - 1) * KB * 4);
     auto issue = [&](int kb) {
         const uint32_t dst = (uint32_t)((kb & 1) * kTileBytes + wave * 4096);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16_sbase(wbase + (size_t)kb * 128, woff[i], ldsW + dst + i * 1024);
-            glds16_sbase(xbase + (size_t)kb * 128, xoff[i], ldsX + dst + i * 1024);
-        }
+        glds16x4_sbase(wbase + (size_t)kb * 128, woff[0], woff[1], woff[2], woff[3], ldsW + dst);
+        glds16x4_sbase(xbase + (size_t)kb * 128, xoff[0], xoff[1], xoff[2], xoff[3], ldsX + dst);
         if (wave < 2) glds4_sbase(XS + kb, soff, ldsS + (uint32_t)((kb & 1) * (kTileM * 4) + wave * 256));
     };
     const float* wsp = WS + (size_t)(n0 >> 7) * KB;  // b_s: one scalar per workgroup and block (scalar loads)
@@ -118,8 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const f32x4 d = mfma_fp8_k128(wa[nt][0], wa[nt][1], xb0, xb1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * ws_cur;
+                fold_scaled(acc[nt][mt], d, sc, ws_cur);
             }
         }
         ws_cur = ws_nxt;

@@ -110,6 +110,14 @@ __device__ __forceinline__ f32x4 mfma_fp8_k128(const i32x4& a0, const i32x4& a1,
 #endif
 }
 
+// acc += (d * a_s) * b_s for the four results of a tile -- the reference's two roundings in its order (triton_kernels.py:357,
+// fused_moe.py:281) -- written on float2 halves so that it compiles to two v_pk_mul_f32 + two v_pk_fma_f32 (4 VALU issues per
+// MFMA instead of the 5-8 the compiler's own pairing left; the tiled GEMMs are instruction-issue-bound, rocprof round 6).
+__device__ __forceinline__ void fold_scaled(f32x4& acc, const f32x4& d, float a_s, float b_s) {
+    const f32x4 t = d * a_s;  // (its result is the fma's multiplicand: contraction cannot merge the two roundings)
+    acc = __builtin_elementwise_fma(t, f32x4{b_s, b_s, b_s, b_s}, acc);
+}
+
 // lane's weight pointer for K block 0: W + row*K + ((j&1)*4 + g)*16, rows clamped to n_rows-1
 __device__ __forceinline__ void w8_lane_ptrs(const fp8_t* Wbase, int n0, int n_rows, int K, int j, int g,
                                              const fp8_t*& p0, const fp8_t*& p1) {
