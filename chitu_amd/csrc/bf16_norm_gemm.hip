@@ -30,14 +30,15 @@ constexpr int kFusedNormMaxRows = 4;
 template <int WK, int MR>
 struct AddNormRegs {
     static constexpr int T = 64 * WK, NCH = kNormWideThreads / T;
-    i32x4 x[MR][NCH], a[MR][NCH], w[NCH];
+    i32x4 x[MR][NCH], a[MR][NCH], a2[MR][NCH], w[NCH];  // a2: the second residual term (round 6; loaded only when there is one)
 };
 
 // every load of the prologue, issued before the caller's first weight loads (loads return in order: the norm then
 // never waits for a weight tile)
 template <int WK, int MR>
 __device__ __forceinline__ void add_norm_issue(AddNormRegs<WK, MR>& r, const bf16_t* x, int64_t x_stride, const bf16_t* add,
-                                               int64_t add_stride, const bf16_t* __restrict__ nw, int M, int n_chunks) {
+                                               int64_t add_stride, const bf16_t* __restrict__ nw, int M, int n_chunks,
+                                               int64_t term2_off = 0) {
     constexpr int T = AddNormRegs<WK, MR>::T, NCH = AddNormRegs<WK, MR>::NCH;
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
@@ -47,6 +48,8 @@ __device__ __forceinline__ void add_norm_issue(AddNormRegs<WK, MR>& r, const bf1
             const int c = min((int)threadIdx.x + i * T, n_chunks - 1);
             r.x[m][i] = *reinterpret_cast<const i32x4*>(x + (int64_t)row * x_stride + c * 8);
             r.a[m][i] = *reinterpret_cast<const i32x4*>(add + (int64_t)row * add_stride + c * 8);
+            // two residual terms (the int8 / bf16 MoE's un-summed top-2 outputs, fused_experts(reduce_topk=False)): the second row
+            if (term2_off != 0) r.a2[m][i] = *reinterpret_cast<const i32x4*>(add + (int64_t)row * add_stride + term2_off + c * 8);
         }
     }
 #pragma unroll
@@ -71,7 +74,8 @@ struct NormOut {
 // nred: [kFusedNormMaxRows][16] floats.  Ends with a workgroup barrier: ybuf is readable.
 template <int WK, int MR, bool POUT = false>
 __device__ __forceinline__ void add_norm_finish(AddNormRegs<WK, MR>& r, bf16_t* sum_out, int64_t sum_stride, bool write_sum,
-                                                int M, int K, float eps, bf16_t* ybuf, float* nred, const NormOut* po = nullptr) {
+                                                int M, int K, float eps, bf16_t* ybuf, float* nred, const NormOut* po = nullptr,
+                                                bool two_terms = false) {
     constexpr int T = AddNormRegs<WK, MR>::T, NCH = AddNormRegs<WK, MR>::NCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_chunks = K >> 3;
@@ -84,6 +88,10 @@ __device__ __forceinline__ void add_norm_finish(AddNormRegs<WK, MR>& r, bf16_t* 
                 const bool act = vt < n_chunks;
                 float v[8];
                 i32x4 sraw;
+                if (two_terms) {  // (workgroup-uniform) add = bf16(float(t0) + float(t1)): chitu_hip_moe_sum's arithmetic for two terms
+                    const i32x4 both[2] = {r.a[m][i], r.a2[m][i]};
+                    r.a[m][i] = sum_terms_bf16x8<2>(both, 2);
+                }
                 add_bf16x8(r.x[m][i], r.a[m][i], v, sraw);
                 r.x[m][i] = sraw;
                 if (write_sum && act) *reinterpret_cast<i32x4*>(sum_out + (int64_t)m * sum_stride + vt * 8) = sraw;
@@ -180,7 +188,8 @@ template <int WK, int D, int MR, bool QKV = false, bool POUT = false>
 __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
     const bf16_t* x, int64_t x_stride, const bf16_t* add, int64_t add_stride, bf16_t* sum_out, int64_t sum_stride,
     const bf16_t* __restrict__ nw, float eps, const bf16_t* __restrict__ W, void* __restrict__ out, int out_dt, int M,
-    int N, int K, QkvPostArgs qa, NormOut po = NormOut{}, float* __restrict__ partial = nullptr, int S = 1) {
+    int N, int K, QkvPostArgs qa, NormOut po = NormOut{}, float* __restrict__ partial = nullptr, int S = 1,
+    int64_t term2_off = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
     __shared__ float red[WK > 1 ? WK * 256 : 1];
     __shared__ float nred[kFusedNormMaxRows * 16];
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
         if (head >= qa.hq) old_len = qa.old_lens[tok];
     }
     AddNormRegs<WK, MR> regs;
-    add_norm_issue<WK, MR>(regs, x, x_stride, add, add_stride, nw, M, K >> 3);
+    add_norm_issue<WK, MR>(regs, x, x_stride, add, add_stride, nw, M, K >> 3, term2_off);
     const int eoff = ((j & 1) * 4 + g) * 8;
     const bf16_t* wp0 = W + (size_t)min(n0 + (j >> 1), N - 1) * K + eoff;
     const bf16_t* wp1 = W + (size_t)min(n0 + 8 + (j >> 1), N - 1) * K + eoff;
@@ -217,7 +226,8 @@ __global__ __launch_bounds__(64 * WK) void bf16_gemm_add_norm_kernel(
             w1[d] = __builtin_nontemporal_load(reinterpret_cast<const s16x8*>(wp1 + ((kb0 + d) << 6)));
         }
     }
-    add_norm_finish<WK, MR, POUT>(regs, sum_out, sum_stride, blockIdx.x == 0 && blockIdx.y == 0, M, K, eps, ybuf, nred, &po);
+    add_norm_finish<WK, MR, POUT>(regs, sum_out, sum_stride, blockIdx.x == 0 && blockIdx.y == 0, M, K, eps, ybuf, nred, &po,
+                                  term2_off != 0);
     // QKV: the page row's address -- old_len arrived with the prologue's loads; its dependent table load is issued here
     // so that the round trip runs under the K loop, not after it
     int64_t dst_row = -1;
@@ -421,11 +431,14 @@ static bool fused_norm_shape_ok(int64_t M, int64_t K) {
 }  // namespace chitu
 
 extern "C" int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
-                                            int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                            int64_t add_row_stride, int32_t add_terms, int64_t add_term_stride,
+                                            void* sum_out_bf16, int64_t sum_row_stride,
                                             const void* norm_weight_bf16, float eps, const void* w_bf16, void* out,
                                             int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* stream) {
     using namespace chitu;
     CHITU_REQUIRE(x_bf16 && add_bf16 && sum_out_bf16 && norm_weight_bf16 && w_bf16 && out);
+    CHITU_REQUIRE(add_terms == 1 || (add_terms == 2 && add_term_stride >= 8 && add_term_stride % 8 == 0));
+    const int64_t term2_off = add_terms == 2 ? add_term_stride : 0;
     CHITU_REQUIRE(M >= 0 && N >= 1 && N < (1 << 30) && K >= 64 && K < (1 << 30) && out_dtype >= 0 && out_dtype <= 2);
     CHITU_REQUIRE(x_row_stride % 8 == 0 && add_row_stride % 8 == 0 && sum_row_stride % 8 == 0);
     if (M == 0) return CHITU_OK;
@@ -440,7 +453,7 @@ extern "C" int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_st
     hipLaunchKernelGGL((bf16_gemm_add_norm_kernel<WKV, DV, MRV>), dim3((unsigned)tiles), dim3(64 * WKV), lds, st,        \
                        (const bf16_t*)x_bf16, x_row_stride, (const bf16_t*)add_bf16, add_row_stride, (bf16_t*)sum_out_bf16, \
                        sum_row_stride, (const bf16_t*)norm_weight_bf16, eps, (const bf16_t*)w_bf16, out, (int)out_dtype, \
-                       (int)M, (int)N, (int)K, QkvPostArgs{})
+                       (int)M, (int)N, (int)K, QkvPostArgs{}, NormOut{}, (float*)nullptr, 1, term2_off)
 #define LAUNCH(WKV, DV)                          \
     do {                                         \
         if (M == 1) LAUNCH_MR(WKV, DV, 1);       \

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kNormWideThreads) void rmsnorm_add_kernel(
     bf16_t* sum_out, int64_t sum_stride, const bf16_t* __restrict__ w, bf16_t* y, int64_t y_stride,
     fp8_t* __restrict__ q, float* __restrict__ qs, int dim, float eps, float qeps, int tile_major) {
     __shared__ float red[kNormWideThreads / 64];
+    __shared__ float red2[QMODE == 3 ? kNormWideThreads / 64 : 1];
     if (QMODE == 2 && MAXT == 1) CHITU_PROBE_MARK(0);
     const int row = blockIdx.x, tid = threadIdx.x;
     const int n_chunks = dim >> 3;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kNormWideThreads) void rmsnorm_add_kernel(
         if (v[0] == 1.2345e30f) CHITU_PROBE_MARK(9);
         CHITU_PROBE_MARK(1);  // inputs arrived, residual added
     }
-    rmsnorm_wide_finish<QMODE>(v, act, row, wraw, y, y_stride, q, qs, dim, eps, qeps, red, tile_major);
+    rmsnorm_wide_finish<QMODE>(v, act, row, wraw, y, y_stride, q, qs, dim, eps, qeps, red, tile_major, red2);
     if (QMODE == 2 && MAXT == 1) CHITU_PROBE_MARK(2);
 }
 
@@ -79,8 +80,9 @@ extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const
     quant_mode &= 3;
     if (quant_mode != 0) {
         CHITU_REQUIRE(q_fp8 && q_scales);
-        if (dim % 128 != 0) return CHITU_ERR_UNSUPPORTED;
-        CHITU_REQUIRE(quant_mode == 1 || quant_mode == 2);
+        if (quant_mode != 3 && dim % 128 != 0) return CHITU_ERR_UNSUPPORTED;
+        // 3 = per-token int8 (q: int8 codes, q_scales [rows]): the residual-add form with one term only
+        CHITU_REQUIRE(quant_mode != 3 || (add_bf16 && add_terms == 1 && !tile_major));
     }
     CHITU_REQUIRE(!tile_major || (quant_mode != 0 && add_bf16));
     CHITU_REQUIRE(add_terms >= 1 && (add_terms == 1 || (add_bf16 && add_term_stride % 8 == 0)));
@@ -97,6 +99,7 @@ extern "C" int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const
         if (add_terms == 1) {
             if (quant_mode == 0) LAUNCHA(0, 1);
             else if (quant_mode == 1) LAUNCHA(1, 1);
+            else if (quant_mode == 3) LAUNCHA(3, 1);
             else LAUNCHA(2, 1);
         } else {
             if (quant_mode == 0) LAUNCHA(0, kNormMaxTerms);

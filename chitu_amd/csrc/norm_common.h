@@ -160,10 +160,14 @@ __device__ __forceinline__ i32x4 sum_terms_bf16x8(const i32x4 (&t)[MAXT], int te
 // with one rounding, optional fp8 quantisation of the rounded y (16 lanes = one 128-wide group).
 // tile_major: the fp8 output in the layout the small-batch GEMMs read with fully coalesced loads (gemm_common.h,
 // "tile-major activations"): q[tile = row / 16][dim / 16][row % 16][16 B], qs[tile][dim / 128][row % 16].
+// QMODE 3 (round 6): the per-token INT8 quantisation of the rounded y (quant_act of the reference's W8A8Linear, quantize/w8a8.py:18-26:
+// scale = max(|y|, 1e-5) / 127 over the whole row, code = clamp(rint(y / scale)) -- w8a8_int8.hip::quant_act_int8_vec_kernel's arithmetic on the
+// same bf16 values): q holds int8 codes [rows, dim], qs one scale per row; `red2` = 16 more floats of LDS for the row maximum.
 template <int QMODE>
 __device__ __forceinline__ void rmsnorm_wide_finish(const float (&v)[8], bool act, int row, const i32x4& wraw, bf16_t* y,
                                                     int64_t y_stride, fp8_t* __restrict__ q, float* __restrict__ qs,
-                                                    int dim, float eps, float qeps, float* red, int tile_major = 0) {
+                                                    int dim, float eps, float qeps, float* red, int tile_major = 0,
+                                                    float* red2 = nullptr) {
     const int tid = threadIdx.x;
     float ss = 0.f;
     if (act) {
@@ -189,7 +193,34 @@ __device__ __forceinline__ void rmsnorm_wide_finish(const float (&v)[8], bool ac
         o[2 * i + 1] = act ? __uint_as_float(h2 & 0xffff0000u) : 0.f;
     }
     if (y && act) *reinterpret_cast<i32x4*>(y + (int64_t)row * y_stride + tid * 8) = out;
-    if (QMODE != 0) {
+    if (QMODE == 3) {
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) amax = __builtin_fmaxf(amax, __builtin_fabsf(o[i]));  // (o = 0 outside the row)
+        amax = wave_reduce_max(amax);
+        if ((tid & 63) == 0) red2[tid >> 6] = amax;
+        __syncthreads();
+        amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < kNormWideThreads / 64; ++i) amax = __builtin_fmaxf(amax, red2[i]);
+        const float sc = __builtin_fmaxf(amax, 1e-5f) / 127.0f;
+        if (act) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float r = rintf(o[k] / sc);
+                r = __builtin_fminf(__builtin_fmaxf(r, -128.f), 127.f);
+                const uint32_t b = (uint32_t)(uint8_t)(int8_t)r;
+                if (k < 4) lo |= b << (8 * k);
+                else hi |= b << (8 * (k - 4));
+            }
+            i32x2 pk;
+            pk[0] = (int)lo;
+            pk[1] = (int)hi;
+            *reinterpret_cast<i32x2*>(q + (int64_t)row * dim + tid * 8) = pk;
+        }
+        if (tid == 0) qs[row] = sc;
+    } else if (QMODE != 0) {
         // dim % 128 == 0 => a 16-lane group is either fully active or fully idle
         float amax = 0.f;
 #pragma unroll

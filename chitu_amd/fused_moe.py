@@ -249,7 +249,7 @@ def fused_experts_impl(
         raise ValueError(f"Unsupported FusedMoe activation: {activation}")
     if use_int8_w8a8:
         return _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts,
-                                   expert_map, w1_scale, w2_scale, reduce_topk, aligned)
+                                   expert_map, w1_scale, w2_scale, reduce_topk, aligned, a1_quant)
     if use_int8_w8a16 or use_int4_w4a16:
         raise NotImplementedError(
             "chitu_amd.fused_moe implements the modes the reference's DeepSeek MoE drives (bf16 experts, fp8_w8a8 "
@@ -421,7 +421,7 @@ def fused_experts_impl(
 
 
 def _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, global_num_experts, expert_map,
-                        w1_scale, w2_scale, reduce_topk, aligned=None):
+                        w1_scale, w2_scale, reduce_topk, aligned=None, a1_quant=None):
     """INT8 W8A8 experts (Mixtral + simple_w8a8, BASELINE config 4): per-token int8 activations, per-channel
     int8 weights.  w1 [E, 2I, K] int8, w1_scale [E, 2I]; w2 [E, N, I] int8, w2_scale [E, N].
     align(16) -> quant_act -> grouped GEMM1 (+ silu*mul) -> quant_act -> grouped GEMM2 (x routed weight) -> sum:
@@ -475,9 +475,17 @@ def _fused_experts_int8(hidden_states, w1, w2, topk_weights, topk_ids, inplace, 
         assert a_sorted.dtype == torch.int32 and a_experts.dtype == torch.int32 and a_npost.dtype == torch.int32
         assert a_sorted.numel() == cap and a_experts.numel() == nblk, "aligned buffers must come from block 16 over global_num_experts"
         sorted_p, experts_p, npost_p = ptr(a_sorted), ptr(a_experts), ptr(a_npost)
-    check(lib.chitu_hip_quant_act_int8(ptr(hidden_states), float_dtype_code(hidden_states.dtype), i64(num_tokens), i64(K),
-                                       P("xq"), P("xs"), st), "moe int8 quant1")
-    check(lib.chitu_hip_moe_i8_gemm1_silu(P("xq"), P("xs"), ptr(w1), ptr(w1_scale), sorted_p, experts_p, npost_p, P("a"),
+    if a1_quant is None:
+        check(lib.chitu_hip_quant_act_int8(ptr(hidden_states), float_dtype_code(hidden_states.dtype), i64(num_tokens), i64(K),
+                                           P("xq"), P("xs"), st), "moe int8 quant1")
+        xq_p, xs_p = P("xq"), P("xs")
+    else:  # the producer (ops.rms_norm(quant="int8")) already quantised the tokens: same codes, one launch less
+        aq_, as_ = a1_quant
+        require_cuda(aq_, as_)
+        assert aq_.dtype == torch.int8 and aq_.is_contiguous() and aq_.numel() == num_tokens * K
+        assert as_.dtype == torch.float32 and as_.is_contiguous() and as_.numel() == num_tokens
+        xq_p, xs_p = ptr(aq_), ptr(as_)
+    check(lib.chitu_hip_moe_i8_gemm1_silu(xq_p, xs_p, ptr(w1), ptr(w1_scale), sorted_p, experts_p, npost_p, P("a"),
                                           i64(numel), i32(topk), i64(I), i64(K), i64(max_mblocks), st), "moe int8 gemm1")
     check(lib.chitu_hip_quant_act_int8(P("a"), i32(0), i64(numel), i64(I), P("aq"), P("as"), st), "moe int8 quant2")
     check(lib.chitu_hip_moe_i8_gemm2(P("aq"), P("as"), ptr(w2), ptr(w2_scale), sorted_p, experts_p, npost_p,

@@ -63,11 +63,12 @@ def _param(*shape, device=None):
 FUSE_NORM_MAX_BS = int(os.environ.get("CHITU_FUSE_NORM_MAX_BS", "2"))
 
 
-def _fuses_norm(x, pending, n_out) -> bool:
+def _fuses_norm(x, pending, n_out, two_terms_ok: bool = False) -> bool:
     """pending must be a plain [bs, dim] tensor: not None (first layer), not a partial whose all-reduce the norm launch
-    itself performs (tensor_parallel.PendingAllReduce, the in-graph xGMI form)."""
-    return (isinstance(pending, torch.Tensor) and pending.dim() == 2 and x.shape[0] <= FUSE_NORM_MAX_BS
-            and ops.bf16_add_norm_fits(x.shape[0], n_out, x.shape[1]))
+    itself performs (tensor_parallel.PendingAllReduce, the in-graph xGMI form).  two_terms_ok: also [bs, 2, dim] (a top-2 MoE's
+    un-summed outputs), for the prologue that takes them (ops.bf16_linear_add_norm)."""
+    dims_ok = isinstance(pending, torch.Tensor) and (pending.dim() == 2 or (two_terms_ok and pending.dim() == 3 and pending.shape[1] == 2))
+    return dims_ok and x.shape[0] <= FUSE_NORM_MAX_BS and ops.bf16_add_norm_fits(x.shape[0], n_out, x.shape[1])
 
 
 class LlamaAttention(torch.nn.Module):

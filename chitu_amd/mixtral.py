@@ -38,6 +38,12 @@ class MixtralArgs:
         return self.dim // self.n_heads
 
 
+# The decode step's launch fusions of round 6 (routing + align in one launch, attn_norm in the qkv GEMM's prologue, the experts'
+# int8 quantisation inside ffn_norm, the top-2 sum inside the next residual add): every one bit-identical to the separate
+# launches; False = the separate launches (the cross-check of tests/test_gpu_mixtral.py, not a product switch).
+FUSE = True
+
+
 class MixtralSparseMoe(torch.nn.Module):
     """Router (bf16) + INT8 W8A8 experts, every rank holding all experts at 1/tp of their width."""
 
@@ -51,13 +57,17 @@ class MixtralSparseMoe(torch.nn.Module):
         self.w2 = torch.nn.Parameter(torch.empty(self.E, args.dim, self.inter, dtype=torch.int8, device=device), requires_grad=False)
         self.w2_scale = torch.nn.Parameter(torch.empty(self.E, args.dim, dtype=torch.float32, device=device), requires_grad=False)
 
-    def forward(self, x):
+    def forward(self, x, x_quant=None, defer_sum: bool = False):
+        """x: ffn_norm output bf16 [tokens, dim]; x_quant: its per-token int8 form when the norm launch produced it.
+        defer_sum: return the un-summed [tokens, topk, dim] expert outputs; the consumer's residual add folds the top-k sum in
+        (ops.rms_norm(add=<3-D>) / ops.bf16_linear_add_norm(add=<[M, 2, K]>), chitu_hip_moe_sum's arithmetic)."""
         # decode-sized batches: moe_align runs inside the routing launch (round 6; as the DeepSeek MoE does since round 1)
-        align = (self.E, fused_moe._MOE_BLOCK_M, None) if _route_align_enabled(x.shape[0]) else None
+        align = (self.E, fused_moe._MOE_BLOCK_M, None) if FUSE and _route_align_enabled(x.shape[0]) else None
         routed = ops.gate_deepseek_v3(x, self.gate, None, 1, 1, self.topk, "softmax_renorm", 1.0, align=align)
         return fused_moe.fused_experts(x, self.w13, self.w2, routed[0], routed[1], inplace=True, use_int8_w8a8=True,
                                        w1_scale=self.w13_scale, w2_scale=self.w2_scale, global_num_experts=self.E,
-                                       aligned=routed[2] if len(routed) > 2 else None)
+                                       aligned=routed[2] if len(routed) > 2 else None, a1_quant=x_quant,
+                                       reduce_topk=not defer_sum)
 
 
 class MixtralBlock(torch.nn.Module):
@@ -70,7 +80,7 @@ class MixtralBlock(torch.nn.Module):
         self.eps = args.norm_eps
 
     def forward(self, x, pending, cos, sin, varlens=None):
-        if varlens is None and _fuses_norm(x, pending, self.attn.wqkv.shape[0]):
+        if FUSE and varlens is None and _fuses_norm(x, pending, self.attn.wqkv.shape[0], two_terms_ok=self.attn.rotary_type != "llama"):
             # small decode batches: residual add + attn_norm run as the prologue of the qkv projection (round 6: the Llama
             # blocks' fusion, bit-identical, one launch less per layer)
             x, a = self.attn.decode_from_residual(x, pending, self.attn_norm, self.eps, cos, sin)
@@ -81,6 +91,14 @@ class MixtralBlock(torch.nn.Module):
                 a = tp.defer_all_reduce(self.attn.decode_forward_paged(hn, cos, sin))
             else:
                 a = tp.defer_all_reduce(self.attn.prefill_forward(hn, cos, sin, varlens))
+        # ffn_norm with the experts' per-token int8 quantisation of its output in the same launch (round 6: quant_act's arithmetic
+        # on the same bf16 values, bit-identical codes; decode only -- prefill keeps the separate launch over thousands of rows)
+        if FUSE and varlens is None and x.is_cuda:
+            x, hn, hq, hs = tp.add_norm(x, a, self.ffn_norm, self.eps, quant="int8")
+            # the top-2 sum moves into the next residual add whenever nothing else needs the summed tensor (one rank, or the
+            # in-graph all-reduce takes the terms): one launch less per layer at every decode batch size
+            defer = tp.defers_topk_sum(hn.shape[0], hn.shape[1], self.ffn.topk)
+            return x, tp.defer_all_reduce(self.ffn(hn, x_quant=(hq, hs), defer_sum=defer))
         x, hn = tp.add_norm(x, a, self.ffn_norm, self.eps)[:2]
         return x, tp.defer_all_reduce(self.ffn(hn))
 

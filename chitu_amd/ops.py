@@ -279,7 +279,8 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
     next fp8 linear would run on its output (model_deepseek_v3.py:98-100).
 
     x [..., dim] bf16 (last dim contiguous, uniform row stride); weight [dim] bf16.
-    quant: None | "act" (act_quant_deepseek_v3) | "group" (per_token_group_quant_fp8, eps 1e-10).
+    quant: None | "act" (act_quant_deepseek_v3) | "group" (per_token_group_quant_fp8, eps 1e-10) | "int8" (per-token int8,
+    quantize/w8a8.py quant_act: q int8 [..., dim], s [...]; needs a plain residual `add`).
     add: optional residual branch; the kernel first forms x_new = bf16(x + add) (the reference's
     `x = x + attn(...)`, model_deepseek_v3.py:1107-1113) and normalises that.  add may carry one extra
     dim, [..., terms, dim] (terms <= 16): the terms are summed first with one bf16 rounding -- the fused
@@ -315,8 +316,12 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
     q = s = None
     mode = 0
     if quant is not None:
-        mode = {"act": 1, "group": 2}[quant]
-        if tile_major:
+        mode = {"act": 1, "group": 2, "int8": 3}[quant]
+        if quant == "int8":
+            assert add is not None and terms == 1 and not tile_major, "int8 output: the residual-add form with one term"
+            q = torch.empty(rows, dim, dtype=torch.int8, device=x.device)
+            s = torch.empty(rows, dtype=torch.float32, device=x.device)
+        elif tile_major:
             assert add is not None and x.dim() == 2, "tile-major output: the residual-add (wide row) form on [rows, dim]"
             mode += 4
             q, s = _tiled_buffers(rows, dim, x.device)
@@ -337,7 +342,8 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out_bf16:
     if quant is not None and tile_major:
         res = (y, TiledQuant(q, s, rows, dim), None)
     else:
-        res = (y,) if quant is None else (y, q.view(*x.shape[:-1], dim), s.view(*x.shape[:-1], dim // 128))
+        res = ((y,) if quant is None else (y, q.view(*x.shape[:-1], dim), s.view(*x.shape[:-1])) if quant == "int8"
+               else (y, q.view(*x.shape[:-1], dim), s.view(*x.shape[:-1], dim // 128)))
     if add is not None:
         res = (sum_out.view(x.shape),) + res
     return res[0] if len(res) == 1 else res
@@ -488,10 +494,17 @@ def fp8_linear_add_norm(x, add, norm_weight, eps, weight, weight_scale, out_dtyp
 def bf16_linear_add_norm(x, add, norm_weight, eps, weight, out_dtype=None):
     """(x_new, F.linear(rms_norm(x_new), weight)) with x_new = x + add, ONE launch (the add and the norm run as the
     GEMM's prologue in every workgroup; bit-identical to rms_norm(x, add=add) followed by bf16_linear).
-    x, add [M, K] bf16 with M <= 4: check bf16_add_norm_fits first."""
+    x, add [M, K] bf16 with M <= 4: check bf16_add_norm_fits first.  add may be [M, 2, K] (contiguous): the two terms are summed
+    first with one bf16 rounding -- a top-2 MoE's un-summed outputs (fused_experts(reduce_topk=False)), as rms_norm(add=<3-D>)."""
     require_cuda(x, add, norm_weight, weight)
     assert x.dtype == torch.bfloat16 and add.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
-    assert x.dim() == 2 and add.shape == x.shape and x.stride(1) == 1 and add.stride(1) == 1 and weight.is_contiguous()
+    terms = 1
+    if add.dim() == 3:
+        assert add.shape[0] == x.shape[0] and add.shape[1] == 2 and add.shape[2] == x.shape[1] and add.is_contiguous()
+        terms = 2
+    else:
+        assert add.shape == x.shape and add.stride(1) == 1
+    assert x.dim() == 2 and x.stride(1) == 1 and weight.is_contiguous()
     assert norm_weight.dtype == torch.bfloat16 and norm_weight.is_contiguous() and norm_weight.numel() == x.shape[1]
     M, K = x.shape
     N = weight.shape[0]
@@ -499,7 +512,8 @@ def bf16_linear_add_norm(x, add, norm_weight, eps, weight, out_dtype=None):
     x_new = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
     out = torch.empty(M, N, dtype=out_dtype or torch.bfloat16, device=x.device)
     check(
-        _lib.lib().chitu_hip_bf16_gemm_add_norm(ptr(x), i64(x.stride(0)), ptr(add), i64(add.stride(0)), ptr(x_new), i64(K),
+        _lib.lib().chitu_hip_bf16_gemm_add_norm(ptr(x), i64(x.stride(0)), ptr(add), i64(add.stride(0)), i32(terms),
+                                                i64(add.stride(1) if terms == 2 else 0), ptr(x_new), i64(K),
                                                 ptr(norm_weight), f32(eps), ptr(weight), ptr(out), float_dtype_code(out.dtype),
                                                 i64(M), i64(N), i64(K), stream_ptr()),
         "bf16_linear_add_norm",

@@ -341,6 +341,8 @@ def add_norm(x, pending, weight, eps, out_bf16=True, quant=None, tile_major=Fals
     tile_major: q comes back as an ops.TiledQuant (s None) wherever a residual is folded in (the wide row form)."""
     from . import ops
 
+    if isinstance(pending, PendingAllReduce) and quant == "int8":
+        pending = pending.resolve()  # (the fused all-reduce launch has the fp8 quantisers only)
     if isinstance(pending, PendingAllReduce):
         res = _xgmi.allreduce_rmsnorm(pending.part, x, weight, eps, out_bf16=out_bf16, quant=quant, tile_major=tile_major)
     elif pending is None:  # (no residual yet: the narrow row form, row-major output whatever tile_major asks for)

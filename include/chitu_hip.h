@@ -274,8 +274,11 @@ int chitu_hip_fp8_gemm_add_norm(const void* x_bf16, int64_t x_row_stride, const 
  * Bit-identical to chitu_hip_rmsnorm(add = ...) followed by chitu_hip_bf16_gemm / chitu_hip_bf16_gemm_silu (same
  * summation orders).  M <= 4, K % 64 == 0, 512 <= K <= 8192, M * K <= 24576 and at least 4 waves of K split for the
  * shape; anything else: CHITU_ERR_UNSUPPORTED (use the two launches).  Row strides in elements, multiples of 8. */
+/* (round 6) add_terms 1 | 2, add_term_stride (elements): with two terms the residual is bf16(float(add[r]) + float(add[r] + stride)) --
+ * chitu_hip_moe_sum's arithmetic for a top-2 MoE whose un-summed outputs [M, 2, K] are handed over (fused_experts(reduce_topk=False)). */
 int chitu_hip_bf16_gemm_add_norm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
-                                 int64_t add_row_stride, void* sum_out_bf16, int64_t sum_row_stride,
+                                 int64_t add_row_stride, int32_t add_terms, int64_t add_term_stride,
+                                 void* sum_out_bf16, int64_t sum_row_stride,
                                  const void* norm_weight_bf16, float eps, const void* w_bf16, void* out,
                                  int32_t out_dtype, int64_t M, int64_t N, int64_t K, void* stream);
 /* chitu_hip_bf16_gemm_add_norm for the merged q|k|v projection of a GQA / MHA layer with chitu_hip_gqa_qkv_post
@@ -474,7 +477,10 @@ int chitu_hip_mla_merge_absorb_uv_quant_fp8(const void* workspace, int32_t num_s
  *   k*add_term_stride + :])) -- chitu_hip_moe_sum's arithmetic, i.e. the fused MoE's top-k sum
  *   (fused_moe.py:1299-1305) folded into the norm that consumes it; add_terms == 1: plain residual.
  *   x [rows, dim] bf16 (row stride given); weight [dim] bf16; y [rows, dim] bf16 or NULL;
- *   q_fp8 [rows, dim], q_scales [rows, dim/128] (dim % 128 == 0 when quantising); dim <= 8192. */
+ *   q_fp8 [rows, dim], q_scales [rows, dim/128] (dim % 128 == 0 when quantising); dim <= 8192.  * quant_mode 3 (round 6; residual-add form with one term, row-major): the per-token INT8 quantisation of the rounded y
+ * instead (quant_act of the reference's W8A8Linear, chitu/quantize/w8a8.py:18-26: scale = max(|y|, 1e-5) / 127 over the row,
+ * code = clamp(rint(y / scale), -128, 127)): q_fp8 then holds int8 codes [rows, dim], q_scales one fp32 per row.
+ */
 int chitu_hip_rmsnorm(const void* x_bf16, int64_t x_row_stride, const void* add_bf16,
                       int64_t add_row_stride, int32_t add_terms, int64_t add_term_stride,
                       void* sum_out_bf16, int64_t sum_row_stride,

@@ -78,8 +78,8 @@ def test_fused_launch_shape_limits_agree_between_python_and_c():
                 if ops.bf16_add_norm_fits(M, N, K):
                     continue
                 unfit += 1
-                rc = lib.chitu_hip_bf16_gemm_add_norm(p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, f32(1e-5), p, p,
-                                                      i32(0), i64(M), i64(N), i64(K), None)
+                rc = lib.chitu_hip_bf16_gemm_add_norm(p, i64(K // 8 * 8), p, i64(K // 8 * 8), i32(1), i64(0), p, i64(K // 8 * 8), p,
+                                                      f32(1e-5), p, p, i32(0), i64(M), i64(N), i64(K), None)
                 assert rc == -2, (M, N, K, rc)
                 rc = lib.chitu_hip_bf16_gemm_silu_add_norm(p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, i64(K // 8 * 8), p, f32(1e-5),
                                                            p, p, i64(M), i64(N), i64(K), None)

@@ -302,3 +302,26 @@ def test_prefill_equals_token_by_token_decode_and_generate():
     free_before = len(cache.free_blocks)
     out1, out2 = model.generate(prompts, 4), model.generate(prompts, 4)
     assert tuple(out1.shape) == (3, 4) and torch.equal(out1, out2) and len(cache.free_blocks) == free_before
+
+
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("N,K", [(6144, 4096), (256, 1024), (1024, 8192)])
+def test_add_norm_gemm_prologue_with_two_residual_terms(M, N, K):
+    """ops.bf16_linear_add_norm(add=[M, 2, K]) (round 6: a top-2 MoE's un-summed outputs handed to the next layer's qkv GEMM) ==
+    moe_sum of the two terms (one bf16 rounding) + rms_norm(add=) + bf16_linear, bit for bit -- and == rms_norm(add=<3-D>), the
+    other consumer of the same hand-off."""
+    from chitu_amd import ops
+
+    if not ops.bf16_add_norm_fits(M, N, K):
+        pytest.skip("shape outside the fused launch")
+    g = torch.Generator().manual_seed(7 * M + N + K)
+    x = (torch.randn(M, K, generator=g) * 2).to(torch.bfloat16).cuda()
+    terms = torch.randn(M, 2, K, generator=g).to(torch.bfloat16).cuda()
+    nw = (1 + 0.2 * torch.randn(K, generator=g)).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    summed = (terms[:, 0].float() + terms[:, 1].float()).to(torch.bfloat16)
+    x_ref, y = ops.rms_norm(x, nw, 1e-5, add=summed)
+    x_ref3, y3 = ops.rms_norm(x, nw, 1e-5, add=terms)
+    assert torch.equal(x_ref, x_ref3) and torch.equal(y, y3)
+    x1, o = ops.bf16_linear_add_norm(x, terms, nw, 1e-5, w)
+    assert torch.equal(x1, x_ref) and torch.equal(o, ops.bf16_linear(y, w))

@@ -10,14 +10,14 @@ from tests.util import assert_close, max_rel_to_peak
 pytestmark = pytest.mark.gpu
 
 
-def build():
+def build(num_hot_req=4):
     from chitu_amd.attn_backend import HipAttnBackend
     from chitu_amd.cache_manager import PagedKVCacheManager
     from chitu_amd.mixtral import MixtralArgs, MixtralDecoder, init_synthetic_
 
     args = MixtralArgs(dim=1024, n_layers=2, n_heads=8, n_kv_heads=2, vocab_size=2048, ffn_dim=512, num_local_experts=8,
                        num_experts_per_tok=2)
-    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=4, block_size=256, max_seq_len=1024, device="cuda",
+    cache = PagedKVCacheManager(0, args.n_layers, num_hot_req=num_hot_req, block_size=256, max_seq_len=1024, device="cuda",
                                 n_local_kv_heads=args.n_kv_heads, head_dim=args.head_dim, dtype=torch.bfloat16)
     model = MixtralDecoder(args, cache, HipAttnBackend(local_n_heads=args.n_heads, max_seq_len=1024), max_position_embeddings=1024,
                            device="cuda")
@@ -78,6 +78,8 @@ def test_layerwise_parity_graph_replay_and_generate():
     for i, layer in enumerate(model.layers):
         with torch.inference_mode():
             xm, pend = layer(x.cuda(), None, cos.cuda(), sin.cuda())
+        if pend.dim() == 3:  # the un-summed top-2 outputs (the next residual add sums them: moe_sum's arithmetic, one rounding)
+            pend = (pend[:, 0].float() + pend[:, 1].float()).to(torch.bfloat16)
         y = (xm + pend).cpu()
         pre = f"layers.{i}."
         y_ref, _, _ = ollama.block(params, pre, x, cos, sin, shadow_k[i], shadow_v[i], table, lens, args.n_heads, 2, 128,
@@ -102,3 +104,43 @@ def test_layerwise_parity_graph_replay_and_generate():
         cache.finalize_cache_all_decode(r)
     out1 = model.generate([[3, 4, 5], [7]], 3)
     assert tuple(out1.shape) == (2, 3) and torch.equal(out1, model.generate([[3, 4, 5], [7]], 3))
+
+
+@pytest.mark.parametrize("bs", [1, 2, 3, 16])
+def test_decode_step_with_the_round_6_fusions_equals_the_separate_launches(bs):
+    """Routing + moe_align in one launch, attn_norm as the prologue of the qkv GEMM (bs <= 2), the experts' int8 quantisation
+    inside ffn_norm, the top-2 sum inside the next residual add (rms_norm(add=<3-D>) or the qkv GEMM's two-term prologue):
+    the logits of two decode steps are bit-identical to the step made of the separate launches (mixtral.FUSE = False)."""
+    from chitu_amd import mixtral
+
+    args, model, cache = build(num_hot_req=16)
+    reqs = [f"f{i}" for i in range(bs)]
+    gen = torch.Generator().manual_seed(11 + bs)
+    for i, r in enumerate(reqs):
+        cache.register_sequence(r, 5 + 13 * i)
+    cache.paged_k_cache.copy_((torch.randn(cache.paged_k_cache.shape, generator=gen) * 0.5).to(torch.bfloat16))
+    cache.paged_v_cache.copy_((torch.randn(cache.paged_v_cache.shape, generator=gen) * 0.5).to(torch.bfloat16))
+    tokens = torch.randint(3, 900, (bs,), generator=gen).cuda()
+    outs = {}
+    try:
+        for fuse in (True, False):
+            mixtral.FUSE = fuse
+            toks, res = tokens, []
+            snap_k, snap_v = cache.paged_k_cache.clone(), cache.paged_v_cache.clone()
+            for step in range(2):
+                cache.prepare_cache_decode(reqs)
+                cache.prepare_block_table_for_decode(reqs)
+                lg = model.decode(toks, use_graph=False).clone()
+                res.append(lg)
+                toks = lg.argmax(dim=-1)
+                cache.finalize_cache_single_decode(reqs)
+            outs[fuse] = res
+            # rewind the two steps for the second pass
+            for r in reqs:
+                cache.seq_lens[r] -= 2
+            cache.paged_k_cache.copy_(snap_k)
+            cache.paged_v_cache.copy_(snap_v)
+    finally:
+        mixtral.FUSE = True
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

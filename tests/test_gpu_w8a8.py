@@ -78,3 +78,26 @@ def test_quant_act_matches_reference_fixture():
     x = torch.from_numpy(g["x"].view(np.int16)).view(torch.float16)
     q, s = w8a8.quant_act(x.cuda())
     assert np.array_equal(q.cpu().numpy(), g["qx"]) and np.array_equal(s.cpu().numpy(), g["sx"])
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 4096), (2, 4096), (16, 4096), (5, 7168), (3, 1000)])
+def test_rms_norm_with_the_int8_quantiser_in_its_launch_is_bit_identical(rows, dim):
+    """ops.rms_norm(add=..., quant="int8") (round 6: the residual add, the norm and quant_act of its rounded output in one
+    launch -- Mixtral's ffn_norm in front of the int8 experts) == ops.rms_norm(add=...) followed by quantize.w8a8.quant_act:
+    same x_new, same y, same int8 codes, same scales; a row of zeros takes quant_act's 1e-5 floor."""
+    from chitu_amd import ops
+    from chitu_amd.quantize.w8a8 import quant_act
+
+    g = torch.Generator().manual_seed(rows * 31 + dim)
+    x = torch.randn(rows, dim, generator=g).to(torch.bfloat16).cuda()
+    a = (torch.randn(rows, dim, generator=g) * 0.3).to(torch.bfloat16).cuda()
+    w = (torch.rand(dim, generator=g) + 0.5).to(torch.bfloat16).cuda()
+    if rows > 2:
+        x[1].zero_()
+        a[1].zero_()
+    x_new0, y0 = ops.rms_norm(x, w, 1e-5, add=a)
+    q0, s0 = quant_act(y0)
+    x_new, y, q, s = ops.rms_norm(x, w, 1e-5, add=a, quant="int8")
+    assert torch.equal(x_new, x_new0) and torch.equal(y, y0)
+    assert q.dtype == torch.int8 and tuple(q.shape) == (rows, dim) and tuple(s.shape) == (rows,)
+    assert torch.equal(q, q0) and torch.equal(s, s0)

@@ -2,6 +2,7 @@
 # One gpurun call that refreshes every trace and counter DESIGN.md section 5 quotes, on the current code:
 #   /usr/local/graft/bin/gpurun --timeout 1800 -- "tools/round_sweep.sh r05_sweep $(git rev-parse --short HEAD)"
 # (the GPU box has no .git: the head the numbers belong to is handed in and stamped into the PMC record).
+# (round 6: every profiled command runs under `timeout` -- an un-wrapped rocprofv3 run once sat on a box for 40 minutes)
 # Writes gpurun_out/<tag>/: the bench line, step breakdowns (bs 16 / 1 / 32) + whole-process kernel traces, the PMC
 # passes (tools/pmc_passes.sh -> pmc_step.json, what bench.py reads as profiles/r03_pmc_step.json), Llama bs-1 trace,
 # prefill timings + trace, bs sweep.  ~2 GPU-minutes of run time on a warm box (r03: 96-108 s).  Copy what is to be judged into profiles/.
@@ -11,11 +12,11 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 echo "$head" > $out/git_head.txt
 cd /tmp && export TMPDIR=/tmp
-python $GRAFT_REPO_ROOT/bench.py > $out/bench.json 2> $out/bench_err.txt
+timeout 600 python $GRAFT_REPO_ROOT/bench.py > $out/bench.json 2> $out/bench_err.txt
 # QUICK=1: the bench line, the bs 16 / bs 1 traces, the PMC passes and the 2048-token prefill trace only (a late-round refresh)
 for bs in 16 1 $([ -z "${QUICK:-}" ] && echo 32); do
   rm -rf /tmp/pb$bs
-  rocprofv3 --kernel-trace --stats -d /tmp/pb$bs -o t -- python $GRAFT_REPO_ROOT/bench.py --bs $bs --steps 8 --warmup 2 --no-bs1 --no-llama --no-cpu-baseline --no-graph-check > /tmp/pb$bs.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pb$bs -o t -- python $GRAFT_REPO_ROOT/bench.py --bs $bs --steps 8 --warmup 2 --no-bs1 --no-llama --no-cpu-baseline --no-graph-check > /tmp/pb$bs.log 2>&1
   python $GRAFT_REPO_ROOT/tools/step_breakdown.py /tmp/pb$bs/t_results.db 8 > $out/step_breakdown_bs$bs.txt
   python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pb$bs/t_results.db > $out/kerneltrace_bs$bs.txt
 done
@@ -23,13 +24,13 @@ bash $GRAFT_REPO_ROOT/tools/pmc_passes.sh $out/pmc > $out/pmc_passes.log 2>&1
 CHITU_GIT_HEAD=$head python $GRAFT_REPO_ROOT/tools/pmc_report.py $out/pmc > $out/pmc_step.json 2>> $out/pmc_passes.log
 cd /tmp
 if [ -z "${QUICK:-}" ]; then
-rm -rf /tmp/pl; rocprofv3 --kernel-trace --stats -d /tmp/pl -o t -- python $GRAFT_REPO_ROOT/tools/llama_ab.py --bs 1 --reps 1 --steps 20 > $out/llama_ab.txt 2>&1
+rm -rf /tmp/pl; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pl -o t -- python $GRAFT_REPO_ROOT/tools/llama_ab.py --bs 1 --reps 1 --steps 20 > $out/llama_ab.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pl/t_results.db --last-fraction 0.45 > $out/kerneltrace_llama_bs1.txt
-rm -rf /tmp/pp; rocprofv3 --kernel-trace --stats -d /tmp/pp -o t -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py 8 > $out/prefill.txt 2>&1
+rm -rf /tmp/pp; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pp -o t -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py 8 > $out/prefill.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pp/t_results.db --last-fraction 0.4 > $out/kerneltrace_prefill.txt
 fi
 # round 5: the 2048-token prefill layer alone (trace + counters), the two prefill attention kernels, the hardware-golden cases
-rm -rf /tmp/pp2; rocprofv3 --kernel-trace --stats -d /tmp/pp2 -o t -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py 8 2048 > $out/prefill_2048.txt 2>&1
+rm -rf /tmp/pp2; timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pp2 -o t -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py 8 2048 > $out/prefill_2048.txt 2>&1
 python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pp2/t_results.db --last-fraction 0.3 > $out/kerneltrace_prefill_2048.txt
 [ -n "${QUICK:-}" ] && { ls -la $out; exit 0; }
 bash $GRAFT_REPO_ROOT/tools/pmc_prefill.sh $tag/pmc_prefill > $out/pmc_prefill.log 2>&1
