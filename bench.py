@@ -66,7 +66,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (the bf16 attention kernels are priced against it)
 EXTRA_BATCHES = tuple(int(b) for b in os.environ.get("CHITU_BENCH_EXTRA_BATCHES", "1,16").split(","))  # (profiling tools: one batch size alone)
 FP8_MFMA_PEAK_TFLOPS = 5000.0  # dense fp8 peak (MX-scaled K = 128 form, measured 4.65 PF): what the fp8 GEMMs are priced against
-PMC_FILE = "r05_pmc_step.json"  # tools/pmc_passes.sh + tools/pmc_report.py, stamped with git head + source digests
+PMC_FILE = "r06_pmc_step.json"  # tools/pmc_passes.sh + tools/pmc_report.py, stamped with git head + source digests
 
 
 def _sha256(path):
@@ -92,6 +92,8 @@ def parse():
     ap.add_argument("--no-bs1", action="store_true", help="skip the extra bs=1 and bs=32 measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="kernel-trace tools only: skip box_calibration (its probes' launches would sit in the trace)")
     ap.add_argument("--no-llama", action="store_true", help="skip the extra Llama-3-8B / DeepSeek-V2-Lite / Mixtral-int8 (BASELINE configs 2, 3, 4) measurements")
     return ap.parse_args()
 
@@ -1341,7 +1343,7 @@ def main():
         if world > 1:
             dist.barrier()
     calib = None
-    if rank == 0:
+    if rank == 0 and not a.no_calibration:
         w2_us = None
         for k in (roofline_array(roof) or []):
             if "gemm2" in str(k.get("kernel", "")):

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for rep in 1 2; do for lib in "$@"; do
   L=""; [ -n "$lib" ] && L=$GRAFT_REPO_ROOT/$lib
   rm -rf /tmp/pa
-  CHITU_HIP_LIB=$L rocprofv3 --kernel-trace --stats -d /tmp/pa -o t -- python $GRAFT_REPO_ROOT/bench.py --bs $bs --steps 8 --warmup 2 --no-bs1 --no-llama --no-cpu-baseline --no-roofline > /tmp/pa.log 2>&1
+  CHITU_HIP_LIB=$L timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pa -o t -- python $GRAFT_REPO_ROOT/bench.py --bs $bs --steps 8 --warmup 2 --no-bs1 --no-llama --no-cpu-baseline --no-roofline --no-calibration > /tmp/pa.log 2>&1
   echo "== ${lib:-in-tree}"
   python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pa/t_results.db --last-fraction 0.7 | grep -E "$pat" | cut -c1-100
 done; done

@@ -8,7 +8,7 @@
 out=$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-args="--layers 8 --steps 2 --warmup 1 --no-graph --no-bs1 --no-llama --no-cpu-baseline --no-roofline $*"
+args="--layers 8 --steps 2 --warmup 1 --no-graph --no-bs1 --no-llama --no-cpu-baseline --no-roofline --no-calibration $*"
 rocprofv3 -L > "$out/counters_available.txt" 2>&1
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES" \

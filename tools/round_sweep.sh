@@ -16,7 +16,7 @@ timeout 600 python $GRAFT_REPO_ROOT/bench.py > $out/bench.json 2> $out/bench_err
 # QUICK=1: the bench line, the bs 16 / bs 1 traces, the PMC passes and the 2048-token prefill trace only (a late-round refresh)
 for bs in 16 1 $([ -z "${QUICK:-}" ] && echo 32); do
   rm -rf /tmp/pb$bs
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pb$bs -o t -- python $GRAFT_REPO_ROOT/bench.py --bs $bs --steps 8 --warmup 2 --no-bs1 --no-llama --no-cpu-baseline --no-graph-check > /tmp/pb$bs.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pb$bs -o t -- python $GRAFT_REPO_ROOT/bench.py --bs $bs --steps 8 --warmup 2 --no-bs1 --no-llama --no-cpu-baseline --no-calibration --no-graph-check > /tmp/pb$bs.log 2>&1
   python $GRAFT_REPO_ROOT/tools/step_breakdown.py /tmp/pb$bs/t_results.db 8 > $out/step_breakdown_bs$bs.txt
   python $GRAFT_REPO_ROOT/tools/rocpd_stats.py /tmp/pb$bs/t_results.db > $out/kerneltrace_bs$bs.txt
 done
