@@ -25,6 +25,9 @@
 // round 6 (profiles/r06_ab_fp8_mx_mfma.txt): 8 waves per workgroup with a four-stage ring (three K blocks in flight, one
 // workgroup per CU): 25-30 % SLOWER at every shape, as the 4-wave rings of round 5 were -- two independent workgroups per CU
 // drift out of phase and fill each other's barrier and request gaps, one workgroup of 8 waves moves in lockstep.
+// An L2 warm-up (every wave touching one line of each of its 64 staging rows 2-8 K blocks ahead with a 4-byte LDS-DMA into a dump
+// area) was measured too: 4-30 % slower, monotonically with the distance (profiles/r06_ab_tiled_l2_warmup.txt) -- a step does not
+// wait for HBM, and the touches are 64 more line requests per wave and step through the same L1.
 #include "common.h"
 #include "gemm_common.h"
 #include "lds_dma.h"
