@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of the tiled fp8 GEMM's L2 warm-up distance (CHITU_TILED_WARM = 0 / 2 / 4 (in-tree) / 6 / 8): build_probe/lib_warm<N>.so from
 # tools/build_variant.sh warm<N> fp8_gemm_tiled.hip -DCHITU_TILED_WARM=<N>;  gpurun -- bash tools/r06_warm_ab.sh
+# (the knob left the kernel with the experiment -- measured slower, profiles/r06_ab_tiled_l2_warmup.txt; kept as the record of how it was timed)
 cd $GRAFT_REPO_ROOT
 for lib in build_probe/lib_warm0.so build_probe/lib_warm2.so "" build_probe/lib_warm6.so build_probe/lib_warm8.so build_probe/lib_warm0.so ""; do
   L=""; [ -n "$lib" ] && L=$GRAFT_REPO_ROOT/$lib
