@@ -24,6 +24,8 @@ __all__ = ["AttnBackend", "HipAttnBackend"]
 # lengths).  32 by the sweep of round 4 (Llama-3-8B bs 1, ctx 1024: 64 -> 3.064, 32 -> 3.041, 16 -> 3.077, 8 -> 3.175 ms/step;
 # from bs 4 on the CU-count term decides; profiles/r04_gqa_split_sweep.txt); CHITU_GQA_MAX_SPLITS overrides it for sweeps.
 _GQA_MAX_SPLITS = int(os.environ.get("CHITU_GQA_MAX_SPLITS", "32"))
+# single-wave workgroups per CU the split count aims for once batch * kv_heads decides (sweeps: CHITU_GQA_WAVES_PER_CU)
+_GQA_WAVES_PER_CU = int(os.environ.get("CHITU_GQA_WAVES_PER_CU", "4"))
 
 
 class AttnBackend:
@@ -433,7 +435,7 @@ class HipAttnBackend(AttnBackend):
             q3 = q3.contiguous()
         if num_splits is None:
             max_steps = max(1, int(block_table.shape[1]) * int(k_cache.shape[1]) // 16)
-            num_splits = max(1, min(max_steps, _GQA_MAX_SPLITS, (4 * _num_cus()) // max(1, bs * Hkv)))
+            num_splits = max(1, min(max_steps, _GQA_MAX_SPLITS, (_GQA_WAVES_PER_CU * _num_cus()) // max(1, bs * Hkv)))
         out = torch.empty(bs, Hq, D, dtype=torch.bfloat16, device=q.device)
         need = bs * Hq * num_splits * (D + 1) * 4 if num_splits > 1 else 1
         ws = workspace.get(need, q.device, "gqa")
