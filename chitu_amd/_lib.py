@@ -147,7 +147,7 @@ def f32(v):
 DEBUG_OPTIONS = {"moe_gemm1_wk": 0, "moe_gemm1_nw": 1, "moe_gemm1_d": 2, "moe_gemm2_cfg": 3, "moe_i8_wk": 4,
                  "gate_generic": 5, "gate_ticket": 6, "sample_radix": 7, "fp8_gemm_wk": 8, "fp8_gemm_deep": 9,
                  "bf16_gemm_wk": 10, "bf16_gemm_deep": 11, "bf16_silu_wk": 12, "fp8_gemm_tiled": 13, "bf16_gemm_tiled": 14,
-                 "gate_small_sort": 15}
+                 "gate_small_sort": 15, "fp8_tiled_tm": 16}
 
 
 def apply_debug_options_from_env():

@@ -30,7 +30,7 @@ namespace chitu {
 enum DebugOption {
     kOptMoeGemm1WK = 0, kOptMoeGemm1NW, kOptMoeGemm1D, kOptMoeGemm2Cfg, kOptMoeI8WK, kOptGateGeneric, kOptGateTicket,
     kOptSampleRadix, kOptFp8GemmWK, kOptFp8GemmDeep, kOptBf16GemmWK, kOptBf16GemmDeep, kOptBf16SiluWK,
-    kOptFp8GemmTiled, kOptBf16GemmTiled, kOptGateSmallSort, kOptCount
+    kOptFp8GemmTiled, kOptBf16GemmTiled, kOptGateSmallSort, kOptFp8TiledTM, kOptCount
 };
 extern int g_debug_options[kOptCount];
 inline int debug_option(DebugOption o) { return g_debug_options[o]; }

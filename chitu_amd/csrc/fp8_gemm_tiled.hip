@@ -21,7 +21,14 @@
 //   token tile.
 // Bound: MFMA on paper (the K = 128 form runs at the fp8 rate, ~5 PFLOP/s dense: 16 MFMAs = 512 matrix-pipe cycles per wave and K
 // block, against 16 ds_read_b128 and ~90 VALU instructions of scale folding); measured 0.17-0.26 of that peak at 2048 tokens --
-// what the waves wait for is each other (one barrier per K block) and the next tile.  Two things were measured and NOT kept in
+// what the waves wait for is each other (one barrier per K block) and the next tile.  Round 6, late: 64-token tiles for small
+// grids (below 256 tiles of 128 tokens a CU holds at most one workgroup and nothing fills its barrier and request gaps; the
+// 64-token form doubles the workgroups at the same arithmetic per output element: wqkv_a at 256-1024 tokens 48 -> 34-40 us, bit-
+// identical), and the step reordered to wait -> barrier -> request -> multiply.  Shader-clock stamps (tools/probe_tiled_steps.py,
+// profiles/r06_ab_tiled_dma_spread.txt) put a 128-token step at ~540 cycles of DMA issue (a wave stands ~64 cycles on a 1 KB
+// piece; the CU's L2 -> LDS path moves ~54 B per clock, tools/probe_lds_fill.hip), ~480 of LDS reads + MFMAs + folds, ~320 of
+// landing wait and ~130 of barrier.  Spreading the pieces between the MFMAs (pinned by unread asm operands) measured 3-8 %
+// slower.  Two more things were measured and NOT kept in
 // round 6 (profiles/r06_ab_fp8_mx_mfma.txt): 8 waves per workgroup with a four-stage ring (three K blocks in flight, one
 // workgroup per CU): 25-30 % SLOWER at every shape, as the 4-wave rings of round 5 were -- two independent workgroups per CU
 // drift out of phase and fill each other's barrier and request gaps, one workgroup of 8 waves moves in lockstep.
@@ -34,39 +41,61 @@
 
 namespace chitu {
 
+// probe builds (-DCHITU_PROBE, tools/probe_tiled_steps.py): shader-clock stamps of workgroup 0's thread 0 at five points of K steps
+// 8 .. 13 -- top, own DMA pieces landed, barrier passed, next stage requested, block multiplied
+#ifdef CHITU_PROBE
+#define TILED_MARK(kb, n)                                                                                     \
+    do {                                                                                                      \
+        if ((kb) >= 8 && (kb) < 14 && threadIdx.x == 0 && blockIdx.x == 0) g_probe_marks[((kb) - 8) * 5 + (n)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define TILED_MARK(kb, n) do {} while (0)
+#endif
+
 #ifndef CHITU_TILED_XCD
 #define CHITU_TILED_XCD 1  // 0: row-major tile order (A/B builds, tools/build_variant.sh)
 #endif
-constexpr int kTileN = 128, kTileM = 128, kTileK = 128;
+constexpr int kTileN = 128, kTileK = 128;
+constexpr int kTiledSmallGrid = 256;  // 128-token tiles below which the 64-token form is launched (sweep: profiles/r06_ab_fp8_tiled_tm64.txt)
 constexpr int kTileBytes = 128 * kTileK;  // one operand tile of one K block in LDS
 
+// TM = token rows per workgroup: 128, or 64 for grids that would not put two workgroups on every CU (launcher): the same
+// arithmetic per output element in the same order, half the MFMA work per K step and workgroup, twice the workgroups.
+template <int TM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void fp8_gemm_tiled_kernel(
     const fp8_t* __restrict__ X, const float* __restrict__ XS, const fp8_t* __restrict__ W, const float* __restrict__ WS,
     void* __restrict__ out, int out_dt, int M, int N, int K) {
+    static_assert(TM == 128 || TM == 64, "token tile");
+    constexpr int MT = TM / 32;  // 16-token MFMA tiles per wave (waves 2 x 2: each 64 weight rows x TM / 2 tokens)
     __shared__ __attribute__((aligned(16))) uint8_t sW[2][kTileBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t sX[2][kTileBytes];
-    __shared__ __attribute__((aligned(16))) float sS[2][kTileM];  // the K block's activation scale of every token row of the tile
+    __shared__ __attribute__((aligned(16))) uint8_t sX[2][TM * kTileK];
+    __shared__ __attribute__((aligned(16))) float sS[2][TM];  // the K block's activation scale of every token row of the tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int wn = wave & 1, wm = wave >> 1;
 #if CHITU_TILED_XCD
     int tile_m, tile_n;  // XCD-blocked order (gemm_common.h): workgroup-uniform, so is the early exit
-    if (!xcd_tile_of((int)blockIdx.x, (M + kTileM - 1) / kTileM, (N + kTileN - 1) / kTileN, tile_m, tile_n)) return;
-    const int n0 = tile_n * kTileN, m0 = tile_m * kTileM;
+    if (!xcd_tile_of((int)blockIdx.x, (M + TM - 1) / TM, (N + kTileN - 1) / kTileN, tile_m, tile_n)) return;
+    const int n0 = tile_n * kTileN, m0 = tile_m * TM;
 #else
-    const int n0 = blockIdx.x * kTileN, m0 = blockIdx.y * kTileM;
+    const int n0 = blockIdx.x * kTileN, m0 = blockIdx.y * TM;
 #endif
     const int KB = K >> 7;
 
     // staging role: wave w brings rows 32 w .. 32 w + 31 of both tiles, four 8-row pieces each (lds_dma.h: lane i -> row
     // 8 n + (i >> 3), source chunk kblock_src_chunk); byte offsets from the tiles' first rows, rows past the matrix re-read
     // its last row (never stored)
-    uint32_t woff[4], xoff[4];
+    // (TM = 64: the token tile is 8 pieces, two per wave)
+    uint32_t woff[4], xoff[MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = wave * 4 + i, r = n * 8 + (lane >> 3), c = kblock_src_chunk(lane, n);
         woff[i] = (uint32_t)(min(r, N - 1 - n0) * K + c * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int n = wave * MT + i, r = n * 8 + (lane >> 3), c = kblock_src_chunk(lane, n);
         xoff[i] = (uint32_t)(min(r, M - 1 - m0) * K + c * 16);
     }
     const fp8_t* wbase = W + (size_t)n0 * K;
@@ -75,35 +104,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the activation scales of the block ride with it: waves 0 and 1 bring 64 tokens' values each (a 4-byte DMA piece).  As
     // plain loads one step ahead (rounds 2-5a) they put an `s_waitcnt vmcnt(0)` of the compiler's into the middle of the MFMA
     // stream -- for `cur = nxt` -- which also waited for the tile just requested: no overlap left within a wave.
-    const uint32_t soff = (uint32_t)(min(m0 + 64 * (wave & 1) + lane, M - 1) * KB * 4);
-    auto issue = [&](int kb) {
-        const uint32_t dst = (uint32_t)((kb & 1) * kTileBytes + wave * 4096);
+    const uint32_t soff = (uint32_t)(min(m0 + 64 * (wave & (TM / 64 - 1)) + lane, M - 1) * KB * 4);
+    auto issue = [&](int kb, int buf) {
+        const uint32_t dst = (uint32_t)(buf * kTileBytes + wave * 4096);
         glds16x4_sbase(wbase + (size_t)kb * 128, woff[0], woff[1], woff[2], woff[3], ldsW + dst);
-        glds16x4_sbase(xbase + (size_t)kb * 128, xoff[0], xoff[1], xoff[2], xoff[3], ldsX + dst);
-        if (wave < 2) glds4_sbase(XS + kb, soff, ldsS + (uint32_t)((kb & 1) * (kTileM * 4) + wave * 256));
+        if constexpr (TM == 128) {
+            glds16x4_sbase(xbase + (size_t)kb * 128, xoff[0], xoff[1], xoff[2], xoff[3], ldsX + dst);
+        } else {
+            const uint32_t dx = (uint32_t)(buf * (TM * kTileK) + wave * 2048);
+            glds16_sbase(xbase + (size_t)kb * 128, xoff[0], ldsX + dx);
+            glds16_sbase(xbase + (size_t)kb * 128, xoff[1], ldsX + dx + 1024);
+        }
+        if (wave < TM / 64)
+            glds4_sbase(XS + kb, soff, ldsS + (uint32_t)(buf * (TM * 4) + (wave & (TM / 64 - 1)) * 256));
     };
     const float* wsp = WS + (size_t)(n0 >> 7) * KB;  // b_s: one scalar per workgroup and block (scalar loads)
     const int foff = kblock_frag_off(j, g);  // this lane's fragment inside a 16-row tile (second half: ^ 64)
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][MT];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    issue(0);
-    float ws_cur = wsp[0], ws_nxt = ws_cur;
-    glds_wait_all();
-    __syncthreads();
+    // double-buffered: block kb + 1 lands while block kb is multiplied; ONE barrier per step (it publishes block kb and retires the
+    // buffer block kb - 1 was read from, which the step's DMA then refills).  A third stage for the 64-token form (two workgroups
+    // per CU still fit) measured equal or slower (profiles/r06_ab_fp8_tiled_tm64.txt).
+    issue(0, 0);
+    float ws_cur = wsp[0];
+    int buf = 0;
     for (int kb = 0; kb < KB; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < KB) {  // the other buffer was last read one step ago, before the barrier that closed it
-            issue(kb + 1);
-            ws_nxt = wsp[kb + 1];
-        }
+        TILED_MARK(kb, 0);
+        glds_wait_all();  // block kb has landed (this wave's pieces) ...
+        TILED_MARK(kb, 1);
+        __syncthreads();  // ... and everyone's; the buffer of block kb - 1 is free
+        TILED_MARK(kb, 2);
+        const float ws_nxt = wsp[min(kb + 1, KB - 1)];
+        if (kb + 1 < KB) issue(kb + 1, buf ^ 1);
+        TILED_MARK(kb, 3);
         // fragments: lane (j, g) takes chunks g and g + 4 of row j of each tile -- the same k subset for the weight rows and
         // the token rows, which is all the dot product needs
-        i32x4 wa[4][2];
+        i32x4 wa[4][2], xb[MT][2];
+        float sc[MT];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const uint8_t* wr = &sW[buf][(wn * 64 + t * 16) * 128];
@@ -111,25 +153,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             wa[t][1] = *reinterpret_cast<const i32x4*>(wr + (foff ^ 64));
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const uint8_t* xr = &sX[buf][(wm * 64 + mt * 16) * 128];
-            const i32x4 xb0 = *reinterpret_cast<const i32x4*>(xr + foff), xb1 = *reinterpret_cast<const i32x4*>(xr + (foff ^ 64));
-            const float sc = sS[buf][wm * 64 + mt * 16 + j];
+        for (int mt = 0; mt < MT; ++mt) {
+            const uint8_t* xr = &sX[buf][(wm * (TM / 2) + mt * 16) * 128];
+            xb[mt][0] = *reinterpret_cast<const i32x4*>(xr + foff);
+            xb[mt][1] = *reinterpret_cast<const i32x4*>(xr + (foff ^ 64));
+            sc[mt] = sS[buf][wm * (TM / 2) + mt * 16 + j];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const f32x4 d = mfma_fp8_k128(wa[nt][0], wa[nt][1], xb0, xb1);
-                fold_scaled(acc[nt][mt], d, sc, ws_cur);
+                const f32x4 d = mfma_fp8_k128(wa[nt][0], wa[nt][1], xb[mt][0], xb[mt][1]);
+                fold_scaled(acc[nt][mt], d, sc[mt], ws_cur);
             }
-        }
+#ifdef CHITU_PROBE
+        if (acc[3][MT - 1][3] == 12345.678f) g_probe_marks[31] = 1;  // (the stamp below waits for the step's last fold)
+#endif
+        TILED_MARK(kb, 4);
         ws_cur = ws_nxt;
-        glds_wait_all();  // block kb + 1 has landed (this wave's pieces) ...
-        __syncthreads();  // ... and everyone's; block kb's buffer is free
+        buf ^= 1;
     }
 
     // C tile (nt, mt): lane holds weight rows n = 4g .. 4g+3 of token column j -> 4 consecutive outputs of one token
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + j;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * (TM / 2) + mt * 16 + j;
         if (m >= M) continue;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -162,13 +210,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // chitu_hip_fp8_gemm_blockscale's large-M form (declared in gemm_common.h, called from fp8_gemm.hip)
 void launch_fp8_gemm_tiled(const fp8_t* a, const float* a_s, const fp8_t* b, const float* b_s, void* out, int out_dt,
                            int64_t M, int64_t N, int64_t K, hipStream_t st) {
+    // 64-token tiles while 128-token ones would leave CUs with fewer than two workgroups (two per CU fit, and two are what
+    // hides a workgroup's barrier and request gaps): R1's wqkv_a at 2048 tokens is 272 tiles of 128.  Option kOptFp8TiledTM forces.
+    const int64_t tiles128 = ((M + 127) / 128) * ((N + kTileN - 1) / kTileN);
+    int tm = tiles128 < kTiledSmallGrid ? 64 : 128;
+    debug_override(kOptFp8TiledTM, tm);
+    if (tm != 64) tm = 128;
 #if CHITU_TILED_XCD
-    const XcdTiling t = xcd_tiling((int)((M + kTileM - 1) / kTileM), (int)((N + kTileN - 1) / kTileN));
+    const XcdTiling t = xcd_tiling((int)((M + tm - 1) / tm), (int)((N + kTileN - 1) / kTileN));
     const dim3 grid((unsigned)(8 * t.Mt * t.Nt));
 #else
-    const dim3 grid((unsigned)((N + kTileN - 1) / kTileN), (unsigned)((M + kTileM - 1) / kTileM));
+    const dim3 grid((unsigned)((N + kTileN - 1) / kTileN), (unsigned)((M + tm - 1) / tm));
 #endif
-    hipLaunchKernelGGL(fp8_gemm_tiled_kernel, grid, dim3(256), 0, st, a, a_s, b, b_s, out, out_dt, (int)M, (int)N, (int)K);
+    if (tm == 64)
+        hipLaunchKernelGGL(fp8_gemm_tiled_kernel<64>, grid, dim3(256), 0, st, a, a_s, b, b_s, out, out_dt, (int)M, (int)N, (int)K);
+    else
+        hipLaunchKernelGGL(fp8_gemm_tiled_kernel<128>, grid, dim3(256), 0, st, a, a_s, b, b_s, out, out_dt, (int)M, (int)N, (int)K);
 }
 
 }  // namespace chitu
@@ -193,3 +250,4 @@ extern "C" int chitu_hip_selftest_xcd_tile_order(int32_t tiles_m, int32_t tiles_
     return CHITU_OK;
 }
 
+CHITU_PROBE_READER(fp8_gemm_tiled)

@@ -2,8 +2,8 @@
 #include "common.h"
 
 namespace chitu {
-int g_debug_options[kOptCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-static_assert(kOptCount == 16, "one initialiser per option");
+int g_debug_options[kOptCount] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static_assert(kOptCount == 17, "one initialiser per option");
 }
 
 extern "C" int chitu_hip_debug_option(int32_t option, int32_t value) {

@@ -325,7 +325,7 @@ int chitu_hip_embed_rope_gather(const int64_t* tokens, const void* embed_bf16, i
  * form for <= 8 blocks per wave (0 = off), 10 / 11 the same two for the bf16 GEMM, 12 K-split waves of the bf16 SwiGLU GEMM,
  * 13 the tiled (compute-shaped) form of the dense fp8 GEMM for M >= 128 (0 = keep streaming the weights per 64 rows),
  * 14 the same for the bf16 GEMM (0 = per 32 rows), 15 the in-routing sort of the one-workgroup route + align launch (0 = the
- * general sort after the routing barrier). */
+ * general sort after the routing barrier), 16 the token-tile height of the tiled fp8 GEMM (64 | 128; heuristic: 64 for small grids). */
 int chitu_hip_debug_option(int32_t option, int32_t value);
 
 /* ---- arithmetic self-test ----------------------------------------------------------------------

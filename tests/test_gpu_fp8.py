@@ -260,6 +260,28 @@ def test_fp8_gemm_tiled_prefill_form_vs_streaming_form_and_oracle(M, N, K):
         assert_close(b16, ref, 5e-3)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 2112, 7168), (2048, 2112, 7168), (1000, 7168, 2048), (129, 200, 128), (333, 136, 384), (65, 130, 256)])
+def test_fp8_gemm_tiled_token_tile_heights_return_the_same_bits(M, N, K):
+    """Round 6: 64-token tiles for grids that would leave CUs with fewer than two workgroups (launcher heuristic; option
+    fp8_tiled_tm forces).  The arithmetic per output element and its order are the 128-token form's: bit-identical fp32 and
+    bf16 outputs on full, ragged and single-tile shapes."""
+    from chitu_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = (torch.randn(M, K, generator=g) * 0.8).to(torch.bfloat16)
+    w, ws = randw(N, K, g)
+    xq, xs = ofp8.act_quant_deepseek_v3(x)
+    xq, xs, w, ws = xq.cuda(), xs.cuda(), w.cuda(), ws.cuda()
+    outs = {}
+    for tm in (64, 128):
+        with _lib.debug_option("fp8_tiled_tm", tm):
+            outs[tm] = (ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.float32),
+                        ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.bfloat16))
+    assert torch.isfinite(outs[64][0]).all()
+    assert torch.equal(outs[64][0], outs[128][0]) and torch.equal(outs[64][1], outs[128][1])
+    assert torch.equal(outs[64][0], ops.fp8_gemm_deepseek_v3(xq, xs, w, ws, out_dtype=torch.float32))  # whichever the heuristic picks
+
+
 # ---------------------------------------------------------------- tile-major activations (the fused step's internal layout)
 @pytest.mark.parametrize("M", [1, 5, 16, 17, 32, 33, 64])
 @pytest.mark.parametrize("N,K", [(2112, 7168), (7168, 2048), (3072, 1536), (200, 512)])

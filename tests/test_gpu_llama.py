@@ -272,6 +272,29 @@ def test_bf16_gemm_tiled_split_k_planes_sum_to_the_gemm(M, N, K, S):
     assert_close(total, torch.nn.functional.linear(x.float(), w.float()), 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(128, 1024, 7168, 1), (1000, 6144, 4096, 1), (257, 200, 512, 1), (2048, 256, 7168, 8), (300, 200, 1024, 4)])
+def test_bf16_gemm_tiled_token_tile_heights_return_the_same_bits(M, N, K, S):
+    """Round 6: 64-token tiles for small grids (launcher heuristic; option fp8_tiled_tm forces either height for both tiled
+    GEMMs).  The same arithmetic per output element in the same order: bit-identical outputs and split-K planes."""
+    from chitu_amd import _lib, ops
+    from chitu_amd._lib import check, i32, i64, ptr, stream_ptr
+
+    g = torch.Generator().manual_seed(M + 2 * N + K + S)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    outs = {}
+    for tm in (64, 128):
+        with _lib.debug_option("fp8_tiled_tm", tm):
+            if S == 1:
+                outs[tm] = ops.bf16_linear(x, w, out_dtype=torch.float32)
+            else:
+                planes = torch.full((S, M, N), float("nan"), dtype=torch.float32, device="cuda")
+                check(_lib.lib().chitu_hip_bf16_gemm(ptr(x), ptr(w), ptr(None), i32(0), i64(M), i64(N), i64(K), i32(S), ptr(planes), stream_ptr()),
+                      "bf16_gemm split-K")
+                outs[tm] = planes
+    assert torch.isfinite(outs[64]).all() and torch.equal(outs[64], outs[128])
+
+
 def test_prefill_equals_token_by_token_decode_and_generate():
     args = tiny_args(2)
     model, cache = build(args)
