@@ -28,7 +28,9 @@
 // profiles/r06_ab_tiled_dma_spread.txt) put a 128-token step at ~540 cycles of DMA issue (a wave stands ~64 cycles on a 1 KB
 // piece; the CU's L2 -> LDS path moves ~54 B per clock, tools/probe_lds_fill.hip), ~480 of LDS reads + MFMAs + folds, ~320 of
 // landing wait and ~130 of barrier.  Spreading the pieces between the MFMAs (pinned by unread asm operands) measured 3-8 %
-// slower.  Two more things were measured and NOT kept in
+// slower; a 256 x 128 tile on 8 waves, a loader / multiplier split of the waves (three-stage ring) and reads-before-requests were
+// built bit-identical and did not beat two 4-wave workgroups per CU either (profiles/r06_ab_fp8_tiled_forms.txt); the scale fold was
+// halved (tiled_fold below).  Two more things were measured and NOT kept in
 // round 6 (profiles/r06_ab_fp8_mx_mfma.txt): 8 waves per workgroup with a four-stage ring (three K blocks in flight, one
 // workgroup per CU): 25-30 % SLOWER at every shape, as the 4-wave rings of round 5 were -- two independent workgroups per CU
 // drift out of phase and fill each other's barrier and request gaps, one workgroup of 8 waves moves in lockstep.
@@ -52,6 +54,21 @@ namespace chitu {
 #define TILED_MARK(kb, n) do {} while (0)
 #endif
 
+// acc += d * (a_s * b_s) for the four results of a tile: ONE VALU pass over the tile per MFMA (two v_pk_fma_f32) where
+// gemm_common.h::fold_scaled -- (d * a_s) * b_s, the reference's order, triton_kernels.py:357 -- takes two.  Two roundings either
+// way (here: the scale product and the fma).  The tiled form is instruction-issue-bound: -6..-10 % from 1024 tokens on
+// (profiles/r06_ab_fp8_tiled_forms.txt, section 4); CHITU_TILED_PREMUL=0 builds the two-pass fold.
+#ifndef CHITU_TILED_PREMUL
+#define CHITU_TILED_PREMUL 1
+#endif
+__device__ __forceinline__ void tiled_fold(f32x4& acc, const f32x4& d, float a_s, float b_s) {
+#if CHITU_TILED_PREMUL
+    const float s = a_s * b_s;
+    acc = __builtin_elementwise_fma(d, f32x4{s, s, s, s}, acc);
+#else
+    fold_scaled(acc, d, a_s, b_s);
+#endif
+}
 #ifndef CHITU_TILED_XCD
 #define CHITU_TILED_XCD 1  // 0: row-major tile order (A/B builds, tools/build_variant.sh)
 #endif
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const f32x4 d = mfma_fp8_k128(wa[nt][0], wa[nt][1], xb[mt][0], xb[mt][1]);
-                fold_scaled(acc[nt][mt], d, sc[mt], ws_cur);
+                tiled_fold(acc[nt][mt], d, sc[mt], ws_cur);
             }
 #ifdef CHITU_PROBE
         if (acc[3][MT - 1][3] == 12345.678f) g_probe_marks[31] = 1;  // (the stamp below waits for the step's last fold)

@@ -3,7 +3,7 @@
 # round's earlier commits (build_probe/lib_warm0.so: 128-token tiles only, request -> multiply -> wait -> barrier), same box:
 #   gpurun -- bash tools/r06_tiled_final_ab.sh   -> [us, TFLOP/s] per shape@tokens(128-token tiles)
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do for cfg in "build_probe/lib_warm0.so:" ":" ":fp8_tiled_tm=128"; do
+for rep in 1 2; do for cfg in ${CFGS:-"build_probe/lib_warm0.so:" ":" ":fp8_tiled_tm=128"}; do
   lib=${cfg%%:*}; opt=${cfg#*:}; L=""; [ -n "$lib" ] && L=$GRAFT_REPO_ROOT/$lib
   echo -n "${lib:-in-tree} ${opt:-heuristic} "
   CHITU_HIP_LIB=$L CHITU_DEBUG_OPTIONS=$opt timeout 200 python - <<'PY' 2>/dev/null
