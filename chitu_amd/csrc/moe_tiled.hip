@@ -37,6 +37,16 @@ __device__ __forceinline__ float moe_tiled_routed_weight(const void* topk_w, int
     return ((const float*)topk_w)[slot];
 }
 
+// probe builds (-DCHITU_PROBE, tools/probe_tiled_steps.py moe): shader-clock stamps of workgroup (0, 0)'s thread 0 at five points of
+// steps 8 .. 13 -- top, own DMA pieces landed, barrier passed, next stage requested, block multiplied
+#ifdef CHITU_PROBE
+#define MOE_TILED_MARK(t, n)                                                                                                  \
+    do {                                                                                                                      \
+        if ((t) >= 8 && (t) < 14 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_probe_marks[((t) - 8) * 5 + (n)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define MOE_TILED_MARK(t, n) do {} while (0)
+#endif
 #ifndef CHITU_MOE_TILED_NREP
 #define CHITU_MOE_TILED_NREP 4  // 1: a workgroup per tile always (A/B builds, tools/build_variant.sh)
 #endif
@@ -270,10 +280,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int nkb = kb + 1, nrep = rep;
         if (nkb == KB) nkb = 0, nrep = rep + 1;
         // stage t has landed (this wave's pieces; stage t + 1, requested a step ago, may still be in flight) ...
+        MOE_TILED_MARK(t, 0);
         if (kMoeRing == 3 && t + 1 < steps) glds_wait_leaving<kPieces>();
         else glds_wait_all();
+        MOE_TILED_MARK(t, 1);
         __syncthreads();  // ... and everyone's; everyone is done with stage t - 1, whose buffer the request below overwrites
+        MOE_TILED_MARK(t, 2);
         if (t + kMoeRing - 1 < steps) issue_next();
+        MOE_TILED_MARK(t, 3);
         if (t + 1 < steps) fetch_scales(nxt, nkb, nrep);
         i32x4 wa[2][2];
         {
@@ -299,6 +313,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int r = 0; r < 4; ++r) acc[nt][mt][r] += (d[r] * sc) * wsc;
             }
         }
+#ifdef CHITU_PROBE
+        if (acc[1][0][3] == 12345.678f) g_probe_marks[31] = 1;  // (the stamp below waits for a fold of this step)
+#endif
+        MOE_TILED_MARK(t, 4);
         if (kb == KB - 1) {  // this tile's last K block: its C leaves now, under the next tile's loads
             store_tile(n0 + rep * 128);
 #pragma unroll
@@ -373,3 +391,5 @@ extern "C" int chitu_hip_moe_gemm2_fp8_tiled(const void* h_fp8, const float* h_s
 #undef LAUNCH2T
     CHITU_RETURN_LAUNCH_STATUS();
 }
+
+CHITU_PROBE_READER(moe_tiled)
