@@ -826,7 +826,9 @@ def roofline_dominant_kernel(model, routing, margs, bs, iters=3):
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_util": mfma_util, "pmc_head": pmc_head,
         "pmc_note": pmc_note,
         "achievable_note": "the chip's measured copy bandwidth is 6.29 TB/s = 0.79 of the 8 TB/s specification "
-                           "(MI355X_MICROARCH.md): that, not 1.0, is the ceiling of `frac` for any streaming kernel",
+                           "(MI355X_MICROARCH.md); a pure cold READ of this launch's own size (395 MB in one pass, register ring, no "
+                           "arithmetic: tools/probe_cold_stream.hip, profiles/r06_probe_cold_stream.txt) tops at 6.6 TB/s = 0.82, and "
+                           "only a 1.9 GB launch amortises ramp and tail up to 7.0 = 0.88: 0.82, not 1.0, is this kernel's ceiling",
         "traffic_source": "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, per launch of this kernel "
                           f"in an eager bs-16 step of the same model (profiles/{PMC_FILE}); mfma_util = SQ_VALU_MFMA_BUSY_CYCLES "
                           "/ (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs), its own pass",
