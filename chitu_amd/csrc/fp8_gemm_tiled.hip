@@ -37,6 +37,8 @@
 // An L2 warm-up (every wave touching one line of each of its 64 staging rows 2-8 K blocks ahead with a 4-byte LDS-DMA into a dump
 // area) was measured too: 4-30 % slower, monotonically with the distance (profiles/r06_ab_tiled_l2_warmup.txt) -- a step does not
 // wait for HBM, and the touches are 64 more line requests per wave and step through the same L1.
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_common.h"
 #include "lds_dma.h"
@@ -149,8 +151,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // per CU still fit) measured equal or slower (profiles/r06_ab_fp8_tiled_tm64.txt).
     issue(0, 0);
     float ws_cur = wsp[0];
-    int buf = 0;
-    for (int kb = 0; kb < KB; ++kb) {
+    // (the buffer index is a compile-time constant of the step: the loop runs two steps per trip, so every fragment read is its
+    // lane's base address + an immediate offset -- with a run-time buffer index each step recomputed ~10 addresses on the VALU)
+    auto step = [&](int kb, auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
         TILED_MARK(kb, 0);
         glds_wait_all();  // block kb has landed (this wave's pieces) ...
         TILED_MARK(kb, 1);
@@ -188,7 +192,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
         TILED_MARK(kb, 4);
         ws_cur = ws_nxt;
-        buf ^= 1;
+    };
+    for (int kb = 0; kb < KB; kb += 2) {
+        step(kb, std::integral_constant<int, 0>{});
+        if (kb + 1 < KB) step(kb + 1, std::integral_constant<int, 1>{});
     }
 
     // C tile (nt, mt): lane holds weight rows n = 4g .. 4g+3 of token column j -> 4 consecutive outputs of one token
